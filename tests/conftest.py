@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    import torch
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        v = z[k]
+        if v.dtype.kind in 'US':
+            out[k] = v
+        elif v.ndim == 0:
+            out[k] = v.item()
+        else:
+            out[k] = torch.from_numpy(v)
+    return out
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden

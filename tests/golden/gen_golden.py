@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER.
+
+Imports the *reference* (hongfz16/HCMoCo, mounted read-only at /root/reference)
+unmodified, drives its own functions on seeded CPU inputs and writes small
+``.npz`` fixtures next to this file.  Nothing of the reference travels: only
+inputs / expected outputs are committed.  The GPU box never runs this script.
+
+Shims (process-local, reference files untouched):
+  1. ``torch.Tensor.cuda`` / ``torch.nn.Module.cuda`` -> identity
+  2. stub modules ``tensorboard_logger``, ``pointnet2_cuda``
+  3. a minimal ``yacs.config.CfgNode`` (attr-dict + merge_from_file via PyYAML)
+  4. cwd = /root/reference/pycontrast (the reference opens yaml by relative path)
+
+Usage:  python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import types
+import argparse
+
+import numpy as np
+import torch
+
+REF = '/root/reference/pycontrast'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- #
+# shims
+# --------------------------------------------------------------------------- #
+def install_shims():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    for name in ('tensorboard_logger', 'pointnet2_cuda'):
+        sys.modules[name] = types.ModuleType(name)
+
+    import yaml
+
+    class CfgNode(dict):
+        def __init__(self, init=None, **kw):
+            super().__init__()
+            for k, v in (init or {}).items():
+                self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def defrost(self):
+            pass
+
+        def freeze(self):
+            pass
+
+        def _merge(self, other):
+            for k, v in other.items():
+                if isinstance(v, dict) and isinstance(self.get(k), dict):
+                    self[k]._merge(v)
+                else:
+                    self[k] = CfgNode(v) if isinstance(v, dict) else v
+
+        def merge_from_file(self, path):
+            with open(path) as f:
+                self._merge(yaml.safe_load(f))
+
+        def merge_from_list(self, lst):
+            pass
+
+    yacs = types.ModuleType('yacs')
+    yacs_config = types.ModuleType('yacs.config')
+    yacs_config.CfgNode = CfgNode
+    yacs.config = yacs_config
+    sys.modules['yacs'] = yacs
+    sys.modules['yacs.config'] = yacs_config
+
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+
+
+def npz(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote %-28s %7.1f KiB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def f32(x):
+    return float(np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x).reshape(-1)[0])
+
+
+# --------------------------------------------------------------------------- #
+# 1. alias tables  (memory/alias_multinomial.py)
+# --------------------------------------------------------------------------- #
+def gen_alias():
+    from memory.alias_multinomial import AliasMethod
+    g = torch.Generator().manual_seed(11)
+    p = torch.rand(97, generator=g) + 0.05
+    p_in = p.clone()
+    am = AliasMethod(p.clone())
+    uni = AliasMethod(torch.ones(1000))
+    uni2 = AliasMethod(torch.ones(4096))
+    npz('alias_tables', probs=p_in, prob=am.prob, alias=am.alias,
+        uni1000_prob=uni.prob, uni1000_alias=uni.alias,
+        uni4096_prob=uni2.prob, uni4096_alias=uni2.alias)
+
+
+# --------------------------------------------------------------------------- #
+# 2. bank NCE  (memory/mem_bank.py CMCMem3 + contrast_trainer._compute_loss_accuracy)
+# --------------------------------------------------------------------------- #
+def gen_bank():
+    from memory.mem_bank import CMCMem3
+    from learning.contrast_trainer import ContrastTrainer
+    import torch.nn as nn
+
+    torch.manual_seed(1234)
+    B, D, n, K, W = 6, 128, 256, 64, 2
+    T, mom = 0.07, 0.5
+    mem = CMCMem3(D, n, K, T, mom)
+    bank0 = [mem.memory_1.clone(), mem.memory_2.clone(), mem.memory_3.clone()]
+
+    drawn = {}
+    orig_draw = mem.multinomial.draw
+
+    def draw(N):
+        out = orig_draw(N)
+        drawn['idx'] = out.clone()
+        return out
+    mem.multinomial.draw = draw
+
+    f = torch.nn.functional.normalize(torch.randn(B * W, 3 * D).view(B * W, 3, D), dim=2)
+    all_x = [f[:, i].contiguous() for i in range(3)]
+    # global indices: a duplicate inside rank 0, and one across ranks (last wins)
+    all_y = torch.tensor([5, 17, 200, 17, 33, 255, 90, 5, 101, 7, 64, 128], dtype=torch.long)
+    x = [a[:B].clone().requires_grad_(True) for a in all_x]
+    y = all_y[:B].clone()
+
+    out = mem(x[0], x[1], x[2], y, all_x[0], all_x[1], all_x[2], all_y)
+    logits, labels = out[:-1], out[-1]
+    idx = drawn['idx'].view(B, K + 1).clone()
+    idx[:, 0] = y
+    bank1 = [mem.memory_1.clone(), mem.memory_2.clone(), mem.memory_3.clone()]
+
+    crit = nn.CrossEntropyLoss()
+    regimes = {
+        'none':      dict(use_depth=None, use_rgb=None),
+        'depth_mix': dict(use_depth=torch.tensor([1, 0, 1, 1, 0, 1]), use_rgb=None),
+        'depth_all0': dict(use_depth=torch.zeros(B, dtype=torch.long), use_rgb=None),
+        'both_mix':  dict(use_depth=torch.tensor([1, 0, 1, 1, 0, 1]),
+                          use_rgb=torch.tensor([1, 1, 0, 1, 1, 1])),
+        'both_none': dict(use_depth=torch.tensor([1, 0, 1, 0, 0, 1]),
+                          use_rgb=torch.tensor([0, 1, 0, 1, 1, 0])),
+    }
+    arrays = dict(B=B, D=D, n=n, K=K, T=T, m=mom,
+                  bank0_1=bank0[0], bank0_2=bank0[1], bank0_3=bank0[2],
+                  bank1_1=bank1[0], bank1_2=bank1[1], bank1_3=bank1[2],
+                  idx=idx, y=y, all_y=all_y,
+                  x1=x[0], x2=x[1], x3=x[2],
+                  all_x1=all_x[0], all_x2=all_x[1], all_x3=all_x[2],
+                  labels=labels)
+    for i, l in enumerate(logits):
+        arrays['logits%d' % i] = l
+    for name, reg in regimes.items():
+        losses, accs = ContrastTrainer._compute_loss_accuracy(
+            logits=list(logits), target=labels, criterion=crit, **reg)
+        total = sum(losses)
+        grads = torch.autograd.grad(total, x, retain_graph=True, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(x[0]) for g in grads]
+        arrays[name + '_losses'] = np.array([f32(l) for l in losses], dtype=np.float32)
+        arrays[name + '_accs'] = np.array([f32(a) for a in accs], dtype=np.float32)
+        for i, g in enumerate(grads):
+            arrays[name + '_gx%d' % (i + 1)] = g
+        if reg['use_depth'] is not None:
+            arrays[name + '_use_depth'] = reg['use_depth']
+        if reg['use_rgb'] is not None:
+            arrays[name + '_use_rgb'] = reg['use_rgb']
+    npz('bank_nce', **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# 3. MoCo queue (memory/mem_moco.py CMCMoCo) -- pointer bookkeeping over two steps
+# --------------------------------------------------------------------------- #
+def gen_moco():
+    from memory.mem_moco import CMCMoCo
+    torch.manual_seed(77)
+    D, K, B = 128, 48, 5
+    moco = CMCMoCo(D, K, 0.2)
+    arrays = dict(D=D, K=K, B=B, T=0.2, queue0_1=moco.memory_1.clone(), queue0_2=moco.memory_2.clone())
+    nrm = torch.nn.functional.normalize
+    for step in range(3):
+        q1, k1, q2, k2 = [nrm(torch.randn(B, D)) for _ in range(4)]
+        all_k1 = torch.cat([k1, nrm(torch.randn(B, D))])
+        all_k2 = torch.cat([k2, nrm(torch.randn(B, D))])
+        l1, l2, lab = moco(q1, k1, q2, k2, all_k1=all_k1, all_k2=all_k2)
+        arrays.update({'s%d_q1' % step: q1, 's%d_k1' % step: k1, 's%d_q2' % step: q2,
+                       's%d_k2' % step: k2, 's%d_all_k1' % step: all_k1, 's%d_all_k2' % step: all_k2,
+                       's%d_logits1' % step: l1, 's%d_logits2' % step: l2,
+                       's%d_index' % step: moco.index,
+                       's%d_queue_1' % step: moco.memory_1.clone(),
+                       's%d_queue_2' % step: moco.memory_2.clone()})
+    npz('moco_queue', **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# 4-6. feature-map losses (learning/contrast_trainer.py :642-892)
+# --------------------------------------------------------------------------- #
+def make_trainer(temperature=0.07, num_samples=16):
+    from learning.contrast_trainer import ContrastTrainer
+    tr = ContrastTrainer.__new__(ContrastTrainer)
+    tr.args = argparse.Namespace(temperature=temperature, pri3d_num_samples_per_image=num_samples)
+    return tr
+
+
+def gen_dense():
+    torch.manual_seed(2024)
+    B, C, h, S = 5, 128, 8, 24
+    H = 4 * h
+    tr = make_trainer(num_samples=S)
+    m1 = torch.randn(B, C, h, h, requires_grad=True)
+    m2 = torch.randn(B, C, h, h, requires_grad=True)
+    depth = torch.randn(B, H, H)
+    mask = torch.zeros(B, H, H)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing='ij')
+    disc = ((yy - H / 2) ** 2 + (xx - H / 2) ** 2) < (0.37 * H) ** 2
+    mask[:, disc] = 1.0
+    mask[3] = 0.0                       # an image with an empty mask is dropped (:677-682)
+    use_depth = torch.tensor([1, 1, 1, 0, 1])
+
+    captured = {}
+    orig = torch.Tensor.multinomial
+
+    def capture(self, *a, **k):
+        out = orig(self, *a, **k)
+        captured['ind'] = out.clone()
+        return out
+    torch.Tensor.multinomial = capture
+    try:
+        losses, accs = tr._compute_soft_pri3d_loss_accuracy(
+            m1, m2, depth, None, use_depth=use_depth, depth_mask=mask, scale=None)
+    finally:
+        torch.Tensor.multinomial = orig
+    g1, g2 = torch.autograd.grad(sum(losses), [m1, m2])
+    # all-zero use_depth early return
+    l0, a0 = tr._compute_soft_pri3d_loss_accuracy(
+        m1, m2, depth, None, use_depth=torch.zeros(B, dtype=torch.long), depth_mask=mask)
+    npz('dense_soft_nce', B=B, C=C, h=h, S=S, temperature=0.07,
+        map1=m1, map2=m2, depth_mask=mask, use_depth=use_depth,
+        sample_ind=captured['ind'],          # [B', S] indices into h*w for the kept images
+        losses=np.array([f32(l) for l in losses], np.float32),
+        accs=np.array([f32(a) for a in accs], np.float32),
+        grad_map1=g1, grad_map2=g2,
+        zero_losses=np.array([f32(l) for l in l0], np.float32))
+
+
+def gen_joint():
+    arrays = {}
+    for J in (13, 16, 17):
+        torch.manual_seed(300 + J)
+        B, C, h = 4, 128, 8
+        tr = make_trainer()
+        m1 = torch.randn(B, C, h, h, requires_grad=True)
+        m2 = torch.randn(B, C, h, h, requires_grad=True)
+        g3 = torch.randn(B, J, C, requires_grad=True)
+        j2d = torch.rand(B, J, 2) * (4 * h)
+        j2d[0, 0] = torch.tensor([-3.0, 5.0])          # negative -> clamp 0
+        j2d[1, 2] = torch.tensor([4.0 * h + 9, 2.0])   # beyond -> clamp h-1
+        j2d[2, 1] = j2d[2, 0]                          # two joints on one pixel
+        vis = (torch.rand(B, J) < 0.8).int()
+        vis[3] = 0                                     # image with no visible joint
+        vis[0, 0] = 1
+        use_depth = torch.tensor([1, 0, 1, 1])
+        import torch.nn as nn
+        crit = [nn.CrossEntropyLoss(), nn.CrossEntropyLoss()]
+        losses, accs = tr._compute_joints_pri3d_loss_accuracy(
+            m1, m2, g3, crit, j2d, vis, use_depth=use_depth)
+        gm1, gm2, gg3 = torch.autograd.grad(sum(losses), [m1, m2, g3])
+        p = 'J%d_' % J
+        arrays.update({p + 'map1': m1, p + 'map2': m2, p + 'feat3': g3, p + 'joints2d': j2d,
+                       p + 'joints_vis': vis, p + 'use_depth': use_depth,
+                       p + 'losses': np.array([f32(l) for l in losses], np.float32),
+                       p + 'accs': np.array([f32(a) for a in accs], np.float32),
+                       p + 'grad_map1': gm1, p + 'grad_map2': gm2, p + 'grad_feat3': gg3})
+        # float64 joints (the loader yields doubles, datasets/dataset.py:594-596)
+        losses64, _ = tr._compute_joints_pri3d_loss_accuracy(
+            m1, m2, g3, crit, j2d.double(), vis, use_depth=use_depth)
+        arrays[p + 'losses_f64joints'] = np.array([f32(l) for l in losses64], np.float32)
+    # all-ignored target -> NaN (torch CE semantics)
+    torch.manual_seed(9)
+    tr = make_trainer()
+    import torch.nn as nn
+    crit = [nn.CrossEntropyLoss(), nn.CrossEntropyLoss()]
+    m = torch.randn(2, 128, 8, 8)
+    lnan, _ = tr._compute_joints_pri3d_loss_accuracy(
+        m, m, torch.randn(2, 16, 128), crit, torch.rand(2, 16, 2) * 32,
+        torch.ones(2, 16).int(), use_depth=torch.zeros(2, dtype=torch.long))
+    arrays['allignored_depth_loss_isnan'] = np.array(bool(torch.isnan(lnan[1])))
+    npz('joint_nce', temperature=0.07, **arrays)
+
+
+def gen_scl():
+    from learning.segment_trainer import SegTrainer as SegmentTrainer  # sibling copy: use_rgb=None semantics
+    arrays = {}
+    torch.manual_seed(4242)
+    B, C, h, J = 4, 128, 8, 16
+    tr = make_trainer()
+    st = SegmentTrainer.__new__(SegmentTrainer)
+    st.args = tr.args
+    m1 = torch.randn(B, C, h, h, requires_grad=True)
+    m2 = torch.randn(B, C, h, h, requires_grad=True)
+    j2d = torch.rand(B, J, 2) * (4 * h)
+    j2d[0, 0] = torch.tensor([-1.0, 40.0])
+    vis = (torch.rand(B, J) < 0.8).int()
+    use_depth = torch.tensor([1, 0, 1, 1])
+    use_rgb = torch.tensor([1, 1, 0, 1])
+    # (a) reference contrast_trainer with a use_rgb tensor
+    la, _ = tr._compute_cross_subject_joints_pri3d_loss(
+        m1, m2, None, None, j2d, vis, use_depth=use_depth, use_rgb=use_rgb)
+    ga = torch.autograd.grad(la[0], [m1, m2])
+    # (b) use_rgb=None semantics from learning/segment_trainer.py:601-606
+    lb, _ = st._compute_cross_subject_joints_pri3d_loss(
+        m1, m2, None, None, j2d, vis, use_depth=use_depth, use_rgb=None)
+    gb = torch.autograd.grad(lb[0], [m1, m2])
+    # (c) early-out
+    lc, _ = tr._compute_cross_subject_joints_pri3d_loss(
+        m1, m2, None, None, j2d, vis, use_depth=torch.zeros(B, dtype=torch.long), use_rgb=use_rgb)
+    arrays.update(map1=m1, map2=m2, joints2d=j2d, joints_vis=vis, use_depth=use_depth, use_rgb=use_rgb,
+                  loss_with_rgb=np.float32(f32(la[0])), grad1_with_rgb=ga[0], grad2_with_rgb=ga[1],
+                  loss_rgb_none=np.float32(f32(lb[0])), grad1_rgb_none=gb[0], grad2_rgb_none=gb[1],
+                  n_early_out=len(lc), early_out=np.array([f32(l) for l in lc], np.float32))
+    npz('scl', temperature=0.07, **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# 7. model surface (networks/build_backbone.py) -- keys/shapes + a pinned forward
+# --------------------------------------------------------------------------- #
+def deterministic_fill(state_dict):
+    """Name-keyed deterministic weights, reproducible without the reference."""
+    import zlib
+    out = {}
+    for k, v in state_dict.items():
+        g = torch.Generator().manual_seed(zlib.crc32(k.encode()) & 0x7fffffff)
+        if k.endswith('num_batches_tracked'):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith('running_var'):
+            out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        elif k.endswith('running_mean'):
+            out[k] = torch.randn(v.shape, generator=g) * 0.05
+        elif v.dim() == 1 and k.endswith('.weight'):     # norm scale
+            out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        elif k.endswith('.bias'):
+            out[k] = torch.randn(v.shape, generator=g) * 0.05
+        elif k.endswith('.e'):
+            out[k] = torch.rand(v.shape, generator=g) + 0.5
+        else:
+            fan_in = max(1, int(np.prod(v.shape[1:]))) if v.dim() > 1 else 1
+            out[k] = torch.randn(v.shape, generator=g) * (1.0 / np.sqrt(fan_in))
+    return out
+
+
+def gen_model():
+    from networks.build_backbone import build_model
+    for skel, J in (('mpii', 16), ('coco_reduce', 13)):
+        opt = argparse.Namespace(modal='RGBD2S', arch='HRNet', jigsaw=False, head='linear', feat_dim=128,
+                                 in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
+                                 skeleton_meta_name=skel, IN_Pretrain=None, depth_Pretrain=None, mem='bank')
+        model, ema = build_model(opt)
+        sd = model.state_dict()
+        keys = list(sd.keys())
+        shapes = [list(v.shape) for v in sd.values()]
+        model.load_state_dict(deterministic_fill(sd))
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 6, 64, 64, generator=g)
+        s = torch.rand(2, J, 2, generator=g) * 2 - 1
+        arrays = dict(keys=np.array(keys), shapes=np.array([str(s_) for s_ in shapes]),
+                      n_params=sum(p.numel() for p in model.parameters()), x=x, s=s)
+        for mode in ('eval', 'train'):
+            getattr(model, mode)()
+            with torch.no_grad():
+                f1, f2, f3, f, aux = model(x, s, return_fm=True)
+            arrays.update({mode + '_f': f, mode + '_feat3': f3,
+                           mode + '_lm1_slice': aux['linear_merge1'][:, :8, ::5, ::5],
+                           mode + '_lm2_slice': aux['linear_merge2'][:, :8, ::5, ::5],
+                           mode + '_feat1_3': f1[3], mode + '_feat2_0_slice': f2[0][:, :, ::7, ::7]})
+        npz('model_hrnet_w18_' + skel, **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# 8. options surface (options/train_options.py)
+# --------------------------------------------------------------------------- #
+def gen_options():
+    from options.train_options import TrainOptions
+    import tempfile
+    import json
+    tmp = tempfile.mkdtemp()
+    cases = {
+        'stage1': ['--method', 'CMCRGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list', '3,3',
+                   '--batch_size', '8', '--nce_k', '256', '--cosine', '--lr_decay_epochs', '30,60'],
+        'custom_warm': ['--method', 'Customize', '--batch_size', '512', '--epochs', '600', '--cosine',
+                        '--learning_rate', '0.06', '--modal', 'CMC', '--mem', 'moco'],
+        'infomin': ['--method', 'InfoMin', '--amp', '--opt_level', 'O1', '--tag', 'x'],
+    }
+    out = {}
+    for name, argv in cases.items():
+        sys.argv = ['main_contrast.py', '--model_path', tmp, '--tb_path', tmp] + argv
+        opt = TrainOptions().parse()
+        d = {k: v for k, v in vars(opt).items() if k not in ('model_path', 'tb_path', 'model_folder', 'tb_folder')}
+        out[name] = dict(argv=argv, opt=d)
+    with open(os.path.join(OUT, 'options_cases.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('wrote options_cases.json')
+
+
+if __name__ == '__main__':
+    install_shims()
+    only = set(sys.argv[1:])
+    sys.argv = sys.argv[:1]
+    gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
+                scl=gen_scl, model=gen_model, options=gen_options)
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn()
