@@ -1,0 +1,99 @@
+"""ctypes binding of libhcmoco_hip.so (the C ABI declared in include/hcmoco_hip.h).
+
+Only plain pointers and sizes cross this boundary: callers pass ``tensor.data_ptr()`` and the
+raw ``hipStream_t`` of the current torch stream.  There is deliberately NO fallback: a missing
+library is an ImportError-class failure, a non-zero return code raises ``HipError``."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libhcmoco_hip.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hcmoco_hip.h')
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class Strides4(C.Structure):
+    _fields_ = [('sN', C.c_int64), ('sC', C.c_int64), ('sH', C.c_int64), ('sW', C.c_int64)]
+
+
+_p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/hcmoco_hip.h one to one
+SIGNATURES = {
+    'hcm_abi_version': (_i, []),
+    'hcm_error_string': (C.c_char_p, [_i]),
+    'hcm_alias_build': (_i, [_p, _i64, _p, _p]),
+    'hcm_alias_draw': (_i, [_p, _p, _i64, _p, _i, _i, _u64, _u64, _p, _p]),
+    'hcm_bank_nce_workspace_bytes': (_sz, [_i, _i, _i]),
+    'hcm_bank_nce_fused': (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f,
+                                _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'hcm_bank_nce_fused_timed': (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f,
+                                      _p, _p, _p, _p, _p, _p, _sz, _p, _i, _p]),
+    'hcm_bank_logits_fwd': (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p]),
+    'hcm_bank_logits_bwd': (_i, [_p, _p, _p, _i64, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    'hcm_bank_update': (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _i, _i, _f, _p]),
+    'hcm_moco_logits': (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p]),
+    'hcm_moco_enqueue': (_i, [_p, _p, _i, _i, _i, _i64, _p]),
+    'hcm_dense_soft_nce_workspace_bytes': (_sz, [_i, _i, _i]),
+    'hcm_dense_soft_nce': (_i, [_p, _p, Strides4, _i, _i, _i, _i, _p, _p, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    'hcm_joint_nce_workspace_bytes': (_sz, [_i, _i, _i]),
+    'hcm_joint_nce': (_i, [_p, _p, Strides4, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f,
+                           _p, _p, _p, _p, _p, _sz, _p]),
+    'hcm_scl_workspace_bytes': (_sz, [_i, _i, _i]),
+    'hcm_scl': (_i, [_p, _p, Strides4, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    'hcm_joint_pixels': (_i, [_p, _i, _i, _p, _p]),
+    'hcm_furthest_point_sampling': (_i, [_i, _i, _i, _p, _p, _p, _p]),
+    'hcm_ball_query': (_i, [_i, _i, _i, _f, _i, _p, _p, _p, _p]),
+    'hcm_group_points': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'hcm_group_points_grad': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'hcm_gather_points': (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
+    'hcm_gather_points_grad': (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
+    'hcm_three_nn': (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
+    'hcm_three_interpolate': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'hcm_three_interpolate_grad': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libhcmoco_hip.so (in-tree, via make + hipcc)."""
+    res = subprocess.run(['make', '-C', CSRC, '-j', '4'], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-8000:])
+    if res.returncode != 0:
+        raise RuntimeError('building libhcmoco_hip.so failed (see output above)')
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises if it has not been built -- there is no
+    fallback implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'libhcmoco_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ '
+                'as g; g.build()"` or `make -C hcmoco_amd/csrc`. hcmoco_amd has no CPU/eager fallback.'
+                % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError: the library does not match the header
+            fn.restype = res
+            fn.argtypes = args
+        if handle.hcm_abi_version() != 1:
+            raise ImportError('libhcmoco_hip.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().hcm_error_string(rc)
+        raise HipError('%s failed: hip error %d (%s)' % (what, rc, msg.decode() if msg else '?'))

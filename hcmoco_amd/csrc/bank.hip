@@ -1,0 +1,778 @@
+// Memory-bank kernels for gfx950 (MI355X): alias draw, fused bank-NCE forward+backward,
+// materialised-logits API mode, momentum update, MoCo queue.
+//
+// Reference behaviour: pycontrast/memory/{alias_multinomial,mem_bank,mem_moco}.py and
+// pycontrast/learning/contrast_trainer.py:212-253.
+//
+// Design (DESIGN.md "bank NCE"): the contraction is a batched gather-GEMV -- every sample
+// has its own K+1 randomly drawn 512-byte rows in each of three banks -- so it is bound by
+// HBM/Infinity-Cache bandwidth, not by MFMA.  One pass over the gathered rows produces all
+// six logit sets, their online-softmax statistics and the six softmax-weighted row sums the
+// backward needs; nothing of size B*(K+1)*D is ever written.
+//
+// Lane layout: a 64-lane wave is four DPP rows of 16 lanes.  Each 16-lane row owns one bank
+// row at a time: lane t holds floats [4t,4t+4) and [64+4t,64+4t+4) of it (two 16-byte loads
+// that coalesce into 256-byte segments), so the dot products reduce with four DPP adds and
+// never touch LDS.  A 256-thread workgroup therefore runs 16 independent "streams", each
+// with its own running max / sum / weighted-row accumulators, merged once at the end.
+#include "hcm_common.h"
+#include "../../include/hcmoco_hip.h"
+
+namespace {
+
+using namespace hcm;
+
+constexpr int kWG = 256;
+constexpr int kStreams = 16;
+constexpr float kNegBig = -1.0e30f;   // "minus infinity" that survives a subtraction
+constexpr float kInvalid = -3.0e30f;  // logit of a padded row: exp2(kInvalid - m) == 0
+
+enum Mode { kFused = 0, kLogitsFwd = 1, kLogitsBwd = 2 };
+
+// pair p -> bank it gathers from (0:M1 1:M2 2:M3) and query modality (0:x1 1:x2 2:x3);
+// order 12,21,23,32,13,31 (mem_bank.py:186-191).
+__device__ __constant__ const int kPairBank[6] = {1, 0, 2, 1, 2, 0};
+__device__ __constant__ const int kPairQuery[6] = {0, 1, 1, 2, 0, 2};
+
+__host__ __device__ inline int rows_per_wg(int B, int K1) {
+  int R = 256;
+  while ((long long)B * ((K1 + R - 1) / R) > 8192 && R < (1 << 20)) R <<= 1;
+  return R;
+}
+
+template <int NV>
+struct Row3 {
+  float4 v[3][NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void load_rows(Row3<NV>& r, const float* __restrict__ b1,
+                                          const float* __restrict__ b2,
+                                          const float* __restrict__ b3, int64_t row, int t) {
+  constexpr int D = 64 * NV;
+  const int64_t off = row * D + 4 * t;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    r.v[0][v] = *reinterpret_cast<const float4*>(b1 + off + 64 * v);
+    r.v[1][v] = *reinterpret_cast<const float4*>(b2 + off + 64 * v);
+    r.v[2][v] = *reinterpret_cast<const float4*>(b3 + off + 64 * v);
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[NV]) {
+  float d = dot4(a[0], b[0]);
+#pragma unroll
+  for (int v = 1; v < NV; ++v) d += dot4(a[v], b[v]);
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass 1: one workgroup = (sample b, chunk of rows).  MODE selects what is done with the
+// six dot products of each gathered row triple.
+//   kFused     : online softmax + weighted row sums -> per-workgroup partials
+//   kLogitsFwd : logits[p][b][k] = dot/T
+//   kLogitsBwd : acc[p] += (grad_logits[p][b][k]/T) * row  -> per-workgroup partials
+// ---------------------------------------------------------------------------------------
+template <int NV, int MODE>
+__global__ __launch_bounds__(kWG) void bank_pass_kernel(
+    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3,
+    const int64_t* __restrict__ idx, const float* __restrict__ x1, const float* __restrict__ x2,
+    const float* __restrict__ x3, const float* __restrict__ glogits, int B, int K1, int R,
+    float scale, float* __restrict__ part_m, float* __restrict__ part_s,
+    float* __restrict__ part_acc, float* __restrict__ l0_out, float* __restrict__ logits_out) {
+  constexpr int D = 64 * NV;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int s = wave * 4 + g;
+  const int kbeg = chunk * R;
+  const int kend = min(K1, kbeg + R);
+  const int niter = (kend - kbeg + kStreams - 1) / kStreams;
+  const int64_t* __restrict__ idxb = idx + (int64_t)b * K1;
+
+  float4 xq[3][NV];
+  if (MODE != kLogitsBwd) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xq[0][v] = *reinterpret_cast<const float4*>(x1 + (int64_t)b * D + 64 * v + 4 * t);
+      xq[1][v] = *reinterpret_cast<const float4*>(x2 + (int64_t)b * D + 64 * v + 4 * t);
+      xq[2][v] = *reinterpret_cast<const float4*>(x3 + (int64_t)b * D + 64 * v + 4 * t);
+    }
+  }
+
+  float m[6], ssum[6];
+  float4 acc[6][NV];
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    m[p] = kNegBig;
+    ssum[p] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[p][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // software pipeline: row index two iterations ahead, row data one iteration ahead
+  auto ld_idx = [&](int it) -> int64_t {
+    const int k = kbeg + it * kStreams + s;
+    return (it < niter && k < kend) ? idxb[k] : (int64_t)0;
+  };
+  Row3<NV> cur, nxt;
+  int64_t r_next = ld_idx(1);
+  load_rows<NV>(cur, b1, b2, b3, ld_idx(0), t);
+
+  for (int it = 0; it < niter; ++it) {
+    const int64_t r_next2 = ld_idx(it + 2);
+    if (it + 1 < niter) load_rows<NV>(nxt, b1, b2, b3, r_next, t);
+    const int k = kbeg + it * kStreams + s;
+    const bool valid = k < kend;
+
+    float d[6];
+    if (MODE != kLogitsBwd) {
+      d[1] = dotv<NV>(xq[1], cur.v[0]);  // x2 . M1
+      d[5] = dotv<NV>(xq[2], cur.v[0]);  // x3 . M1
+      d[0] = dotv<NV>(xq[0], cur.v[1]);  // x1 . M2
+      d[3] = dotv<NV>(xq[2], cur.v[1]);  // x3 . M2
+      d[2] = dotv<NV>(xq[1], cur.v[2]);  // x2 . M3
+      d[4] = dotv<NV>(xq[0], cur.v[2]);  // x1 . M3
+#pragma unroll
+      for (int p = 0; p < 6; ++p) d[p] = row16_sum(d[p]) * scale;
+    }
+
+    if (MODE == kFused) {
+      if (k == 0 && t == 0) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) l0_out[b * 6 + p] = d[p];
+      }
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const float l = valid ? d[p] : kInvalid;
+        if (__any(l > m[p])) {  // rare after the first rows: ~ln(#rows) record highs per stream
+          const float mn = fmaxf(m[p], l);
+          const float a = fast_exp2(m[p] - mn);
+          ssum[p] *= a;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) scale4(acc[p][v], a);
+          m[p] = mn;
+        }
+        const float pr = fast_exp2(l - m[p]);
+        ssum[p] += pr;
+        const int c = (p == 1 || p == 5) ? 0 : ((p == 0 || p == 3) ? 1 : 2);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) fma4(acc[p][v], pr, cur.v[c][v]);
+      }
+    } else if (MODE == kLogitsFwd) {
+      if (valid && t == 0) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) logits_out[((int64_t)p * B + b) * K1 + k] = d[p];
+      }
+    } else {  // kLogitsBwd
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const float wgt = valid ? glogits[((int64_t)p * B + b) * K1 + k] * scale : 0.f;
+        const int c = (p == 1 || p == 5) ? 0 : ((p == 0 || p == 3) ? 1 : 2);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) fma4(acc[p][v], wgt, cur.v[c][v]);
+      }
+    }
+    cur = nxt;
+    r_next = r_next2;
+  }
+  if (MODE == kLogitsFwd) return;
+
+  // ---- merge the 4 lane-rows of the wave (lanes ^16, ^32) ----
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      float a = 1.f, bs = 1.f;
+      if (MODE == kFused) {
+        const float mo = __shfl_xor(m[p], off, 64);
+        const float so = __shfl_xor(ssum[p], off, 64);
+        const float mn = fmaxf(m[p], mo);
+        a = fast_exp2(m[p] - mn);
+        bs = fast_exp2(mo - mn);
+        ssum[p] = ssum[p] * a + so * bs;
+        m[p] = mn;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float4 o;
+        o.x = __shfl_xor(acc[p][v].x, off, 64);
+        o.y = __shfl_xor(acc[p][v].y, off, 64);
+        o.z = __shfl_xor(acc[p][v].z, off, 64);
+        o.w = __shfl_xor(acc[p][v].w, off, 64);
+        acc[p][v].x = acc[p][v].x * a + o.x * bs;
+        acc[p][v].y = acc[p][v].y * a + o.y * bs;
+        acc[p][v].z = acc[p][v].z * a + o.z * bs;
+        acc[p][v].w = acc[p][v].w * a + o.w * bs;
+      }
+    }
+  }
+
+  // ---- merge the 4 waves through LDS, write one partial per workgroup ----
+  __shared__ float lds_acc[4][6][D];
+  __shared__ float lds_m[4][6];
+  __shared__ float lds_s[4][6];
+  if (g == 0) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        *reinterpret_cast<float4*>(&lds_acc[wave][p][64 * v + 4 * t]) = acc[p][v];
+      if (t == 0) {
+        lds_m[wave][p] = m[p];
+        lds_s[wave][p] = ssum[p];
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t pbase = ((int64_t)b * nchunks + chunk) * 6;
+  for (int e = threadIdx.x; e < 6 * D; e += kWG) {
+    const int p = e / D, col = e - p * D;
+    float out;
+    if (MODE == kFused) {
+      const float M = fmaxf(fmaxf(lds_m[0][p], lds_m[1][p]), fmaxf(lds_m[2][p], lds_m[3][p]));
+      float sc[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sc[w] = fast_exp2(lds_m[w][p] - M);
+      out = lds_acc[0][p][col] * sc[0] + lds_acc[1][p][col] * sc[1] + lds_acc[2][p][col] * sc[2] +
+            lds_acc[3][p][col] * sc[3];
+      if (col == 0) {
+        part_m[pbase + p] = M;
+        part_s[pbase + p] = lds_s[0][p] * sc[0] + lds_s[1][p] * sc[1] + lds_s[2][p] * sc[2] +
+                            lds_s[3][p] * sc[3];
+      }
+    } else {
+      out = lds_acc[0][p][col] + lds_acc[1][p][col] + lds_acc[2][p][col] + lds_acc[3][p][col];
+    }
+    part_acc[(pbase + p) * D + col] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row selection of _compute_loss_accuracy (contrast_trainer.py:223-250), evaluated by every
+// workgroup that needs it (B is tiny).  cnt[p] = |R_p|, 0 marks a degenerate set.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool row_selected(int p, int b, const int32_t* use_depth,
+                                             const int32_t* use_rgb, bool any_sel) {
+  if (use_rgb != nullptr) {
+    if (!any_sel) return p >= 4;
+    return use_depth[b] == 1 && use_rgb[b] == 1;
+  }
+  if (use_depth != nullptr) {
+    if (!any_sel) return p >= 4;
+    return p >= 4 ? true : (use_depth[b] == 1);
+  }
+  return true;
+}
+
+// Pass 2 (fused): one workgroup per sample merges the chunk partials of that sample.
+template <int D>
+__global__ __launch_bounds__(kWG) void bank_finish_kernel(
+    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3,
+    const int64_t* __restrict__ idx, const int32_t* __restrict__ use_depth,
+    const int32_t* __restrict__ use_rgb, int B, int K1, int nchunks, float invT,
+    const float* __restrict__ part_m, const float* __restrict__ part_s,
+    const float* __restrict__ part_acc, const float* __restrict__ l0,
+    float* __restrict__ ps_loss, float* __restrict__ ps_correct, float* __restrict__ gx1,
+    float* __restrict__ gx2, float* __restrict__ gx3) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // scale[nchunks][6]
+  __shared__ float sM[6], sS[6];
+  __shared__ float sG[6][D];
+  __shared__ int sCntSel, sCntAll;
+  const int b = blockIdx.x, tid = threadIdx.x;
+
+  if (tid == 0) { sCntSel = 0; sCntAll = 0; }
+  __syncthreads();
+  {
+    int sel = 0;
+    for (int i = tid; i < B; i += kWG) {
+      bool v = true;
+      if (use_rgb != nullptr) v = use_depth[i] == 1 && use_rgb[i] == 1;
+      else if (use_depth != nullptr) v = use_depth[i] == 1;
+      sel += v ? 1 : 0;
+    }
+    if (sel) atomicAdd(&sCntSel, sel);
+  }
+  if (tid < 6) {
+    const int p = tid;
+    float M = kNegBig;
+    for (int c = 0; c < nchunks; ++c) M = fmaxf(M, part_m[((int64_t)b * nchunks + c) * 6 + p]);
+    float S = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      const float sc = fast_exp2(part_m[((int64_t)b * nchunks + c) * 6 + p] - M);
+      dyn[c * 6 + p] = sc;
+      S += part_s[((int64_t)b * nchunks + c) * 6 + p] * sc;
+    }
+    sM[p] = M;
+    sS[p] = S;
+  }
+  __syncthreads();
+  const int cnt_sel = sCntSel;
+  const bool any_sel = cnt_sel > 0;
+  const bool masked = use_depth != nullptr;  // use_rgb implies use_depth
+
+  const int64_t r0 = idx[(int64_t)b * K1];
+  for (int e = tid; e < 6 * D; e += kWG) {
+    const int p = e / D, col = e - p * D;
+    float a = 0.f;
+    for (int c = 0; c < nchunks; ++c)
+      a += part_acc[(((int64_t)b * nchunks + c) * 6 + p) * D + col] * dyn[c * 6 + p];
+    const float* bank = (kPairBank[p] == 0) ? b1 : (kPairBank[p] == 1 ? b2 : b3);
+    const float row0 = bank[r0 * D + col];
+    // |R_p| : sets 0-3 follow the mask, sets 4-5 use every row unless use_rgb is given
+    int cnt;
+    if (!masked) cnt = B;
+    else if (use_rgb != nullptr) cnt = any_sel ? cnt_sel : (p >= 4 ? B : 0);
+    else cnt = (p >= 4) ? B : cnt_sel;
+    const bool selrow = row_selected(p, b, use_depth, use_rgb, any_sel) && cnt > 0;
+    sG[p][col] = selrow ? (a / sS[p] - row0) * (invT / (float)cnt) : 0.f;
+  }
+  if (tid < 6) {
+    const int p = tid;
+    const float lse2 = sM[p] + fast_log2(sS[p]);
+    const float l02 = l0[b * 6 + p];
+    ps_loss[b * 6 + p] = (lse2 - l02) * HCM_LN2;
+    ps_correct[b * 6 + p] = (l02 >= sM[p]) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * D; e += kWG) {
+    const int a = e / D, col = e - a * D;
+    // x1: pairs 0,4   x2: pairs 1,2   x3: pairs 3,5
+    const float v = (a == 0) ? sG[0][col] + sG[4][col]
+                             : (a == 1 ? sG[1][col] + sG[2][col] : sG[3][col] + sG[5][col]);
+    float* out = (a == 0) ? gx1 : (a == 1 ? gx2 : gx3);
+    out[(int64_t)b * D + col] = v;
+  }
+}
+
+// Pass 3 (fused): fixed-order reduction over the batch -> 6 losses, 6 accuracies.
+__global__ void bank_reduce_kernel(const float* __restrict__ ps_loss,
+                                   const float* __restrict__ ps_correct,
+                                   const int32_t* __restrict__ use_depth,
+                                   const int32_t* __restrict__ use_rgb, int B,
+                                   float* __restrict__ losses6, float* __restrict__ accs6) {
+  const int p = threadIdx.x;
+  if (p >= 6) return;
+  int cnt_sel = 0;
+  for (int i = 0; i < B; ++i) {
+    bool v = true;
+    if (use_rgb != nullptr) v = use_depth[i] == 1 && use_rgb[i] == 1;
+    else if (use_depth != nullptr) v = use_depth[i] == 1;
+    cnt_sel += v ? 1 : 0;
+  }
+  const bool any_sel = cnt_sel > 0;
+  float sl = 0.f, sc = 0.f;
+  int cnt = 0;
+  for (int i = 0; i < B; ++i) {
+    if (row_selected(p, i, use_depth, use_rgb, any_sel)) {
+      sl += ps_loss[i * 6 + p];
+      sc += ps_correct[i * 6 + p];
+      ++cnt;
+    }
+  }
+  const bool degenerate = (use_depth != nullptr) && !any_sel && p < 4;
+  losses6[p] = (degenerate || cnt == 0) ? 0.f : sl / (float)cnt;
+  accs6[p] = (degenerate || cnt == 0) ? 0.f : 100.f * sc / (float)cnt;
+}
+
+// Pass 2 (API-mode backward): gx_a[b] = sum over chunks and over the two pairs of a.
+template <int D>
+__global__ __launch_bounds__(kWG) void bank_logits_bwd_finish_kernel(
+    int nchunks, const float* __restrict__ part_acc, float* __restrict__ gx1,
+    float* __restrict__ gx2, float* __restrict__ gx3) {
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < 3 * D; e += kWG) {
+    const int a = e / D, col = e - a * D;
+    const int p0 = (a == 0) ? 0 : (a == 1 ? 1 : 3);
+    const int p1 = (a == 0) ? 4 : (a == 1 ? 2 : 5);
+    float v = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      const int64_t base = ((int64_t)b * nchunks + c) * 6;
+      v += part_acc[(base + p0) * D + col] + part_acc[(base + p1) * D + col];
+    }
+    float* out = (a == 0) ? gx1 : (a == 1 ? gx2 : gx3);
+    out[(int64_t)b * D + col] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row 3: momentum update.  grid (BW, 3 banks), one wave per (j, bank).
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void bank_update_kernel(float* __restrict__ b1,
+                                                         float* __restrict__ b2,
+                                                         float* __restrict__ b3,
+                                                         const float* __restrict__ x1,
+                                                         const float* __restrict__ x2,
+                                                         const float* __restrict__ x3,
+                                                         const int64_t* __restrict__ y, int BW,
+                                                         float mom, float one_minus_mom) {
+  const int j = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
+  const int64_t row = y[j];
+  // last occurrence wins (torch CPU index_copy_ order)
+  bool later_dup = false;
+  for (int jj = j + 1 + lane; jj < BW; jj += 64) later_dup |= (y[jj] == row);
+  if (__any(later_dup)) return;
+  float* bank = which == 0 ? b1 : (which == 1 ? b2 : b3);
+  const float* x = which == 0 ? x1 : (which == 1 ? x2 : x3);
+  constexpr int PER = D / 64;
+  float w[PER];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int col = lane + 64 * i;
+    const float old = bank[row * D + col];
+    const float xv = x[(int64_t)j * D + col];
+    w[i] = __fadd_rn(__fmul_rn(old, mom), __fmul_rn(xv, one_minus_mom));
+    ss = fmaf(w[i], w[i], ss);
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) bank[row * D + lane + 64 * i] = w[i] / denom;
+}
+
+// ---------------------------------------------------------------------------------------
+// Row 1: alias draw with Philox4x32-10.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(kWG) void alias_draw_kernel(const float* __restrict__ prob,
+                                                         const int64_t* __restrict__ alias,
+                                                         int64_t n, const int64_t* __restrict__ y,
+                                                         int K1, int64_t total, uint64_t seed,
+                                                         uint64_t offset, int64_t* __restrict__ idx) {
+  for (int64_t e = (int64_t)blockIdx.x * kWG + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kWG) {
+    if (y != nullptr && (e % K1) == 0) {
+      idx[e] = y[e / K1];
+      continue;
+    }
+    uint32_t c[4] = {(uint32_t)e, (uint32_t)((uint64_t)e >> 32), (uint32_t)offset,
+                     (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
+    const int64_t kk = (int64_t)(r64 % (uint64_t)n);
+    const float u = (float)(c[2] >> 8) * 5.9604644775390625e-08f;  // 2^-24
+    idx[e] = (u < prob[kk]) ? kk : alias[kk];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// MoCo queue (mem_moco.py:15-49): logits [B, K+1], enqueue.
+// One 16-lane row per queue row, queries staged in LDS.
+// ---------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(kWG) void moco_logits_kernel(const float* __restrict__ q,
+                                                          const float* __restrict__ kpos,
+                                                          const float* __restrict__ queue, int B,
+                                                          int K, float invT,
+                                                          float* __restrict__ logits) {
+  constexpr int D = 64 * NV;
+  extern __shared__ __attribute__((aligned(16))) float sq[];  // [B][D]
+  for (int e = threadIdx.x; e < B * D; e += kWG) sq[e] = q[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  const int rows_total = K + B;  // K queue rows, then B "positive" rows (one per sample)
+  for (int r = (blockIdx.x * 4 + wave) * 4 + g; r < rows_total; r += gridDim.x * 16) {
+    float4 row[NV];
+    const float* src = (r < K) ? queue + (int64_t)r * D : kpos + (int64_t)(r - K) * D;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) row[v] = *reinterpret_cast<const float4*>(src + 64 * v + 4 * t);
+    if (r < K) {
+      for (int b = 0; b < B; ++b) {
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          d += dot4(row[v], *reinterpret_cast<const float4*>(&sq[b * D + 64 * v + 4 * t]));
+        d = row16_sum(d);
+        if (t == 0) logits[(int64_t)b * (K + 1) + 1 + r] = d * invT;
+      }
+    } else {
+      const int b = r - K;
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        d += dot4(row[v], *reinterpret_cast<const float4*>(&sq[b * D + 64 * v + 4 * t]));
+      d = row16_sum(d);
+      if (t == 0) logits[(int64_t)b * (K + 1)] = d * invT;
+    }
+  }
+}
+
+__global__ void moco_enqueue_kernel(float* __restrict__ queue, const float* __restrict__ all_k,
+                                    int n_new, int K, int D, int64_t index) {
+  // rows (index + j) % K ; if n_new > K later rows overwrite earlier ones (index_copy_ order)
+  const int j = blockIdx.x;
+  if (j + K < n_new) return;  // a later j' = j + K writes the same slot and wins
+  const int64_t dst = (index + j) % K;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) queue[dst * D + c] = all_k[(int64_t)j * D + c];
+}
+
+inline bool dim_ok(int D) { return D == 64 || D == 128; }
+
+struct FusedWs {
+  float *part_m, *part_s, *part_acc, *l0, *ps_loss, *ps_correct;
+  size_t bytes;
+};
+inline FusedWs carve(void* ws, int B, int K1, int D) {
+  const int R = rows_per_wg(B, K1);
+  const size_t nch = (size_t)((K1 + R - 1) / R);
+  size_t off = 0;  // in floats
+  auto take = [&](size_t n) {
+    const size_t o = off;
+    off += (n + 3) & ~(size_t)3;  // keep every region 16-byte aligned
+    return o;
+  };
+  const size_t o_m = take((size_t)B * nch * 6), o_s = take((size_t)B * nch * 6);
+  const size_t o_l0 = take((size_t)B * 6), o_pl = take((size_t)B * 6), o_pc = take((size_t)B * 6);
+  const size_t o_acc = take((size_t)B * nch * 6 * D);
+  FusedWs o;
+  float* base = reinterpret_cast<float*>(ws);
+  o.part_m = base ? base + o_m : nullptr;
+  o.part_s = base ? base + o_s : nullptr;
+  o.l0 = base ? base + o_l0 : nullptr;
+  o.ps_loss = base ? base + o_pl : nullptr;
+  o.ps_correct = base ? base + o_pc : nullptr;
+  o.part_acc = base ? base + o_acc : nullptr;
+  o.bytes = off * sizeof(float);
+  return o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hcm_abi_version(void) { return HCM_ABI_VERSION; }
+const char* hcm_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+size_t hcm_bank_nce_workspace_bytes(int B, int K1, int D) { return carve(nullptr, B, K1, D).bytes; }
+
+int hcm_bank_nce_fused(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                       const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                       const int32_t* use_depth, const int32_t* use_rgb, int B, int K1, int D,
+                       float T, float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
+                       void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
+  (void)n;
+  if (!dim_ok(D) || B <= 0 || K1 <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
+  if (use_rgb != nullptr && use_depth == nullptr) return (int)hipErrorInvalidValue;
+  const FusedWs ws = carve(workspace, B, K1, D);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = rows_per_wg(B, K1);
+  const int nch = (K1 + R - 1) / R;
+  const float invT = (float)(1.0 / (double)T);
+  const float scale2 = (float)((double)HCM_LOG2E / (double)T);
+  dim3 grid(nch, B);
+  if (D == 128) {
+    bank_pass_kernel<2, kFused><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, nullptr,
+                                                      B, K1, R, scale2, ws.part_m, ws.part_s,
+                                                      ws.part_acc, ws.l0, nullptr);
+    HCM_CHECK_LAUNCH();
+    bank_finish_kernel<128><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
+        bank1, bank2, bank3, idx, use_depth, use_rgb, B, K1, nch, invT, ws.part_m, ws.part_s,
+        ws.part_acc, ws.l0, ws.ps_loss, ws.ps_correct, gx1, gx2, gx3);
+  } else {
+    bank_pass_kernel<1, kFused><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, nullptr,
+                                                      B, K1, R, scale2, ws.part_m, ws.part_s,
+                                                      ws.part_acc, ws.l0, nullptr);
+    HCM_CHECK_LAUNCH();
+    bank_finish_kernel<64><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
+        bank1, bank2, bank3, idx, use_depth, use_rgb, B, K1, nch, invT, ws.part_m, ws.part_s,
+        ws.part_acc, ws.l0, ws.ps_loss, ws.ps_correct, gx1, gx2, gx3);
+  }
+  HCM_CHECK_LAUNCH();
+  bank_reduce_kernel<<<1, 64, 0, st>>>(ws.ps_loss, ws.ps_correct, use_depth, use_rgb, B, losses6,
+                                       accs6);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_bank_nce_fused_timed(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                             const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                             const int32_t* use_depth, const int32_t* use_rgb, int B, int K1, int D,
+                             float T, float* losses6, float* accs6, float* gx1, float* gx2,
+                             float* gx3, void* workspace, size_t workspace_bytes,
+                             hcm_stream_t stream, int reps, float* ms_per_pass_host) {
+  if (reps <= 0 || ms_per_pass_host == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  hipError_t e = hipEventCreate(&e0);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreate(&e1);
+  if (e != hipSuccess) return (int)e;
+  int rc = 0;
+  hipEventRecord(e0, st);
+  for (int i = 0; i < reps && rc == 0; ++i)
+    rc = hcm_bank_nce_fused(bank1, bank2, bank3, n, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D,
+                            T, losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes, stream);
+  hipEventRecord(e1, st);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc != 0) return rc;
+  if (e != hipSuccess) return (int)e;
+  *ms_per_pass_host = ms / (float)reps;
+  return 0;
+}
+
+int hcm_bank_logits_fwd(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                        const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                        int B, int K1, int D, float T, float* logits, hcm_stream_t stream) {
+  (void)n;
+  if (!dim_ok(D) || B <= 0 || K1 <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
+  const int R = rows_per_wg(B, K1);
+  dim3 grid((K1 + R - 1) / R, B);
+  const float invT = (float)(1.0 / (double)T);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    bank_pass_kernel<2, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
+                                                          nullptr, B, K1, R, invT, nullptr, nullptr,
+                                                          nullptr, nullptr, logits);
+  else
+    bank_pass_kernel<1, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
+                                                          nullptr, B, K1, R, invT, nullptr, nullptr,
+                                                          nullptr, nullptr, logits);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_bank_logits_bwd(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                        const int64_t* idx, const float* grad_logits, int B, int K1, int D, float T,
+                        float* gx1, float* gx2, float* gx3, void* workspace,
+                        size_t workspace_bytes, hcm_stream_t stream) {
+  (void)n;
+  if (!dim_ok(D) || B <= 0 || K1 <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
+  const FusedWs ws = carve(workspace, B, K1, D);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  const int R = rows_per_wg(B, K1);
+  const int nch = (K1 + R - 1) / R;
+  dim3 grid(nch, B);
+  const float invT = (float)(1.0 / (double)T);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) {
+    bank_pass_kernel<2, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr, nullptr,
+                                                          nullptr, grad_logits, B, K1, R, invT,
+                                                          nullptr, nullptr, ws.part_acc, nullptr,
+                                                          nullptr);
+    HCM_CHECK_LAUNCH();
+    bank_logits_bwd_finish_kernel<128><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
+  } else {
+    bank_pass_kernel<1, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr, nullptr,
+                                                          nullptr, grad_logits, B, K1, R, invT,
+                                                          nullptr, nullptr, ws.part_acc, nullptr,
+                                                          nullptr);
+    HCM_CHECK_LAUNCH();
+    bank_logits_bwd_finish_kernel<64><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
+  }
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_bank_update(float* bank1, float* bank2, float* bank3, int64_t n, const float* all_x1,
+                    const float* all_x2, const float* all_x3, const int64_t* all_y, int BW, int D,
+                    float momentum, hcm_stream_t stream) {
+  (void)n;
+  if (!dim_ok(D) || BW <= 0) return (int)hipErrorInvalidValue;
+  const float omm = (float)(1.0 - (double)momentum);
+  dim3 grid(BW, 3);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    bank_update_kernel<128><<<grid, 64, 0, st>>>(bank1, bank2, bank3, all_x1, all_x2, all_x3, all_y,
+                                                 BW, momentum, omm);
+  else
+    bank_update_kernel<64><<<grid, 64, 0, st>>>(bank1, bank2, bank3, all_x1, all_x2, all_x3, all_y,
+                                                BW, momentum, omm);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_alias_build(const float* probs_host, int64_t n, float* prob_out_host,
+                    int64_t* alias_out_host) {
+  // memory/alias_multinomial.py:7-42, fp32 arithmetic, LIFO work lists.
+  if (n <= 0 || probs_host == nullptr || prob_out_host == nullptr || alias_out_host == nullptr)
+    return (int)hipErrorInvalidValue;
+  int64_t* stack_small = new int64_t[n];
+  int64_t* stack_large = new int64_t[n];
+  int64_t ns = 0, nl = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    prob_out_host[k] = (float)n * probs_host[k];
+    alias_out_host[k] = 0;
+    if (prob_out_host[k] < 1.0f) stack_small[ns++] = k;
+    else stack_large[nl++] = k;
+  }
+  while (ns > 0 && nl > 0) {
+    const int64_t small = stack_small[--ns];
+    const int64_t large = stack_large[--nl];
+    alias_out_host[small] = large;
+    volatile float tmp = prob_out_host[large] - 1.0f;  // two separately rounded fp32 ops
+    prob_out_host[large] = tmp + prob_out_host[small];
+    if (prob_out_host[large] < 1.0f) stack_small[ns++] = large;
+    else stack_large[nl++] = large;
+  }
+  for (int64_t i = 0; i < ns; ++i) prob_out_host[stack_small[i]] = 1.0f;
+  for (int64_t i = 0; i < nl; ++i) prob_out_host[stack_large[i]] = 1.0f;
+  delete[] stack_small;
+  delete[] stack_large;
+  return 0;
+}
+
+int hcm_alias_draw(const float* prob, const int64_t* alias, int64_t n, const int64_t* y, int B,
+                   int K1, uint64_t seed, uint64_t offset, int64_t* idx, hcm_stream_t stream) {
+  if (n <= 0 || B <= 0 || K1 <= 0) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)B * K1;
+  int blocks = (int)((total + kWG - 1) / kWG);
+  if (blocks > 4096) blocks = 4096;
+  alias_draw_kernel<<<blocks, kWG, 0, (hipStream_t)stream>>>(prob, alias, n, y, K1, total, seed,
+                                                            offset, idx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_moco_logits(const float* q, const float* k, const float* queue, int B, int K, int D, float T,
+                    float* logits, hcm_stream_t stream) {
+  if (!dim_ok(D) || B <= 0 || K <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)B * D * sizeof(float);
+  if (lds > 128 * 1024) return (int)hipErrorInvalidValue;
+  const float invT = (float)(1.0 / (double)T);
+  int blocks = (K + B + 15) / 16;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(moco_logits_kernel<2>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    moco_logits_kernel<2><<<blocks, kWG, lds, st>>>(q, k, queue, B, K, invT, logits);
+  } else {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(moco_logits_kernel<1>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    moco_logits_kernel<1><<<blocks, kWG, lds, st>>>(q, k, queue, B, K, invT, logits);
+  }
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_moco_enqueue(float* queue, const float* all_k, int n_new, int K, int D, int64_t index,
+                     hcm_stream_t stream) {
+  if (n_new <= 0 || K <= 0 || D <= 0) return (int)hipErrorInvalidValue;
+  moco_enqueue_kernel<<<n_new, 128, 0, (hipStream_t)stream>>>(queue, all_k, n_new, K, D, index);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Device-side helpers shared by the gfx950 kernels of libhcmoco_hip.so.
+// CDNA4 only: 64-lane wavefronts, DPP row = 16 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HCM_LOG2E 1.4426950408889634f
+#define HCM_LN2 0.6931471805599453f
+
+#define HCM_CHECK_LAUNCH()                     \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+namespace hcm {
+
+// One DPP-modified move: lane <- lane' of the same 16-lane row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// All-reduce (sum / max) over the 16 lanes of a DPP row: xor-1, xor-2 inside the quad,
+// then row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+
+// All-reduce over the whole 64-lane wave (row16 + two cross-row exchanges).
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& r) {
+  acc.x = fmaf(s, r.x, acc.x);
+  acc.y = fmaf(s, r.y, acc.y);
+  acc.z = fmaf(s, r.z, acc.z);
+  acc.w = fmaf(s, r.w, acc.w);
+}
+__device__ __forceinline__ void scale4(float4& acc, float s) {
+  acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
+}
+
+}  // namespace hcm

@@ -1,0 +1,401 @@
+// PointNet++ point ops for gfx950.
+//
+// Same contract as the reference's launcher layer (pycontrast/networks/pointnet2/src/*_gpu.h):
+// fp32 data, int32 indices, caller-allocated and caller-initialised outputs, asynchronous on the
+// given stream.  Launch failures are returned instead of exit(-1).
+//
+// This translation unit is compiled with -ffp-contract=off: squared distances are evaluated as
+// ((dx*dx + dy*dy) + dz*dz) in un-fused IEEE fp32, the arithmetic the index-producing kernels
+// (FPS, ball query, three-NN) are bit-exact against (oracle/pointnet2_oracle.c).
+//
+// MI355X notes: the three search kernels stage the scanned cloud through LDS in coalesced tiles
+// and read it back as wave-wide broadcasts; gather/scatter kernels load each index once and walk
+// a block of channels with it (the reference re-reads the index for every channel); FPS keeps
+// the whole cloud and its running min-distances in registers/LDS for all m serial rounds.
+#include "hcm_common.h"
+#include "../../include/hcmoco_hip.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather / group : out[b,c,q] = points[b,c,idx[b,q]]        (q = m  or  q = npoints*nsample)
+// sampling_gpu.cu:8-24, group_points_gpu.cu:47-66
+// ------------------------------------------------------------------------------------------
+constexpr int kCB = 16;  // channels walked per loaded index
+
+__global__ __launch_bounds__(kT) void gather_rows_kernel(int c, int n, int q,
+                                                         const float* __restrict__ points,
+                                                         const int* __restrict__ idx,
+                                                         float* __restrict__ out) {
+  const int b = blockIdx.z, pos = blockIdx.x * kT + threadIdx.x;
+  if (pos >= q) return;
+  const int src = idx[(int64_t)b * q + pos];
+  const int c0 = blockIdx.y * kCB, c1 = min(c, c0 + kCB);
+  const float* p = points + ((int64_t)b * c + c0) * n + src;
+  float* o = out + ((int64_t)b * c + c0) * q + pos;
+  for (int ch = c0; ch < c1; ++ch, p += n, o += q) *o = *p;
+}
+
+// grad: grad_points[b,c,idx[b,q]] += grad_out[b,c,q]   (atomic; order-dependent fp32 sums as in
+// the reference, group_points_gpu.cu:8-25 / sampling_gpu.cu:46-63)
+__global__ __launch_bounds__(kT) void scatter_rows_kernel(int c, int n, int q,
+                                                          const float* __restrict__ grad_out,
+                                                          const int* __restrict__ idx,
+                                                          float* __restrict__ grad_points) {
+  const int b = blockIdx.z, pos = blockIdx.x * kT + threadIdx.x;
+  if (pos >= q) return;
+  const int dst = idx[(int64_t)b * q + pos];
+  const int c0 = blockIdx.y * kCB, c1 = min(c, c0 + kCB);
+  const float* g = grad_out + ((int64_t)b * c + c0) * q + pos;
+  float* o = grad_points + ((int64_t)b * c + c0) * n + dst;
+  for (int ch = c0; ch < c1; ++ch, g += q, o += n) atomicAdd(o, *g);
+}
+
+// ------------------------------------------------------------------------------------------
+// three_interpolate: out[b,c,n] = sum_j w[b,n,j] * points[b,c,idx[b,n,j]]
+// interpolate_gpu.cu:77-97 / :120-142
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void three_interp_kernel(int c, int m, int n,
+                                                          const float* __restrict__ points,
+                                                          const int* __restrict__ idx,
+                                                          const float* __restrict__ weight,
+                                                          float* __restrict__ out) {
+  const int b = blockIdx.z, pos = blockIdx.x * kT + threadIdx.x;
+  if (pos >= n) return;
+  const int64_t t3 = ((int64_t)b * n + pos) * 3;
+  const int i0 = idx[t3], i1 = idx[t3 + 1], i2 = idx[t3 + 2];
+  const float w0 = weight[t3], w1 = weight[t3 + 1], w2 = weight[t3 + 2];
+  const int c0 = blockIdx.y * kCB, c1 = min(c, c0 + kCB);
+  const float* p = points + ((int64_t)b * c + c0) * m;
+  float* o = out + ((int64_t)b * c + c0) * n + pos;
+  for (int ch = c0; ch < c1; ++ch, p += m, o += n) *o = (w0 * p[i0] + w1 * p[i1]) + w2 * p[i2];
+}
+
+__global__ __launch_bounds__(kT) void three_interp_grad_kernel(int c, int n, int m,
+                                                               const float* __restrict__ grad_out,
+                                                               const int* __restrict__ idx,
+                                                               const float* __restrict__ weight,
+                                                               float* __restrict__ grad_points) {
+  const int b = blockIdx.z, pos = blockIdx.x * kT + threadIdx.x;
+  if (pos >= n) return;
+  const int64_t t3 = ((int64_t)b * n + pos) * 3;
+  const int i0 = idx[t3], i1 = idx[t3 + 1], i2 = idx[t3 + 2];
+  const float w0 = weight[t3], w1 = weight[t3 + 1], w2 = weight[t3 + 2];
+  const int c0 = blockIdx.y * kCB, c1 = min(c, c0 + kCB);
+  const float* g = grad_out + ((int64_t)b * c + c0) * n + pos;
+  float* o = grad_points + ((int64_t)b * c + c0) * m;
+  for (int ch = c0; ch < c1; ++ch, g += n, o += m) {
+    const float gv = *g;
+    atomicAdd(o + i0, gv * w0);
+    atomicAdd(o + i1, gv * w1);
+    atomicAdd(o + i2, gv * w2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ball query (ball_query_gpu.cu:9-45): first `nsample` points, in index order, with d2 < r^2;
+// the first hit pre-fills all nsample slots; centres with no hit keep the caller's zeros.
+// One thread per centre; the scanned cloud goes through LDS in tiles of kTile points.
+// ------------------------------------------------------------------------------------------
+constexpr int kTile = 1024;
+
+__global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                        const float* __restrict__ new_xyz,
+                                                        const float* __restrict__ xyz,
+                                                        int* __restrict__ idx) {
+  __shared__ float tile[kTile * 3];
+  const int b = blockIdx.y, pt = blockIdx.x * kT + threadIdx.x;
+  const bool live = pt < m;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  if (live) {
+    const float* c = new_xyz + ((int64_t)b * m + pt) * 3;
+    cx = c[0]; cy = c[1]; cz = c[2];
+  }
+  int* out = idx + ((int64_t)b * m + (live ? pt : 0)) * nsample;
+  const float* cloud = xyz + (int64_t)b * n * 3;
+  int cnt = live ? 0 : nsample;
+  for (int base = 0; base < n; base += kTile) {
+    const int len = min(kTile, n - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 3; e += kT) tile[e] = cloud[(int64_t)base * 3 + e];
+    __syncthreads();
+    if (cnt < nsample) {
+      for (int k = 0; k < len; ++k) {
+        const float d2 = sqdist(cx, cy, cz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) out[l] = base + k;
+          out[cnt] = base + k;
+          if (++cnt >= nsample) break;
+        }
+      }
+    }
+    if (__syncthreads_count(cnt < nsample) == 0) break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// three_nn (interpolate_gpu.cu:9-52): three smallest squared distances, strict '<', first wins.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
+                                                      const float* __restrict__ unknown,
+                                                      const float* __restrict__ known,
+                                                      float* __restrict__ dist2,
+                                                      int* __restrict__ idx) {
+  __shared__ float tile[kTile * 3];
+  const int b = blockIdx.y, pt = blockIdx.x * kT + threadIdx.x;
+  const bool live = pt < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (live) {
+    const float* u = unknown + ((int64_t)b * n + pt) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  // The reference keeps the bests in doubles initialised to 1e40 and compares the float d
+  // against them: every finite d wins over 1e40, +inf / NaN never do, and an unset slot is
+  // stored back as +inf.  Float trackers initialised to +inf behave identically.
+  float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+  int i1 = 0, i2 = 0, i3 = 0;
+  const float* cloud = known + (int64_t)b * m * 3;
+  for (int base = 0; base < m; base += kTile) {
+    const int len = min(kTile, m - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 3; e += kT) tile[e] = cloud[(int64_t)base * 3 + e];
+    __syncthreads();
+    for (int k = 0; k < len; ++k) {
+      const float d = sqdist(ux, uy, uz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
+      if (d < b1) {
+        b3 = b2; i3 = i2;
+        b2 = b1; i2 = i1;
+        b1 = d; i1 = base + k;
+      } else if (d < b2) {
+        b3 = b2; i3 = i2;
+        b2 = d; i2 = base + k;
+      } else if (d < b3) {
+        b3 = d; i3 = base + k;
+      }
+    }
+  }
+  if (live) {
+    const int64_t o = ((int64_t)b * n + pt) * 3;
+    dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
+    idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// furthest point sampling (sampling_gpu.cu:93-209).
+// Virtual thread id of point k is (k % bs), bs = largest power of two <= n, capped at 1024
+// (cuda_utils.h:10-14).  Per thread the reference keeps the first strict maximum over ascending
+// k; its LDS tree then folds slot t+s into slot t for s = bs/2 .. 1, keeping slot t on ties
+// (:86-91, :140-200).  A candidate of thread T therefore beats an equal-valued candidate of
+// thread T' iff bitreverse_{log2 bs}(T) < bitreverse_{log2 bs}(T'): the winner is the maximum
+// under the total order (value desc, bit-reversed virtual tid asc), and any reduction shape that
+// honours this order is bit-identical to the reference tree.
+// One workgroup of bs threads per cloud; thread t owns points t, t+bs, ... in registers.
+// ------------------------------------------------------------------------------------------
+struct Cand {
+  float v;
+  int tid;
+  int k;
+};
+__device__ __forceinline__ bool better(const Cand& a, const Cand& b) {  // a beats b ?
+  return a.v > b.v || (a.v == b.v && a.tid < b.tid);
+}
+
+template <int PER>
+__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log2bs,
+                                                   const float* __restrict__ dataset,
+                                                   float* __restrict__ temp,
+                                                   int* __restrict__ idxs) {
+  extern __shared__ __attribute__((aligned(16))) float sxyz[];  // [n*3] when PER > 0
+  __shared__ float red_v[16];
+  __shared__ int red_tid[16], red_k[16];
+  __shared__ int s_old;
+  if (m <= 0) return;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* cloud = dataset + (int64_t)b * n * 3;
+  float* tmp = temp + (int64_t)b * n;
+  int* out = idxs + (int64_t)b * m;
+  const bool active = tid < bs;
+  // tie-break key: bit-reversed virtual thread id; idle threads (tid >= bs) sort last
+  const int key = active ? (log2bs == 0 ? 0 : (int)(__brev((unsigned)tid) >> (32 - log2bs))) : 0x7ffffff0 + 0 * tid;
+  const int nwaves = (blockDim.x + 63) >> 6;
+
+  float px[PER > 0 ? PER : 1], py[PER > 0 ? PER : 1], pz[PER > 0 ? PER : 1], pt[PER > 0 ? PER : 1];
+  if (PER > 0) {
+    for (int e = tid; e < n * 3; e += blockDim.x) sxyz[e] = cloud[e];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int k = tid + j * bs;
+      if (active && k < n) {
+        px[j] = cloud[3 * k]; py[j] = cloud[3 * k + 1]; pz[j] = cloud[3 * k + 2];
+        pt[j] = tmp[k];
+      } else {
+        px[j] = py[j] = pz[j] = 0.f; pt[j] = 0.f;
+      }
+    }
+  }
+  if (tid == 0) { out[0] = 0; s_old = 0; }
+  __syncthreads();
+
+  for (int r = 1; r < m; ++r) {
+    const int old = s_old;
+    float ox, oy, oz;
+    if (PER > 0) { ox = sxyz[3 * old]; oy = sxyz[3 * old + 1]; oz = sxyz[3 * old + 2]; }
+    else { ox = cloud[3 * old]; oy = cloud[3 * old + 1]; oz = cloud[3 * old + 2]; }
+    Cand c{-1.f, key, 0};
+    if (PER > 0) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int k = tid + j * bs;
+        if (active && k < n) {
+          const float d = sqdist(px[j], py[j], pz[j], ox, oy, oz);
+          const float d2 = fminf(d, pt[j]);
+          pt[j] = d2;
+          if (d2 > c.v) { c.v = d2; c.k = k; }
+        }
+      }
+    } else if (active) {
+      for (int k = tid; k < n; k += bs) {
+        const float d = sqdist(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
+        const float d2 = fminf(d, tmp[k]);
+        tmp[k] = d2;
+        if (d2 > c.v) { c.v = d2; c.k = k; }
+      }
+    }
+    // wave butterfly on (v, tid, k)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      Cand o{__shfl_xor(c.v, off, 64), __shfl_xor(c.tid, off, 64), __shfl_xor(c.k, off, 64)};
+      if (better(o, c)) c = o;
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) { red_v[wave] = c.v; red_tid[wave] = c.tid; red_k[wave] = c.k; }
+    __syncthreads();
+    if (tid < 64) {
+      Cand w{tid < nwaves ? red_v[tid] : -2.f, tid < nwaves ? red_tid[tid] : 0x7fffffff,
+             tid < nwaves ? red_k[tid] : 0};
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        Cand o{__shfl_xor(w.v, off, 64), __shfl_xor(w.tid, off, 64), __shfl_xor(w.k, off, 64)};
+        if (better(o, w)) w = o;
+      }
+      if (tid == 0) { s_old = w.k; out[r] = w.k; }
+    }
+    __syncthreads();
+  }
+  if (PER > 0) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int k = tid + j * bs;
+      if (active && k < n) tmp[k] = pt[j];
+    }
+  }
+}
+
+inline int opt_n_threads(int work) {  // cuda_utils.h:10-14
+  int p = 1;
+  while ((p << 1) <= work && (p << 1) <= 1024) p <<= 1;
+  return p;
+}
+
+inline dim3 grid3(int q, int c, int b) { return dim3((q + kT - 1) / kT, (c + kCB - 1) / kCB, b); }
+
+}  // namespace
+
+extern "C" {
+
+int hcm_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,
+                      float* out, hcm_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return b < 0 || c < 0 || npoints < 0 ? (int)hipErrorInvalidValue : 0;
+  gather_rows_kernel<<<grid3(npoints, c, b), kT, 0, (hipStream_t)stream>>>(c, n, npoints, points, idx, out);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int* idx,
+                           float* grad_points, hcm_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return b < 0 || c < 0 || npoints < 0 ? (int)hipErrorInvalidValue : 0;
+  scatter_rows_kernel<<<grid3(npoints, c, b), kT, 0, (hipStream_t)stream>>>(c, n, npoints, grad_out, idx, grad_points);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                     const int* idx, float* out, hcm_stream_t stream) {
+  const int q = npoints * nsample;
+  if (b <= 0 || c <= 0 || q <= 0) return b < 0 || c < 0 || q < 0 ? (int)hipErrorInvalidValue : 0;
+  gather_rows_kernel<<<grid3(q, c, b), kT, 0, (hipStream_t)stream>>>(c, n, q, points, idx, out);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                          const int* idx, float* grad_points, hcm_stream_t stream) {
+  const int q = npoints * nsample;
+  if (b <= 0 || c <= 0 || q <= 0) return b < 0 || c < 0 || q < 0 ? (int)hipErrorInvalidValue : 0;
+  scatter_rows_kernel<<<grid3(q, c, b), kT, 0, (hipStream_t)stream>>>(c, n, q, grad_out, idx, grad_points);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
+                          const float* weight, float* out, hcm_stream_t stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return b < 0 || c < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
+  three_interp_kernel<<<grid3(n, c, b), kT, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                               const float* weight, float* grad_points, hcm_stream_t stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return b < 0 || c < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
+  three_interp_grad_kernel<<<grid3(n, c, b), kT, 0, (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                   const float* xyz, int* idx, hcm_stream_t stream) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return b < 0 || m < 0 || nsample < 0 ? (int)hipErrorInvalidValue : 0;
+  dim3 grid((m + kT - 1) / kT, b);
+  ball_query_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                 int* idx, hcm_stream_t stream) {
+  if (b <= 0 || n <= 0) return b < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
+  dim3 grid((n + kT - 1) / kT, b);
+  three_nn_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
+                                hcm_stream_t stream) {
+  if (b <= 0 || n <= 0 || m <= 0) return b < 0 || n < 0 || m < 0 ? (int)hipErrorInvalidValue : 0;
+  const int bs = opt_n_threads(n);
+  const int threads = bs < 64 ? 64 : bs;
+  const int per = (n + bs - 1) / bs;
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  const size_t lds = (size_t)n * 3 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define HCM_FPS(P)                                                                          \
+  do {                                                                                      \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P>),                        \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+    fps_kernel<P><<<b, threads, lds, st>>>(n, m, bs, log2bs, dataset, temp, idxs);                   \
+  } while (0)
+  if (per <= 1 && lds <= 150 * 1024) HCM_FPS(1);
+  else if (per <= 2 && lds <= 150 * 1024) HCM_FPS(2);
+  else if (per <= 4 && lds <= 150 * 1024) HCM_FPS(4);
+  else if (per <= 8 && lds <= 150 * 1024) HCM_FPS(8);
+  else fps_kernel<0><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
+#undef HCM_FPS
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+"""torch-facing wrappers over the C ABI of libhcmoco_hip.so.
+
+Every function here takes ROCm tensors, hands raw device pointers + the current HIP stream to
+the C entry points of ``include/hcmoco_hip.h`` and wraps the result in a
+``torch.autograd.Function`` where a backward exists.  No op has a CPU or eager fallback:
+CPU tensors raise ``RuntimeError`` and a missing library raises ``ImportError``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Strides4, check
+
+
+# --------------------------------------------------------------------------- #
+# plumbing
+# --------------------------------------------------------------------------- #
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('hcmoco_amd.%s needs ROCm device tensors (no CPU fallback exists)' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s: expected %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s: tensor must be contiguous' % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def _opt(t, dtype, name):
+    return C.c_void_p(0) if t is None else _dev(t, dtype, name)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i32(t):
+    """Mask vectors arrive as int64/int32/bool/float from the loader; the ABI takes int32."""
+    if t is None:
+        return None
+    return t.to(dtype=torch.int32).contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------- #
+# row 1: alias sampler
+# --------------------------------------------------------------------------- #
+def alias_build(probs):
+    """Host-side Walker tables (memory/alias_multinomial.py:7-42) -> (prob fp32[n], alias int64[n])."""
+    probs = torch.as_tensor(probs, dtype=torch.float32).clone().contiguous()
+    if probs.sum() > 1:
+        probs = probs / probs.sum()
+    n = probs.numel()
+    prob = torch.empty(n, dtype=torch.float32)
+    alias = torch.empty(n, dtype=torch.int64)
+    check(_lib.lib().hcm_alias_build(C.c_void_p(probs.data_ptr()), n, C.c_void_p(prob.data_ptr()),
+                                     C.c_void_p(alias.data_ptr())), 'hcm_alias_build')
+    return prob, alias
+
+
+def alias_draw(prob, alias, y, B, K1, seed, offset):
+    """idx [B,K1] int64, idx[:,0]=y (mem_bank.py:176-177), Philox-keyed by (seed, offset)."""
+    idx = torch.empty(B, K1, dtype=torch.int64, device=prob.device)
+    check(_lib.lib().hcm_alias_draw(_dev(prob, torch.float32, 'alias_draw'), _dev(alias, torch.int64, 'alias_draw'),
+                                    prob.numel(), _opt(y, torch.int64, 'alias_draw'), B, K1,
+                                    seed & (2 ** 64 - 1), offset & (2 ** 64 - 1),
+                                    _dev(idx, torch.int64, 'alias_draw'), _stream()), 'hcm_alias_draw')
+    return idx
+
+
+# --------------------------------------------------------------------------- #
+# rows 2+4: fused bank NCE
+# --------------------------------------------------------------------------- #
+def bank_nce_fused_raw(banks, idx, xs, T, use_depth=None, use_rgb=None):
+    """One launch sequence -> (losses[6], accs[6], [gx1,gx2,gx3]); gx = d sum(losses)/dx."""
+    x1, x2, x3 = xs
+    B, D = x1.shape
+    K1 = idx.shape[1]
+    dev = x1.device
+    out = torch.empty(12, dtype=torch.float32, device=dev)
+    gx = torch.empty(3, B, D, dtype=torch.float32, device=dev)
+    ud, ur = _i32(use_depth), _i32(use_rgb)
+    L = _lib.lib()
+    nbytes = L.hcm_bank_nce_workspace_bytes(B, K1, D)
+    ws = _ws(nbytes, dev)
+    check(L.hcm_bank_nce_fused(
+        _dev(banks[0], torch.float32, 'bank_nce'), _dev(banks[1], torch.float32, 'bank_nce'),
+        _dev(banks[2], torch.float32, 'bank_nce'), banks[0].shape[0],
+        _dev(idx, torch.int64, 'bank_nce'),
+        _dev(x1, torch.float32, 'bank_nce'), _dev(x2, torch.float32, 'bank_nce'), _dev(x3, torch.float32, 'bank_nce'),
+        _opt(ud, torch.int32, 'bank_nce'), _opt(ur, torch.int32, 'bank_nce'),
+        B, K1, D, float(T),
+        C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 24),
+        C.c_void_p(gx[0].data_ptr()), C.c_void_p(gx[1].data_ptr()), C.c_void_p(gx[2].data_ptr()),
+        C.c_void_p(ws.data_ptr()), nbytes, _stream()), 'hcm_bank_nce_fused')
+    return out[:6], out[6:], [gx[0], gx[1], gx[2]]
+
+
+class _BankNCEFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, x3, bank1, bank2, bank3, idx, T, use_depth, use_rgb):
+        losses, accs, gx = bank_nce_fused_raw([bank1, bank2, bank3], idx,
+                                              [x1.contiguous(), x2.contiguous(), x3.contiguous()],
+                                              T, use_depth, use_rgb)
+        ctx.save_for_backward(*gx)
+        ctx.mark_non_differentiable(accs)
+        return losses.sum(), losses.detach().clone(), accs
+
+    @staticmethod
+    def backward(ctx, g_total, g_losses, g_accs):
+        gx1, gx2, gx3 = ctx.saved_tensors
+        return (gx1 * g_total, gx2 * g_total, gx3 * g_total) + (None,) * 7
+
+
+def bank_nce_fused(xs, banks, idx, T, use_depth=None, use_rgb=None):
+    """Differentiable total = sum of the six bank CE losses, plus (detached) losses[6], accs[6]."""
+    return _BankNCEFused.apply(xs[0], xs[1], xs[2], banks[0], banks[1], banks[2], idx, T, use_depth, use_rgb)
+
+
+def bank_nce_fused_timed(banks, idx, xs, T, reps, use_depth=None):
+    """Mean ms per fused pass measured with hipEvents on the launch stream (bench/roofline)."""
+    x1, x2, x3 = xs
+    B, D = x1.shape
+    K1 = idx.shape[1]
+    dev = x1.device
+    out = torch.empty(12, dtype=torch.float32, device=dev)
+    gx = torch.empty(3, B, D, dtype=torch.float32, device=dev)
+    ud = _i32(use_depth)
+    L = _lib.lib()
+    nbytes = L.hcm_bank_nce_workspace_bytes(B, K1, D)
+    ws = _ws(nbytes, dev)
+    ms = C.c_float(0.0)
+    check(L.hcm_bank_nce_fused_timed(
+        _dev(banks[0], torch.float32, 'bank_nce'), _dev(banks[1], torch.float32, 'bank_nce'),
+        _dev(banks[2], torch.float32, 'bank_nce'), banks[0].shape[0], _dev(idx, torch.int64, 'bank_nce'),
+        _dev(x1, torch.float32, 'bank_nce'), _dev(x2, torch.float32, 'bank_nce'), _dev(x3, torch.float32, 'bank_nce'),
+        _opt(ud, torch.int32, 'bank_nce'), C.c_void_p(0), B, K1, D, float(T),
+        C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 24),
+        C.c_void_p(gx[0].data_ptr()), C.c_void_p(gx[1].data_ptr()), C.c_void_p(gx[2].data_ptr()),
+        C.c_void_p(ws.data_ptr()), nbytes, _stream(), int(reps), C.byref(ms)), 'hcm_bank_nce_fused_timed')
+    return float(ms.value)
+
+
+# --------------------------------------------------------------------------- #
+# API mode: materialised logits (the literal CMCMem3.forward contract)
+# --------------------------------------------------------------------------- #
+class _BankLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, x3, bank1, bank2, bank3, idx, T):
+        x1, x2, x3 = x1.contiguous(), x2.contiguous(), x3.contiguous()
+        B, D = x1.shape
+        K1 = idx.shape[1]
+        logits = torch.empty(6, B, K1, dtype=torch.float32, device=x1.device)
+        check(_lib.lib().hcm_bank_logits_fwd(
+            _dev(bank1, torch.float32, 'bank_logits'), _dev(bank2, torch.float32, 'bank_logits'),
+            _dev(bank3, torch.float32, 'bank_logits'), bank1.shape[0], _dev(idx, torch.int64, 'bank_logits'),
+            _dev(x1, torch.float32, 'bank_logits'), _dev(x2, torch.float32, 'bank_logits'),
+            _dev(x3, torch.float32, 'bank_logits'), B, K1, D, float(T),
+            C.c_void_p(logits.data_ptr()), _stream()), 'hcm_bank_logits_fwd')
+        # the banks are mutated right after forward (mem_bank.py:195-203); backward must see the
+        # rows the logits were computed from, so keep a copy of exactly those rows' owners.
+        ctx.save_for_backward(bank1.clone(), bank2.clone(), bank3.clone(), idx)
+        ctx.T, ctx.shape = float(T), (B, K1, D)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        bank1, bank2, bank3, idx = ctx.saved_tensors
+        B, K1, D = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty(3, B, D, dtype=torch.float32, device=g.device)
+        L = _lib.lib()
+        nbytes = L.hcm_bank_nce_workspace_bytes(B, K1, D)
+        ws = _ws(nbytes, g.device)
+        check(L.hcm_bank_logits_bwd(
+            _dev(bank1, torch.float32, 'bank_logits'), _dev(bank2, torch.float32, 'bank_logits'),
+            _dev(bank3, torch.float32, 'bank_logits'), bank1.shape[0], _dev(idx, torch.int64, 'bank_logits'),
+            _dev(g, torch.float32, 'bank_logits'), B, K1, D, ctx.T,
+            C.c_void_p(gx[0].data_ptr()), C.c_void_p(gx[1].data_ptr()), C.c_void_p(gx[2].data_ptr()),
+            C.c_void_p(ws.data_ptr()), nbytes, _stream()), 'hcm_bank_logits_bwd')
+        return gx[0], gx[1], gx[2], None, None, None, None, None
+
+
+def bank_logits(xs, banks, idx, T):
+    """logits [6,B,K+1] in the order 12,21,23,32,13,31 (mem_bank.py:186-191), differentiable in x."""
+    return _BankLogits.apply(xs[0], xs[1], xs[2], banks[0], banks[1], banks[2], idx, T)
+
+
+# --------------------------------------------------------------------------- #
+# row 3: momentum update (in place, no grad)
+# --------------------------------------------------------------------------- #
+@torch.no_grad()
+def bank_update(banks, all_xs, all_y, momentum):
+    BW, D = all_xs[0].shape
+    check(_lib.lib().hcm_bank_update(
+        _dev(banks[0], torch.float32, 'bank_update'), _dev(banks[1], torch.float32, 'bank_update'),
+        _dev(banks[2], torch.float32, 'bank_update'), banks[0].shape[0],
+        _dev(all_xs[0].detach().contiguous(), torch.float32, 'bank_update'),
+        _dev(all_xs[1].detach().contiguous(), torch.float32, 'bank_update'),
+        _dev(all_xs[2].detach().contiguous(), torch.float32, 'bank_update'),
+        _dev(all_y.contiguous(), torch.int64, 'bank_update'), BW, D, float(momentum), _stream()),
+        'hcm_bank_update')
+
+
+# --------------------------------------------------------------------------- #
+# MoCo queue (secondary)
+# --------------------------------------------------------------------------- #
+@torch.no_grad()
+def moco_logits(q, k, queue, T):
+    B, D = q.shape
+    K = queue.shape[0]
+    out = torch.empty(B, K + 1, dtype=torch.float32, device=q.device)
+    check(_lib.lib().hcm_moco_logits(_dev(q.contiguous(), torch.float32, 'moco'), _dev(k.contiguous(), torch.float32, 'moco'),
+                                     _dev(queue, torch.float32, 'moco'), B, K, D, float(T),
+                                     _dev(out, torch.float32, 'moco'), _stream()), 'hcm_moco_logits')
+    return out
+
+
+@torch.no_grad()
+def moco_enqueue(queue, all_k, index):
+    n_new, D = all_k.shape
+    K = queue.shape[0]
+    check(_lib.lib().hcm_moco_enqueue(_dev(queue, torch.float32, 'moco'),
+                                      _dev(all_k.detach().contiguous(), torch.float32, 'moco'),
+                                      n_new, K, D, int(index), _stream()), 'hcm_moco_enqueue')
+    return (int(index) + n_new) % K
+
+
+# --------------------------------------------------------------------------- #
+# rows 5-7: feature-map losses
+# --------------------------------------------------------------------------- #
+def _strides(t):
+    s = t.stride()
+    return Strides4(s[0], s[1], s[2], s[3])
+
+
+def _check_maps(m1, m2, name):
+    if m1.shape != m2.shape or m1.stride() != m2.stride():
+        raise ValueError('%s: the two feature maps must share shape and strides' % name)
+    if m1.shape[1] != 128:
+        raise ValueError('%s: C must be 128' % name)
+    if not m1.is_cuda or m1.dtype != torch.float32:
+        raise RuntimeError('hcmoco_amd.%s needs fp32 ROCm device tensors (no CPU fallback exists)' % name)
+
+
+def _dense_map(t):
+    """Maps are read in place through their strides; only overlapping/odd layouts are copied."""
+    if t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last):
+        return t
+    return t.contiguous()
+
+
+def joint_pixels(joints2d, h):
+    """pix [B,J] int64 = clamp(floor(j/4),0,h-1) row-major (contrast_trainer.py:757-761)."""
+    j = joints2d.to(torch.float32).contiguous()
+    B, J = j.shape[:2]
+    pix = torch.empty(B, J, dtype=torch.int64, device=j.device)
+    check(_lib.lib().hcm_joint_pixels(_dev(j, torch.float32, 'joint_pixels'), B * J, h,
+                                      _dev(pix, torch.int64, 'joint_pixels'), _stream()), 'hcm_joint_pixels')
+    return pix
+
+
+class _FmapLosses(torch.autograd.Function):
+    """Rows 5-7 in one autograd node: the three losses share the two feature maps, so their
+    map gradients are accumulated into ONE pair of zero-initialised buffers by the kernels."""
+
+    @staticmethod
+    def forward(ctx, map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
+                temperature, do_dense, do_joint, do_scl):
+        map1, map2 = _dense_map(map1), _dense_map(map2)
+        _check_maps(map1, map2, 'fmap_losses')
+        B, Cc, h, w = map1.shape
+        dev = map1.device
+        L = _lib.lib()
+        st = _strides(map1)
+        g1 = torch.zeros_like(map1)        # preserves the memory format -> same strides
+        g2 = torch.zeros_like(map2)
+        assert g1.stride() == map1.stride()
+        out = torch.zeros(9, dtype=torch.float32, device=dev)   # dense4 | joint4 | scl1
+        ud, ur = _i32(use_depth), _i32(use_rgb)
+        J = pix.shape[1] if pix is not None else 0
+        gfeat3 = None
+        p1, p2 = C.c_void_p(map1.data_ptr()), C.c_void_p(map2.data_ptr())
+        pg1, pg2 = C.c_void_p(g1.data_ptr()), C.c_void_p(g2.data_ptr())
+        if do_dense:
+            S = sample_ind.shape[1]
+            nb = L.hcm_dense_soft_nce_workspace_bytes(B, S, Cc)
+            ws = _ws(nb, dev)
+            check(L.hcm_dense_soft_nce(p1, p2, st, B, Cc, h, w,
+                                       _dev(sample_ind, torch.int64, 'dense'), _dev(_i32(keep), torch.int32, 'dense'),
+                                       S, float(temperature), C.c_void_p(out.data_ptr()), pg1, pg2,
+                                       C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_dense_soft_nce')
+        if do_joint:
+            feat3c = feat3.contiguous()
+            gfeat3 = torch.empty_like(feat3c)
+            nb = L.hcm_joint_nce_workspace_bytes(B, J, Cc)
+            ws = _ws(nb, dev)
+            check(L.hcm_joint_nce(p1, p2, st, B, Cc, h, w, _dev(feat3c, torch.float32, 'joint'),
+                                  _dev(pix, torch.int64, 'joint'), _dev(_i32(joints_vis), torch.int32, 'joint'),
+                                  _opt(ud, torch.int32, 'joint'), J, float(temperature),
+                                  C.c_void_p(out.data_ptr() + 16), pg1, pg2,
+                                  C.c_void_p(gfeat3.data_ptr()), C.c_void_p(ws.data_ptr()), nb, _stream()),
+                  'hcm_joint_nce')
+        if do_scl:
+            nb = L.hcm_scl_workspace_bytes(B, J, Cc)
+            ws = _ws(nb, dev)
+            check(L.hcm_scl(p1, p2, st, B, Cc, h, w, _dev(pix, torch.int64, 'scl'),
+                            _dev(ud, torch.int32, 'scl'), _opt(ur, torch.int32, 'scl'), J, float(temperature),
+                            C.c_void_p(out.data_ptr() + 32), pg1, pg2,
+                            C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_scl')
+        ctx.save_for_backward(g1, g2, gfeat3 if gfeat3 is not None else torch.empty(0, device=dev))
+        ctx.has_g3 = gfeat3 is not None
+        total = out[0] + out[1] + out[4] + out[5] + out[8]
+        return total, out.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g_total, g_out):
+        g1, g2, g3 = ctx.saved_tensors
+        return (g1 * g_total, g2 * g_total, (g3 * g_total) if ctx.has_g3 else None) + (None,) * 10
+
+
+def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb, temperature,
+                do_dense=True, do_joint=True, do_scl=True):
+    """total (differentiable in map1, map2, feat3) and the 9 detached meters
+    [loss_r2d, loss_d2r, acc_r2d, acc_d2r, loss_rgb2j, loss_d2j, acc_rgb2j, acc_d2j, loss_scl]."""
+    return _FmapLosses.apply(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
+                             temperature, do_dense, do_joint, do_scl)

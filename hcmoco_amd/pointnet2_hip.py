@@ -1,0 +1,82 @@
+"""Drop-in for the reference's pybind module ``pointnet2_cuda``
+(/root/reference/pycontrast/networks/pointnet2/src/pointnet2_api.cpp:10-24).
+
+Same nine function names, same positional arguments, same ownership rules: the CALLER allocates
+and pre-initialises every output tensor (see pointnet2_utils.py in the reference); the wrappers
+only read device pointers of contiguous fp32/int32 ROCm tensors and launch on the current
+stream.  Unlike the reference, a bad argument or a failed launch raises instead of ``exit(-1)``.
+
+    import hcmoco_amd.pointnet2_hip as pointnet2      # instead of: import pointnet2_cuda as pointnet2
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .hip_ops import _dev, _stream
+
+
+def _f(t, name):
+    return _dev(t, torch.float32, name)
+
+
+def _i(t, name):
+    return _dev(t, torch.int32, name)
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    check(_lib.lib().hcm_ball_query(b, n, m, float(radius), nsample, _f(new_xyz, 'ball_query'),
+                                    _f(xyz, 'ball_query'), _i(idx, 'ball_query'), _stream()), 'hcm_ball_query')
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    check(_lib.lib().hcm_group_points(b, c, n, npoints, nsample, _f(points, 'group_points'),
+                                      _i(idx, 'group_points'), _f(out, 'group_points'), _stream()),
+          'hcm_group_points')
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    check(_lib.lib().hcm_group_points_grad(b, c, n, npoints, nsample, _f(grad_out, 'group_points_grad'),
+                                           _i(idx, 'group_points_grad'), _f(grad_points, 'group_points_grad'),
+                                           _stream()), 'hcm_group_points_grad')
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    check(_lib.lib().hcm_gather_points(b, c, n, npoints, _f(points, 'gather_points'), _i(idx, 'gather_points'),
+                                       _f(out, 'gather_points'), _stream()), 'hcm_gather_points')
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    check(_lib.lib().hcm_gather_points_grad(b, c, n, npoints, _f(grad_out, 'gather_points_grad'),
+                                            _i(idx, 'gather_points_grad'), _f(grad_points, 'gather_points_grad'),
+                                            _stream()), 'hcm_gather_points_grad')
+    return 1
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    check(_lib.lib().hcm_furthest_point_sampling(b, n, m, _f(points, 'fps'), _f(temp, 'fps'), _i(idx, 'fps'),
+                                                 _stream()), 'hcm_furthest_point_sampling')
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    check(_lib.lib().hcm_three_nn(b, n, m, _f(unknown, 'three_nn'), _f(known, 'three_nn'), _f(dist2, 'three_nn'),
+                                  _i(idx, 'three_nn'), _stream()), 'hcm_three_nn')
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    check(_lib.lib().hcm_three_interpolate(b, c, m, n, _f(points, 'three_interpolate'), _i(idx, 'three_interpolate'),
+                                           _f(weight, 'three_interpolate'), _f(out, 'three_interpolate'), _stream()),
+          'hcm_three_interpolate')
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    check(_lib.lib().hcm_three_interpolate_grad(b, c, n, m, _f(grad_out, 'three_interpolate_grad'),
+                                                _i(idx, 'three_interpolate_grad'), _f(weight, 'three_interpolate_grad'),
+                                                _f(grad_points, 'three_interpolate_grad'), _stream()),
+          'hcm_three_interpolate_grad')

@@ -1,0 +1,186 @@
+/*
+ * hcmoco_hip.h -- C ABI of libhcmoco_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the HCMoCo contrastive pre-training hot path
+ * (SURVEY.md section 8).  Plain pointers and sizes only: every pointer is a
+ * DEVICE pointer unless its comment says "host".  All entry points are
+ * asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, keep no
+ * global state, never allocate, and return a hipError_t value as int
+ * (0 == hipSuccess).  The caller owns every buffer, including workspaces whose
+ * size is reported by the matching *_workspace_bytes() function.
+ *
+ * File:line citations name the reference interface (under
+ * /root/reference/pycontrast) that each entry point replaces.
+ */
+#ifndef HCMOCO_HIP_H
+#define HCMOCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hcm_stream_t; /* hipStream_t */
+
+#define HCM_ABI_VERSION 1
+int hcm_abi_version(void);
+/* hipGetErrorString() for a value returned by any entry point. */
+const char* hcm_error_string(int err);
+
+/* ------------------------------------------------------------------------ *
+ * Row 1 -- alias sampler.  memory/alias_multinomial.py:7-42 (__init__),
+ * :48-65 (draw).
+ * ------------------------------------------------------------------------ */
+/* HOST function.  Walker tables for `probs[n]` exactly as AliasMethod.__init__
+ * builds them (fp32 arithmetic, LIFO work lists).  prob_out[n], alias_out[n]: host. */
+int hcm_alias_build(const float* probs_host, int64_t n, float* prob_out_host, int64_t* alias_out_host);
+
+/* idx[b*K1 + k] = draw for k>0, idx[b*K1] = y[b]  (mem_bank.py:176-177).
+ * Counter based: element e = b*K1+k uses Philox4x32-10(ctr={e_lo,e_hi,off_lo,off_hi}, key=seed):
+ *   kk = (r0<<32|r1) % n ; u = (r2>>8)*2^-24 ; out = u < prob[kk] ? kk : alias[kk].
+ * y may be NULL (no positive column written: plain draw of B*K1 samples). */
+int hcm_alias_draw(const float* prob, const int64_t* alias, int64_t n,
+                   const int64_t* y, int B, int K1, uint64_t seed, uint64_t offset,
+                   int64_t* idx, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Rows 2+4 fused -- CMCMem3.forward gather + _compute_logit (memory/mem_bank.py:172-193,
+ * :30-40) + _compute_loss_accuracy / CrossEntropyLoss / accuracy
+ * (learning/contrast_trainer.py:212-253, learning/util.py:24-38) + their backward.
+ *
+ * banks: 3 x [n, D] fp32 row-major (D in {64,128}); idx [B, K1] int64 with idx[:,0] = y;
+ * x1..x3 [B, D].  use_depth / use_rgb: [B] int32 or NULL, selecting the rows each of
+ * the six logit sets averages over (contrast_trainer.py:223-250; sets are ordered
+ * 12,21,23,32,13,31).  Outputs: losses[6], accs[6] (percent), gx1..gx3 [B, D]
+ * (d sum(losses) / d x), all fp32.  logits are never materialised.
+ * ------------------------------------------------------------------------ */
+size_t hcm_bank_nce_workspace_bytes(int B, int K1, int D);
+int hcm_bank_nce_fused(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                       const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                       const int32_t* use_depth, const int32_t* use_rgb,
+                       int B, int K1, int D, float T,
+                       float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
+                       void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
+/* API mode (materialised logits, the literal CMCMem3.forward contract, mem_bank.py:186-205):
+ * logits [6, B, K1] fp32; backward takes d loss/d logits in the same layout. */
+int hcm_bank_logits_fwd(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                        const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                        int B, int K1, int D, float T, float* logits, hcm_stream_t stream);
+int hcm_bank_logits_bwd(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                        const int64_t* idx, const float* grad_logits,
+                        int B, int K1, int D, float T, float* gx1, float* gx2, float* gx3,
+                        void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Row 3 -- BaseMem._update_memory (memory/mem_bank.py:15-28), all three banks in one launch.
+ * all_x* [BW, D], all_y [BW] int64 in gather (rank-major) order.  Reads use the
+ * pre-update rows; duplicate y: the LAST occurrence writes (torch CPU index_copy_).
+ * ------------------------------------------------------------------------ */
+int hcm_bank_update(float* bank1, float* bank2, float* bank3, int64_t n,
+                    const float* all_x1, const float* all_x2, const float* all_x3,
+                    const int64_t* all_y, int BW, int D, float momentum, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * MoCo queue (secondary) -- memory/mem_moco.py:15-49.
+ * logits [B, K+1] = cat(q.k, q @ queue^T)/T ; enqueue rows (index + j) % K.
+ * ------------------------------------------------------------------------ */
+int hcm_moco_logits(const float* q, const float* k, const float* queue, int B, int K, int D, float T,
+                    float* logits, hcm_stream_t stream);
+int hcm_moco_enqueue(float* queue, const float* all_k, int n_new, int K, int D, int64_t index,
+                     hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Rows 5-7 -- feature-map losses (learning/contrast_trainer.py:642-892), forward + backward.
+ * Feature maps are addressed through element strides {sN, sC, sH, sW} so both NCHW and
+ * channels-last tensors are read in place; C must be 128.  Gradients wrt the maps are
+ * ACCUMULATED (+=) into gmap1/gmap2 (same strides), which the caller zero-fills once per
+ * step; all three losses add into the same gradient buffers.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int64_t sN, sC, sH, sW;
+} hcm_strides4;
+
+/* Row 5: _compute_soft_pri3d_loss_accuracy (:642-723).  sample_ind [B, S] int64 flat
+ * pixel index (row*w + col) per image; keep [B] int32 (image has a non-empty mask, :677-682);
+ * rows of sample_ind for dropped images are ignored.  out4 = {loss_r2d, loss_d2r, acc_r2d, acc_d2r}. */
+size_t hcm_dense_soft_nce_workspace_bytes(int B, int S, int C);
+int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                       const int64_t* sample_ind, const int32_t* keep, int S, float temperature,
+                       float* out4, float* gmap1, float* gmap2,
+                       void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
+/* Row 6: _compute_joints_pri3d_loss_accuracy (:744-828).  pix [B, J] int64 flat pixel of each
+ * joint (clamp(floor(j/4))), feat3 [B, J, C] contiguous, joints_vis [B, J] int32,
+ * use_depth [B] int32 or NULL.  out4 = {loss_rgb, loss_d, acc_rgb, acc_d}.
+ * gfeat3 [B, J, C] is OVERWRITTEN. */
+size_t hcm_joint_nce_workspace_bytes(int B, int J, int C);
+int hcm_joint_nce(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                  const float* feat3, const int64_t* pix, const int32_t* joints_vis,
+                  const int32_t* use_depth, int J, float temperature,
+                  float* out4, float* gmap1, float* gmap2, float* gfeat3,
+                  void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
+/* Row 7: _compute_cross_subject_joints_pri3d_loss (:830-892; use_rgb==NULL follows
+ * learning/segment_trainer.py:601-606).  out1 = {loss}. */
+size_t hcm_scl_workspace_bytes(int B, int J, int C);
+int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+            const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+            float temperature, float* out1, float* gmap1, float* gmap2,
+            void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
+/* joint_pixels: pix[b,j] = clamp(floor(j2d[b,j,0]/4),0,h-1)*h + clamp(floor(j2d[b,j,1]/4),0,h-1)
+ * (contrast_trainer.py:757-761).  joints2d [B, J, 2] fp32. */
+int hcm_joint_pixels(const float* joints2d, int BJ, int h, int64_t* pix, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
+ * reference's C launcher layer (networks/pointnet2/src/<name>_gpu.h), which the pybind
+ * module `pointnet2_cuda` (src/pointnet2_api.cpp:10-24) wraps: the caller allocates and
+ * pre-initialises every output (idx zero-filled, temp filled with 1e10, grads zero-filled;
+ * networks/pointnet2/pointnet2_utils.py:25-26,55,67,94-95,128,146,172,190,218).
+ * Launch failures are RETURNED (the reference calls exit(-1)).
+ * ------------------------------------------------------------------------ */
+/* src/sampling_gpu.h : furthest_point_sampling_kernel_launcher */
+int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
+                                hcm_stream_t stream);
+/* src/ball_query_gpu.h:12-13 : ball_query_kernel_launcher_fast */
+int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                   const float* xyz, int* idx, hcm_stream_t stream);
+/* src/group_points_gpu.h : group_points_kernel_launcher_fast / group_points_grad_kernel_launcher_fast */
+int hcm_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                     const int* idx, float* out, hcm_stream_t stream);
+int hcm_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                          const int* idx, float* grad_points, hcm_stream_t stream);
+/* src/sampling_gpu.h : gather_points_kernel_launcher_fast / gather_points_grad_kernel_launcher_fast */
+int hcm_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,
+                      float* out, hcm_stream_t stream);
+int hcm_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int* idx,
+                           float* grad_points, hcm_stream_t stream);
+/* src/interpolate_gpu.h : three_nn_kernel_launcher_fast (dist2 = SQUARED distances) */
+int hcm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                 int* idx, hcm_stream_t stream);
+/* src/interpolate_gpu.h : three_interpolate_kernel_launcher_fast / _grad_ */
+int hcm_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
+                          const float* weight, float* out, hcm_stream_t stream);
+int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                               const float* weight, float* grad_points, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Measurement helper: launches `reps` back-to-back hcm_bank_nce_fused passes bracketed by
+ * hipEvents on `stream` and returns the mean milliseconds per pass (host float).
+ * ------------------------------------------------------------------------ */
+int hcm_bank_nce_fused_timed(const float* bank1, const float* bank2, const float* bank3, int64_t n,
+                             const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                             const int32_t* use_depth, const int32_t* use_rgb,
+                             int B, int K1, int D, float T,
+                             float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
+                             void* workspace, size_t workspace_bytes, hcm_stream_t stream,
+                             int reps, float* ms_per_pass_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCMOCO_HIP_H */

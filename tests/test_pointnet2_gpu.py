@@ -1,0 +1,119 @@
+"""GPU parity of the PointNet++ HIP ops against oracle/pointnet2_oracle.c,
+called through the `pointnet2_cuda`-compatible wrapper module.  Indices bit-exact; fp32 sums of
+the atomic scatter kernels to 1e-5 relative (accumulation order is not defined, as in the reference)."""
+import pytest
+import torch
+
+from oracle import pointnet2_oracle as P
+
+pytestmark = pytest.mark.gpu
+
+
+def mod():
+    import hcmoco_amd.pointnet2_hip as m
+    return m
+
+
+def d():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def cloud(B, N, seed, dup=True):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(B, N, 3, generator=g)
+    if dup and N > 8:   # sampling with replacement upstream guarantees duplicate points (build_backbone.py:427)
+        src = torch.randint(0, N, (B, N // 4), generator=g)
+        dst = torch.randint(0, N, (B, N // 4), generator=g)
+        for b in range(B):
+            xyz[b, dst[b]] = xyz[b, src[b]]
+    return xyz
+
+
+@pytest.mark.parametrize('N,M', [(5, 5), (37, 20), (64, 64), (100, 33), (1024, 256), (1500, 700), (4096, 1024),
+                                 (9000, 50)])
+def test_fps_bit_exact(N, M):
+    xyz = cloud(2, N, N * 7 + M)
+    ref, ref_temp = P.furthest_point_sampling(xyz, M)
+    out = torch.zeros(2, M, dtype=torch.int32, device=d())
+    temp = torch.full((2, N), 1e10, device=d())
+    mod().furthest_point_sampling_wrapper(2, N, M, xyz.to(d()), temp, out)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(temp.cpu(), ref_temp)
+
+
+def test_fps_known_answer_tie_break():
+    xyz = torch.tensor([[[0., 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0], [10, 0, 0]]])
+    out = torch.zeros(1, 5, dtype=torch.int32, device=d())
+    temp = torch.full((1, 5), 1e10, device=d())
+    mod().furthest_point_sampling_wrapper(1, 5, 5, xyz.to(d()), temp, out)
+    assert out.cpu().tolist() == [[0, 4, 3, 2, 1]]
+
+
+@pytest.mark.parametrize('N,M,r,ns', [(10, 4, 0.3, 3), (300, 300, 0.2, 16), (4096, 1024, 0.125, 32),
+                                      (2500, 777, 0.05, 16), (1024, 256, 1.0, 32)])
+def test_ball_query_bit_exact(N, M, r, ns):
+    xyz = cloud(2, N, N + M)
+    new_xyz = xyz[:, torch.randperm(N)[:M]].contiguous()
+    new_xyz[:, 0] = 50.0   # a centre with an empty ball
+    ref = P.ball_query(r, ns, xyz, new_xyz)
+    idx = torch.zeros(2, M, ns, dtype=torch.int32, device=d())
+    mod().ball_query_wrapper(2, N, M, r, ns, new_xyz.to(d()), xyz.to(d()), idx)
+    assert torch.equal(idx.cpu(), ref)
+    assert idx[:, 0].abs().sum() == 0
+
+
+@pytest.mark.parametrize('n,m', [(7, 2), (256, 64), (4096, 1024), (3000, 4096)])
+def test_three_nn_bit_exact(n, m):
+    unknown, known = cloud(2, n, n), cloud(2, m, m + 1)
+    rd, ri = P.three_nn(unknown, known)
+    dist2 = torch.zeros(2, n, 3, device=d())
+    idx = torch.zeros(2, n, 3, dtype=torch.int32, device=d())
+    mod().three_nn_wrapper(2, n, m, unknown.to(d()), known.to(d()), dist2, idx)
+    assert torch.equal(idx.cpu(), ri)
+    assert torch.equal(dist2.cpu(), rd)
+
+
+def test_group_gather_interpolate_and_grads():
+    torch.manual_seed(1)
+    B, C, N, npts, ns = 2, 37, 500, 128, 16
+    pts = torch.randn(B, C, N)
+    idx = torch.randint(0, N, (B, npts, ns), dtype=torch.int32)
+    out = torch.empty(B, C, npts, ns, device=d())
+    mod().group_points_wrapper(B, C, N, npts, ns, pts.to(d()), idx.to(d()), out)
+    assert torch.equal(out.cpu(), P.group_points(pts, idx))
+    go = torch.randn(B, C, npts, ns)
+    g = torch.zeros(B, C, N, device=d())
+    mod().group_points_grad_wrapper(B, C, N, npts, ns, go.to(d()), idx.to(d()), g)
+    assert torch.allclose(g.cpu(), P.group_points_grad(go, idx, N), rtol=1e-5, atol=1e-5)
+
+    gi = torch.randint(0, N, (B, 77), dtype=torch.int32)
+    out = torch.empty(B, C, 77, device=d())
+    mod().gather_points_wrapper(B, C, N, 77, pts.to(d()), gi.to(d()), out)
+    assert torch.equal(out.cpu(), P.gather_points(pts, gi))
+    go = torch.randn(B, C, 77)
+    g = torch.zeros(B, C, N, device=d())
+    mod().gather_points_grad_wrapper(B, C, N, 77, go.to(d()), gi.to(d()), g)
+    assert torch.allclose(g.cpu(), P.gather_points_grad(go, gi, N), rtol=1e-5, atol=1e-5)
+
+    n, m = 900, 200
+    feats = torch.randn(B, C, m)
+    ii = torch.randint(0, m, (B, n, 3), dtype=torch.int32)
+    w = torch.rand(B, n, 3)
+    w = w / w.sum(-1, keepdim=True)
+    out = torch.empty(B, C, n, device=d())
+    mod().three_interpolate_wrapper(B, C, m, n, feats.to(d()), ii.to(d()), w.to(d()), out)
+    assert torch.equal(out.cpu(), P.three_interpolate(feats, ii, w))
+    go = torch.randn(B, C, n)
+    g = torch.zeros(B, C, m, device=d())
+    mod().three_interpolate_grad_wrapper(B, C, n, m, go.to(d()), ii.to(d()), w.to(d()), g)
+    assert torch.allclose(g.cpu(), P.three_interpolate_grad(go, ii, w, m), rtol=1e-4, atol=1e-5)
+
+
+def test_bad_arguments_raise_instead_of_exit():
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        mod().ball_query_wrapper(1, 4, 2, 0.1, 2, torch.zeros(1, 2, 3), torch.zeros(1, 4, 3),
+                                 torch.zeros(1, 2, 2, dtype=torch.int32))
+    with pytest.raises(TypeError):
+        mod().ball_query_wrapper(1, 4, 2, 0.1, 2, torch.zeros(1, 2, 3, device=d()), torch.zeros(1, 4, 3, device=d()),
+                                 torch.zeros(1, 2, 2, dtype=torch.int64, device=d()))
