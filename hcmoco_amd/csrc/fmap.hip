@@ -1,12 +1,796 @@
-// placeholder, replaced by the real kernels
+// Feature-map contrastive losses for gfx950 (MI355X): dense intra-sample soft InfoNCE,
+// joint<->graph-node InfoNCE and the cross-subject SCL, forward + backward
+// (pycontrast/learning/contrast_trainer.py:642-892).
+//
+// Structure
+//   gather_norm_kernel   one wave per sampled pixel: strided read of the 128 channels straight out
+//                        of the NCHW / channels-last map, L2-normalise, store the unit row.
+//   strip_kernel<Policy> S x S (dense, per image) or N x N (SCL) similarity on the fp32 MFMA
+//                        (v_mfma_f32_16x16x4_f32): a 256-thread workgroup owns 64 query rows (one
+//                        16-row strip per wave) and walks the key set in 16-row tiles staged once
+//                        per workgroup in LDS.  STATS pass: online row softmax + soft-target sums.
+//                        GRAD pass: re-forms the tile, builds the logit gradient in registers,
+//                        transposes it through LDS and feeds a second MFMA chain (G x K) -- the
+//                        S x S matrices never exist in memory.
+//   joint_nce_kernel     one workgroup per image (J<=32 joints, launch/latency bound): VALU.
+//   scatter_rows_kernel  deterministic owner-computes scatter-add of the sampled-pixel gradients
+//                        into the map gradient (duplicates summed in index order, no atomics).
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
-extern "C" {
-size_t hcm_dense_soft_nce_workspace_bytes(int, int, int) { return 0; }
-int hcm_dense_soft_nce(const float*, const float*, hcm_strides4, int, int, int, int, const int64_t*, const int32_t*, int, float, float*, float*, float*, void*, size_t, hcm_stream_t) { return (int)hipErrorNotSupported; }
-size_t hcm_joint_nce_workspace_bytes(int, int, int) { return 0; }
-int hcm_joint_nce(const float*, const float*, hcm_strides4, int, int, int, int, const float*, const int64_t*, const int32_t*, const int32_t*, int, float, float*, float*, float*, float*, void*, size_t, hcm_stream_t) { return (int)hipErrorNotSupported; }
-size_t hcm_scl_workspace_bytes(int, int, int) { return 0; }
-int hcm_scl(const float*, const float*, hcm_strides4, int, int, int, int, const int64_t*, const int32_t*, const int32_t*, int, float, float*, float*, float*, void*, size_t, hcm_stream_t) { return (int)hipErrorNotSupported; }
-int hcm_joint_pixels(const float*, int, int, int64_t*, hcm_stream_t) { return (int)hipErrorNotSupported; }
+
+namespace {
+
+using namespace hcm;
+
+constexpr int kC = 128;  // linear_merge channels (build_backbone.py:243-245)
+constexpr int kWG = 256;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct MapView {
+  int64_t sN, sC, sH, sW;
+  int w;
+  __device__ __forceinline__ int64_t at(int b, int ch, int pix) const {
+    return b * sN + ch * sC + (int64_t)(pix / w) * sH + (int64_t)(pix % w) * sW;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// gather + L2 normalise (F.normalize, eps 1e-12).  rows r = b*R + s; grid.y selects the map.
+// F [2][nrows][128]; invn [2][nrows] = 1/max(|x|,eps), stored NEGATIVE when the clamp was active
+// (then d xhat/dx = I/eps, without the projection term).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void gather_norm_kernel(const float* __restrict__ map1,
+                                                          const float* __restrict__ map2,
+                                                          MapView mv, const int64_t* __restrict__ pix,
+                                                          int R, int nrows,
+                                                          const int32_t* __restrict__ keep,
+                                                          float* __restrict__ F,
+                                                          float* __restrict__ invn) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int mod = blockIdx.y;
+  if (r >= nrows) return;
+  const int b = r / R;
+  float* out = F + ((int64_t)mod * nrows + r) * kC;
+  if (keep != nullptr && keep[b] == 0) {
+    out[lane] = 0.f;
+    out[lane + 64] = 0.f;
+    if (lane == 0) invn[(int64_t)mod * nrows + r] = 0.f;
+    return;
+  }
+  const float* map = mod == 0 ? map1 : map2;
+  const int p = (int)pix[r];
+  const float x0 = map[mv.at(b, lane, p)];
+  const float x1 = map[mv.at(b, lane + 64, p)];
+  const float nrm = sqrtf(wave_sum(fmaf(x0, x0, x1 * x1)));
+  const float den = fmaxf(nrm, 1e-12f);
+  out[lane] = x0 / den;
+  out[lane + 64] = x1 / den;
+  if (lane == 0) invn[(int64_t)mod * nrows + r] = (nrm < 1e-12f) ? -1.f / den : 1.f / den;
 }
+
+// ------------------------------------------------------------------------------------------
+// Target / weight policies of the strip kernel.  meta is one int per row.
+// ------------------------------------------------------------------------------------------
+struct DensePolicy {
+  // soft target exp(-|q_r - q_c|_2) from integer pixel coordinates (contrast_trainer.py:702-706)
+  int w;
+  __device__ __forceinline__ float weight(int mr, int mc, int r, int c) const {
+    const float dy = (float)(mr / w - mc / w), dx = (float)(mr % w - mc % w);
+    return __expf(-sqrtf(dy * dy + dx * dx));
+  }
+  // row statistics -> (loss term, alpha, beta):  G = alpha*softmax - beta*weight
+  __device__ __forceinline__ void finish(float lse, float tdot, float z, float& loss, float& alpha,
+                                         float& beta) const {
+    loss = lse - tdot / z;
+    alpha = 1.f;
+    beta = 1.f / z;
+  }
+};
+struct SclPolicy {
+  // positives: same joint id, different row, both rows' modality present (:873-885)
+  // meta = joint id | (valid << 16)
+  __device__ __forceinline__ float weight(int mr, int mc, int r, int c) const {
+    return ((mr & 0xffff) == (mc & 0xffff) && r != c && (mr >> 16) && (mc >> 16)) ? 1.f : 0.f;
+  }
+  __device__ __forceinline__ void finish(float lse, float tdot, float z, float& loss, float& alpha,
+                                         float& beta) const {
+    const float c = fmaxf(z, 1.f);
+    loss = (z * lse - tdot) / c;
+    alpha = z / c;
+    beta = 1.f / c;
+  }
+};
+
+struct StripArgs {
+  const float* F;       // [2][nbatch*S][128] unit rows (dense: modality 0 = rgb, 1 = depth)
+  const float* invn;    // [2][nbatch*S]
+  const int* meta;      // [nbatch*S] (dense) or [2*nbatch*S] (scl)
+  const int32_t* keep;  // [nbatch] or null
+  int S;                // rows per problem
+  int nbatch;
+  int symmetric;        // 1: SCL (Q = K = all 2*nbatch*S rows, one problem); 0: dense
+  float inv_tau;
+  const float* gscale;  // device scalar: 1/(B'S) or 1/N (0 disables the loss)
+  float* stat;          // [norient][rows][4] = lse, alpha, beta, unused
+  float* rowloss;       // [norient][rows]
+  float* rowcorrect;    // [norient][rows]
+  float* dX;            // [2][nbatch*S][128]  gradient wrt the gathered (un-normalised) rows
+};
+
+constexpr int kKS = 144;  // LDS row stride of the key tile (16 mod 32 -> conflict-free b32 reads)
+
+template <class Policy, bool GRAD>
+__global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
+  __shared__ __attribute__((aligned(16))) float sK[16 * kKS];
+  __shared__ float sG[4][16][17];
+  __shared__ int sMetaC[16];
+  __shared__ float sStatC[16][3];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int np = lane & 15, g = lane >> 4;
+  const int o = blockIdx.z;  // orientation (dense): 0 -> Q = depth rows, K = rgb rows; 1 -> swapped
+  const int b = blockIdx.y;
+  const int rows_total = a.nbatch * a.S;           // rows per modality
+  const int S = a.symmetric ? 2 * rows_total : a.S;  // problem size
+  if (!a.symmetric && a.keep != nullptr && a.keep[b] == 0) return;
+
+  const int qmod = a.symmetric ? 0 : (o == 0 ? 1 : 0);
+  const int kmod = a.symmetric ? 0 : 1 - qmod;
+  const int64_t base = a.symmetric ? 0 : (int64_t)b * a.S;
+  const float* Q = a.F + ((int64_t)qmod * rows_total + base) * kC;
+  const float* K = a.F + ((int64_t)kmod * rows_total + base) * kC;
+  const int* metaQ = a.meta + base;
+  const int* metaK = a.meta + base;
+  const int64_t statQ = ((int64_t)o * (a.symmetric ? S : rows_total) + base);  // own stats
+  const int64_t statK = a.symmetric ? 0 : ((int64_t)(1 - o) * rows_total + base);  // other orientation
+
+  const int row0 = blockIdx.x * 64 + wave * 16;  // first row of this wave's strip
+  // A operand: lane (m = np, kslot = g) holds Q[row0+np][16j + 4g + e], j<8, e<4
+  float4 qf[8];
+  {
+    const int r = row0 + np;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      qf[j] = (r < S) ? *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 16 * j + 4 * g)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // rows owned in the C layout: row0 + 4g + reg
+  int mrow[4];
+  float lse_r[4], al_r[4], be_r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = row0 + 4 * g + q;
+    mrow[q] = (r < S) ? metaQ[r] : 0;
+    if (GRAD) {
+      lse_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 0] : 0.f;
+      al_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 1] : 0.f;
+      be_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 2] : 0.f;
+    }
+  }
+  const float gs = GRAD ? *a.gscale : 0.f;
+
+  float m[4], ssum[4], td[4], z[4], best[4];
+  int bestc[4];
+  v4f dq[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    m[q] = -1.0e30f; ssum[q] = 0.f; td[q] = 0.f; z[q] = 0.f; best[q] = -3.0e38f; bestc[q] = 0;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) dq[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (S + 15) / 16;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int c0 = tile * 16;
+    __syncthreads();  // previous tile fully consumed
+    {
+      // cooperative load of K[c0 .. c0+16) into LDS: 16 rows x 32 float4 = 512 float4, 2 per thread
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = threadIdx.x + h * kWG;
+        const int rr = e >> 5, cc = (e & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + rr < S) v = *reinterpret_cast<const float4*>(K + (int64_t)(c0 + rr) * kC + cc);
+        *reinterpret_cast<float4*>(&sK[rr * kKS + cc]) = v;
+      }
+      if (threadIdx.x < 16) {
+        const int c = c0 + threadIdx.x;
+        sMetaC[threadIdx.x] = (c < S) ? metaK[c] : 0;
+        if (GRAD) {
+          sStatC[threadIdx.x][0] = (c < S) ? a.stat[(statK + c) * 4 + 0] : 0.f;
+          sStatC[threadIdx.x][1] = (c < S) ? a.stat[(statK + c) * 4 + 1] : 0.f;
+          sStatC[threadIdx.x][2] = (c < S) ? a.stat[(statK + c) * 4 + 2] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+
+    // GEMM 1: P[16 x 16] = Qstrip . Ktile^T   (32 x v_mfma_f32_16x16x4_f32)
+    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 kb = *reinterpret_cast<const float4*>(&sK[np * kKS + 16 * j + 4 * g]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, acc, 0, 0, 0);
+    }
+    // C layout: acc[q] = P[row0 + 4g + q][c0 + np]
+    const int c = c0 + np;
+    const bool cvalid = c < S;
+    const int mc = sMetaC[np];
+
+    if (!GRAD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = row0 + 4 * g + q;
+        if (cvalid && r < S) {
+          const float P = acc[q] * a.inv_tau;
+          const float wgt = pol.weight(mrow[q], mc, r, c);
+          const float mn = fmaxf(m[q], P);
+          ssum[q] = ssum[q] * __expf(m[q] - mn) + __expf(P - mn);
+          m[q] = mn;
+          td[q] = fmaf(wgt, P, td[q]);
+          z[q] += wgt;
+          if (P > best[q]) { best[q] = P; bestc[q] = c; }
+        }
+      }
+    } else {
+      const float lse_c = sStatC[np][0], al_c = sStatC[np][1], be_c = sStatC[np][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = row0 + 4 * g + q;
+        float G = 0.f;
+        if (cvalid && r < S) {
+          const float P = acc[q] * a.inv_tau;
+          const float wgt = pol.weight(mrow[q], mc, r, c);
+          G = al_r[q] * __expf(P - lse_r[q]) - be_r[q] * wgt + al_c * __expf(P - lse_c) - be_c * wgt;
+          G *= gs * a.inv_tau;
+        }
+        sG[wave][4 * g + q][np] = G;
+      }
+      __syncthreads();  // sG visible (also orders the LDS traffic of the four waves)
+      // GEMM 2: dQ[16 x 128] += G[16 x 16] . Ktile[16 x 128]   (4 k-steps x 8 channel tiles)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float av = sG[wave][np][4 * ks + g];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+          const float bv = sK[(4 * ks + g) * kKS + 16 * nt + np];
+          dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dq[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (!GRAD) {
+    // merge the 16 lanes (columns) that share each row: they sit in one DPP row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float M = row16_max(m[q]);
+      const float sAll = row16_sum(ssum[q] * __expf(m[q] - M));
+      const float tdAll = row16_sum(td[q]);
+      const float zAll = row16_sum(z[q]);
+      const float bAll = row16_max(best[q]);
+      // lowest column among the maxima (torch.argmax returns the first)
+      const float cand = (best[q] == bAll) ? (float)bestc[q] : 3.0e38f;
+      const float cmin = -row16_max(-cand);
+      const int r = row0 + 4 * g + q;
+      if (np == 0 && r < S) {
+        const float lse = M + __logf(sAll);
+        float loss, alpha, beta;
+        pol.finish(lse, tdAll, zAll, loss, alpha, beta);
+        a.stat[(statQ + r) * 4 + 0] = lse;
+        a.stat[(statQ + r) * 4 + 1] = alpha;
+        a.stat[(statQ + r) * 4 + 2] = beta;
+        a.rowloss[statQ + r] = loss;
+        a.rowcorrect[statQ + r] = ((int)cmin == r) ? 1.f : 0.f;
+      }
+    }
+  } else {
+    // dq[nt][q] = d loss / d qhat[row0+4g+q][16nt+np]; push it through F.normalize
+    const int64_t qrow_base = (int64_t)qmod * rows_total + base;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = row0 + 4 * g + q;
+      const bool rv = r < S;
+      float fh[8];
+      float dot = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        fh[nt] = rv ? Q[(int64_t)r * kC + 16 * nt + np] : 0.f;
+        dot = fmaf(dq[nt][q], fh[nt], dot);
+      }
+      dot = row16_sum(dot);
+      if (rv) {
+        const float inv = a.invn[qrow_base + r];
+        float* dst = a.dX + (qrow_base + r) * kC;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          dst[16 * nt + np] = (inv < 0.f) ? dq[nt][q] * (-inv) : (dq[nt][q] - dot * fh[nt]) * inv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// small helper kernels
+// ------------------------------------------------------------------------------------------
+// dense: gscale = 1/(B' * S) with B' = #kept images (0 when none); meta = pixel index
+__global__ void dense_prep_kernel(const int32_t* __restrict__ keep, int B, int S,
+                                  const int64_t* __restrict__ sample_ind, int* __restrict__ meta,
+                                  float* __restrict__ gscale) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int cnt = 0;
+    for (int i = 0; i < B; ++i) cnt += keep[i] != 0;
+    *gscale = cnt > 0 ? 1.f / ((float)cnt * (float)S) : 0.f;
+  }
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * S; e += gridDim.x * blockDim.x)
+    meta[e] = (int)sample_ind[e];
+}
+
+// scl: rows u = (mod, b, j); meta = j | valid<<16 ; gscale = 1/N, or 0 when use_depth.sum()==0
+__global__ void scl_prep_kernel(const int32_t* __restrict__ use_depth,
+                                const int32_t* __restrict__ use_rgb, int B, int J,
+                                int* __restrict__ meta, float* __restrict__ gscale) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int any = 0;
+    for (int i = 0; i < B; ++i) any += use_depth[i] != 0;
+    *gscale = any > 0 ? 1.f / (float)(2 * B * J) : 0.f;
+  }
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * B * J; e += gridDim.x * blockDim.x) {
+    const int mod = e / (B * J), bb = (e % (B * J)) / J, j = e % J;
+    const int valid = mod == 0 ? (use_rgb == nullptr ? 1 : (use_rgb[bb] != 0)) : (use_depth[bb] != 0);
+    meta[e] = j | (valid << 16);
+  }
+}
+
+// fixed-order block reduction of n floats (deterministic): each thread a strided partial, then a tree
+__device__ float block_sum(const float* __restrict__ v, int n, float* sh) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += v[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// out4 = {loss_r2d, loss_d2r, acc_r2d, acc_d2r}; orientation 1 rows are the r2d terms.
+// Rows of dropped images were never written by the stats pass -> masked here through keep.
+__global__ __launch_bounds__(kWG) void dense_finish_kernel(const float* __restrict__ rowloss,
+                                                           const float* __restrict__ rowcorrect,
+                                                           const int32_t* __restrict__ keep, int B,
+                                                           int S, const float* __restrict__ gscale,
+                                                           float* __restrict__ out4) {
+  __shared__ float sh[kWG];
+  const int n = B * S;
+  float v[4];
+  for (int k = 0; k < 4; ++k) {
+    const float* src = (k < 2 ? rowloss : rowcorrect) + (int64_t)((k & 1) == 0 ? 1 : 0) * n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += kWG)
+      if (keep[i / S] != 0) acc += src[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kWG / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    v[k] = sh[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float gsc = *gscale;  // 1/(B'S), 0 when nothing is kept (reference early return -> zeros)
+    out4[0] = v[0] * gsc; out4[1] = v[1] * gsc; out4[2] = v[2] * gsc; out4[3] = v[3] * gsc;
+  }
+}
+
+__global__ __launch_bounds__(kWG) void scl_finish_kernel(const float* __restrict__ rowloss, int N,
+                                                         const float* __restrict__ gscale,
+                                                         float* __restrict__ out1) {
+  __shared__ float sh[kWG];
+  const float s = block_sum(rowloss, N, sh);
+  if (threadIdx.x == 0) out1[0] = s * (*gscale);
+}
+
+// ------------------------------------------------------------------------------------------
+// Owner-computes scatter-add of row gradients into the map gradient.
+// dX [2][B*R][128]; pix [B*R]; one wave per (mod, row).  A row owns its pixel when no EARLIER row
+// of the same image has the same pixel; the owner adds its own and all later duplicates' rows in
+// index order -> deterministic, no atomics (torch.gather backward sums duplicates too).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void scatter_rows_kernel(const float* __restrict__ dX,
+                                                           const int64_t* __restrict__ pix, int R,
+                                                           int nrows, const int32_t* __restrict__ keep,
+                                                           MapView mv, float* __restrict__ gmap1,
+                                                           float* __restrict__ gmap2) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int mod = blockIdx.y;
+  if (r >= nrows) return;
+  const int b = r / R, s = r - b * R;
+  if (keep != nullptr && keep[b] == 0) return;
+  const int64_t p = pix[r];
+  const int64_t* pb = pix + (int64_t)b * R;
+  bool earlier = false;
+  for (int i = lane; i < s; i += 64) earlier |= (pb[i] == p);
+  if (__any(earlier)) return;
+  const float* src = dX + ((int64_t)mod * nrows + (int64_t)b * R) * kC;
+  float a0 = src[(int64_t)s * kC + lane], a1 = src[(int64_t)s * kC + lane + 64];
+  for (int i0 = s + 1; i0 < R; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned long long mask = __ballot(i < R && pb[i] == p);
+    unsigned long long mm = mask;
+    while (mm) {
+      const int bit = __ffsll((long long)mm) - 1;
+      mm &= mm - 1;
+      a0 += src[(int64_t)(i0 + bit) * kC + lane];
+      a1 += src[(int64_t)(i0 + bit) * kC + lane + 64];
+    }
+  }
+  float* gm = mod == 0 ? gmap1 : gmap2;
+  gm[mv.at(b, lane, (int)p)] += a0;
+  gm[mv.at(b, lane + 64, (int)p)] += a1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Row 6: joint <-> graph-node InfoNCE, one workgroup per image.
+// ------------------------------------------------------------------------------------------
+constexpr int kJMax = 32;
+constexpr int kLS = kC + 1;  // LDS row stride
+
+__global__ __launch_bounds__(kWG) void joint_nce_kernel(
+    const float* __restrict__ map1, const float* __restrict__ map2, MapView mv,
+    const float* __restrict__ feat3, const int64_t* __restrict__ pix,
+    const int32_t* __restrict__ vis, const int32_t* __restrict__ use_depth, int B, int J,
+    float inv_tau, float* __restrict__ part /*[B][6]*/, float* __restrict__ dX /*[2][B*J][128]*/,
+    float* __restrict__ gfeat3) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sV = lds;                     // [3][J][kLS] unit rows: graph nodes, rgb joints, depth joints
+  float* sD = sV + 3 * J * kLS;        // [3][J][kLS] gradients wrt the unit rows
+  float* sA = sD + 3 * J * kLS;        // [2][J][J+1] logits -> logit gradients
+  float* sInv = sA + 2 * J * (J + 1);  // [3][J]
+  float* sRaw = sInv + 3 * J;          // [3][J] dot(d, vhat) scratch
+  __shared__ int sCnt[2];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  if (tid == 0) { sCnt[0] = 0; sCnt[1] = 0; }
+  __syncthreads();
+  {  // global counts of valid targets (rgb: visible; depth: visible and use_depth)
+    int c0 = 0, c1 = 0;
+    for (int e = tid; e < B * J; e += kWG) {
+      const int v = vis[e] != 0;
+      c0 += v;
+      c1 += v && (use_depth == nullptr || use_depth[e / J] != 0);
+    }
+    if (c0) atomicAdd(&sCnt[0], c0);
+    if (c1) atomicAdd(&sCnt[1], c1);
+  }
+  // 1. load + normalise 3J rows, one wave per row
+  for (int rr = wave; rr < 3 * J; rr += 4) {
+    const int which = rr / J, j = rr - which * J;
+    float x0, x1;
+    if (which == 0) {
+      x0 = feat3[((int64_t)b * J + j) * kC + lane];
+      x1 = feat3[((int64_t)b * J + j) * kC + lane + 64];
+    } else {
+      const float* map = which == 1 ? map1 : map2;
+      const int p = (int)pix[(int64_t)b * J + j];
+      x0 = map[mv.at(b, lane, p)];
+      x1 = map[mv.at(b, lane + 64, p)];
+    }
+    const float nrm = sqrtf(wave_sum(fmaf(x0, x0, x1 * x1)));
+    const float den = fmaxf(nrm, 1e-12f);
+    sV[(which * J + j) * kLS + lane] = x0 / den;
+    sV[(which * J + j) * kLS + lane + 64] = x1 / den;
+    if (lane == 0) sInv[which * J + j] = (nrm < 1e-12f) ? -1.f / den : 1.f / den;
+  }
+  __syncthreads();
+  const int cnt[2] = {sCnt[0], sCnt[1]};
+  // 2. logits A_m[i][j] = ghat_i . fhat_{m,j} / tau
+  for (int e = tid; e < 2 * J * J; e += kWG) {
+    const int mm = e / (J * J), i = (e / J) % J, j = e % J;
+    const float* gi = sV + i * kLS;
+    const float* fj = sV + ((1 + mm) * J + j) * kLS;
+    float d = 0.f;
+    for (int c = 0; c < kC; ++c) d = fmaf(gi[c], fj[c], d);
+    sA[(mm * J + i) * (J + 1) + j] = d * inv_tau;
+  }
+  __syncthreads();
+  // 3. column softmax over nodes i, CE target j, arg-max; A <- dA
+  float lossnum = 0.f, ncorrect = 0.f, nvalid = 0.f;
+  if (tid < 2 * J) {
+    const int mm = tid / J, j = tid - mm * J;
+    float* col = sA + mm * J * (J + 1) + j;
+    float mx = -3.0e38f;
+    int arg = 0;
+    for (int i = 0; i < J; ++i) {
+      const float v = col[i * (J + 1)];
+      if (v > mx) { mx = v; arg = i; }
+    }
+    float se = 0.f;
+    for (int i = 0; i < J; ++i) se += __expf(col[i * (J + 1)] - mx);
+    const float lse = mx + __logf(se);
+    const bool valid = vis[(int64_t)b * J + j] != 0 &&
+                       (mm == 0 || use_depth == nullptr || use_depth[b] != 0);
+    const float diag = col[j * (J + 1)];
+    if (valid) {
+      lossnum = lse - diag;
+      ncorrect = (arg == j) ? 1.f : 0.f;
+      nvalid = 1.f;
+    }
+    const float sc = (valid && cnt[mm] > 0) ? 1.f / (float)cnt[mm] : 0.f;
+    for (int i = 0; i < J; ++i) {
+      const float pr = __expf(col[i * (J + 1)] - lse);
+      col[i * (J + 1)] = (pr - (i == j ? 1.f : 0.f)) * sc;
+    }
+  }
+  // per-image partial sums (fixed order): lanes 0..J-1 -> rgb, J..2J-1 -> depth
+  {
+    __shared__ float sRed[3][2 * kJMax];
+    if (tid < 2 * J) { sRed[0][tid] = lossnum; sRed[1][tid] = ncorrect; sRed[2][tid] = nvalid; }
+    __syncthreads();
+    if (tid < 6) {
+      const int mm = tid & 1, what = tid >> 1;
+      float s = 0.f;
+      for (int j = 0; j < J; ++j) s += sRed[what][mm * J + j];
+      part[(int64_t)b * 6 + what * 2 + mm] = s;
+    }
+  }
+  __syncthreads();
+  // 4. gradients wrt the unit rows
+  for (int e = tid; e < 3 * J * kC; e += kWG) {
+    const int which = e / (J * kC), r = (e / kC) % J, c = e % kC;
+    float d = 0.f;
+    if (which == 0) {  // d ghat[i=r] = sum_m sum_j dA_m[i][j] fhat_m[j]
+      for (int mm = 0; mm < 2; ++mm)
+        for (int j = 0; j < J; ++j)
+          d = fmaf(sA[(mm * J + r) * (J + 1) + j], sV[((1 + mm) * J + j) * kLS + c], d);
+    } else {           // d fhat_m[j=r] = sum_i dA_m[i][j] ghat[i]
+      const int mm = which - 1;
+      for (int i = 0; i < J; ++i) d = fmaf(sA[(mm * J + i) * (J + 1) + r], sV[i * kLS + c], d);
+    }
+    sD[(which * J + r) * kLS + c] = d * inv_tau;
+  }
+  __syncthreads();
+  // 5. normalize backward, one wave per row
+  for (int rr = wave; rr < 3 * J; rr += 4) {
+    const int which = rr / J, j = rr - which * J;
+    const float v0 = sV[rr * kLS + lane], v1 = sV[rr * kLS + lane + 64];
+    const float d0 = sD[rr * kLS + lane], d1 = sD[rr * kLS + lane + 64];
+    const float dot = wave_sum(fmaf(d0, v0, d1 * v1));
+    const float inv = sInv[rr];
+    const float o0 = inv < 0.f ? d0 * (-inv) : (d0 - dot * v0) * inv;
+    const float o1 = inv < 0.f ? d1 * (-inv) : (d1 - dot * v1) * inv;
+    float* dst = which == 0 ? gfeat3 + ((int64_t)b * J + j) * kC
+                            : dX + ((int64_t)(which - 1) * B * J + (int64_t)b * J + j) * kC;
+    dst[lane] = o0;
+    dst[lane + 64] = o1;
+  }
+  (void)sRaw;
+}
+
+// out4 = {loss_rgb, loss_d, acc_rgb, acc_d}.  An empty target set gives 0/0 = NaN like
+// nn.CrossEntropyLoss; accuracy averages ncorrect/nvalid over images with nvalid > 0 (:812-822).
+__global__ void joint_finish_kernel(const float* __restrict__ part, int B, float* __restrict__ out4) {
+  const int mm = threadIdx.x;
+  if (mm >= 2) return;
+  float lsum = 0.f, cnt = 0.f, accsum = 0.f, nimg = 0.f;
+  for (int b = 0; b < B; ++b) {
+    lsum += part[b * 6 + 0 + mm];
+    const float nv = part[b * 6 + 4 + mm];
+    cnt += nv;
+    if (nv > 0.f) { accsum += part[b * 6 + 2 + mm] / nv; nimg += 1.f; }
+  }
+  out4[mm] = lsum / cnt;
+  out4[2 + mm] = accsum / nimg;
+}
+
+__global__ void joint_pixels_kernel(const float* __restrict__ j2d, int n, int h,
+                                    int64_t* __restrict__ pix) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  // (original_joints2d // 4).long() clamped to [0, h-1]  (contrast_trainer.py:757-761)
+  int r = (int)floorf(j2d[2 * e] / 4.f), c = (int)floorf(j2d[2 * e + 1] / 4.f);
+  r = min(max(r, 0), h - 1);
+  c = min(max(c, 0), h - 1);
+  pix[e] = (int64_t)r * h + c;
+}
+
+// ---- workspace carving (all regions 16-byte aligned) --------------------------------------
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  template <class T>
+  T* take(size_t n) {
+    const size_t o = off;
+    off += (n * sizeof(T) + 15) & ~(size_t)15;
+    return base ? reinterpret_cast<T*>(base + o) : nullptr;
+  }
+};
+
+struct DenseWs {
+  float *F, *invn, *stat, *rowloss, *rowcorrect, *dX, *gscale;
+  int* meta;
+  size_t bytes;
+};
+DenseWs carve_dense(void* ws, int B, int S) {
+  Carver c(ws);
+  DenseWs o;
+  const size_t rows = (size_t)B * S;
+  o.F = c.take<float>(2 * rows * kC);
+  o.dX = c.take<float>(2 * rows * kC);
+  o.invn = c.take<float>(2 * rows);
+  o.stat = c.take<float>(2 * rows * 4);
+  o.rowloss = c.take<float>(2 * rows);
+  o.rowcorrect = c.take<float>(2 * rows);
+  o.meta = c.take<int>(rows);
+  o.gscale = c.take<float>(4);
+  o.bytes = c.off;
+  return o;
+}
+struct SclWs {
+  float *F, *invn, *stat, *rowloss, *rowcorrect, *dX, *gscale;
+  int* meta;
+  size_t bytes;
+};
+SclWs carve_scl(void* ws, int B, int J) {
+  Carver c(ws);
+  SclWs o;
+  const size_t rows = (size_t)B * J;
+  o.F = c.take<float>(2 * rows * kC);
+  o.dX = c.take<float>(2 * rows * kC);
+  o.invn = c.take<float>(2 * rows);
+  o.stat = c.take<float>(2 * rows * 4);
+  o.rowloss = c.take<float>(2 * rows);
+  o.rowcorrect = c.take<float>(2 * rows);
+  o.meta = c.take<int>(2 * rows);
+  o.gscale = c.take<float>(4);
+  o.bytes = c.off;
+  return o;
+}
+struct JointWs {
+  float *part, *dX;
+  size_t bytes;
+};
+JointWs carve_joint(void* ws, int B, int J) {
+  Carver c(ws);
+  JointWs o;
+  o.part = c.take<float>((size_t)B * 6);
+  o.dX = c.take<float>((size_t)2 * B * J * kC);
+  o.bytes = c.off;
+  return o;
+}
+
+inline MapView view(hcm_strides4 st, int w) { return MapView{st.sN, st.sC, st.sH, st.sW, w}; }
+
+}  // namespace
+
+extern "C" {
+
+size_t hcm_dense_soft_nce_workspace_bytes(int B, int S, int C) {
+  (void)C;
+  return carve_dense(nullptr, B, S).bytes;
+}
+
+int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h,
+                       int w, const int64_t* sample_ind, const int32_t* keep, int S,
+                       float temperature, float* out4, float* gmap1, float* gmap2, void* workspace,
+                       size_t workspace_bytes, hcm_stream_t stream) {
+  if (C != kC || B <= 0 || S <= 0 || h <= 0 || w <= 0 || !(temperature > 0.f) || keep == nullptr)
+    return (int)hipErrorInvalidValue;
+  const DenseWs ws = carve_dense(workspace, B, S);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = B * S;
+  const MapView mv = view(st, w);
+  dense_prep_kernel<<<(rows + 255) / 256, 256, 0, s>>>(keep, B, S, sample_ind, ws.meta, ws.gscale);
+  HCM_CHECK_LAUNCH();
+  gather_norm_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(map1, map2, mv, sample_ind, S, rows,
+                                                             keep, ws.F, ws.invn);
+  HCM_CHECK_LAUNCH();
+  StripArgs a;
+  a.F = ws.F; a.invn = ws.invn; a.meta = ws.meta; a.keep = keep; a.S = S; a.nbatch = B;
+  a.symmetric = 0; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
+  a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
+  const dim3 grid((S + 63) / 64, B, 2);
+  DensePolicy pol{w};
+  strip_kernel<DensePolicy, false><<<grid, kWG, 0, s>>>(a, pol);
+  HCM_CHECK_LAUNCH();
+  strip_kernel<DensePolicy, true><<<grid, kWG, 0, s>>>(a, pol);
+  HCM_CHECK_LAUNCH();
+  dense_finish_kernel<<<1, kWG, 0, s>>>(ws.rowloss, ws.rowcorrect, keep, B, S, ws.gscale, out4);
+  HCM_CHECK_LAUNCH();
+  scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, sample_ind, S, rows, keep, mv,
+                                                              gmap1, gmap2);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t hcm_scl_workspace_bytes(int B, int J, int C) {
+  (void)C;
+  return carve_scl(nullptr, B, J).bytes;
+}
+
+int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+            const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+            float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+            size_t workspace_bytes, hcm_stream_t stream) {
+  if (C != kC || B <= 0 || J <= 0 || J > 0xffff || h <= 0 || w <= 0 || !(temperature > 0.f) ||
+      use_depth == nullptr)
+    return (int)hipErrorInvalidValue;
+  const SclWs ws = carve_scl(workspace, B, J);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = B * J, N = 2 * rows;
+  const MapView mv = view(st, w);
+  scl_prep_kernel<<<(N + 255) / 256, 256, 0, s>>>(use_depth, use_rgb, B, J, ws.meta, ws.gscale);
+  HCM_CHECK_LAUNCH();
+  gather_norm_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(map1, map2, mv, pix, J, rows, nullptr,
+                                                             ws.F, ws.invn);
+  HCM_CHECK_LAUNCH();
+  StripArgs a;
+  a.F = ws.F; a.invn = ws.invn; a.meta = ws.meta; a.keep = nullptr; a.S = J; a.nbatch = B;
+  a.symmetric = 1; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
+  a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
+  const dim3 grid((N + 63) / 64, 1, 1);
+  SclPolicy pol;
+  strip_kernel<SclPolicy, false><<<grid, kWG, 0, s>>>(a, pol);
+  HCM_CHECK_LAUNCH();
+  strip_kernel<SclPolicy, true><<<grid, kWG, 0, s>>>(a, pol);
+  HCM_CHECK_LAUNCH();
+  scl_finish_kernel<<<1, kWG, 0, s>>>(ws.rowloss, N, ws.gscale, out1);
+  HCM_CHECK_LAUNCH();
+  scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, pix, J, rows, nullptr, mv,
+                                                              gmap1, gmap2);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t hcm_joint_nce_workspace_bytes(int B, int J, int C) {
+  (void)C;
+  return carve_joint(nullptr, B, J).bytes;
+}
+
+int hcm_joint_nce(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                  const float* feat3, const int64_t* pix, const int32_t* joints_vis,
+                  const int32_t* use_depth, int J, float temperature, float* out4, float* gmap1,
+                  float* gmap2, float* gfeat3, void* workspace, size_t workspace_bytes,
+                  hcm_stream_t stream) {
+  if (C != kC || B <= 0 || J <= 0 || J > kJMax || h <= 0 || w <= 0 || !(temperature > 0.f))
+    return (int)hipErrorInvalidValue;
+  const JointWs ws = carve_joint(workspace, B, J);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const MapView mv = view(st, w);
+  const size_t lds = (size_t)(6 * J * kLS + 2 * J * (J + 1) + 6 * J) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(joint_nce_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  joint_nce_kernel<<<B, kWG, lds, s>>>(map1, map2, mv, feat3, pix, joints_vis, use_depth, B, J,
+                                       (float)(1.0 / (double)temperature), ws.part, ws.dX, gfeat3);
+  HCM_CHECK_LAUNCH();
+  joint_finish_kernel<<<1, 64, 0, s>>>(ws.part, B, out4);
+  HCM_CHECK_LAUNCH();
+  const int rows = B * J;
+  scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, pix, J, rows, nullptr, mv,
+                                                              gmap1, gmap2);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_joint_pixels(const float* joints2d, int BJ, int h, int64_t* pix, hcm_stream_t stream) {
+  if (BJ <= 0 || h <= 0) return (int)hipErrorInvalidValue;
+  joint_pixels_kernel<<<(BJ + 255) / 256, 256, 0, (hipStream_t)stream>>>(joints2d, BJ, h, pix);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -255,6 +255,10 @@ def _dense_map(t):
 
 def joint_pixels(joints2d, h):
     """pix [B,J] int64 = clamp(floor(j/4),0,h-1) row-major (contrast_trainer.py:757-761)."""
+    if joints2d.dtype == torch.float64:
+        # the loader yields doubles (datasets/dataset.py:594-596) and the reference floor-divides in
+        # that dtype; floor first so the fp32 hand-off cannot move a value across a multiple of 4
+        joints2d = torch.floor(joints2d / 4) * 4
     j = joints2d.to(torch.float32).contiguous()
     B, J = j.shape[:2]
     pix = torch.empty(B, J, dtype=torch.int64, device=j.device)

@@ -337,7 +337,7 @@ def joint_nce(map1, map2, feat3, joints2d, joints_vis, temperature, use_depth=No
         diag = ls[:, ar, ar]                                          # [B,j]
         if cnt == 0:
             losses.append(torch.tensor(float('nan'), dtype=dt))
-            dA = torch.full_like(A, float('nan'))
+            dA = torch.zeros_like(A)        # nll_loss backward: ignored targets get 0, so do all of them
         else:
             losses.append(-(diag * v).sum() / cnt)
             onehot = torch.eye(J, dtype=dt).expand(B, J, J)
