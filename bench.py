@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the HCMoCo contrastive pre-training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+            --master-port P bench.py --gpus N --steps K --warmup W)
+
+A "step" = one full second-stage training step (BASELINE.json configs[1]) on a synthetic batch
+already resident in HBM: 2x HRNet-w18 + SemGCN forward, packed feature/index all-gather, fused
+memory-bank NCE (K=16384 negatives per sample out of three 131072x128 banks), dense
+intra-sample soft-InfoNCE (S=400), joint<->graph InfoNCE and cross-subject SCL (J=17), backward,
+SGD step, momentum bank update.  fp32 throughout (the reference's arithmetic).  Rank 0 prints ONE
+JSON line; `value` is whole-job samples/s = B*N*K / max-over-ranks(time of K steps).
+
+roofline    : the dominant hand-written kernel (the bank gather pass, HBM-bound).  `achieved` =
+              algorithmic bytes per launch / mean launch duration measured with hipEvents placed
+              around that kernel, on its stream, INSIDE the timed steps (hcm_prof_enable/read).
+cpu_baseline: the same training step on the host CPU (model in torch-CPU, losses by the oracle =
+              a port of the reference math), rank 0 / N=1 only, on a bounded sample (2 timed
+              steps at batch 8), all host threads.  A reported baseline, never the thing measured.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps):
+    from hcmoco_amd.pycontrast.options.train_options import TrainOptions
+    argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18',
+            '--in_channel_list', '3,3', '--linear_feat_map', '1', '--modality_missing', '1',
+            '--pri3d_num_samples_per_image', '400', '--temperature', '0.07', '--nce_k', str(nce_k),
+            '--nce_m', '0.5', '--batch_size', str(batch_global), '--skeleton_meta_name', skeleton,
+            '--learning_rate', '0.03', '--dist-backend', backend, '--synthetic',
+            '--synthetic_n_data', str(n_data), '--synthetic_size', str(size), '--synthetic_steps', str(steps),
+            '--model_path', tmp, '--tb_path', tmp, '--seed', '0', '--print_freq', '1000000']
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return TrainOptions().parse(argv)
+
+
+def build(args, trainer, engine_device):
+    from hcmoco_amd.pycontrast.networks.build_backbone import build_model
+    from hcmoco_amd.pycontrast.memory.build_memory import build_mem
+    from hcmoco_amd.pycontrast.datasets.synthetic import build_synthetic_contrast_loader
+    torch.manual_seed(0)
+    model, _ = build_model(args)
+    data, loader, _ = build_synthetic_contrast_loader(args, engine_device, args.rank, args.world_size)
+    contrast = build_mem(args, len(data))
+    contrast.to(engine_device)
+    opt = torch.optim.SGD(model.parameters(), lr=args.learning_rate, momentum=args.momentum,
+                          weight_decay=args.weight_decay)
+    model, _, opt = trainer.wrap_up(model, None, opt)
+    trainer.broadcast_memory(contrast)
+    model.train()
+    return model, contrast, opt, data
+
+
+def cpu_baseline(nce_k, n_data, size, skeleton, batch=8, steps=2):
+    """Bounded CPU leg: same step, same config, batch 8, oracle losses.  ~10-30 s of CPU work."""
+    import tempfile
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    from oracle.oracle_engine import OracleLossEngine       # oracle = checker/baseline only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    args = make_args(batch, nce_k, n_data, size, skeleton, 'gloo', tempfile.mkdtemp(), steps + 1)
+    args.rank, args.world_size, args.local_rank, args.channels_last = 0, 1, 0, False
+    trainer = ContrastTrainer(args, engine=OracleLossEngine())
+    trainer.device = torch.device('cpu')
+    model, contrast, opt, data = build(args, trainer, 'cpu')
+    it = iter(data)
+    trainer.train_step(next(it), model, contrast, opt, stage2=True)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_step(next(it), model, contrast, opt, stage2=True)
+    dt = time.perf_counter() - t0
+    return {'value': round(batch * steps / dt, 3), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed steps (after 1 warm-up) of the same stage-2 step at batch %d, K=%d, %dx%d, '
+                      'torch-CPU model + oracle losses, %d threads' % (steps, batch, nce_k, size, size, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch_per_gpu', type=int, default=32)
+    ap.add_argument('--nce_k', type=int, default=16384)
+    ap.add_argument('--n_data', type=int, default=131072)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--skeleton', type=str, default='coco17')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
+    ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dev = torch.device('cuda', torch.cuda.current_device())
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world)        # RCCL over xGMI
+
+    import tempfile
+    from hcmoco_amd import hip_ops
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    B = a.batch_per_gpu
+    args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, 'nccl', tempfile.mkdtemp(),
+                     a.steps + a.warmup)
+    args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
+    args.channels_last = bool(a.channels_last)
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    trainer = ContrastTrainer(args)                                          # HIP loss engine
+    trainer.device = dev
+    model, contrast, opt, data = build(args, trainer, dev)
+
+    it = iter(data)
+    for _ in range(a.warmup):
+        trainer.train_step(next(it), model, contrast, opt, stage2=True)
+    hip_ops.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = trainer.train_step(next(it), model, contrast, opt, stage2=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = hip_ops.prof_read()
+    hip_ops.prof_enable(False)
+    tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+    dt = float(tdt.item())
+    loss = float(last['loss'].item())
+    if not (loss == loss):
+        raise SystemExit('non-finite loss in the timed region')
+
+    if rank == 0:
+        K1, D = a.nce_k + 1, 128
+        # algorithmic bytes of one gather pass: 3 gathered rows + the int64 row index
+        # per (sample, negative), plus the 3 query rows and 3 gradient rows per sample
+        bytes_per_sample = 3 * K1 * D * 4 + K1 * 8 + 12 * D * 4
+        bytes_per_launch = B * bytes_per_sample
+        avg_ms = kern_ms / max(kern_n, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None
+        out = {
+            'metric': 'pretrain samples/sec (RGB+depth+kpt triples) HRNet-w18',
+            'value': round(B * world * a.steps / dt, 3), 'unit': 'samples/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(1e3 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'second-stage HCMoCo step (bank NCE + dense + joint + SCL losses, fwd+bwd+SGD+bank '
+                                   'update), HRNet-w18 x2 + SemGCN, %dx%d RGB+depth+%s keypoints'
+                                   % (a.size, a.size, a.skeleton),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
+                       'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
+                       'channels_last': bool(a.channels_last), 'final_loss': round(loss, 4)},
+            'roofline': {'kernel': 'bank_pass_kernel<2,fused> (gather + 6 logit sets + online softmax + d/dx)',
+                         'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': None, 'bytes_per_launch': bytes_per_launch,
+                         'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

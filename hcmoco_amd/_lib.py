@@ -56,6 +56,8 @@ SIGNATURES = {
     'hcm_three_nn': (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_three_interpolate': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_three_interpolate_grad': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'hcm_prof_enable': (_i, [_i]),
+    'hcm_prof_read': (_i, [_p, _p]),
 }
 
 _lib = None

@@ -144,6 +144,18 @@ def bank_nce_fused_timed(banks, idx, xs, T, reps, use_depth=None):
     return float(ms.value)
 
 
+def prof_enable(on):
+    """Start/stop (and clear) hipEvent timing of the fused gather pass inside the library."""
+    check(_lib.lib().hcm_prof_enable(1 if on else 0), 'hcm_prof_enable')
+
+
+def prof_read():
+    """(total ms, launches) of the gather-pass kernel since prof_enable(True); synchronises."""
+    total, n = C.c_double(0.0), C.c_int64(0)
+    check(_lib.lib().hcm_prof_read(C.byref(total), C.byref(n)), 'hcm_prof_read')
+    return float(total.value), int(n.value)
+
+
 # --------------------------------------------------------------------------- #
 # API mode: materialised logits (the literal CMCMem3.forward contract)
 # --------------------------------------------------------------------------- #

@@ -1,0 +1,261 @@
+"""Contrastive pre-training loops (first stage: bank NCE; second stage: + dense, joint, SCL losses).
+
+Host-side mirror of /root/reference/pycontrast/learning/contrast_trainer.py -- same public
+methods (``wrap_up, broadcast_memory, resume_model, save, train, logging``), same checkpoint
+layout and the same positional batch tuple -- around a loss engine whose
+product implementation is the HIP kernels of this repo (learning/engine.py).
+
+What changed relative to the reference, and why:
+  * one packed all-gather per step ([B, 386] floats: features + bit-cast index) instead of two;
+  * all three banks are broadcast at start-up (the reference forgets ``memory_3``);
+  * meters stay on the device; the host syncs only every ``print_freq`` steps (reference: 13/step);
+  * ``use_depth is None`` means "every sample has depth" and ``use_rgb is None`` "every sample has
+    RGB" in the SCL loss (learning/segment_trainer.py:601-606); the reference crashes there.
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from .base_trainer import BaseTrainer
+from .engine import HipLossEngine
+from .util import AverageMeter
+
+
+class ContrastTrainer(BaseTrainer):
+    def __init__(self, args, engine=None):
+        super().__init__(args)
+        self.engine = engine if engine is not None else HipLossEngine()
+
+    # ------------------------------------------------------------------ set-up / bookkeeping
+    def logging(self, epoch, logs, lr):
+        if self.args.rank != 0:
+            return
+        names = ('loss', 'acc', 'jig_loss', 'jig_acc')
+        if self.logger is not None:
+            for name, v in zip(names, logs):
+                self.logger.log_value(name, v, epoch)
+            self.logger.log_value('learning_rate', lr, epoch)
+        else:
+            print('epoch {} '.format(epoch) + ' '.join('{} {:.4f}'.format(n, v) for n, v in zip(names, logs)) +
+                  ' learning_rate {:.6f}'.format(lr))
+
+    def wrap_up(self, model, model_ema, optimizer):
+        args = self.args
+        model.to(self.device)
+        if getattr(args, 'channels_last', False):
+            model.to(memory_format=torch.channels_last)
+        if isinstance(model_ema, torch.nn.Module):
+            model_ema.to(self.device)
+        if args.amp:
+            raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            ids = [self.device.index] if self.device.type == 'cuda' else None
+            model = DDP(model, device_ids=ids, gradient_as_bucket_view=True)
+        if isinstance(model_ema, torch.nn.Module):
+            self.momentum_update(self.unwrap(model), model_ema, 0)
+        return model, model_ema, optimizer
+
+    @staticmethod
+    def unwrap(model):
+        return model.module if isinstance(model, DDP) else model
+
+    def broadcast_memory(self, contrast):
+        """rank 0's banks everywhere -- all of them (contrast_trainer.py:81-91 skips memory_3)."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        for name, buf in contrast.named_buffers():
+            dist.broadcast(buf, 0)
+
+    def _model_state(self, model):
+        """'module.'-prefixed keys whether or not DDP wraps the model (main_contrast.py:57-58 and
+        transfer_ckpt.py strip that 7-character prefix)."""
+        sd = model.state_dict()
+        return sd if isinstance(model, DDP) else {'module.' + k: v for k, v in sd.items()}
+
+    def _load_model_state(self, model, sd):
+        if not isinstance(model, DDP):
+            sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+        model.load_state_dict(sd)
+
+    def resume_model(self, model, model_ema, contrast, optimizer):
+        args = self.args
+        start_epoch = 1
+        if args.resume:
+            if os.path.isfile(args.resume):
+                ckpt = torch.load(args.resume, map_location='cpu')
+                start_epoch = ckpt['epoch'] + 1
+                self._load_model_state(model, ckpt['model'])
+                contrast.load_state_dict(ckpt['contrast'])
+                optimizer.load_state_dict(ckpt['optimizer'])
+                if isinstance(model_ema, torch.nn.Module):
+                    model_ema.load_state_dict(ckpt['model_ema'])
+                print("=> resume successfully '{}' (epoch {})".format(args.resume, ckpt['epoch']))
+                del ckpt
+            else:
+                print("=> no checkpoint found at '{}'".format(args.resume))
+        return start_epoch
+
+    def save(self, model, model_ema, contrast, optimizer, epoch):
+        args = self.args
+        if args.local_rank != 0:
+            return
+        print('==> Saving...')
+        state = {'model': self._model_state(model), 'contrast': contrast.state_dict(),
+                 'optimizer': optimizer.state_dict(), 'epoch': epoch}
+        if isinstance(model_ema, torch.nn.Module):
+            state['model_ema'] = model_ema.state_dict()
+        torch.save(state, os.path.join(args.model_folder, 'current.pth'))
+        if epoch % args.save_freq == 0:
+            torch.save(state, os.path.join(args.model_folder, 'ckpt_epoch_{}.pth'.format(epoch)))
+
+    # ------------------------------------------------------------------ collectives
+    @staticmethod
+    def _global_gather(x):
+        """reference helper (contrast_trainer.py:160-165), kept for API users."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return x
+        out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, x.contiguous())
+        return torch.cat(out, dim=0)
+
+    @staticmethod
+    def pack_features(f, index):
+        """[B, D3] fp32 + [B] int64 -> [B, D3+2] fp32 (the index travels bit-cast in two floats)."""
+        tail = index.to(torch.int64).contiguous().view(torch.int32).view(-1, 2).view(torch.float32)
+        return torch.cat([f.detach().to(torch.float32), tail], dim=1).contiguous()
+
+    @staticmethod
+    def unpack_features(packed):
+        f = packed[:, :-2]
+        index = packed[:, -2:].contiguous().view(torch.int32).view(-1).view(torch.int64)
+        return f, index
+
+    def _packed_gather(self, f, index):
+        """One collective per step; rank-major row order (it defines the duplicate-update winner)."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return f.detach(), index
+        mine = self.pack_features(f, index)
+        out = torch.empty(dist.get_world_size() * mine.shape[0], mine.shape[1], dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(out, mine)
+        return self.unpack_features(out)
+
+    # ------------------------------------------------------------------ one training step
+    def _to_dev(self, t):
+        return t.to(self.device, non_blocking=True) if isinstance(t, torch.Tensor) else t
+
+    def train_step(self, data, model, contrast, optimizer, stage2):
+        """Forward, losses, backward, SGD step, bank update for one batch tuple.
+        Returns a dict of DEVICE scalars (no host sync)."""
+        args = self.args
+        inputs = self._to_dev(data[0]).float()
+        index = self._to_dev(data[1])
+        skeleton = self._to_dev(data[2])
+        use_depth = self._to_dev(data[6]) if args.modality_missing else None
+        use_rgb = self._to_dev(data[11]) if len(data) > 11 else None
+        if getattr(args, 'channels_last', False):
+            inputs = inputs.contiguous(memory_format=torch.channels_last)
+
+        if stage2:
+            _feat1, _feat2, _feat3, f, aux = model(inputs, skeleton, return_fm=True)
+        else:
+            f = model(inputs, skeleton)
+        all_f, all_index = self._packed_gather(f, index)
+        f1, f2, f3 = torch.chunk(f, 3, dim=1)
+        all_f1, all_f2, all_f3 = torch.chunk(all_f, 3, dim=1)
+
+        out = {}
+        if stage2:      # stage 2 hands only use_depth to the bank CE (contrast_trainer.py:965-967)
+            total, losses, accs = self.engine.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+                                                   use_depth=use_depth)
+            fm_total, meters = self.engine.fmap(
+                aux['linear_merge1'], aux['linear_merge2'], _feat3, self._to_dev(data[7]),
+                self._to_dev(data[4]), self._to_dev(data[5]), use_depth, use_rgb,
+                args.pri3d_num_samples_per_image, args.temperature)
+            loss = total + fm_total
+            out['fmap'] = meters
+        else:           # stage 1 (contrast_trainer.py:592-594)
+            total, losses, accs = self.engine.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+                                                   use_depth=use_depth, use_rgb=use_rgb)
+            loss = total
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+        out.update(loss=loss.detach(), bank_losses=losses, bank_accs=accs)
+        return out
+
+    # ------------------------------------------------------------------ epoch loops
+    def train(self, epoch, train_loader, model, model_ema, contrast, criterion, optimizer):
+        args = self.args
+        model.train()
+        t0 = time.time()
+        if args.mem == 'moco':
+            raise NotImplementedError('the MoCo training loop needs the RGB/CMC ResNet models, which are '
+                                      'outside this build (SURVEY 0-1); the queue module itself is in memory/mem_moco.py')
+        if args.mem == 'bank':
+            outs = self._train_mem_skeleton3d(epoch, train_loader, model, contrast, criterion, optimizer)
+        elif args.mem == 'bank+jointspri3d':
+            outs = self._train_bank_joints_pri3d_cmc3(epoch, train_loader, model, contrast, None, None, optimizer)
+        else:
+            raise NotImplementedError(args.mem)
+        print('epoch {}, total time {:.2f}'.format(epoch, time.time() - t0))
+        return outs
+
+    def _run_epoch(self, epoch, train_loader, model, contrast, optimizer, stage2):
+        args = self.args
+        model.train()
+        bt, dt = AverageMeter(), AverageMeter()
+        loss_m = AverageMeter()
+        acc_m = [AverageMeter() for _ in range(3)]
+        pair_loss_m = [AverageMeter() for _ in range(3)]
+        fmap_m = [AverageMeter() for _ in range(9)]
+        end = time.time()
+        nb = len(train_loader)
+        for idx, data in enumerate(train_loader):
+            dt.update(time.time() - end)
+            bsz = data[0].size(0)
+            self.warmup_learning_rate(epoch, idx, nb, optimizer)
+            out = self.train_step(data, model, contrast, optimizer, stage2)
+            loss_m.update(out['loss'], bsz)
+            for k in range(3):   # pairs (12,21) (23,32) (13,31) averaged like the reference (:982-987)
+                acc_m[k].update(0.5 * (out['bank_accs'][2 * k] + out['bank_accs'][2 * k + 1]), bsz)
+                pair_loss_m[k].update(0.5 * (out['bank_losses'][2 * k] + out['bank_losses'][2 * k + 1]), bsz)
+            if stage2:
+                for k in range(9):
+                    fmap_m[k].update(out['fmap'][k], bsz)
+            bt.update(time.time() - end)
+            end = time.time()
+            if args.local_rank == 0 and (idx + 1) % args.print_freq == 0:
+                msg = ('Train: [{0}][{1}/{2}]\tBT {3:.3f} ({4:.3f})\tDT {5:.3f} ({6:.3f})\tL {7:.3f} ({8:.3f})\t'
+                       'a_I {9:.3f} {10:.3f} {11:.3f}').format(epoch, idx + 1, nb, bt.val, bt.avg, dt.val, dt.avg,
+                                                            loss_m.val, loss_m.avg, acc_m[0].avg, acc_m[1].avg,
+                                                            acc_m[2].avg)
+                if stage2:
+                    f = [m.avg for m in fmap_m]
+                    msg += ('\tp3d {0:.3f} {2:.3f} {1:.3f} {3:.3f}\tj {4:.3f} {6:.3f} {5:.3f} {7:.3f}\tscl {8:.3f}'
+                            .format(*f))
+                print(msg)
+                sys.stdout.flush()
+        return loss_m, acc_m, pair_loss_m
+
+    def _train_mem_skeleton3d(self, epoch, train_loader, model, contrast, criterion, optimizer):
+        """stage 1 (contrast_trainer.py:532-640): returns the six per-pair meters."""
+        assert not self.args.jigsaw
+        _, acc_m, pl = self._run_epoch(epoch, train_loader, model, contrast, optimizer, stage2=False)
+        return pl[0].avg, acc_m[0].avg, pl[1].avg, acc_m[1].avg, pl[2].avg, acc_m[2].avg
+
+    def _train_bank_joints_pri3d_cmc3(self, epoch, train_loader, model, contrast, criterion_contrast,
+                                      criterion_pri3d, optimizer):
+        """stage 2 (contrast_trainer.py:894-1039): (loss, acc12, jig_loss=0, jig_acc=0)."""
+        loss_m, acc_m, _ = self._run_epoch(epoch, train_loader, model, contrast, optimizer, stage2=True)
+        return loss_m.avg, acc_m[0].avg, 0.0, 0.0
+
+    @staticmethod
+    def momentum_update(model, model_ema, m):
+        """model_ema = m * model_ema + (1 - m) * model (contrast_trainer.py:1041-1045)."""
+        with torch.no_grad():
+            for p1, p2 in zip(model.parameters(), model_ema.parameters()):
+                p2.mul_(m).add_(p1.detach(), alpha=1 - m)

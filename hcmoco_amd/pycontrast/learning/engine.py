@@ -1,0 +1,49 @@
+"""Loss engine of the contrastive trainer: the seam between host code and the HIP kernels.
+
+``HipLossEngine`` is the product path: every method lands in ``libhcmoco_hip.so`` through
+``hcmoco_amd.hip_ops`` and raises on CPU tensors / a missing library.  The trainer only talks to
+this interface, which is what lets the CPU test-suite drive the same training loop with an
+oracle-backed engine (oracle/oracle_engine.py) without the product ever importing the oracle.
+"""
+import torch
+import torch.nn.functional as F
+
+from ... import hip_ops
+
+
+class HipLossEngine(object):
+    name = 'hip'
+
+    # ---- SURVEY 8a rows 1-4 -------------------------------------------------------------
+    def bank(self, contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+             use_depth=None, use_rgb=None, idx=None):
+        """-> (total, losses[6], accs[6]); updates the banks in place after the reads."""
+        return contrast.forward_loss(f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+                                     use_depth=use_depth, use_rgb=use_rgb, idx=idx)
+
+    # ---- sampling shared by rows 5-7 (host-side torch glue, stream ordered, no sync) ----------
+    @staticmethod
+    def dense_samples(depth_mask, h, w, num_samples, use_depth=None, generator=None):
+        """Pixel sampling of _compute_soft_pri3d_loss_accuracy (contrast_trainer.py:671-685):
+        nearest-resize the mask, keep images whose resized mask is non-empty, draw S pixels per
+        kept image with replacement.  Dropped images get placeholder indices and keep=0."""
+        m = F.interpolate(depth_mask.unsqueeze(1).float(), size=(h, w), mode='nearest').reshape(depth_mask.shape[0], h * w)
+        keep = m.sum(-1) > 0
+        if use_depth is not None:                       # reference early return (:663-665)
+            keep = keep & (use_depth.sum() > 0)
+        weights = m + (~keep).unsqueeze(1).to(m.dtype)  # all-ones rows for dropped images: never read
+        ind = torch.multinomial(weights, num_samples, replacement=True, generator=generator)
+        return ind, keep.to(torch.int32)
+
+    # ---- SURVEY 8a rows 5-7 -------------------------------------------------------------
+    def fmap(self, map1, map2, feat3, depth_mask, joints2d, joints_vis, use_depth, use_rgb,
+             num_samples, temperature, sample_ind=None, keep=None):
+        """-> (total, meters[9]) for the dense, joint and SCL losses (contrast_trainer.py:969-980).
+        meters = [loss_r2d, loss_d2r, acc_r2d, acc_d2r, loss_rgb2j, loss_d2j, acc_rgb2j, acc_d2j, loss_scl]."""
+        B, C, h, w = map1.shape
+        assert h == w                                   # contrast_trainer.py:751
+        if sample_ind is None:
+            sample_ind, keep = self.dense_samples(depth_mask, h, w, num_samples, use_depth)
+        pix = hip_ops.joint_pixels(joints2d, h)
+        ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=map1.device)
+        return hip_ops.fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, ud, use_rgb, temperature)

@@ -1,0 +1,12 @@
+"""``build_mem(opt, n_data)`` (reference: /root/reference/pycontrast/memory/build_memory.py:5-17)."""
+from .mem_bank import CMCMem3
+from .mem_moco import RGBMoCo, CMCMoCo
+
+
+def build_mem(opt, n_data):
+    if opt.mem.startswith('bank'):
+        return CMCMem3(opt.feat_dim, n_data, opt.nce_k, opt.nce_t, opt.nce_m)
+    if opt.mem == 'moco':
+        mem_func = RGBMoCo if opt.modal == 'RGB' else CMCMoCo
+        return mem_func(opt.feat_dim, opt.nce_k, opt.nce_t)
+    raise NotImplementedError('mem not suported: {}'.format(opt.mem))

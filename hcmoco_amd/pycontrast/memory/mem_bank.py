@@ -1,0 +1,73 @@
+"""Three-modality instance-discrimination memory bank.
+
+Reference: /root/reference/pycontrast/memory/mem_bank.py:157-205 (``CMCMem3``), :15-40
+(``BaseMem``).  Same constructor, buffers (``memory_1/2/3`` [n_data, n_dim], L2-normalised randn),
+``forward`` signature and return tuple.  Two ways in:
+
+``forward(...)``        the literal reference contract: six materialised logit tensors + labels,
+                        differentiable through ``x1..x3`` (HIP kernels ``hcm_bank_logits_fwd/bwd``).
+``forward_loss(...)``   what this build's trainer uses: the fused kernel computes the six
+                        cross-entropy losses, accuracies and d/dx in one pass over the gathered
+                        rows and never materialises a logit (``hcm_bank_nce_fused``).
+
+Both draw the K negatives with ``AliasMethod`` on the device, place the positive in column 0 and
+apply the momentum update AFTER the reads (mem_bank.py:195-203).  ``idx=`` injects the row
+indices explicitly (parity mode).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import hip_ops
+from .alias_multinomial import AliasMethod
+
+
+class BaseMem(nn.Module):
+    def __init__(self, K=65536, T=0.07, m=0.5):
+        super().__init__()
+        self.K, self.T, self.m = K, T, m
+
+
+class CMCMem3(BaseMem):
+    def __init__(self, n_dim, n_data, K=65536, T=0.07, m=0.5, seed=None):
+        super().__init__(K, T, m)
+        self.n_dim, self.n_data = n_dim, n_data
+        self.multinomial = AliasMethod(torch.ones(n_data), seed=seed)
+        for name in ('memory_1', 'memory_2', 'memory_3'):
+            self.register_buffer(name, F.normalize(torch.randn(n_data, n_dim)))
+
+    # nn.Module.cuda()/.to() move the buffers; the sampler tables follow
+    def _apply(self, fn):
+        super()._apply(fn)
+        self.multinomial.to(self.memory_1.device)
+        return self
+
+    def banks(self):
+        return [self.memory_1, self.memory_2, self.memory_3]
+
+    def _indices(self, y, idx):
+        if idx is not None:
+            assert idx.shape == (y.shape[0], self.K + 1)
+            return idx.contiguous()
+        return self.multinomial.draw_with_positive(y, self.K + 1)
+
+    def _update(self, x1, x2, x3, y, all_x1, all_x2, all_x3, all_y):
+        if all_x1 is not None and all_x2 is not None and all_x3 is not None and all_y is not None:
+            hip_ops.bank_update(self.banks(), [all_x1, all_x2, all_x3], all_y, self.m)
+        else:
+            hip_ops.bank_update(self.banks(), [x1, x2, x3], y, self.m)
+
+    def forward(self, x1, x2, x3, y, all_x1=None, all_x2=None, all_x3=None, all_y=None, idx=None):
+        idx = self._indices(y, idx)
+        logits = hip_ops.bank_logits([x1, x2, x3], self.banks(), idx, self.T)
+        labels = torch.zeros(x1.shape[0], dtype=torch.long, device=x1.device)
+        self._update(x1, x2, x3, y, all_x1, all_x2, all_x3, all_y)
+        return logits[0], logits[1], logits[2], logits[3], logits[4], logits[5], labels
+
+    def forward_loss(self, x1, x2, x3, y, all_x1=None, all_x2=None, all_x3=None, all_y=None,
+                     use_depth=None, use_rgb=None, idx=None):
+        """-> (total, losses[6], accs[6]); total = sum(losses) is differentiable in x1..x3."""
+        idx = self._indices(y, idx)
+        total, losses, accs = hip_ops.bank_nce_fused([x1, x2, x3], self.banks(), idx, self.T, use_depth, use_rgb)
+        self._update(x1, x2, x3, y, all_x1, all_x2, all_x3, all_y)
+        return total, losses, accs

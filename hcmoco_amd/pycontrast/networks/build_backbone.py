@@ -1,0 +1,123 @@
+"""Encoder plugin surface: ``build_model(opt) -> (model, model_ema)``.
+
+Reference: /root/reference/pycontrast/networks/build_backbone.py:186-303 (RGBD2S HRNet model),
+:516-566 (registry + factory).  Registry key = ``opt.modal + opt.arch + ('Mul' if jigsaw else
+'Sin')``; constructors take the same positional arguments; ``state_dict`` top-level names are
+``encoder1, encoder2, encoder3, head1-3, encoder1_linear, encoder2_linear``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .hrnet import HighResolutionNet
+from .sgcn import create_sgcn
+from .util import Normalize
+
+
+class CMC3HRNetSGCNSingleHead(nn.Module):
+    """RGB HRNet + depth HRNet + SemGCN keypoint encoder, one linear+L2 head each."""
+
+    def __init__(self, name='HRNet', head='linear', feat_dim=128, in_channel_list=(3, 3, 3),
+                 linear_feat_map=False, width=18, pool_method='mean', opt=None):
+        super().__init__()
+        assert name == 'HRNet'
+        assert pool_method in ('mean', 'max')
+        if width not in (18, 32, 48):
+            raise NotImplementedError(width)
+        if head != 'linear':
+            raise NotImplementedError('head not supported: {}'.format(head))
+        self.opt = opt
+        self.in_channel_list = list(in_channel_list)
+        self.linear_feat_map = linear_feat_map
+        self.width = width
+        self.pool_method = pool_method
+        dim_in = sum(width * 2 ** i for i in range(4))
+        sgcn_dim = 128
+        self.encoder1 = HighResolutionNet(width)
+        self.encoder2 = HighResolutionNet(width)
+        self.encoder3 = create_sgcn(opt.skeleton_meta_name, sgcn_dim, 4)
+        self.head1 = nn.Sequential(nn.Linear(dim_in, feat_dim), Normalize(2))
+        self.head2 = nn.Sequential(nn.Linear(dim_in, feat_dim), Normalize(2))
+        self.head3 = nn.Sequential(nn.Linear(sgcn_dim, feat_dim), Normalize(2))
+        if self.linear_feat_map:
+            self.encoder1_linear = nn.Conv2d(dim_in, sgcn_dim, kernel_size=1, stride=1, bias=True)
+            self.encoder2_linear = nn.Conv2d(dim_in, sgcn_dim, kernel_size=1, stride=1, bias=True)
+
+    @staticmethod
+    def merge_all_res(maps):
+        """Upsample the three coarser maps to the finest grid and concatenate (:247-254)."""
+        size = maps[0].shape[-2:]
+        ups = [maps[0]] + [F.interpolate(m, size=size, mode='bilinear', align_corners=False) for m in maps[1:]]
+        return torch.cat(ups, 1)
+
+    def _pool(self, maps):
+        red = torch.amax if self.pool_method == 'max' else torch.mean
+        return torch.cat([red(m, dim=(2, 3)) for m in maps], 1)
+
+    def forward(self, x, s, mode=0, return_fm=False):
+        """mode 0/1: projected + L2-normalised features; 2: raw pooled features (:256-303)."""
+        x1, x2 = torch.split(x, self.in_channel_list, dim=1)
+        _feat1 = self.encoder1(x1)
+        _feat2 = self.encoder2(x2)
+        _feat3 = self.encoder3(s)
+        avg1, avg2, avg3 = self._pool(_feat1), self._pool(_feat2), _feat3.mean(1)
+        if mode in (0, 1):
+            feat1, feat2, feat3 = self.head1(avg1), self.head2(avg2), self.head3(avg3)
+        else:
+            feat1, feat2, feat3 = avg1, avg2, avg3
+        f = torch.cat((feat1, feat2, feat3), dim=1)
+        if not return_fm:
+            return f
+        if self.linear_feat_map:
+            merge1, merge2 = self.merge_all_res(_feat1), self.merge_all_res(_feat2)
+            return _feat1, _feat2, _feat3, f, {
+                'merge1': merge1, 'merge2': merge2,
+                'linear_merge1': self.encoder1_linear(merge1),
+                'linear_merge2': self.encoder2_linear(merge2),
+            }
+        return _feat1, _feat2, _feat3, avg1, avg2, avg3, f
+
+
+NAME_TO_FUNC = {
+    'RGBD2SHRNetSin': CMC3HRNetSGCNSingleHead,
+}
+
+
+def register_model(key, ctor):
+    """Plugin hook: add an encoder under ``modal+arch+('Sin'|'Mul')``."""
+    NAME_TO_FUNC[key] = ctor
+
+
+def _load_encoder(encoder, path, tag):
+    print('Init {} from {}'.format(tag, path))
+    ckpt = torch.load(path, map_location='cpu')
+    own = encoder.state_dict()
+    for k, v in ckpt.items():
+        if k in own:
+            own[k] = v
+        else:
+            print('{} not matched.'.format(k))
+    encoder.load_state_dict(own)
+
+
+def build_model(opt):
+    key = opt.modal + opt.arch + ('Mul' if opt.jigsaw else 'Sin')
+    if key not in NAME_TO_FUNC:
+        raise NotImplementedError('model not supported: {}'.format(key))
+    model = NAME_TO_FUNC[key](opt.arch, opt.head, opt.feat_dim, opt.in_channel_list, opt.linear_feat_map,
+                              opt.width, opt.pool_method, opt)
+    if getattr(opt, 'IN_Pretrain', None) is not None:
+        if not opt.arch.startswith('HRNet'):
+            raise NotImplementedError
+        _load_encoder(model.encoder1, opt.IN_Pretrain, 'Encoder1')
+    if getattr(opt, 'depth_Pretrain', None) is not None:
+        if not opt.arch.startswith('HRNet'):
+            raise NotImplementedError
+        _load_encoder(model.encoder2, opt.depth_Pretrain, 'Encoder2')
+    # MoCo's momentum copy: the reference builds it without `opt` and fails for the RGBD2S models
+    # (build_backbone.py:561-562); here it gets the same options.
+    model_ema = None
+    if opt.mem == 'moco':
+        model_ema = NAME_TO_FUNC[key](opt.arch, opt.head, opt.feat_dim, opt.in_channel_list,
+                                      opt.linear_feat_map, opt.width, opt.pool_method, opt)
+    return model, model_ema

@@ -1,0 +1,201 @@
+"""HRNetV2 backbone (w18 / w32 / w48) returning the four multi-resolution maps.
+
+Encoder plugin of the pre-training path; runs on stock PyTorch-ROCm (MIOpen convolutions) -- the
+hand-written HIP kernels of this repo start where these maps are consumed.  Topology, parameter
+names (``state_dict`` keys) and initialisation follow the reference
+(/root/reference/pycontrast/networks/official_hrnet/official_hrnet.py:247-454 and its three yaml
+files), so ImageNet / first-stage checkpoints load unchanged.  The topology is a Python table
+here instead of a yacs config read from a cwd-relative yaml path (official_hrnet.py:498-503).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_MOMENTUM = 0.01                                           # official_hrnet.py:23
+
+# stage -> (modules, blocks per branch, block type); branch widths = width * 2**i
+STAGES = {
+    'stage1': dict(modules=1, branches=1, blocks=4, kind='bottleneck', planes=64),
+    'stage2': dict(modules=1, branches=2, blocks=4, kind='basic'),
+    'stage3': dict(modules=4, branches=3, blocks=4, kind='basic'),
+    'stage4': dict(modules=3, branches=4, blocks=4, kind='basic'),
+}
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+
+
+def _conv_bn(cin, cout, k, stride=1, relu=False):
+    layers = [nn.Conv2d(cin, cout, k, stride, k // 2, bias=False), _bn(cout)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = _bn(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = _bn(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + skip)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = _bn(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = _bn(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = _bn(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + skip)
+
+
+def _block_chain(block, cin, planes, n):
+    down = None
+    if cin != planes * block.expansion:
+        down = nn.Sequential(nn.Conv2d(cin, planes * block.expansion, 1, bias=False), _bn(planes * block.expansion))
+    layers = [block(cin, planes, 1, down)]
+    layers += [block(planes * block.expansion, planes) for _ in range(n - 1)]
+    return nn.Sequential(*layers)
+
+
+class HighResolutionModule(nn.Module):
+    """Parallel branches followed by full cross-resolution fusion (official_hrnet.py:108-244)."""
+
+    def __init__(self, widths, blocks):
+        super().__init__()
+        nb = len(widths)
+        self.num_branches = nb
+        self.branches = nn.ModuleList([_block_chain(BasicBlock, w, w, blocks) for w in widths])
+        self.relu = nn.ReLU(inplace=True)
+        if nb == 1:
+            self.fuse_layers = None
+            return
+        rows = []
+        for i in range(nb):
+            row = []
+            for j in range(nb):
+                if j > i:                      # coarser -> finer: 1x1 conv, upsampled in forward
+                    row.append(_conv_bn(widths[j], widths[i], 1))
+                elif j == i:
+                    row.append(None)
+                else:                          # finer -> coarser: (i-j) stride-2 3x3 convs
+                    steps = [_conv_bn(widths[j], widths[j], 3, 2, relu=True) for _ in range(i - j - 1)]
+                    steps.append(_conv_bn(widths[j], widths[i], 3, 2))
+                    row.append(nn.Sequential(*steps))
+            rows.append(nn.ModuleList(row))
+        self.fuse_layers = nn.ModuleList(rows)
+
+    def forward(self, xs):
+        xs = [br(x) for br, x in zip(self.branches, xs)]
+        if self.num_branches == 1:
+            return xs
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            y = xs[0] if i == 0 else row[0](xs[0])
+            for j in range(1, self.num_branches):
+                if j == i:
+                    y = y + xs[j]
+                elif j > i:
+                    y = y + F.interpolate(row[j](xs[j]), size=xs[i].shape[-2:], mode='bilinear')
+                else:
+                    y = y + row[j](xs[j])
+            outs.append(self.relu(y))
+        return outs
+
+
+class HighResolutionNet(nn.Module):
+    def __init__(self, width=18):
+        super().__init__()
+        self.width = width
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = _bn(64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = _bn(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = _block_chain(Bottleneck, 64, 64, 4)
+        prev = [256]
+        for s in (2, 3, 4):
+            cfg = STAGES['stage%d' % s]
+            widths = [width * 2 ** i for i in range(cfg['branches'])]
+            setattr(self, 'transition%d' % (s - 1), self._transition(prev, widths))
+            setattr(self, 'stage%d' % s, nn.Sequential(*[HighResolutionModule(widths, cfg['blocks'])
+                                                         for _ in range(cfg['modules'])]))
+            prev = widths
+        self.out_channels = prev
+        self.init_weights()
+
+    @staticmethod
+    def _transition(prev, cur):
+        layers = []
+        for i, c in enumerate(cur):
+            if i < len(prev):
+                layers.append(None if prev[i] == c else _conv_bn(prev[i], c, 3, relu=True))
+            else:    # new, coarser branch: stride-2 convs from the last previous branch
+                steps = []
+                for k in range(i + 1 - len(prev)):
+                    last = k == i - len(prev)
+                    steps.append(_conv_bn(prev[-1], c if last else prev[-1], 3, 2, relu=True))
+                layers.append(nn.Sequential(*steps))
+        return nn.ModuleList(layers)
+
+    def init_weights(self):
+        """normal(std=0.001) convs, unit BN (official_hrnet.py:456-463)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.001)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.layer1(x)
+        ys = [x]
+        for s in (2, 3, 4):
+            trans = getattr(self, 'transition%d' % (s - 1))
+            xs = []
+            for i, t in enumerate(trans):
+                if t is None:
+                    xs.append(ys[i])
+                else:   # stage 2 branches all start from the stem; later new branches from the coarsest map
+                    xs.append(t(ys[-1] if (s > 2 or len(ys) == 1) else ys[i]))
+            ys = getattr(self, 'stage%d' % s)(xs)
+        return ys
+
+
+def get_hrnet_w18_backbone():
+    return HighResolutionNet(18)
+
+
+def get_hrnet_w32_backbone():
+    return HighResolutionNet(32)
+
+
+def get_hrnet_w48_backbone():
+    return HighResolutionNet(48)

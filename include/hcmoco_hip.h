@@ -180,6 +180,13 @@ int hcm_bank_nce_fused_timed(const float* bank1, const float* bank2, const float
                              void* workspace, size_t workspace_bytes, hcm_stream_t stream,
                              int reps, float* ms_per_pass_host);
 
+/* In-library timing of the dominant kernel (the gather pass of hcm_bank_nce_fused): while enabled,
+ * every launch is bracketed by hipEvents on its own stream.  hcm_prof_read synchronises those
+ * events and returns their summed duration and count (host pointers).  hcm_prof_enable(x) also
+ * clears what was recorded.  This is the library's only process-global state; not thread safe. */
+int hcm_prof_enable(int enable);
+int hcm_prof_read(double* total_ms_host, int64_t* launches_host);
+
 #ifdef __cplusplus
 }
 #endif

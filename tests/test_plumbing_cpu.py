@@ -1,0 +1,157 @@
+"""BASELINE config 1 ("plumbing, no GPU") and the host logic around the kernels, on CPU:
+the real entry point / trainer / model / synthetic source / checkpointing run end to end with an
+oracle-backed loss engine injected by the test; the product engine itself must fail loudly on CPU."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+from hcmoco_amd.pycontrast import main_contrast
+from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+from hcmoco_amd.pycontrast.learning.engine import HipLossEngine
+from hcmoco_amd.pycontrast.learning.util import AverageMeter
+from oracle.oracle_engine import OracleLossEngine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def base_args(tmp, method, extra=()):
+    return ['--method', method, '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list', '3,3',
+            '--batch_size', '4', '--nce_k', '64', '--world-size', '1', '--dist-backend', 'gloo', '--synthetic',
+            '--synthetic_n_data', '256', '--synthetic_size', '64', '--synthetic_steps', '2', '--epochs', '1',
+            '--print_freq', '1', '--save_freq', '1', '--model_path', tmp, '--tb_path', tmp, '--seed', '3',
+            '--learning_rate', '0.01'] + list(extra)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_pg(monkeypatch):
+    monkeypatch.setenv('MASTER_PORT', str(29500 + os.getpid() % 2000))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
+        monkeypatch.delenv(k, raising=False)
+    yield
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def test_config1_stage1_runs_on_cpu_with_oracle_engine():
+    tmp = tempfile.mkdtemp()
+    outs, trainer, model, contrast = main_contrast.main(base_args(tmp, 'CMCRGBD2S'), engine=OracleLossEngine())
+    assert len(outs) == 6 and all(torch.isfinite(torch.tensor(outs)))
+    ck = torch.load(os.path.join(trainer.args.model_folder, 'current.pth'), map_location='cpu')
+    assert set(ck) == {'model', 'contrast', 'optimizer', 'epoch'}
+    assert all(k.startswith('module.') for k in ck['model'])                  # reference checkpoint layout
+    assert set(ck['contrast']) == {'memory_1', 'memory_2', 'memory_3'}
+    assert os.path.exists(os.path.join(trainer.args.model_folder, 'ckpt_epoch_1.pth'))
+
+
+def test_stage2_accepts_method_name_runs_and_updates_only_indexed_rows():
+    tmp = tempfile.mkdtemp()
+    argv = base_args(tmp, 'CMCJointsPri3DRGBD2S', ['--linear_feat_map', '1', '--modality_missing', '1',
+                                                    '--pri3d_num_samples_per_image', '16', '--synthetic_steps', '1'])
+    torch.manual_seed(3)
+    outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
+    assert trainer.args.mem == 'bank+jointspri3d' and len(outs) == 4 and outs[0] == outs[0]
+    # bank rows changed only at the batch's indices (stage-1 -> 2 hand-off relies on it)
+    torch.manual_seed(3)                       # replay main(): seed -> build_model -> build_mem
+    from hcmoco_amd.pycontrast.memory.build_memory import build_mem
+    from hcmoco_amd.pycontrast.networks.build_backbone import build_model
+    build_model(trainer.args)
+    fresh = build_mem(trainer.args, 256)
+    data = trainer_data_indices(trainer)
+    changed = (fresh.memory_1 != contrast.memory_1).any(dim=1).nonzero().flatten().tolist()
+    assert sorted(changed) == sorted(data)
+    # stage-2 resume from the stage-1 style checkpoint
+    argv2 = argv + ['--resume', os.path.join(trainer.args.model_folder, 'current.pth'), '--epochs', '2']
+    torch.distributed.destroy_process_group()
+    outs2, trainer2, *_ = main_contrast.main(argv2, engine=OracleLossEngine())
+    assert outs2 is not None
+
+
+def trainer_data_indices(trainer):
+    from hcmoco_amd.pycontrast.datasets.synthetic import build_synthetic_contrast_loader
+    ds, _, _ = build_synthetic_contrast_loader(trainer.args, 'cpu', 0, 1)
+    return ds.pool[0][1].tolist()
+
+
+def test_product_engine_fails_loudly_without_gpu():
+    tmp = tempfile.mkdtemp()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        main_contrast.main(base_args(tmp, 'CMCRGBD2S'))          # default engine = HIP kernels
+
+
+def test_pack_unpack_features_bit_exact_index():
+    f = torch.randn(5, 384)
+    index = torch.tensor([0, 1, 2 ** 31 + 5, 2 ** 40 + 123456789, 131071])
+    packed = ContrastTrainer.pack_features(f, index)
+    assert packed.shape == (5, 386)
+    f2, i2 = ContrastTrainer.unpack_features(packed.clone())
+    assert torch.equal(f2, f) and torch.equal(i2, index)
+
+
+def test_average_meter_defers_sync_and_lr_schedule():
+    m = AverageMeter()
+    m.update(torch.tensor(2.0), 4)
+    m.update(4.0, 4)
+    assert m.avg == 3.0 and m.val == 4.0
+    import argparse
+    from hcmoco_amd.pycontrast.learning.base_trainer import BaseTrainer
+    args = argparse.Namespace(learning_rate=0.1, cosine=False, lr_decay_epochs=[2, 4], lr_decay_rate=0.1, epochs=10)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    tr = BaseTrainer(args)
+    assert abs(tr.adjust_learning_rate(opt, 2) - 0.1) < 1e-12 and abs(tr.adjust_learning_rate(opt, 3) - 0.01) < 1e-12
+    assert abs(tr.adjust_learning_rate(opt, 5) - 0.001) < 1e-12
+
+
+def test_dense_samples_follow_the_mask():
+    mask = torch.zeros(3, 32, 32)
+    mask[0, 8:16, 8:16] = 1
+    mask[2, :, :4] = 1
+    ind, keep = HipLossEngine.dense_samples(mask, 8, 8, 50)
+    assert keep.tolist() == [1, 0, 1]
+    rows, cols = ind[0] // 8, ind[0] % 8
+    assert bool(((rows >= 2) & (rows < 4) & (cols >= 2) & (cols < 4)).all())
+    assert bool((ind[2] % 8 == 0).all())
+    _, keep0 = HipLossEngine.dense_samples(mask, 8, 8, 50, use_depth=torch.zeros(3))
+    assert keep0.tolist() == [0, 0, 0]
+
+
+WORKER = r'''
+import os, sys, tempfile, torch
+sys.path.insert(0, %r)
+from hcmoco_amd.pycontrast import main_contrast
+from oracle.oracle_engine import OracleLossEngine
+rank = int(os.environ['RANK'])
+tmp = tempfile.mkdtemp()
+argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18',
+        '--in_channel_list', '3,3', '--batch_size', '4', '--nce_k', '32', '--dist-backend', 'gloo', '--synthetic',
+        '--synthetic_n_data', '128', '--synthetic_size', '64', '--synthetic_steps', '2', '--epochs', '1',
+        '--linear_feat_map', '1', '--modality_missing', '1', '--pri3d_num_samples_per_image', '8',
+        '--model_path', tmp, '--tb_path', tmp, '--seed', '5', '--print_freq', '100']
+outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
+# parameters only: BatchNorm running statistics are per-replica by design (local batches)
+w = torch.cat([p.detach().flatten().double() for p in trainer.unwrap(model).parameters()])
+torch.save({'bank': [b.clone() for b in contrast.banks()], 'wsum': w.sum(), 'wabs': w.abs().sum()},
+           os.path.join(%r, 'rank%%d.pt' %% rank))
+'''
+
+
+def test_world_size_2_gloo_replicas_stay_identical():
+    """N>1 path on CPU: packed all-gather -> the SAME rank-major bank update on every replica,
+    all three banks broadcast at start, DDP-averaged gradients -> identical weights."""
+    out = tempfile.mkdtemp()
+    script = os.path.join(out, 'worker.py')
+    with open(script, 'w') as f:
+        f.write(WORKER % (ROOT, out))
+    port = str(20000 + os.getpid() % 20000)
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', port, script],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    r0, r1 = (torch.load(os.path.join(out, 'rank%d.pt' % r)) for r in (0, 1))
+    for b0, b1 in zip(r0['bank'], r1['bank']):
+        assert torch.equal(b0, b1)                                     # replicated banks stay bit-identical
+    assert float(r0['wsum']) == float(r1['wsum']) and float(r0['wabs']) == float(r1['wabs'])
