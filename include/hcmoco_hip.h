@@ -5,7 +5,8 @@
  * (SURVEY.md section 8).  Plain pointers and sizes only: every pointer is a
  * DEVICE pointer unless its comment says "host".  All entry points are
  * asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, keep no
- * global state, never allocate, and return a hipError_t value as int
+ * global state (sole exception: the opt-in timing hooks hcm_prof_*), never
+ * allocate device memory, and return a hipError_t value as int
  * (0 == hipSuccess).  The caller owns every buffer, including workspaces whose
  * size is reported by the matching *_workspace_bytes() function.
  *
