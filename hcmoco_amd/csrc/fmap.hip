@@ -603,6 +603,51 @@ __global__ void joint_pixels_kernel(const float* __restrict__ j2d, int n, int h,
   pix[e] = (int64_t)r * h + c;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Bilinear up-sampling, align_corners=False (F.interpolate(..., mode='bilinear'), used by HRNet's
+// fuse layers, official_hrnet.py:231-236, and merge_all_res, build_backbone.py:247-254).
+// PyTorch's NCHW forward kernel walks all N*C planes inside each thread (strided stores) and costs
+// 22.5 ms of a 130 ms step on MI355X (profiles/r01_bench_one_step_summary.csv); this one gives each
+// thread four consecutive output pixels of one plane -> 16-byte coalesced stores, inputs from L1/L2.
+// Same arithmetic as at::native::upsample_bilinear2d (area_pixel_compute_source_index).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void upsample_bilinear_kernel(const float* __restrict__ in,
+                                                                float* __restrict__ out, int planes,
+                                                                int Hi, int Wi, int Ho, int Wo,
+                                                                float sy, float sx) {
+  const int wq = (Wo + 3) >> 2;  // groups of four output columns
+  const int64_t total = (int64_t)planes * Ho * wq;
+  for (int64_t e = (int64_t)blockIdx.x * kWG + threadIdx.x; e < total; e += (int64_t)gridDim.x * kWG) {
+    const int q = (int)(e % wq);
+    const int oy = (int)((e / wq) % Ho);
+    const int64_t pl = e / ((int64_t)wq * Ho);
+    const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float* r0 = in + (pl * Hi + y0) * Wi;
+    const float* r1 = in + (pl * Hi + y1) * Wi;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ox = 4 * q + k;
+      const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+      int x0 = (int)fx;
+      x0 = min(x0, Wi - 1);
+      const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+      const float lx = fx - (float)x0, hx = 1.f - lx;
+      v[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+    }
+    float* dst = out + (pl * Ho + oy) * Wo + 4 * q;
+    if (4 * q + 3 < Wo && ((Wo & 3) == 0)) {
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int k = 0; k < 4 && 4 * q + k < Wo; ++k) dst[k] = v[k];
+    }
+  }
+}
+
 // ---- workspace carving (all regions 16-byte aligned) --------------------------------------
 struct Carver {
   char* base;
@@ -782,6 +827,18 @@ int hcm_joint_nce(const float* map1, const float* map2, hcm_strides4 st, int B, 
   const int rows = B * J;
   scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, pix, J, rows, nullptr, mv,
                                                               gmap1, gmap2);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho, int Wo, float* out,
+                            hcm_stream_t stream) {
+  if (planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)planes * Ho * ((Wo + 3) / 4);
+  int64_t blocks = (total + kWG - 1) / kWG;
+  if (blocks > 16384) blocks = 16384;
+  upsample_bilinear_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
+      in, out, planes, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -344,3 +344,33 @@ def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth,
     [loss_r2d, loss_d2r, acc_r2d, acc_d2r, loss_rgb2j, loss_d2j, acc_rgb2j, acc_d2j, loss_scl]."""
     return _FmapLosses.apply(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
                              temperature, do_dense, do_joint, do_scl)
+
+
+# --------------------------------------------------------------------------- #
+# row 8 helper: bilinear up-sampling used by the HRNet fuse layers and merge_all_res
+# --------------------------------------------------------------------------- #
+class _UpsampleBilinear(torch.autograd.Function):
+    """Forward: hcm_upsample_bilinear2d (coalesced, ~10x faster than ATen's NCHW forward on MI355X).
+    Backward: ATen's upsample_bilinear2d_backward (already fast: 29 us/launch in the r01 profile)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = x.contiguous()
+        N, Cc, Hi, Wi = x.shape
+        Ho, Wo = int(size[0]), int(size[1])
+        out = torch.empty(N, Cc, Ho, Wo, dtype=torch.float32, device=x.device)
+        check(_lib.lib().hcm_upsample_bilinear2d(_dev(x, torch.float32, 'upsample_bilinear'), N * Cc, Hi, Wi, Ho, Wo,
+                                                 C.c_void_p(out.data_ptr()), _stream()), 'hcm_upsample_bilinear2d')
+        ctx.in_shape, ctx.size = (N, Cc, Hi, Wi), (Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gi = torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), list(ctx.size), list(ctx.in_shape), False,
+                                                         None, None)
+        return gi, None
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for fp32 NCHW ROCm tensors."""
+    return _UpsampleBilinear.apply(x, tuple(size))

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .hrnet import HighResolutionNet
+from .hrnet import HighResolutionNet, upsample_bilinear
 from .sgcn import create_sgcn
 from .util import Normalize
 
@@ -47,7 +47,7 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
     def merge_all_res(maps):
         """Upsample the three coarser maps to the finest grid and concatenate (:247-254)."""
         size = maps[0].shape[-2:]
-        ups = [maps[0]] + [F.interpolate(m, size=size, mode='bilinear', align_corners=False) for m in maps[1:]]
+        ups = [maps[0]] + [upsample_bilinear(m, size) for m in maps[1:]]
         return torch.cat(ups, 1)
 
     def _pool(self, maps):

@@ -13,6 +13,16 @@ import torch.nn.functional as F
 
 BN_MOMENTUM = 0.01                                           # official_hrnet.py:23
 
+
+def upsample_bilinear(x, size):
+    """``F.interpolate(x, size, mode='bilinear')`` (align_corners=False).  On the MI355X the forward
+    runs in ``hcm_upsample_bilinear2d`` (ATen's NCHW forward is the single largest kernel of the
+    step there, profiles/r01_bench_one_step_summary.csv); CPU tensors use ATen."""
+    if x.is_cuda and x.dtype == torch.float32:
+        from ... import hip_ops
+        return hip_ops.upsample_bilinear(x, size)
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+
 # stage -> (modules, blocks per branch, block type); branch widths = width * 2**i
 STAGES = {
     'stage1': dict(modules=1, branches=1, blocks=4, kind='bottleneck', planes=64),
@@ -121,7 +131,7 @@ class HighResolutionModule(nn.Module):
                 if j == i:
                     y = y + xs[j]
                 elif j > i:
-                    y = y + F.interpolate(row[j](xs[j]), size=xs[i].shape[-2:], mode='bilinear')
+                    y = y + upsample_bilinear(row[j](xs[j]), xs[i].shape[-2:])
                 else:
                     y = y + row[j](xs[j])
             outs.append(self.relu(y))

@@ -136,6 +136,13 @@ int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
  * (contrast_trainer.py:757-761).  joints2d [B, J, 2] fp32. */
 int hcm_joint_pixels(const float* joints2d, int BJ, int h, int64_t* pix, hcm_stream_t stream);
 
+/* Row 8 helper (feature-map producer): F.interpolate(x, size=(Ho,Wo), mode='bilinear',
+ * align_corners=False) forward on `planes` = N*C contiguous [Hi,Wi] planes -> [Ho,Wo] planes
+ * (HRNet fuse layers, networks/official_hrnet/official_hrnet.py:231-236; merge_all_res,
+ * networks/build_backbone.py:247-254). */
+int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho, int Wo, float* out,
+                            hcm_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
  * reference's C launcher layer (networks/pointnet2/src/<name>_gpu.h), which the pybind

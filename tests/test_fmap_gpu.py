@@ -163,3 +163,19 @@ def test_determinism_bitwise():
     a = run(*args)
     b = run(*args)
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
+@pytest.mark.parametrize('shape,size', [((2, 5, 8, 8), (16, 16)), ((3, 7, 4, 4), (32, 32)), ((1, 3, 5, 7), (11, 13)),
+                                        ((2, 4, 16, 16), (16, 16)), ((32, 36, 32, 32), (64, 64)), ((2, 2, 9, 9), (4, 6))])
+def test_upsample_bilinear_matches_aten(shape, size):
+    """Row 8 helper vs the plain PyTorch fp32 op, forward and backward."""
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device=d(), requires_grad=True)
+    y = ops().upsample_bilinear(x, size)
+    ref = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False)
+    assert y.shape == ref.shape
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
+    g = torch.randn_like(ref)
+    gx, = torch.autograd.grad(y, x, g)
+    gr, = torch.autograd.grad(ref, x, g)
+    assert torch.allclose(gx, gr, rtol=1e-4, atol=1e-5)
