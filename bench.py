@@ -49,7 +49,7 @@ def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps):
         return TrainOptions().parse(argv)
 
 
-def build(args, trainer, engine_device):
+def build(args, trainer, engine_device, graphs=False):
     from hcmoco_amd.pycontrast.networks.build_backbone import build_model
     from hcmoco_amd.pycontrast.memory.build_memory import build_mem
     from hcmoco_amd.pycontrast.datasets.synthetic import build_synthetic_contrast_loader
@@ -60,6 +60,8 @@ def build(args, trainer, engine_device):
     contrast.to(engine_device)
     opt = torch.optim.SGD(model.parameters(), lr=args.learning_rate, momentum=args.momentum,
                           weight_decay=args.weight_decay)
+    if graphs:
+        trainer.enable_graphs(model, data.pool[0], stage2=True)
     model, _, opt = trainer.wrap_up(model, None, opt)
     trainer.broadcast_memory(contrast)
     model.train()
@@ -102,6 +104,8 @@ def main():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
     ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
+    ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '1')),
+                    help='capture the encoder forward/backward as hipGraphs')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -130,7 +134,7 @@ def main():
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     trainer = ContrastTrainer(args)                                          # HIP loss engine
     trainer.device = dev
-    model, contrast, opt, data = build(args, trainer, dev)
+    model, contrast, opt, data = build(args, trainer, dev, graphs=bool(a.graphs))
 
     it = iter(data)
     for _ in range(a.warmup):
@@ -176,7 +180,8 @@ def main():
                                    % (a.size, a.size, a.skeleton),
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
-                       'channels_last': bool(a.channels_last), 'final_loss': round(loss, 4)},
+                       'channels_last': bool(a.channels_last), 'hip_graphs': bool(a.graphs),
+                       'final_loss': round(loss, 4)},
             'roofline': {'kernel': 'bank_pass_kernel<2,fused> (gather + 6 logit sets + online softmax + d/dx)',
                          'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -29,6 +29,21 @@ class ContrastTrainer(BaseTrainer):
     def __init__(self, args, engine=None):
         super().__init__(args)
         self.engine = engine if engine is not None else HipLossEngine()
+        self.graphed = None          # GraphedEncoder once enable_graphs() ran
+        self.manual_allreduce = False
+
+    def enable_graphs(self, model, sample_batch, stage2=True):
+        """Capture the encoder forward/backward as hipGraphs (learning/graphed.py).  Call BEFORE
+        wrap_up: in graph mode the model is not wrapped in DistributedDataParallel; gradients are
+        averaged by one explicit all-reduce per step instead."""
+        from .graphed import GraphedEncoder, broadcast_model
+        model.to(self.device)
+        broadcast_model(model)
+        model.train()
+        x = self._to_dev(sample_batch[0]).float()
+        self.graphed = GraphedEncoder(model, x, self._to_dev(sample_batch[2]), stage2=stage2)
+        self.manual_allreduce = dist.is_initialized() and dist.get_world_size() > 1
+        return model
 
     # ------------------------------------------------------------------ set-up / bookkeeping
     def logging(self, epoch, logs, lr):
@@ -52,7 +67,7 @@ class ContrastTrainer(BaseTrainer):
             model_ema.to(self.device)
         if args.amp:
             raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized() and dist.get_world_size() > 1 and self.graphed is None:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             model = DDP(model, device_ids=ids, gradient_as_bucket_view=True)
         if isinstance(model_ema, torch.nn.Module):
@@ -159,7 +174,13 @@ class ContrastTrainer(BaseTrainer):
         if getattr(args, 'channels_last', False):
             inputs = inputs.contiguous(memory_format=torch.channels_last)
 
-        if stage2:
+        if self.graphed is not None:
+            outs = self.graphed(inputs, skeleton)
+            f = outs[0]
+            if stage2:
+                aux = {'linear_merge1': outs[1], 'linear_merge2': outs[2]}
+                _feat3 = outs[3]
+        elif stage2:
             _feat1, _feat2, _feat3, f, aux = model(inputs, skeleton, return_fm=True)
         else:
             f = model(inputs, skeleton)
@@ -183,6 +204,9 @@ class ContrastTrainer(BaseTrainer):
             loss = total
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.manual_allreduce:
+            from .graphed import allreduce_grads
+            allreduce_grads([p for g in optimizer.param_groups for p in g['params']], dist.get_world_size())
         optimizer.step()
         out.update(loss=loss.detach(), bank_losses=losses, bank_accs=accs)
         return out
