@@ -50,6 +50,10 @@ class SemGraphConv(nn.Module):
         nn.init.xavier_uniform_(self.W.data, gain=1.414)
         self.register_buffer('adj', adj.clone(), persistent=False)
         self.register_buffer('m', adj > 0, persistent=False)
+        # flat positions of the edges in row-major order (what ``adj[self.m] = self.e`` enumerates);
+        # indexing with them instead of the boolean mask avoids a device->host sync (nonzero) and
+        # keeps the layer capturable in a hipGraph
+        self.register_buffer('m_idx', (adj > 0).flatten().nonzero().flatten(), persistent=False)
         self.e = nn.Parameter(torch.ones(1, int((adj > 0).sum())))
         if bias:
             self.bias = nn.Parameter(torch.zeros(out_features))
@@ -59,8 +63,9 @@ class SemGraphConv(nn.Module):
             self.register_parameter('bias', None)
 
     def edge_weights(self):
-        logits = torch.full_like(self.adj, -9e15)
-        logits[self.m] = self.e.reshape(-1)
+        n = self.adj.shape[0]
+        logits = torch.full((n * n,), -9e15, dtype=self.e.dtype, device=self.e.device)
+        logits = logits.index_copy(0, self.m_idx, self.e.reshape(-1)).view(n, n)
         return F.softmax(logits, dim=1)
 
     def forward(self, x):
