@@ -648,6 +648,32 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_kernel(const float* __r
   }
 }
 
+// channels-last variant: memory is [N][H][W][C]; one thread per (pixel, channel), channel fastest.
+__global__ __launch_bounds__(kWG) void upsample_bilinear_nhwc_kernel(const float* __restrict__ in,
+                                                                     float* __restrict__ out, int N,
+                                                                     int Cc, int Hi, int Wi, int Ho,
+                                                                     int Wo, float sy, float sx) {
+  const int64_t total = (int64_t)N * Ho * Wo * Cc;
+  for (int64_t e = (int64_t)blockIdx.x * kWG + threadIdx.x; e < total; e += (int64_t)gridDim.x * kWG) {
+    const int c = (int)(e % Cc);
+    const int ox = (int)((e / Cc) % Wo);
+    const int oy = (int)((e / ((int64_t)Cc * Wo)) % Ho);
+    const int64_t n = e / ((int64_t)Cc * Wo * Ho);
+    const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int x0 = min((int)fx, Wi - 1);
+    const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float lx = fx - (float)x0, hx = 1.f - lx;
+    const float* base = in + n * Hi * Wi * Cc + c;
+    const float v00 = base[((int64_t)y0 * Wi + x0) * Cc], v01 = base[((int64_t)y0 * Wi + x1) * Cc];
+    const float v10 = base[((int64_t)y1 * Wi + x0) * Cc], v11 = base[((int64_t)y1 * Wi + x1) * Cc];
+    out[e] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
 // ---- workspace carving (all regions 16-byte aligned) --------------------------------------
 struct Carver {
   char* base;
@@ -839,6 +865,18 @@ int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho,
   if (blocks > 16384) blocks = 16384;
   upsample_bilinear_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
       in, out, planes, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                                 float* out, hcm_stream_t stream) {
+  if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  int64_t blocks = (total + kWG - 1) / kWG;
+  if (blocks > 32768) blocks = 32768;
+  upsample_bilinear_nhwc_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
+      in, out, N, C, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
   HCM_CHECK_LAUNCH();
   return 0;
 }

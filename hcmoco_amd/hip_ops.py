@@ -355,19 +355,28 @@ class _UpsampleBilinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, size):
-        x = x.contiguous()
         N, Cc, Hi, Wi = x.shape
         Ho, Wo = int(size[0]), int(size[1])
+        ctx.in_shape, ctx.size = (N, Cc, Hi, Wi), (Ho, Wo)
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError('hcmoco_amd.upsample_bilinear needs fp32 ROCm tensors (no CPU fallback exists)')
+        nhwc = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        if nhwc:        # stay in the encoder's memory format: no layout round trip
+            out = torch.empty(N, Cc, Ho, Wo, dtype=torch.float32, device=x.device,
+                              memory_format=torch.channels_last)
+            check(_lib.lib().hcm_upsample_bilinear2d_nhwc(C.c_void_p(x.data_ptr()), N, Cc, Hi, Wi, Ho, Wo,
+                                                          C.c_void_p(out.data_ptr()), _stream()),
+                  'hcm_upsample_bilinear2d_nhwc')
+            return out
+        x = x.contiguous()
         out = torch.empty(N, Cc, Ho, Wo, dtype=torch.float32, device=x.device)
         check(_lib.lib().hcm_upsample_bilinear2d(_dev(x, torch.float32, 'upsample_bilinear'), N * Cc, Hi, Wi, Ho, Wo,
                                                  C.c_void_p(out.data_ptr()), _stream()), 'hcm_upsample_bilinear2d')
-        ctx.in_shape, ctx.size = (N, Cc, Hi, Wi), (Ho, Wo)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        gi = torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), list(ctx.size), list(ctx.in_shape), False,
-                                                         None, None)
+        gi = torch.ops.aten.upsample_bilinear2d_backward(g, list(ctx.size), list(ctx.in_shape), False, None, None)
         return gi, None
 
 

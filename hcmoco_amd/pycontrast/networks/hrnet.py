@@ -32,8 +32,19 @@ STAGES = {
 }
 
 
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d minus its per-layer ``num_batches_tracked += 1`` launch: with a fixed momentum
+    the counter never enters the arithmetic, and an HRNet-w18 pair has 618 BN layers (one 5 us kernel
+    each per step).  ``HighResolutionNet.forward`` advances all counters with ONE foreach launch, so
+    the buffers (and checkpoints) evolve exactly as in the reference."""
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                            self.training or not self.track_running_stats, self.momentum, self.eps)
+
+
 def _bn(c):
-    return nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+    return BatchNorm2d(c, momentum=BN_MOMENTUM)
 
 
 def _conv_bn(cin, cout, k, stride=1, relu=False):
@@ -158,6 +169,13 @@ class HighResolutionNet(nn.Module):
             prev = widths
         self.out_channels = prev
         self.init_weights()
+        self._counters = None
+
+    def _count_batch(self):
+        if self._counters is None or self._counters[0].device != self.conv1.weight.device:
+            self._counters = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        with torch.no_grad():
+            torch._foreach_add_(self._counters, 1)
 
     @staticmethod
     def _transition(prev, cur):
@@ -183,6 +201,8 @@ class HighResolutionNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
+        if self.training:
+            self._count_batch()
         x = self.relu(self.bn1(self.conv1(x)))
         x = self.relu(self.bn2(self.conv2(x)))
         x = self.layer1(x)

@@ -142,6 +142,9 @@ int hcm_joint_pixels(const float* joints2d, int BJ, int h, int64_t* pix, hcm_str
  * networks/build_backbone.py:247-254). */
 int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho, int Wo, float* out,
                             hcm_stream_t stream);
+/* Same op on channels-last memory: in [N,Hi,Wi,C] -> out [N,Ho,Wo,C]. */
+int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                                 float* out, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the

@@ -179,3 +179,11 @@ def test_upsample_bilinear_matches_aten(shape, size):
     gx, = torch.autograd.grad(y, x, g)
     gr, = torch.autograd.grad(ref, x, g)
     assert torch.allclose(gx, gr, rtol=1e-4, atol=1e-5)
+    # channels-last input stays channels-last
+    xc = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yc = ops().upsample_bilinear(xc, size)
+    assert torch.allclose(yc, ref, rtol=1e-5, atol=1e-6)
+    if shape[1] > 1 and size[0] * size[1] > 1:
+        assert yc.is_contiguous(memory_format=torch.channels_last)
+    gc, = torch.autograd.grad(yc, xc, g)
+    assert torch.allclose(gc, gr, rtol=1e-4, atol=1e-5)

@@ -79,3 +79,16 @@ def test_coco17_extension_and_moco_ema():
     model, ema = build_model(opt)
     assert ema is not None
     assert model(torch.randn(1, 6, 64, 64), torch.rand(1, 17, 2), mode=2).shape == (1, 270 * 2 + 128)
+
+
+def test_batch_counters_advance_once_per_training_forward():
+    model, _ = build_model(make_opt('mpii'))
+    model.train()
+    model(torch.randn(2, 6, 64, 64), torch.rand(2, 16, 2))
+    model(torch.randn(2, 6, 64, 64), torch.rand(2, 16, 2))
+    sd = model.state_dict()
+    counters = [v for k, v in sd.items() if k.endswith('num_batches_tracked') and k.startswith('encoder1')]
+    assert len(counters) > 300 and all(int(c) == 2 for c in counters)       # as nn.BatchNorm2d would count
+    model.eval()
+    model(torch.randn(1, 6, 64, 64), torch.rand(1, 16, 2))
+    assert int(sd['encoder1.bn1.num_batches_tracked']) == 2
