@@ -16,8 +16,9 @@ roofline    : the dominant hand-written kernel (the bank gather pass, HBM-bound)
               algorithmic bytes per launch / mean launch duration measured with hipEvents placed
               around that kernel, on its stream, INSIDE the timed steps (hcm_prof_enable/read).
 cpu_baseline: the same training step on the host CPU (model in torch-CPU, losses by the oracle =
-              a port of the reference math), rank 0 / N=1 only, on a bounded sample (2 timed
-              steps at batch 8), all host threads.  A reported baseline, never the thing measured.
+              a port of the reference math), rank 0 / N=1 only, on a bounded sample (batch 4, ~20 s
+              of steps, <=16 threads) in a CPU-only subprocess with a hard timeout.  A reported
+              baseline, never the thing measured.
 """
 import argparse
 import json
@@ -68,27 +69,52 @@ def build(args, trainer, engine_device, graphs=False):
     return model, contrast, opt, data
 
 
-def cpu_baseline(nce_k, n_data, size, skeleton, batch=8, steps=2):
-    """Bounded CPU leg: same step, same config, batch 8, oracle losses.  ~10-30 s of CPU work."""
+def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s):
+    """Runs in a fresh CPU-only process (see cpu_baseline): same step, same config, oracle losses."""
     import tempfile
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     from oracle.oracle_engine import OracleLossEngine       # oracle = checker/baseline only
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    args = make_args(batch, nce_k, n_data, size, skeleton, 'gloo', tempfile.mkdtemp(), steps + 1)
+    threads = torch.get_num_threads()
+    args = make_args(batch, nce_k, n_data, size, skeleton, 'gloo', tempfile.mkdtemp(), 64)
     args.rank, args.world_size, args.local_rank, args.channels_last = 0, 1, 0, False
     trainer = ContrastTrainer(args, engine=OracleLossEngine())
     trainer.device = torch.device('cpu')
     model, contrast, opt, data = build(args, trainer, 'cpu')
     it = iter(data)
-    trainer.train_step(next(it), model, contrast, opt, stage2=True)          # warm-up
     t0 = time.perf_counter()
-    for _ in range(steps):
+    trainer.train_step(next(it), model, contrast, opt, stage2=True)          # warm-up
+    warm = time.perf_counter() - t0
+    steps, t0 = 0, time.perf_counter()
+    while steps < 1 or (time.perf_counter() - t0 + warm < budget_s and steps < 8):
         trainer.train_step(next(it), model, contrast, opt, stage2=True)
+        steps += 1
     dt = time.perf_counter() - t0
-    return {'value': round(batch * steps / dt, 3), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed steps (after 1 warm-up) of the same stage-2 step at batch %d, K=%d, %dx%d, '
-                      'torch-CPU model + oracle losses, %d threads' % (steps, batch, nce_k, size, size, cores)}
+    return {'value': round(batch * steps / dt, 3), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d timed step(s) after 1 warm-up of the same stage-2 step at batch %d, K=%d, %dx%d, '
+                      'torch-CPU model + oracle losses, %d threads' % (steps, batch, nce_k, size, size, threads)}
+
+
+def cpu_baseline(nce_k, n_data, size, skeleton, batch=4, budget_s=20.0, timeout_s=240):
+    """Bounded CPU leg in a subprocess (clean thread pool, hard timeout) -> dict or None."""
+    import subprocess
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu_baseline_worker', '--nce_k', str(nce_k), '--n_data',
+           str(n_data), '--size', str(size), '--skeleton', skeleton, '--batch_per_gpu', str(batch),
+           '--cpu_budget_s', str(budget_s)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
+        for line in reversed(res.stdout.splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return {'value': None, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+                'sample': 'cpu leg failed: ' + (res.stderr.strip().splitlines() or ['?'])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+                'sample': 'cpu leg exceeded %d s and was stopped' % timeout_s}
 
 
 def main():
@@ -102,11 +128,16 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--skeleton', type=str, default='coco17')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_baseline_worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu_budget_s', type=float, default=20.0)
     ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
     ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
-    ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '1')),
+    ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '0')),
                     help='capture the encoder forward/backward as hipGraphs')
     a = ap.parse_args()
+    if a.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker(a.nce_k, a.n_data, a.size, a.skeleton, a.batch_per_gpu, a.cpu_budget_s)))
+        return
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
