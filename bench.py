@@ -200,6 +200,16 @@ def main():
         bytes_per_launch = B * bytes_per_sample
         avg_ms = kern_ms / max(kern_n, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read live);
+        # reported only when the committed measurement was taken at this exact configuration
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bank_pass_pmc.json')))
+            c = pmc['config']
+            if (c['B'], c['K'], c['n_data'], c['D']) == (B, a.nce_k, a.n_data, D):
+                traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_bank_pass_pmc.json'
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': 'pretrain samples/sec (RGB+depth+kpt triples) HRNet-w18',
             'value': round(B * world * a.steps / dt, 3), 'unit': 'samples/s',
@@ -217,7 +227,7 @@ def main():
                          'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'bytes_per_launch': bytes_per_launch,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
         }
         if world == 1 and not a.no_cpu_baseline:
