@@ -16,8 +16,9 @@ import torch
 
 class SyntheticContrastData(object):
     def __init__(self, n_data, batch_size, size=256, joints=16, steps=50, device='cpu', rank=0, world=1,
-                 seed=0, pool=4, p_depth=0.75):
+                 seed=0, pool=4, p_depth=0.75, ntu=False):
         self.n_data, self.batch_size, self.size, self.joints = n_data, batch_size, size, joints
+        self.ntu = ntu               # append the NTU-only items 9-15 (needed by the HRNetPN arch)
         self.steps, self.device, self.rank, self.world = steps, torch.device(device), rank, world
         self.pool = [self._make(seed * 1000003 + i, p_depth) for i in range(pool)]
 
@@ -44,6 +45,16 @@ class SyntheticContrastData(object):
         vis = (torch.rand(B, J, generator=gl) < 0.85).int()
         batch = [torch.cat([rgb, depth], 1).contiguous(), index, skeleton, torch.zeros(B, 25, 3), j2d, vis,
                  use_depth, mask, torch.ones(B)]
+        if self.ntu:
+            # identity pixel grid of a 1080x1920 frame cropped to a centred person box and
+            # nearest-resized to size x size; per-sample mean depth in metres
+            ys = torch.linspace(240, 840, H).round().int()
+            xs = torch.linspace(660, 1260, H).round().int()
+            gy, gx = torch.meshgrid(ys, xs, indexing='ij')
+            grid_xy = torch.stack([gy, gx], -1).unsqueeze(0).expand(B, H, H, 2).contiguous()
+            mean = torch.rand(B, generator=gl) * 2 + 2
+            batch += [torch.zeros(B, H, H, dtype=torch.long), torch.zeros(B, dtype=torch.long), torch.ones(B, dtype=torch.long),
+                      grid_xy, torch.full((B,), 1080), torch.full((B,), 1920), mean]
         return [t.to(self.device) for t in batch]
 
     def __iter__(self):
@@ -73,5 +84,6 @@ def build_synthetic_contrast_loader(opt, device, rank=0, world=1):
     from ..networks.sgcn import num_joints
     per_rank = max(1, opt.batch_size // max(1, world))
     data = SyntheticContrastData(opt.synthetic_n_data, per_rank, opt.synthetic_size, num_joints(opt.skeleton_meta_name),
-                                 opt.synthetic_steps, device, rank, world, seed=opt.seed or 0)
+                                 opt.synthetic_steps, device, rank, world, seed=opt.seed or 0,
+                                 ntu=(opt.arch == 'HRNetPN'))
     return data, _Loader(data), _Sampler()

@@ -174,7 +174,14 @@ class ContrastTrainer(BaseTrainer):
         if getattr(args, 'channels_last', False):
             inputs = inputs.contiguous(memory_format=torch.channels_last)
 
-        if self.graphed is not None:
+        if args.arch == 'HRNetPN':      # extra NTU items (appendix B rows 12-15; contrast_trainer.py:932-936)
+            extra = (self._to_dev(data[7]), self._to_dev(data[12]), int(data[13][0]), int(data[14][0]),
+                     self._to_dev(data[15]))
+            if stage2:
+                _feat1, _feat2, _feat3, f, aux = model(inputs, skeleton, *extra, return_fm=True)
+            else:
+                f = model(inputs, skeleton, *extra)
+        elif self.graphed is not None:
             outs = self.graphed(inputs, skeleton)
             f = outs[0]
             if stage2:

@@ -1,0 +1,66 @@
+"""Set-abstraction (multi-scale grouping) and feature-propagation modules
+(/root/reference/pycontrast/networks/pointnet2/pointnet2_modules.py:10-156)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class PointnetSAModuleMSG(nn.Module):
+    """FPS -> gather centres -> per scale: ball query, group, shared MLP, max-pool over the ball."""
+
+    def __init__(self, *, npoint, radii, nsamples, mlps, bn=True, use_xyz=True, pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint, self.pool_method = npoint, pool_method
+        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            spec = list(spec)
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+    def forward(self, xyz, features=None, new_xyz=None):
+        if new_xyz is None and self.npoint is not None:
+            picks = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            y = mlp(grouper(xyz, new_xyz, features))                       # (B, C, npoint, nsample)
+            if self.pool_method == 'max_pool':
+                y = F.max_pool2d(y, kernel_size=[1, y.size(3)])
+            elif self.pool_method == 'avg_pool':
+                y = F.avg_pool2d(y, kernel_size=[1, y.size(3)])
+            else:
+                raise NotImplementedError
+            outs.append(y.squeeze(-1))
+        return new_xyz, torch.cat(outs, dim=1)
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    def __init__(self, *, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True, pool_method='max_pool'):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
+                         pool_method=pool_method)
+
+
+class PointnetFPModule(nn.Module):
+    """inverse-distance interpolation from the 3 nearest known points, skip concat, shared MLP."""
+
+    def __init__(self, *, mlp, bn=True):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        feats = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
+        return self.mlp(feats.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,45 @@
+"""Conv/BN building blocks with the reference's module names, so ``state_dict`` keys match
+(/root/reference/pycontrast/networks/pointnet2/pytorch_utils.py:5-200):
+``...layer{i}.conv.weight``, ``...layer{i}.bn.bn.weight`` etc."""
+import torch.nn as nn
+
+
+class _BN(nn.Sequential):
+    def __init__(self, norm, channels):
+        super().__init__()
+        self.add_module('bn', norm(channels))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0)
+
+
+class _ConvBNAct(nn.Sequential):
+    """conv (kaiming-normal, bias only without BN) -> BN -> activation (post-activation form)."""
+
+    def __init__(self, conv, norm, cin, cout, bn, activation):
+        super().__init__()
+        unit = conv(cin, cout, kernel_size=1, stride=1, padding=0, bias=not bn)
+        nn.init.kaiming_normal_(unit.weight)
+        if not bn:
+            nn.init.constant_(unit.bias, 0)
+        self.add_module('conv', unit)
+        if bn:
+            self.add_module('bn', _BN(norm, cout))
+        if activation is not None:
+            self.add_module('activation', activation)
+
+
+class Conv1d(_ConvBNAct):
+    def __init__(self, in_size, out_size, *, bn=False, activation=nn.ReLU(inplace=True)):
+        super().__init__(nn.Conv1d, nn.BatchNorm1d, in_size, out_size, bn, activation)
+
+
+class Conv2d(_ConvBNAct):
+    def __init__(self, in_size, out_size, *, bn=False, activation=nn.ReLU(inplace=True)):
+        super().__init__(nn.Conv2d, nn.BatchNorm2d, in_size, out_size, bn, activation)
+
+
+class SharedMLP(nn.Sequential):
+    def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True)):
+        super().__init__()
+        for i in range(len(args) - 1):
+            self.add_module('layer{}'.format(i), Conv2d(args[i], args[i + 1], bn=bn, activation=activation))

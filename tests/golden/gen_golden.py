@@ -393,6 +393,18 @@ def gen_model():
         npz('model_hrnet_w18_' + skel, **arrays)
 
 
+def gen_model_pn():
+    """HRNetPN arch: state_dict keys/shapes only (its forward needs the CUDA point ops)."""
+    from networks.build_backbone import build_model
+    opt = argparse.Namespace(modal='RGBD2S', arch='HRNetPN', jigsaw=False, head='linear', feat_dim=128,
+                             in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
+                             skeleton_meta_name='mpii', IN_Pretrain=None, depth_Pretrain=None, mem='bank')
+    model, _ = build_model(opt)
+    sd = model.state_dict()
+    npz('model_hrnetpn_w18_keys', keys=np.array(list(sd.keys())), shapes=np.array([str(list(v.shape)) for v in sd.values()]),
+        n_params=sum(p.numel() for p in model.parameters()))
+
+
 # --------------------------------------------------------------------------- #
 # 8. options surface (options/train_options.py)
 # --------------------------------------------------------------------------- #
@@ -424,7 +436,7 @@ if __name__ == '__main__':
     only = set(sys.argv[1:])
     sys.argv = sys.argv[:1]
     gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
-                scl=gen_scl, model=gen_model, options=gen_options)
+                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options)
     for name, fn in gens.items():
         if not only or name in only:
             fn()
