@@ -73,8 +73,15 @@ def test_pointnet2_msg_hip_matches_oracle_shim():
     init = Pointnet2MSG(input_channels=0).state_dict()          # same seed -> same initial weights
     out, grads, _ = run_msg('cuda:0', hip, pts, init)
     assert torch.allclose(out, ref_out, rtol=2e-3, atol=2e-3), float((out - ref_out).abs().max())
-    bad = [k for k in ref_grads
-           if float((grads[k] - ref_grads[k]).norm() / ref_grads[k].norm().clamp_min(1e-12)) > 2e-2]
+    # gradients: atomics (scatter order) and max-pool tie routing differ between the two runs, so
+    # compare each tensor relative to its own norm, or -- for near-zero gradients such as BN biases
+    # that a following BatchNorm almost cancels -- relative to the largest gradient in the net
+    scale = max(float(g.norm()) for g in ref_grads.values())
+    bad = {}
+    for k in ref_grads:
+        err = float((grads[k] - ref_grads[k]).norm())
+        if err > 2e-2 * float(ref_grads[k].norm()) and err > 1e-4 * scale:
+            bad[k] = (err, float(ref_grads[k].norm()), scale)
     assert not bad, bad
 
 
