@@ -166,6 +166,7 @@ def main():
     trainer = ContrastTrainer(args)                                          # HIP loss engine
     trainer.device = dev
     model, contrast, opt, data = build(args, trainer, dev, graphs=bool(a.graphs))
+    torch.cuda.manual_seed(1234 + rank)          # per-replica pixel sampling; weights were built from seed 0
 
     it = iter(data)
     for _ in range(a.warmup):

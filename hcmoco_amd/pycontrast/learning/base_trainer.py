@@ -51,6 +51,9 @@ class BaseTrainer(object):
             env['WORLD_SIZE'], env['RANK'] = str(world), str(rank)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
+        if use_gpu and world > 1:
+            # per-replica device generator (pixel sampling); weights stay identical via the CPU seed
+            torch.cuda.manual_seed((torch.initial_seed() + 7919 * rank) & 0x7fffffffffffffff)
         ngpus_per_node = max(1, ngpus_per_node)
         args.distributed = True
         args.world_size = world

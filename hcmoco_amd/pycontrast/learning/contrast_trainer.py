@@ -69,7 +69,9 @@ class ContrastTrainer(BaseTrainer):
             raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
         if dist.is_initialized() and dist.get_world_size() > 1 and self.graphed is None:
             ids = [self.device.index] if self.device.type == 'cuda' else None
-            model = DDP(model, device_ids=ids, gradient_as_bucket_view=True)
+            # stage 1 never touches the 1x1 feature-map projections when --linear_feat_map 1 is set
+            unused = args.mem == 'bank' and bool(getattr(args, 'linear_feat_map', 0))
+            model = DDP(model, device_ids=ids, gradient_as_bucket_view=True, find_unused_parameters=unused)
         if isinstance(model_ema, torch.nn.Module):
             self.momentum_update(self.unwrap(model), model_ema, 0)
         return model, model_ema, optimizer

@@ -14,7 +14,13 @@ from ... import hip_ops
 class AliasMethod(object):
     def __init__(self, probs, seed=None):
         self.prob, self.alias = hip_ops.alias_build(probs)
-        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)
+        if seed is None:
+            # replicas must draw DIFFERENT negatives (the reference's per-process generators are
+            # unsynchronised): fold the rank into the Philox key
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            seed = torch.initial_seed() ^ (rank * 0x9E3779B97F4A7C15)
+        self.seed = int(seed) & (2 ** 64 - 1)
         self.offset = 0
 
     def cuda(self, device=None):
