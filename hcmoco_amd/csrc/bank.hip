@@ -15,6 +15,7 @@
 // that coalesce into 256-byte segments), so the dot products reduce with four DPP adds and
 // never touch LDS.  A 256-thread workgroup therefore runs 16 independent "streams", each
 // with its own running max / sum / weighted-row accumulators, merged once at the end.
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -38,6 +39,10 @@ __device__ __constant__ const int kPairBank[6] = {1, 0, 2, 1, 2, 0};
 __device__ __constant__ const int kPairQuery[6] = {0, 1, 1, 2, 0, 2};
 
 __host__ __device__ inline int rows_per_wg(int B, int K1) {
+#ifndef __HIP_DEVICE_COMPILE__
+  static const int forced = getenv("HCM_BANK_ROWS") ? atoi(getenv("HCM_BANK_ROWS")) : 0;
+  if (forced > 0) return forced;
+#endif
   int R = 256;
   while ((long long)B * ((K1 + R - 1) / R) > 8192 && R < (1 << 20)) R <<= 1;
   return R;
@@ -77,8 +82,8 @@ __device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[N
 //   kLogitsFwd : logits[p][b][k] = dot/T
 //   kLogitsBwd : acc[p] += (grad_logits[p][b][k]/T) * row  -> per-workgroup partials
 // ---------------------------------------------------------------------------------------
-template <int NV, int MODE>
-__global__ __launch_bounds__(kWG) void bank_pass_kernel(
+template <int NV, int MODE, int PF = 1, int MINW = 1>
+__global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3,
     const int64_t* __restrict__ idx, const float* __restrict__ x1, const float* __restrict__ x2,
     const float* __restrict__ x3, const float* __restrict__ glogits, int B, int K1, int R,
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(kWG) void bank_pass_kernel(
 
   for (int it = 0; it < niter; ++it) {
     const int64_t r_next2 = ld_idx(it + 2);
-    if (it + 1 < niter) load_rows<NV>(nxt, b1, b2, b3, r_next, t);
+    if (PF && it + 1 < niter) load_rows<NV>(nxt, b1, b2, b3, r_next, t);
     const int k = kbeg + it * kStreams + s;
     const bool valid = k < kend;
 
@@ -177,7 +182,8 @@ __global__ __launch_bounds__(kWG) void bank_pass_kernel(
         for (int v = 0; v < NV; ++v) fma4(acc[p][v], wgt, cur.v[c][v]);
       }
     }
-    cur = nxt;
+    if (PF) cur = nxt;
+    else if (it + 1 < niter) load_rows<NV>(cur, b1, b2, b3, r_next, t);
     r_next = r_next2;
   }
   if (MODE == kLogitsFwd) return;
@@ -638,9 +644,19 @@ int hcm_bank_nce_fused(const float* bank1, const float* bank2, const float* bank
   dim3 grid(nch, B);
   ProfSpan span(st);  // brackets the dominant kernel only
   if (D == 128) {
-    bank_pass_kernel<2, kFused><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, nullptr,
-                                                      B, K1, R, scale2, ws.part_m, ws.part_s,
-                                                      ws.part_acc, ws.l0, nullptr);
+    static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
+#define HCM_LAUNCH_PASS(PF, MINW)                                                                 \
+  bank_pass_kernel<2, kFused, PF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
+                                                              nullptr, B, K1, R, scale2, ws.part_m, \
+                                                              ws.part_s, ws.part_acc, ws.l0, nullptr)
+    switch (variant) {
+      case 1: HCM_LAUNCH_PASS(1, 3); break;
+      case 2: HCM_LAUNCH_PASS(0, 3); break;
+      case 3: HCM_LAUNCH_PASS(0, 4); break;
+      case 4: HCM_LAUNCH_PASS(0, 2); break;
+      default: HCM_LAUNCH_PASS(1, 1); break;
+    }
+#undef HCM_LAUNCH_PASS
     span.stop();
     HCM_CHECK_LAUNCH();
     bank_finish_kernel<128><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
