@@ -1,20 +1,36 @@
 """Micro-benchmark of the fused bank-NCE pass on the GPU box (hipEvent timing through the C ABI).
-Prints achieved algorithmic GB/s:  bytes = 3*B*(K+1)*D*4 + B*(K+1)*8 + 12*B*D*4  (SURVEY 8d)."""
-import sys
+Sweeps the kernel variants (HCM_BANK_VARIANT / HCM_BANK_ROWS are read once per process, so each
+configuration runs in its own subprocess).  Prints achieved algorithmic GB/s:
+bytes = 3*B*(K+1)*D*4 + B*(K+1)*8 + 12*B*D*4  (SURVEY 8d)."""
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from hcmoco_amd import hip_ops
+import subprocess
+import sys
 
-d = torch.device('cuda:0')
-torch.manual_seed(0)
-nrm = torch.nn.functional.normalize
-for n, K, B in [(131072, 16384, 32), (131072, 65536, 32), (1048576, 65536, 32), (131072, 4096, 32)]:
-    D = 128
-    banks = [nrm(torch.randn(n, D, device=d)) for _ in range(3)]
-    xs = [nrm(torch.randn(B, D, device=d)) for _ in range(3)]
-    idx = torch.randint(0, n, (B, K + 1), device=d)
-    hip_ops.bank_nce_fused_timed(banks, idx, xs, 0.07, 3)
-    ms = hip_ops.bank_nce_fused_timed(banks, idx, xs, 0.07, 20)
-    by = 3 * B * (K + 1) * D * 4 + B * (K + 1) * 8 + 12 * B * D * 4
-    print('n=%d K=%d B=%d  %.3f ms/pass  %.1f GB/s algorithmic (%.1f MB)' % (n, K, B, ms, by / ms / 1e6, by / 1e6), flush=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == 'worker':
+    sys.path.insert(0, ROOT)
+    import torch
+    from hcmoco_amd import hip_ops
+    d = torch.device('cuda:0')
+    torch.manual_seed(0)
+    nrm = torch.nn.functional.normalize
+    for n, K, B in [(131072, 16384, 32), (131072, 65536, 32)]:
+        D = 128
+        banks = [nrm(torch.randn(n, D, device=d)) for _ in range(3)]
+        xs = [nrm(torch.randn(B, D, device=d)) for _ in range(3)]
+        idx = torch.randint(0, n, (B, K + 1), device=d)
+        hip_ops.prof_enable(True)
+        for _ in range(25):
+            hip_ops.bank_nce_fused_raw(banks, idx, xs, 0.07)
+        ms, cnt = hip_ops.prof_read()
+        hip_ops.prof_enable(False)
+        whole = hip_ops.bank_nce_fused_timed(banks, idx, xs, 0.07, 20)
+        by = 3 * B * (K + 1) * D * 4 + B * (K + 1) * 8 + 12 * B * D * 4
+        print('  K=%6d  pass %.1f us -> %.0f GB/s   whole op %.1f us' % (K, 1e3 * ms / cnt, by / (ms / cnt) / 1e6, 1e3 * whole),
+              flush=True)
+else:
+    for variant in (0, 1, 2, 3, 4):
+        for rows in (0, 512, 1024):
+            env = dict(os.environ, HCM_BANK_VARIANT=str(variant), HCM_BANK_ROWS=str(rows))
+            print('variant %d rows %d' % (variant, rows), flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), 'worker'], env=env)
