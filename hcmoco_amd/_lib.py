@@ -25,6 +25,7 @@ _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_fl
 
 # name -> (restype, argtypes); mirrors include/hcmoco_hip.h one to one
 SIGNATURES = {
+    # *_bf16 twins are added below the table (same argument lists, uint16 bank pointers)
     'hcm_abi_version': (_i, []),
     'hcm_error_string': (C.c_char_p, [_i]),
     'hcm_alias_build': (_i, [_p, _i64, _p, _p]),
@@ -61,6 +62,10 @@ SIGNATURES = {
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
 }
+
+for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits_fwd', 'hcm_bank_logits_bwd',
+              'hcm_bank_update'):
+    SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]
 
 _lib = None
 

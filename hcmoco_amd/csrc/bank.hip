@@ -53,6 +53,26 @@ struct Row3 {
   float4 v[3][NV];
 };
 
+// ---- bank storage types -----------------------------------------------------------------
+// float: the reference's arithmetic.  bf16_t (BASELINE config 5): rows stored as bfloat16
+// (256 B instead of 512 B per row -> half the gather traffic), every product/sum still fp32.
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) {  // round to nearest even
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) { *p = (bf16_t)((u >> 16) | 0x40); return; }  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  *p = (bf16_t)(u >> 16);
+}
+// first column held by float4 slot v of lane t (t = lane within its 16-lane row):
+//   float: [4t,4t+4) and [64+4t,64+4t+4)   (two 256-byte coalesced segments per 16 lanes)
+//   bf16 : [8t,8t+4) and [8t+4,8t+8)       (one 16-byte load = 8 contiguous bf16 per lane)
+template <class T> __device__ __forceinline__ int colbase(int t, int v);
+template <> __device__ __forceinline__ int colbase<float>(int t, int v) { return 64 * v + 4 * t; }
+template <> __device__ __forceinline__ int colbase<bf16_t>(int t, int v) { return 8 * t + 4 * v; }
+
 template <int NV>
 __device__ __forceinline__ void load_rows(Row3<NV>& r, const float* __restrict__ b1,
                                           const float* __restrict__ b2,
@@ -65,6 +85,25 @@ __device__ __forceinline__ void load_rows(Row3<NV>& r, const float* __restrict__
     r.v[1][v] = *reinterpret_cast<const float4*>(b2 + off + 64 * v);
     r.v[2][v] = *reinterpret_cast<const float4*>(b3 + off + 64 * v);
   }
+}
+__device__ __forceinline__ void unpack8(const uint4& q, float4& lo, float4& hi) {
+  lo = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                   __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+  hi = make_float4(__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u),
+                   __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u));
+}
+template <int NV>
+__device__ __forceinline__ void load_rows(Row3<NV>& r, const bf16_t* __restrict__ b1,
+                                          const bf16_t* __restrict__ b2,
+                                          const bf16_t* __restrict__ b3, int64_t row, int t) {
+  static_assert(NV == 2, "bf16 banks need D == 128");
+  const int64_t off = row * 128 + 8 * t;
+  const uint4 q1 = *reinterpret_cast<const uint4*>(b1 + off);
+  const uint4 q2 = *reinterpret_cast<const uint4*>(b2 + off);
+  const uint4 q3 = *reinterpret_cast<const uint4*>(b3 + off);
+  unpack8(q1, r.v[0][0], r.v[0][1]);
+  unpack8(q2, r.v[1][0], r.v[1][1]);
+  unpack8(q3, r.v[2][0], r.v[2][1]);
 }
 
 template <int NV>
@@ -82,9 +121,9 @@ __device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[N
 //   kLogitsFwd : logits[p][b][k] = dot/T
 //   kLogitsBwd : acc[p] += (grad_logits[p][b][k]/T) * row  -> per-workgroup partials
 // ---------------------------------------------------------------------------------------
-template <int NV, int MODE, int PF = 1, int MINW = 1>
+template <class T, int NV, int MODE, int PF = 1, int MINW = 1>
 __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
-    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3,
+    const T* __restrict__ b1, const T* __restrict__ b2, const T* __restrict__ b3,
     const int64_t* __restrict__ idx, const float* __restrict__ x1, const float* __restrict__ x2,
     const float* __restrict__ x3, const float* __restrict__ glogits, int B, int K1, int R,
     float scale, float* __restrict__ part_m, float* __restrict__ part_s,
@@ -103,9 +142,9 @@ __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
   if (MODE != kLogitsBwd) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      xq[0][v] = *reinterpret_cast<const float4*>(x1 + (int64_t)b * D + 64 * v + 4 * t);
-      xq[1][v] = *reinterpret_cast<const float4*>(x2 + (int64_t)b * D + 64 * v + 4 * t);
-      xq[2][v] = *reinterpret_cast<const float4*>(x3 + (int64_t)b * D + 64 * v + 4 * t);
+      xq[0][v] = *reinterpret_cast<const float4*>(x1 + (int64_t)b * D + colbase<T>(t, v));
+      xq[1][v] = *reinterpret_cast<const float4*>(x2 + (int64_t)b * D + colbase<T>(t, v));
+      xq[2][v] = *reinterpret_cast<const float4*>(x3 + (int64_t)b * D + colbase<T>(t, v));
     }
   }
 
@@ -227,7 +266,7 @@ __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
     for (int p = 0; p < 6; ++p) {
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        *reinterpret_cast<float4*>(&lds_acc[wave][p][64 * v + 4 * t]) = acc[p][v];
+        *reinterpret_cast<float4*>(&lds_acc[wave][p][colbase<T>(t, v)]) = acc[p][v];
       if (t == 0) {
         lds_m[wave][p] = m[p];
         lds_s[wave][p] = ssum[p];
@@ -276,9 +315,9 @@ __device__ __forceinline__ bool row_selected(int p, int b, const int32_t* use_de
 }
 
 // Pass 2 (fused): one workgroup per sample merges the chunk partials of that sample.
-template <int D>
+template <class T, int D>
 __global__ __launch_bounds__(kWG) void bank_finish_kernel(
-    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ b3,
+    const T* __restrict__ b1, const T* __restrict__ b2, const T* __restrict__ b3,
     const int64_t* __restrict__ idx, const int32_t* __restrict__ use_depth,
     const int32_t* __restrict__ use_rgb, int B, int K1, int nchunks, float invT,
     const float* __restrict__ part_m, const float* __restrict__ part_s,
@@ -327,8 +366,8 @@ __global__ __launch_bounds__(kWG) void bank_finish_kernel(
     float a = 0.f;
     for (int c = 0; c < nchunks; ++c)
       a += part_acc[(((int64_t)b * nchunks + c) * 6 + p) * D + col] * dyn[c * 6 + p];
-    const float* bank = (kPairBank[p] == 0) ? b1 : (kPairBank[p] == 1 ? b2 : b3);
-    const float row0 = bank[r0 * D + col];
+    const T* bank = (kPairBank[p] == 0) ? b1 : (kPairBank[p] == 1 ? b2 : b3);
+    const float row0 = ldf(bank + r0 * D + col);
     // |R_p| : sets 0-3 follow the mask, sets 4-5 use every row unless use_rgb is given
     int cnt;
     if (!masked) cnt = B;
@@ -408,10 +447,10 @@ __global__ __launch_bounds__(kWG) void bank_logits_bwd_finish_kernel(
 // ---------------------------------------------------------------------------------------
 // Row 3: momentum update.  grid (BW, 3 banks), one wave per (j, bank).
 // ---------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(64) void bank_update_kernel(float* __restrict__ b1,
-                                                         float* __restrict__ b2,
-                                                         float* __restrict__ b3,
+template <class T, int D>
+__global__ __launch_bounds__(64) void bank_update_kernel(T* __restrict__ b1,
+                                                         T* __restrict__ b2,
+                                                         T* __restrict__ b3,
                                                          const float* __restrict__ x1,
                                                          const float* __restrict__ x2,
                                                          const float* __restrict__ x3,
@@ -423,7 +462,7 @@ __global__ __launch_bounds__(64) void bank_update_kernel(float* __restrict__ b1,
   bool later_dup = false;
   for (int jj = j + 1 + lane; jj < BW; jj += 64) later_dup |= (y[jj] == row);
   if (__any(later_dup)) return;
-  float* bank = which == 0 ? b1 : (which == 1 ? b2 : b3);
+  T* bank = which == 0 ? b1 : (which == 1 ? b2 : b3);
   const float* x = which == 0 ? x1 : (which == 1 ? x2 : x3);
   constexpr int PER = D / 64;
   float w[PER];
@@ -431,7 +470,7 @@ __global__ __launch_bounds__(64) void bank_update_kernel(float* __restrict__ b1,
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int col = lane + 64 * i;
-    const float old = bank[row * D + col];
+    const float old = ldf(bank + row * D + col);
     const float xv = x[(int64_t)j * D + col];
     w[i] = __fadd_rn(__fmul_rn(old, mom), __fmul_rn(xv, one_minus_mom));
     ss = fmaf(w[i], w[i], ss);
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(64) void bank_update_kernel(float* __restrict__ b1,
   ss = wave_sum(ss);
   const float denom = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
-  for (int i = 0; i < PER; ++i) bank[row * D + lane + 64 * i] = w[i] / denom;
+  for (int i = 0; i < PER; ++i) stf(bank + row * D + lane + 64 * i, w[i] / denom);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -592,6 +631,175 @@ struct ProfSpan {
 
 }  // namespace
 
+// ---- host launch logic, shared by the fp32 and bf16 entry points -----------------------------
+namespace {
+
+template <class T>
+int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* idx, const float* x1,
+               const float* x2, const float* x3, const int32_t* use_depth, const int32_t* use_rgb,
+               int B, int K1, int D, float T_, float* losses6, float* accs6, float* gx1, float* gx2,
+               float* gx3, void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  if (!dim_ok(D) || (kBf16 && D != 128) || B <= 0 || K1 <= 0 || !(T_ > 0.f))
+    return (int)hipErrorInvalidValue;
+  if (use_rgb != nullptr && use_depth == nullptr) return (int)hipErrorInvalidValue;
+  const FusedWs ws = carve(workspace, B, K1, D);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = rows_per_wg(B, K1);
+  const int nch = (K1 + R - 1) / R;
+  const float invT = (float)(1.0 / (double)T_);
+  const float scale2 = (float)((double)HCM_LOG2E / (double)T_);
+  dim3 grid(nch, B);
+  ProfSpan span(st);  // brackets the dominant kernel only
+  if (D == 128) {
+    static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
+#define HCM_LAUNCH_PASS(PF, MINW)                                                                   \
+  bank_pass_kernel<T, 2, kFused, PF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
+                                                                 nullptr, B, K1, R, scale2, ws.part_m, \
+                                                                 ws.part_s, ws.part_acc, ws.l0, nullptr)
+    switch (variant) {  // tuning variants (tools/tune_bank.py); 0 is the measured best
+      case 1: HCM_LAUNCH_PASS(1, 3); break;
+      case 2: HCM_LAUNCH_PASS(0, 3); break;
+      case 4: HCM_LAUNCH_PASS(0, 2); break;
+      default: HCM_LAUNCH_PASS(1, 1); break;
+    }
+#undef HCM_LAUNCH_PASS
+    span.stop();
+    HCM_CHECK_LAUNCH();
+    bank_finish_kernel<T, 128><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
+        bank1, bank2, bank3, idx, use_depth, use_rgb, B, K1, nch, invT, ws.part_m, ws.part_s,
+        ws.part_acc, ws.l0, ws.ps_loss, ws.ps_correct, gx1, gx2, gx3);
+  } else {
+    if constexpr (!kBf16) {
+      bank_pass_kernel<T, 1, kFused><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
+                                                           nullptr, B, K1, R, scale2, ws.part_m,
+                                                           ws.part_s, ws.part_acc, ws.l0, nullptr);
+      span.stop();
+      HCM_CHECK_LAUNCH();
+      bank_finish_kernel<T, 64><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
+          bank1, bank2, bank3, idx, use_depth, use_rgb, B, K1, nch, invT, ws.part_m, ws.part_s,
+          ws.part_acc, ws.l0, ws.ps_loss, ws.ps_correct, gx1, gx2, gx3);
+    }
+  }
+  HCM_CHECK_LAUNCH();
+  bank_reduce_kernel<<<1, 64, 0, st>>>(ws.ps_loss, ws.ps_correct, use_depth, use_rgb, B, losses6,
+                                       accs6);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+template <class T>
+int logits_fwd_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* idx,
+                    const float* x1, const float* x2, const float* x3, int B, int K1, int D, float T_,
+                    float* logits, hcm_stream_t stream) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  if (!dim_ok(D) || (kBf16 && D != 128) || B <= 0 || K1 <= 0 || !(T_ > 0.f))
+    return (int)hipErrorInvalidValue;
+  const int R = rows_per_wg(B, K1);
+  dim3 grid((K1 + R - 1) / R, B);
+  const float invT = (float)(1.0 / (double)T_);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) {
+    bank_pass_kernel<T, 2, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
+                                                             nullptr, B, K1, R, invT, nullptr,
+                                                             nullptr, nullptr, nullptr, logits);
+  } else {
+    if constexpr (!kBf16)
+      bank_pass_kernel<T, 1, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
+                                                               nullptr, B, K1, R, invT, nullptr,
+                                                               nullptr, nullptr, nullptr, logits);
+  }
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+template <class T>
+int logits_bwd_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* idx,
+                    const float* grad_logits, int B, int K1, int D, float T_, float* gx1, float* gx2,
+                    float* gx3, void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  if (!dim_ok(D) || (kBf16 && D != 128) || B <= 0 || K1 <= 0 || !(T_ > 0.f))
+    return (int)hipErrorInvalidValue;
+  const FusedWs ws = carve(workspace, B, K1, D);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
+  const int R = rows_per_wg(B, K1);
+  const int nch = (K1 + R - 1) / R;
+  dim3 grid(nch, B);
+  const float invT = (float)(1.0 / (double)T_);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) {
+    bank_pass_kernel<T, 2, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr,
+                                                             nullptr, nullptr, grad_logits, B, K1, R,
+                                                             invT, nullptr, nullptr, ws.part_acc,
+                                                             nullptr, nullptr);
+    HCM_CHECK_LAUNCH();
+    bank_logits_bwd_finish_kernel<128><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
+  } else {
+    if constexpr (!kBf16) {
+      bank_pass_kernel<T, 1, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr,
+                                                               nullptr, nullptr, grad_logits, B, K1,
+                                                               R, invT, nullptr, nullptr, ws.part_acc,
+                                                               nullptr, nullptr);
+      HCM_CHECK_LAUNCH();
+      bank_logits_bwd_finish_kernel<64><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
+    }
+  }
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+template <class T>
+int update_impl(T* bank1, T* bank2, T* bank3, const float* all_x1, const float* all_x2,
+                const float* all_x3, const int64_t* all_y, int BW, int D, float momentum,
+                hcm_stream_t stream) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  if (!dim_ok(D) || (kBf16 && D != 128) || BW <= 0) return (int)hipErrorInvalidValue;
+  const float omm = (float)(1.0 - (double)momentum);
+  dim3 grid(BW, 3);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    bank_update_kernel<T, 128><<<grid, 64, 0, st>>>(bank1, bank2, bank3, all_x1, all_x2, all_x3,
+                                                    all_y, BW, momentum, omm);
+  else
+    bank_update_kernel<T, 64><<<grid, 64, 0, st>>>(bank1, bank2, bank3, all_x1, all_x2, all_x3,
+                                                   all_y, BW, momentum, omm);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+template <class T>
+int fused_timed_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* idx,
+                     const float* x1, const float* x2, const float* x3, const int32_t* use_depth,
+                     const int32_t* use_rgb, int B, int K1, int D, float T_, float* losses6,
+                     float* accs6, float* gx1, float* gx2, float* gx3, void* workspace,
+                     size_t workspace_bytes, hcm_stream_t stream, int reps, float* ms_per_pass_host) {
+  if (reps <= 0 || ms_per_pass_host == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  hipError_t e = hipEventCreate(&e0);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreate(&e1);
+  if (e != hipSuccess) return (int)e;
+  int rc = 0;
+  hipEventRecord(e0, st);
+  for (int i = 0; i < reps && rc == 0; ++i)
+    rc = fused_impl<T>(bank1, bank2, bank3, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D, T_,
+                       losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes, stream);
+  hipEventRecord(e1, st);
+  e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc != 0) return rc;
+  if (e != hipSuccess) return (int)e;
+  *ms_per_pass_host = ms / (float)reps;
+  return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int hcm_prof_enable(int enable) {
@@ -632,51 +840,18 @@ int hcm_bank_nce_fused(const float* bank1, const float* bank2, const float* bank
                        float T, float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
                        void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
   (void)n;
-  if (!dim_ok(D) || B <= 0 || K1 <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
-  if (use_rgb != nullptr && use_depth == nullptr) return (int)hipErrorInvalidValue;
-  const FusedWs ws = carve(workspace, B, K1, D);
-  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  const int R = rows_per_wg(B, K1);
-  const int nch = (K1 + R - 1) / R;
-  const float invT = (float)(1.0 / (double)T);
-  const float scale2 = (float)((double)HCM_LOG2E / (double)T);
-  dim3 grid(nch, B);
-  ProfSpan span(st);  // brackets the dominant kernel only
-  if (D == 128) {
-    static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
-#define HCM_LAUNCH_PASS(PF, MINW)                                                                 \
-  bank_pass_kernel<2, kFused, PF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
-                                                              nullptr, B, K1, R, scale2, ws.part_m, \
-                                                              ws.part_s, ws.part_acc, ws.l0, nullptr)
-    switch (variant) {
-      case 1: HCM_LAUNCH_PASS(1, 3); break;
-      case 2: HCM_LAUNCH_PASS(0, 3); break;
-      case 3: HCM_LAUNCH_PASS(0, 4); break;
-      case 4: HCM_LAUNCH_PASS(0, 2); break;
-      default: HCM_LAUNCH_PASS(1, 1); break;
-    }
-#undef HCM_LAUNCH_PASS
-    span.stop();
-    HCM_CHECK_LAUNCH();
-    bank_finish_kernel<128><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
-        bank1, bank2, bank3, idx, use_depth, use_rgb, B, K1, nch, invT, ws.part_m, ws.part_s,
-        ws.part_acc, ws.l0, ws.ps_loss, ws.ps_correct, gx1, gx2, gx3);
-  } else {
-    bank_pass_kernel<1, kFused><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, nullptr,
-                                                      B, K1, R, scale2, ws.part_m, ws.part_s,
-                                                      ws.part_acc, ws.l0, nullptr);
-    span.stop();
-    HCM_CHECK_LAUNCH();
-    bank_finish_kernel<64><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(
-        bank1, bank2, bank3, idx, use_depth, use_rgb, B, K1, nch, invT, ws.part_m, ws.part_s,
-        ws.part_acc, ws.l0, ws.ps_loss, ws.ps_correct, gx1, gx2, gx3);
-  }
-  HCM_CHECK_LAUNCH();
-  bank_reduce_kernel<<<1, 64, 0, st>>>(ws.ps_loss, ws.ps_correct, use_depth, use_rgb, B, losses6,
-                                       accs6);
-  HCM_CHECK_LAUNCH();
-  return 0;
+  return fused_impl<float>(bank1, bank2, bank3, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D, T,
+                           losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes, stream);
+}
+int hcm_bank_nce_fused_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3,
+                            int64_t n, const int64_t* idx, const float* x1, const float* x2,
+                            const float* x3, const int32_t* use_depth, const int32_t* use_rgb, int B,
+                            int K1, int D, float T, float* losses6, float* accs6, float* gx1,
+                            float* gx2, float* gx3, void* workspace, size_t workspace_bytes,
+                            hcm_stream_t stream) {
+  (void)n;
+  return fused_impl<bf16_t>(bank1, bank2, bank3, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D, T,
+                            losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes, stream);
 }
 
 int hcm_bank_nce_fused_timed(const float* bank1, const float* bank2, const float* bank3, int64_t n,
@@ -685,49 +860,36 @@ int hcm_bank_nce_fused_timed(const float* bank1, const float* bank2, const float
                              float T, float* losses6, float* accs6, float* gx1, float* gx2,
                              float* gx3, void* workspace, size_t workspace_bytes,
                              hcm_stream_t stream, int reps, float* ms_per_pass_host) {
-  if (reps <= 0 || ms_per_pass_host == nullptr) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  hipEvent_t e0, e1;
-  hipError_t e = hipEventCreate(&e0);
-  if (e != hipSuccess) return (int)e;
-  e = hipEventCreate(&e1);
-  if (e != hipSuccess) return (int)e;
-  int rc = 0;
-  hipEventRecord(e0, st);
-  for (int i = 0; i < reps && rc == 0; ++i)
-    rc = hcm_bank_nce_fused(bank1, bank2, bank3, n, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D,
-                            T, losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes, stream);
-  hipEventRecord(e1, st);
-  e = hipEventSynchronize(e1);
-  float ms = 0.f;
-  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  if (rc != 0) return rc;
-  if (e != hipSuccess) return (int)e;
-  *ms_per_pass_host = ms / (float)reps;
-  return 0;
+  (void)n;
+  return fused_timed_impl<float>(bank1, bank2, bank3, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D,
+                                 T, losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes, stream,
+                                 reps, ms_per_pass_host);
+}
+int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2,
+                                  const uint16_t* bank3, int64_t n, const int64_t* idx,
+                                  const float* x1, const float* x2, const float* x3,
+                                  const int32_t* use_depth, const int32_t* use_rgb, int B, int K1,
+                                  int D, float T, float* losses6, float* accs6, float* gx1,
+                                  float* gx2, float* gx3, void* workspace, size_t workspace_bytes,
+                                  hcm_stream_t stream, int reps, float* ms_per_pass_host) {
+  (void)n;
+  return fused_timed_impl<bf16_t>(bank1, bank2, bank3, idx, x1, x2, x3, use_depth, use_rgb, B, K1, D,
+                                  T, losses6, accs6, gx1, gx2, gx3, workspace, workspace_bytes,
+                                  stream, reps, ms_per_pass_host);
 }
 
 int hcm_bank_logits_fwd(const float* bank1, const float* bank2, const float* bank3, int64_t n,
                         const int64_t* idx, const float* x1, const float* x2, const float* x3,
                         int B, int K1, int D, float T, float* logits, hcm_stream_t stream) {
   (void)n;
-  if (!dim_ok(D) || B <= 0 || K1 <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
-  const int R = rows_per_wg(B, K1);
-  dim3 grid((K1 + R - 1) / R, B);
-  const float invT = (float)(1.0 / (double)T);
-  hipStream_t st = (hipStream_t)stream;
-  if (D == 128)
-    bank_pass_kernel<2, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
-                                                          nullptr, B, K1, R, invT, nullptr, nullptr,
-                                                          nullptr, nullptr, logits);
-  else
-    bank_pass_kernel<1, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
-                                                          nullptr, B, K1, R, invT, nullptr, nullptr,
-                                                          nullptr, nullptr, logits);
-  HCM_CHECK_LAUNCH();
-  return 0;
+  return logits_fwd_impl<float>(bank1, bank2, bank3, idx, x1, x2, x3, B, K1, D, T, logits, stream);
+}
+int hcm_bank_logits_fwd_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3,
+                             int64_t n, const int64_t* idx, const float* x1, const float* x2,
+                             const float* x3, int B, int K1, int D, float T, float* logits,
+                             hcm_stream_t stream) {
+  (void)n;
+  return logits_fwd_impl<bf16_t>(bank1, bank2, bank3, idx, x1, x2, x3, B, K1, D, T, logits, stream);
 }
 
 int hcm_bank_logits_bwd(const float* bank1, const float* bank2, const float* bank3, int64_t n,
@@ -735,49 +897,29 @@ int hcm_bank_logits_bwd(const float* bank1, const float* bank2, const float* ban
                         float* gx1, float* gx2, float* gx3, void* workspace,
                         size_t workspace_bytes, hcm_stream_t stream) {
   (void)n;
-  if (!dim_ok(D) || B <= 0 || K1 <= 0 || !(T > 0.f)) return (int)hipErrorInvalidValue;
-  const FusedWs ws = carve(workspace, B, K1, D);
-  if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
-  const int R = rows_per_wg(B, K1);
-  const int nch = (K1 + R - 1) / R;
-  dim3 grid(nch, B);
-  const float invT = (float)(1.0 / (double)T);
-  hipStream_t st = (hipStream_t)stream;
-  if (D == 128) {
-    bank_pass_kernel<2, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr, nullptr,
-                                                          nullptr, grad_logits, B, K1, R, invT,
-                                                          nullptr, nullptr, ws.part_acc, nullptr,
-                                                          nullptr);
-    HCM_CHECK_LAUNCH();
-    bank_logits_bwd_finish_kernel<128><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
-  } else {
-    bank_pass_kernel<1, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr, nullptr,
-                                                          nullptr, grad_logits, B, K1, R, invT,
-                                                          nullptr, nullptr, ws.part_acc, nullptr,
-                                                          nullptr);
-    HCM_CHECK_LAUNCH();
-    bank_logits_bwd_finish_kernel<64><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
-  }
-  HCM_CHECK_LAUNCH();
-  return 0;
+  return logits_bwd_impl<float>(bank1, bank2, bank3, idx, grad_logits, B, K1, D, T, gx1, gx2, gx3,
+                                workspace, workspace_bytes, stream);
+}
+int hcm_bank_logits_bwd_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3,
+                             int64_t n, const int64_t* idx, const float* grad_logits, int B, int K1,
+                             int D, float T, float* gx1, float* gx2, float* gx3, void* workspace,
+                             size_t workspace_bytes, hcm_stream_t stream) {
+  (void)n;
+  return logits_bwd_impl<bf16_t>(bank1, bank2, bank3, idx, grad_logits, B, K1, D, T, gx1, gx2, gx3,
+                                 workspace, workspace_bytes, stream);
 }
 
 int hcm_bank_update(float* bank1, float* bank2, float* bank3, int64_t n, const float* all_x1,
                     const float* all_x2, const float* all_x3, const int64_t* all_y, int BW, int D,
                     float momentum, hcm_stream_t stream) {
   (void)n;
-  if (!dim_ok(D) || BW <= 0) return (int)hipErrorInvalidValue;
-  const float omm = (float)(1.0 - (double)momentum);
-  dim3 grid(BW, 3);
-  hipStream_t st = (hipStream_t)stream;
-  if (D == 128)
-    bank_update_kernel<128><<<grid, 64, 0, st>>>(bank1, bank2, bank3, all_x1, all_x2, all_x3, all_y,
-                                                 BW, momentum, omm);
-  else
-    bank_update_kernel<64><<<grid, 64, 0, st>>>(bank1, bank2, bank3, all_x1, all_x2, all_x3, all_y,
-                                                BW, momentum, omm);
-  HCM_CHECK_LAUNCH();
-  return 0;
+  return update_impl<float>(bank1, bank2, bank3, all_x1, all_x2, all_x3, all_y, BW, D, momentum, stream);
+}
+int hcm_bank_update_bf16(uint16_t* bank1, uint16_t* bank2, uint16_t* bank3, int64_t n,
+                         const float* all_x1, const float* all_x2, const float* all_x3,
+                         const int64_t* all_y, int BW, int D, float momentum, hcm_stream_t stream) {
+  (void)n;
+  return update_impl<bf16_t>(bank1, bank2, bank3, all_x1, all_x2, all_x3, all_y, BW, D, momentum, stream);
 }
 
 int hcm_alias_build(const float* probs_host, int64_t n, float* prob_out_host,

@@ -41,6 +41,16 @@ def _i32(t):
     return t.to(dtype=torch.int32).contiguous()
 
 
+def _bank_entry(name, banks):
+    """(C function, torch dtype) for fp32 or bf16 bank storage (BASELINE config 5)."""
+    dt = banks[0].dtype
+    if dt == torch.float32:
+        return getattr(_lib.lib(), name), dt
+    if dt == torch.bfloat16:
+        return getattr(_lib.lib(), name + '_bf16'), dt
+    raise TypeError('banks must be float32 or bfloat16, got %s' % dt)
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -84,11 +94,12 @@ def bank_nce_fused_raw(banks, idx, xs, T, use_depth=None, use_rgb=None):
     gx = torch.empty(3, B, D, dtype=torch.float32, device=dev)
     ud, ur = _i32(use_depth), _i32(use_rgb)
     L = _lib.lib()
+    fn, bdt = _bank_entry('hcm_bank_nce_fused', banks)
     nbytes = L.hcm_bank_nce_workspace_bytes(B, K1, D)
     ws = _ws(nbytes, dev)
-    check(L.hcm_bank_nce_fused(
-        _dev(banks[0], torch.float32, 'bank_nce'), _dev(banks[1], torch.float32, 'bank_nce'),
-        _dev(banks[2], torch.float32, 'bank_nce'), banks[0].shape[0],
+    check(fn(
+        _dev(banks[0], bdt, 'bank_nce'), _dev(banks[1], bdt, 'bank_nce'),
+        _dev(banks[2], bdt, 'bank_nce'), banks[0].shape[0],
         _dev(idx, torch.int64, 'bank_nce'),
         _dev(x1, torch.float32, 'bank_nce'), _dev(x2, torch.float32, 'bank_nce'), _dev(x3, torch.float32, 'bank_nce'),
         _opt(ud, torch.int32, 'bank_nce'), _opt(ur, torch.int32, 'bank_nce'),
@@ -133,9 +144,10 @@ def bank_nce_fused_timed(banks, idx, xs, T, reps, use_depth=None):
     nbytes = L.hcm_bank_nce_workspace_bytes(B, K1, D)
     ws = _ws(nbytes, dev)
     ms = C.c_float(0.0)
-    check(L.hcm_bank_nce_fused_timed(
-        _dev(banks[0], torch.float32, 'bank_nce'), _dev(banks[1], torch.float32, 'bank_nce'),
-        _dev(banks[2], torch.float32, 'bank_nce'), banks[0].shape[0], _dev(idx, torch.int64, 'bank_nce'),
+    fn, bdt = _bank_entry('hcm_bank_nce_fused_timed', banks)
+    check(fn(
+        _dev(banks[0], bdt, 'bank_nce'), _dev(banks[1], bdt, 'bank_nce'),
+        _dev(banks[2], bdt, 'bank_nce'), banks[0].shape[0], _dev(idx, torch.int64, 'bank_nce'),
         _dev(x1, torch.float32, 'bank_nce'), _dev(x2, torch.float32, 'bank_nce'), _dev(x3, torch.float32, 'bank_nce'),
         _opt(ud, torch.int32, 'bank_nce'), C.c_void_p(0), B, K1, D, float(T),
         C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 24),
@@ -166,9 +178,10 @@ class _BankLogits(torch.autograd.Function):
         B, D = x1.shape
         K1 = idx.shape[1]
         logits = torch.empty(6, B, K1, dtype=torch.float32, device=x1.device)
-        check(_lib.lib().hcm_bank_logits_fwd(
-            _dev(bank1, torch.float32, 'bank_logits'), _dev(bank2, torch.float32, 'bank_logits'),
-            _dev(bank3, torch.float32, 'bank_logits'), bank1.shape[0], _dev(idx, torch.int64, 'bank_logits'),
+        fn, bdt = _bank_entry('hcm_bank_logits_fwd', [bank1])
+        check(fn(
+            _dev(bank1, bdt, 'bank_logits'), _dev(bank2, bdt, 'bank_logits'),
+            _dev(bank3, bdt, 'bank_logits'), bank1.shape[0], _dev(idx, torch.int64, 'bank_logits'),
             _dev(x1, torch.float32, 'bank_logits'), _dev(x2, torch.float32, 'bank_logits'),
             _dev(x3, torch.float32, 'bank_logits'), B, K1, D, float(T),
             C.c_void_p(logits.data_ptr()), _stream()), 'hcm_bank_logits_fwd')
@@ -187,9 +200,10 @@ class _BankLogits(torch.autograd.Function):
         L = _lib.lib()
         nbytes = L.hcm_bank_nce_workspace_bytes(B, K1, D)
         ws = _ws(nbytes, g.device)
-        check(L.hcm_bank_logits_bwd(
-            _dev(bank1, torch.float32, 'bank_logits'), _dev(bank2, torch.float32, 'bank_logits'),
-            _dev(bank3, torch.float32, 'bank_logits'), bank1.shape[0], _dev(idx, torch.int64, 'bank_logits'),
+        fn, bdt = _bank_entry('hcm_bank_logits_bwd', [bank1])
+        check(fn(
+            _dev(bank1, bdt, 'bank_logits'), _dev(bank2, bdt, 'bank_logits'),
+            _dev(bank3, bdt, 'bank_logits'), bank1.shape[0], _dev(idx, torch.int64, 'bank_logits'),
             _dev(g, torch.float32, 'bank_logits'), B, K1, D, ctx.T,
             C.c_void_p(gx[0].data_ptr()), C.c_void_p(gx[1].data_ptr()), C.c_void_p(gx[2].data_ptr()),
             C.c_void_p(ws.data_ptr()), nbytes, _stream()), 'hcm_bank_logits_bwd')
@@ -207,9 +221,10 @@ def bank_logits(xs, banks, idx, T):
 @torch.no_grad()
 def bank_update(banks, all_xs, all_y, momentum):
     BW, D = all_xs[0].shape
-    check(_lib.lib().hcm_bank_update(
-        _dev(banks[0], torch.float32, 'bank_update'), _dev(banks[1], torch.float32, 'bank_update'),
-        _dev(banks[2], torch.float32, 'bank_update'), banks[0].shape[0],
+    fn, bdt = _bank_entry('hcm_bank_update', banks)
+    check(fn(
+        _dev(banks[0], bdt, 'bank_update'), _dev(banks[1], bdt, 'bank_update'),
+        _dev(banks[2], bdt, 'bank_update'), banks[0].shape[0],
         _dev(all_xs[0].detach().contiguous(), torch.float32, 'bank_update'),
         _dev(all_xs[1].detach().contiguous(), torch.float32, 'bank_update'),
         _dev(all_xs[2].detach().contiguous(), torch.float32, 'bank_update'),

@@ -29,12 +29,14 @@ class BaseMem(nn.Module):
 
 
 class CMCMem3(BaseMem):
-    def __init__(self, n_dim, n_data, K=65536, T=0.07, m=0.5, seed=None):
+    def __init__(self, n_dim, n_data, K=65536, T=0.07, m=0.5, seed=None, bank_dtype=torch.float32):
+        """``bank_dtype=torch.bfloat16`` (BASELINE config 5, a build-side option) stores the banks in
+        bf16 -- half the gather traffic; all products and sums stay fp32 in the kernels."""
         super().__init__(K, T, m)
         self.n_dim, self.n_data = n_dim, n_data
         self.multinomial = AliasMethod(torch.ones(n_data), seed=seed)
         for name in ('memory_1', 'memory_2', 'memory_3'):
-            self.register_buffer(name, F.normalize(torch.randn(n_data, n_dim)))
+            self.register_buffer(name, F.normalize(torch.randn(n_data, n_dim)).to(bank_dtype))
 
     # nn.Module.cuda()/.to() move the buffers; the sampler tables follow
     def _apply(self, fn):

@@ -97,6 +97,8 @@ BASE_FLAGS = [
     (('--synthetic_n_data',), dict(type=_I, default=131072)),
     (('--synthetic_size',), dict(type=_I, default=256)),
     (('--synthetic_steps',), dict(type=_I, default=50, help='batches per epoch in synthetic mode')),
+    (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
+                             help='storage type of the memory banks (bf16: BASELINE config 5)')),
 ]
 
 

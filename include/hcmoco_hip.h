@@ -75,6 +75,26 @@ int hcm_bank_logits_bwd(const float* bank1, const float* bank2, const float* ban
                         int B, int K1, int D, float T, float* gx1, float* gx2, float* gx3,
                         void* workspace, size_t workspace_bytes, hcm_stream_t stream);
 
+/* bf16 bank storage (BASELINE config 5): banks are [n, 128] bfloat16 (raw uint16 bits), every
+ * product and sum stays fp32, the update rounds to nearest even.  Same contracts as the fp32
+ * entry points above/below; D must be 128. */
+int hcm_bank_nce_fused_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3, int64_t n,
+                            const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                            const int32_t* use_depth, const int32_t* use_rgb,
+                            int B, int K1, int D, float T,
+                            float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
+                            void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+int hcm_bank_logits_fwd_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3, int64_t n,
+                             const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                             int B, int K1, int D, float T, float* logits, hcm_stream_t stream);
+int hcm_bank_logits_bwd_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3, int64_t n,
+                             const int64_t* idx, const float* grad_logits,
+                             int B, int K1, int D, float T, float* gx1, float* gx2, float* gx3,
+                             void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+int hcm_bank_update_bf16(uint16_t* bank1, uint16_t* bank2, uint16_t* bank3, int64_t n,
+                         const float* all_x1, const float* all_x2, const float* all_x3,
+                         const int64_t* all_y, int BW, int D, float momentum, hcm_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Row 3 -- BaseMem._update_memory (memory/mem_bank.py:15-28), all three banks in one launch.
  * all_x* [BW, D], all_y [BW] int64 in gather (rank-major) order.  Reads use the
@@ -190,6 +210,13 @@ int hcm_bank_nce_fused_timed(const float* bank1, const float* bank2, const float
                              float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
                              void* workspace, size_t workspace_bytes, hcm_stream_t stream,
                              int reps, float* ms_per_pass_host);
+int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2, const uint16_t* bank3, int64_t n,
+                                  const int64_t* idx, const float* x1, const float* x2, const float* x3,
+                                  const int32_t* use_depth, const int32_t* use_rgb,
+                                  int B, int K1, int D, float T,
+                                  float* losses6, float* accs6, float* gx1, float* gx2, float* gx3,
+                                  void* workspace, size_t workspace_bytes, hcm_stream_t stream,
+                                  int reps, float* ms_per_pass_host);
 
 /* In-library timing of the dominant kernel (the gather pass of hcm_bank_nce_fused): while enabled,
  * every launch is bracketed by hipEvents on its own stream.  hcm_prof_read synchronises those

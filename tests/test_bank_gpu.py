@@ -208,3 +208,53 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops().bank_nce_fused_raw([torch.randn(8, 128)] * 3, torch.zeros(2, 3, dtype=torch.long),
                                  [torch.randn(2, 128)] * 3, 0.07)
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 bank storage (BASELINE config 5).  The oracle runs on the SAME bf16-rounded rows in fp32, so
+# the tolerances stay the fp32 ones; only the update's final rounding is a bf16 ulp.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,K,n', [(4, 100, 300), (32, 4096, 20000)])
+def test_bf16_banks_fused_logits_and_update(B, K, n):
+    torch.manual_seed(B + K)
+    d = dev()
+    D, T, mom = 128, 0.07, 0.5
+    nrm = torch.nn.functional.normalize
+    banks16 = [nrm(torch.randn(n, D)).to(torch.bfloat16) for _ in range(3)]
+    banks32 = [b.float() for b in banks16]
+    xs = [nrm(torch.randn(B, D)) for _ in range(3)]
+    idx = torch.randint(0, n, (B, K + 1))
+    ud = (torch.rand(B) < 0.7).long()
+    ud[0] = 1
+    lo, ao, go, logits_o = O.bank_nce(banks32, idx, xs, T, use_depth=ud)
+    gb = [b.to(d) for b in banks16]
+    l, a, gx = ops().bank_nce_fused_raw(gb, idx.to(d), [x.to(d) for x in xs], T, ud.to(d))
+    assert torch.allclose(l.cpu(), lo, rtol=LOSS_RTOL, atol=1e-6)
+    assert torch.allclose(a.cpu(), ao, atol=1e-3)
+    for i in range(3):
+        assert rel_l2(gx[i], go[i]) < GRAD_REL_L2
+    xg = [x.to(d).requires_grad_(True) for x in xs]
+    lg = ops().bank_logits(xg, gb, idx.to(d), T)
+    for p in range(6):
+        assert torch.allclose(lg[p].cpu(), logits_o[p], rtol=0, atol=LOGIT_ATOL)
+    lg.sum().backward()
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    sum(t.sum() for t in O.bank_logits(banks32, idx, xo, T)).backward()
+    for i in range(3):
+        assert rel_l2(xg[i].grad, xo[i].grad) < GRAD_REL_L2
+    # update: fp32 math on the bf16 rows, result rounded to nearest-even bf16; last duplicate wins
+    all_y = torch.randint(0, n, (2 * B,))
+    all_y[-1] = all_y[0]
+    all_x = [nrm(torch.randn(2 * B, D)) for _ in range(3)]
+    ops().bank_update(gb, [x.to(d) for x in all_x], all_y.to(d), mom)
+    torch.cuda.synchronize()
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[all_y] = True
+    for i in range(3):
+        new = gb[i].cpu()
+        assert new.dtype == torch.bfloat16
+        assert torch.equal(new[~touched].view(torch.int16), banks16[i][~touched].view(torch.int16))   # bit-exact
+        ref = O.bank_update(banks32[i], all_x[i], all_y, mom)
+        err = (new.float() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all())                                       # <= 1 bf16 ulp
+        assert float((new.float()[touched].norm(dim=1) - 1).abs().max()) < 1e-2
