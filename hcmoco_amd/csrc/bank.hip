@@ -342,18 +342,21 @@ __global__ __launch_bounds__(kWG) void bank_finish_kernel(
     }
     if (sel) atomicAdd(&sCntSel, sel);
   }
-  if (tid < 6) {
-    const int p = tid;
+  if (tid < 192) {  // 32 threads per pair: strided partial max / sum, then a fixed 32-lane tree
+    const int p = tid >> 5, j = tid & 31;
     float M = kNegBig;
-    for (int c = 0; c < nchunks; ++c) M = fmaxf(M, part_m[((int64_t)b * nchunks + c) * 6 + p]);
+    for (int c = j; c < nchunks; c += 32) M = fmaxf(M, part_m[((int64_t)b * nchunks + c) * 6 + p]);
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 32));
     float S = 0.f;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = j; c < nchunks; c += 32) {
       const float sc = fast_exp2(part_m[((int64_t)b * nchunks + c) * 6 + p] - M);
       dyn[c * 6 + p] = sc;
       S += part_s[((int64_t)b * nchunks + c) * 6 + p] * sc;
     }
-    sM[p] = M;
-    sS[p] = S;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) S += __shfl_xor(S, off, 32);
+    if (j == 0) { sM[p] = M; sS[p] = S; }
   }
   __syncthreads();
   const int cnt_sel = sCntSel;
@@ -394,34 +397,37 @@ __global__ __launch_bounds__(kWG) void bank_finish_kernel(
   }
 }
 
-// Pass 3 (fused): fixed-order reduction over the batch -> 6 losses, 6 accuracies.
-__global__ void bank_reduce_kernel(const float* __restrict__ ps_loss,
-                                   const float* __restrict__ ps_correct,
-                                   const int32_t* __restrict__ use_depth,
-                                   const int32_t* __restrict__ use_rgb, int B,
-                                   float* __restrict__ losses6, float* __restrict__ accs6) {
-  const int p = threadIdx.x;
-  if (p >= 6) return;
-  int cnt_sel = 0;
-  for (int i = 0; i < B; ++i) {
+// Pass 3 (fused): fixed-shape (deterministic) reduction over the batch -> 6 losses, 6 accuracies.
+// One wave per pair: lane i takes samples i, i+64, ...; wave_sum is a fixed butterfly.
+__global__ __launch_bounds__(384) void bank_reduce_kernel(const float* __restrict__ ps_loss,
+                                                          const float* __restrict__ ps_correct,
+                                                          const int32_t* __restrict__ use_depth,
+                                                          const int32_t* __restrict__ use_rgb, int B,
+                                                          float* __restrict__ losses6,
+                                                          float* __restrict__ accs6) {
+  const int p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float fsel = 0.f;
+  for (int i = lane; i < B; i += 64) {
     bool v = true;
     if (use_rgb != nullptr) v = use_depth[i] == 1 && use_rgb[i] == 1;
     else if (use_depth != nullptr) v = use_depth[i] == 1;
-    cnt_sel += v ? 1 : 0;
+    fsel += v ? 1.f : 0.f;
   }
-  const bool any_sel = cnt_sel > 0;
-  float sl = 0.f, sc = 0.f;
-  int cnt = 0;
-  for (int i = 0; i < B; ++i) {
+  const bool any_sel = wave_sum(fsel) > 0.f;
+  float sl = 0.f, sc = 0.f, cnt = 0.f;
+  for (int i = lane; i < B; i += 64) {
     if (row_selected(p, i, use_depth, use_rgb, any_sel)) {
       sl += ps_loss[i * 6 + p];
       sc += ps_correct[i * 6 + p];
-      ++cnt;
+      cnt += 1.f;
     }
   }
-  const bool degenerate = (use_depth != nullptr) && !any_sel && p < 4;
-  losses6[p] = (degenerate || cnt == 0) ? 0.f : sl / (float)cnt;
-  accs6[p] = (degenerate || cnt == 0) ? 0.f : 100.f * sc / (float)cnt;
+  sl = wave_sum(sl); sc = wave_sum(sc); cnt = wave_sum(cnt);
+  if (lane == 0) {
+    const bool degenerate = (use_depth != nullptr) && !any_sel && p < 4;
+    losses6[p] = (degenerate || cnt == 0.f) ? 0.f : sl / cnt;
+    accs6[p] = (degenerate || cnt == 0.f) ? 0.f : 100.f * sc / cnt;
+  }
 }
 
 // Pass 2 (API-mode backward): gx_a[b] = sum over chunks and over the two pairs of a.
@@ -683,7 +689,7 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
     }
   }
   HCM_CHECK_LAUNCH();
-  bank_reduce_kernel<<<1, 64, 0, st>>>(ws.ps_loss, ws.ps_correct, use_depth, use_rgb, B, losses6,
+  bank_reduce_kernel<<<1, 384, 0, st>>>(ws.ps_loss, ws.ps_correct, use_depth, use_rgb, B, losses6,
                                        accs6);
   HCM_CHECK_LAUNCH();
   return 0;

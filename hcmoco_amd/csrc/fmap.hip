@@ -363,31 +363,33 @@ __device__ float block_sum(const float* __restrict__ v, int n, float* sh) {
 
 // out4 = {loss_r2d, loss_d2r, acc_r2d, acc_d2r}; orientation 1 rows are the r2d terms.
 // Rows of dropped images were never written by the stats pass -> masked here through keep.
-__global__ __launch_bounds__(kWG) void dense_finish_kernel(const float* __restrict__ rowloss,
-                                                           const float* __restrict__ rowcorrect,
-                                                           const int32_t* __restrict__ keep, int B,
-                                                           int S, const float* __restrict__ gscale,
-                                                           float* __restrict__ out4) {
-  __shared__ float sh[kWG];
-  const int n = B * S;
-  float v[4];
-  for (int k = 0; k < 4; ++k) {
-    const float* src = (k < 2 ? rowloss : rowcorrect) + (int64_t)((k & 1) == 0 ? 1 : 0) * n;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += kWG)
-      if (keep[i / S] != 0) acc += src[i];
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = kWG / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-      __syncthreads();
+__global__ __launch_bounds__(1024) void dense_finish_kernel(const float* __restrict__ rowloss,
+                                                            const float* __restrict__ rowcorrect,
+                                                            const int32_t* __restrict__ keep, int B,
+                                                            int S, const float* __restrict__ gscale,
+                                                            float* __restrict__ out4) {
+  // fixed-shape reduction (deterministic): strided per-thread partials, wave butterfly, 16-wave tree
+  __shared__ float sh[4][16];
+  const int n = B * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < n; i += 1024) {
+    if (keep[i / S] != 0) {
+      v[0] += rowloss[n + i];      // loss_r2d: orientation 1
+      v[1] += rowloss[i];          // loss_d2r: orientation 0
+      v[2] += rowcorrect[n + i];
+      v[3] += rowcorrect[i];
     }
-    v[k] = sh[0];
-    __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const float gsc = *gscale;  // 1/(B'S), 0 when nothing is kept (reference early return -> zeros)
-    out4[0] = v[0] * gsc; out4[1] = v[1] * gsc; out4[2] = v[2] * gsc; out4[3] = v[3] * gsc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = wave_sum(v[k]);
+    if (lane == 0) sh[k][wave] = v[k];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += sh[tid][w];
+    out4[tid] = s * (*gscale);   // 1/(B'S); 0 when nothing is kept (reference early return -> zeros)
   }
 }
 
@@ -777,7 +779,7 @@ int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, in
   HCM_CHECK_LAUNCH();
   strip_kernel<DensePolicy, true><<<grid, kWG, 0, s>>>(a, pol);
   HCM_CHECK_LAUNCH();
-  dense_finish_kernel<<<1, kWG, 0, s>>>(ws.rowloss, ws.rowcorrect, keep, B, S, ws.gscale, out4);
+  dense_finish_kernel<<<1, 1024, 0, s>>>(ws.rowloss, ws.rowcorrect, keep, B, S, ws.gscale, out4);
   HCM_CHECK_LAUNCH();
   scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, sample_ind, S, rows, keep, mv,
                                                               gmap1, gmap2);
