@@ -676,6 +676,79 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_nhwc_kernel(const float
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sampled-pixel feature-map producer.  merge_all_res (bilinear up-sampling of the
+// three coarser HRNet branches + concat, build_backbone.py:247-254) followed by the 1x1 projection
+// (:243-245) is linear, and the three losses read only S+J pixels per image out of h*w: sample the
+// branches AT those pixels (4 bilinear taps each) into a [rows, Ctot] matrix and project only that
+// (one small library GEMM on the host side).  No 270-channel concat, no full-resolution projection.
+//   rows r = b*R + s ; pixel pix[r] = py*w0 + px on the finest (h0 x w0) grid.
+// ------------------------------------------------------------------------------------------
+struct Taps {
+  int y0, y1, x0, x1;
+  float hy, ly, hx, lx;
+};
+__device__ __forceinline__ Taps bilinear_taps(int py, int px, int hi, int wi, float sy, float sx) {
+  Taps t;
+  const float fy = fmaxf(sy * ((float)py + 0.5f) - 0.5f, 0.f);
+  const float fx = fmaxf(sx * ((float)px + 0.5f) - 0.5f, 0.f);
+  t.y0 = min((int)fy, hi - 1);
+  t.x0 = min((int)fx, wi - 1);
+  t.y1 = t.y0 + (t.y0 < hi - 1 ? 1 : 0);
+  t.x1 = t.x0 + (t.x0 < wi - 1 ? 1 : 0);
+  t.ly = fy - (float)t.y0; t.hy = 1.f - t.ly;
+  t.lx = fx - (float)t.x0; t.hx = 1.f - t.lx;
+  return t;
+}
+
+// one wave per row; lanes walk the branch's channels
+__global__ __launch_bounds__(kWG) void sample_rows_kernel(const float* __restrict__ x, hcm_strides4 st,
+                                                          int C, int hi, int wi, int h0, int w0,
+                                                          const int64_t* __restrict__ pix, int R,
+                                                          int nrows, float* __restrict__ out, int ldo,
+                                                          int col0) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const int b = r / R;
+  const int p = (int)pix[r];
+  const Taps t = bilinear_taps(p / w0, p % w0, hi, wi, (float)hi / (float)h0, (float)wi / (float)w0);
+  const int64_t base = b * st.sN;
+  const int64_t o00 = base + t.y0 * st.sH + t.x0 * st.sW, o01 = base + t.y0 * st.sH + t.x1 * st.sW;
+  const int64_t o10 = base + t.y1 * st.sH + t.x0 * st.sW, o11 = base + t.y1 * st.sH + t.x1 * st.sW;
+  for (int c = lane; c < C; c += 64) {
+    const int64_t oc = c * st.sC;
+    out[(int64_t)r * ldo + col0 + c] = t.hy * (t.hx * x[o00 + oc] + t.lx * x[o01 + oc]) +
+                                       t.ly * (t.hx * x[o10 + oc] + t.lx * x[o11 + oc]);
+  }
+}
+
+// backward: gx[b, c, tap] += weight * g[r, col0 + c]   (atomic, like ATen's own bilinear backward)
+__global__ __launch_bounds__(kWG) void scatter_sample_rows_kernel(const float* __restrict__ g, int ldo,
+                                                                  int col0, hcm_strides4 st, int C,
+                                                                  int hi, int wi, int h0, int w0,
+                                                                  const int64_t* __restrict__ pix,
+                                                                  int R, int nrows,
+                                                                  float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const int b = r / R;
+  const int p = (int)pix[r];
+  const Taps t = bilinear_taps(p / w0, p % w0, hi, wi, (float)hi / (float)h0, (float)wi / (float)w0);
+  const int64_t base = b * st.sN;
+  const int64_t o00 = base + t.y0 * st.sH + t.x0 * st.sW, o01 = base + t.y0 * st.sH + t.x1 * st.sW;
+  const int64_t o10 = base + t.y1 * st.sH + t.x0 * st.sW, o11 = base + t.y1 * st.sH + t.x1 * st.sW;
+  for (int c = lane; c < C; c += 64) {
+    const float gv = g[(int64_t)r * ldo + col0 + c];
+    const int64_t oc = c * st.sC;
+    atomicAdd(gx + o00 + oc, gv * t.hy * t.hx);
+    atomicAdd(gx + o01 + oc, gv * t.hy * t.lx);
+    atomicAdd(gx + o10 + oc, gv * t.ly * t.hx);
+    atomicAdd(gx + o11 + oc, gv * t.ly * t.lx);
+  }
+}
+
 // ---- workspace carving (all regions 16-byte aligned) --------------------------------------
 struct Carver {
   char* base;
@@ -757,6 +830,17 @@ int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, in
                        int w, const int64_t* sample_ind, const int32_t* keep, int S,
                        float temperature, float* out4, float* gmap1, float* gmap2, void* workspace,
                        size_t workspace_bytes, hcm_stream_t stream) {
+  return hcm_dense_soft_nce_coords(map1, map2, st, B, C, h, w, sample_ind, nullptr, w, keep, S,
+                                   temperature, out4, gmap1, gmap2, workspace, workspace_bytes, stream);
+}
+
+int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                              int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                              int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                              float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                              hcm_stream_t stream) {
+  if (coord_ind == nullptr) { coord_ind = sample_ind; coord_w = w; }
+  if (coord_w <= 0) return (int)hipErrorInvalidValue;
   if (C != kC || B <= 0 || S <= 0 || h <= 0 || w <= 0 || !(temperature > 0.f) || keep == nullptr)
     return (int)hipErrorInvalidValue;
   const DenseWs ws = carve_dense(workspace, B, S);
@@ -764,7 +848,7 @@ int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, in
   hipStream_t s = (hipStream_t)stream;
   const int rows = B * S;
   const MapView mv = view(st, w);
-  dense_prep_kernel<<<(rows + 255) / 256, 256, 0, s>>>(keep, B, S, sample_ind, ws.meta, ws.gscale);
+  dense_prep_kernel<<<(rows + 255) / 256, 256, 0, s>>>(keep, B, S, coord_ind, ws.meta, ws.gscale);
   HCM_CHECK_LAUNCH();
   gather_norm_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(map1, map2, mv, sample_ind, S, rows,
                                                              keep, ws.F, ws.invn);
@@ -774,7 +858,7 @@ int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, in
   a.symmetric = 0; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
   const dim3 grid((S + 63) / 64, B, 2);
-  DensePolicy pol{w};
+  DensePolicy pol{coord_w};
   strip_kernel<DensePolicy, false><<<grid, kWG, 0, s>>>(a, pol);
   HCM_CHECK_LAUNCH();
   strip_kernel<DensePolicy, true><<<grid, kWG, 0, s>>>(a, pol);
@@ -879,6 +963,29 @@ int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, 
   if (blocks > 32768) blocks = 32768;
   upsample_bilinear_nhwc_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
       in, out, N, C, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_sample_rows(const float* x, hcm_strides4 st, int B, int C, int hi, int wi, int h0, int w0,
+                    const int64_t* pix, int R, float* out, int ldo, int col0, hcm_stream_t stream) {
+  if (B <= 0 || C <= 0 || hi <= 0 || wi <= 0 || h0 <= 0 || w0 <= 0 || R <= 0 || ldo < col0 + C)
+    return (int)hipErrorInvalidValue;
+  const int nrows = B * R;
+  sample_rows_kernel<<<(nrows + 3) / 4, kWG, 0, (hipStream_t)stream>>>(x, st, C, hi, wi, h0, w0, pix, R,
+                                                                       nrows, out, ldo, col0);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_sample_rows_grad(const float* grad_rows, int ldo, int col0, hcm_strides4 st, int B, int C,
+                         int hi, int wi, int h0, int w0, const int64_t* pix, int R, float* gx,
+                         hcm_stream_t stream) {
+  if (B <= 0 || C <= 0 || hi <= 0 || wi <= 0 || h0 <= 0 || w0 <= 0 || R <= 0 || ldo < col0 + C)
+    return (int)hipErrorInvalidValue;
+  const int nrows = B * R;
+  scatter_sample_rows_kernel<<<(nrows + 3) / 4, kWG, 0, (hipStream_t)stream>>>(
+      grad_rows, ldo, col0, st, C, hi, wi, h0, w0, pix, R, nrows, gx);
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -300,7 +300,7 @@ class _FmapLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
-                temperature, do_dense, do_joint, do_scl):
+                temperature, do_dense, do_joint, do_scl, coord_ind=None, coord_w=0):
         map1, map2 = _dense_map(map1), _dense_map(map2)
         _check_maps(map1, map2, 'fmap_losses')
         B, Cc, h, w = map1.shape
@@ -320,10 +320,12 @@ class _FmapLosses(torch.autograd.Function):
             S = sample_ind.shape[1]
             nb = L.hcm_dense_soft_nce_workspace_bytes(B, S, Cc)
             ws = _ws(nb, dev)
-            check(L.hcm_dense_soft_nce(p1, p2, st, B, Cc, h, w,
-                                       _dev(sample_ind, torch.int64, 'dense'), _dev(_i32(keep), torch.int32, 'dense'),
-                                       S, float(temperature), C.c_void_p(out.data_ptr()), pg1, pg2,
-                                       C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_dense_soft_nce')
+            check(L.hcm_dense_soft_nce_coords(p1, p2, st, B, Cc, h, w,
+                                              _dev(sample_ind, torch.int64, 'dense'),
+                                              _opt(coord_ind, torch.int64, 'dense'), int(coord_w),
+                                              _dev(_i32(keep), torch.int32, 'dense'),
+                                              S, float(temperature), C.c_void_p(out.data_ptr()), pg1, pg2,
+                                              C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_dense_soft_nce_coords')
         if do_joint:
             feat3c = feat3.contiguous()
             gfeat3 = torch.empty_like(feat3c)
@@ -350,15 +352,94 @@ class _FmapLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, g_out):
         g1, g2, g3 = ctx.saved_tensors
-        return (g1 * g_total, g2 * g_total, (g3 * g_total) if ctx.has_g3 else None) + (None,) * 10
+        return (g1 * g_total, g2 * g_total, (g3 * g_total) if ctx.has_g3 else None) + (None,) * 12
 
 
 def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb, temperature,
-                do_dense=True, do_joint=True, do_scl=True):
+                do_dense=True, do_joint=True, do_scl=True, coord_ind=None, coord_w=0):
     """total (differentiable in map1, map2, feat3) and the 9 detached meters
-    [loss_r2d, loss_d2r, acc_r2d, acc_d2r, loss_rgb2j, loss_d2j, acc_rgb2j, acc_d2j, loss_scl]."""
+    [loss_r2d, loss_d2r, acc_r2d, acc_d2r, loss_rgb2j, loss_d2j, acc_rgb2j, acc_d2j, loss_scl].
+    ``coord_ind``/``coord_w``: pixel coordinates of the dense soft target when ``sample_ind`` is only
+    a gather index (row mode, see ``fmap_losses_rows``)."""
     return _FmapLosses.apply(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
-                             temperature, do_dense, do_joint, do_scl)
+                             temperature, do_dense, do_joint, do_scl, coord_ind, coord_w)
+
+
+# --------------------------------------------------------------------------- #
+# row 8, sampled form (SURVEY 8f-1): project only the pixels the losses read
+# --------------------------------------------------------------------------- #
+class _SampledProjection(torch.autograd.Function):
+    """rows[b, r] = W . [x0[p]; bilinear(x1)[p]; bilinear(x2)[p]; bilinear(x3)[p]] + bias at p = pix[b, r]
+    == ``encoder_linear(merge_all_res(maps))[b, :, p]`` (build_backbone.py:243-254), without the
+    270-channel concat or the full-resolution projection.  The bilinear sampling / its backward are
+    HIP kernels (hcm_sample_rows / _grad); the [B*R, 270] x [270, 128] product is one library GEMM."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, pix, *maps):
+        B, R = pix.shape
+        h0, w0 = maps[0].shape[-2:]
+        ctot = sum(m.shape[1] for m in maps)
+        xs = torch.empty(B * R, ctot, dtype=torch.float32, device=pix.device)
+        maps = [_dense_map(m) for m in maps]
+        L = _lib.lib()
+        col = 0
+        for m in maps:
+            if not m.is_cuda or m.dtype != torch.float32:
+                raise RuntimeError('hcmoco_amd.sampled_projection needs fp32 ROCm tensors (no CPU fallback exists)')
+            check(L.hcm_sample_rows(C.c_void_p(m.data_ptr()), _strides(m), B, m.shape[1], m.shape[2], m.shape[3],
+                                    h0, w0, _dev(pix, torch.int64, 'sample_rows'), R,
+                                    C.c_void_p(xs.data_ptr()), ctot, col, _stream()), 'hcm_sample_rows')
+            col += m.shape[1]
+        w2 = weight.reshape(weight.shape[0], ctot)
+        rows = torch.addmm(bias, xs, w2.t())
+        ctx.save_for_backward(xs, weight, pix)
+        ctx.meta = [(tuple(m.shape), m.stride(), m.is_contiguous()) for m in maps]
+        ctx.h0w0 = (h0, w0)
+        return rows.view(B, R, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, grows):
+        xs, weight, pix = ctx.saved_tensors
+        B, R = pix.shape
+        ctot = xs.shape[1]
+        g2 = grows.reshape(B * R, -1).contiguous()
+        w2 = weight.reshape(weight.shape[0], ctot)
+        gxs = torch.mm(g2, w2)                                   # [B*R, ctot]
+        gw = torch.mm(g2.t(), xs).view_as(weight)
+        gb = g2.sum(0)
+        L = _lib.lib()
+        h0, w0 = ctx.h0w0
+        gmaps, col = [], 0
+        for shape, stride, contig in ctx.meta:
+            gm = torch.zeros(shape, dtype=torch.float32, device=grows.device)
+            if not contig:
+                gm = gm.contiguous(memory_format=torch.channels_last)
+            check(L.hcm_sample_rows_grad(C.c_void_p(gxs.data_ptr()), ctot, col, _strides(gm), B, shape[1], shape[2],
+                                         shape[3], h0, w0, _dev(pix, torch.int64, 'sample_rows'), R,
+                                         C.c_void_p(gm.data_ptr()), _stream()), 'hcm_sample_rows_grad')
+            gmaps.append(gm)
+            col += shape[1]
+        return (gw, gb, None) + tuple(gmaps)
+
+
+def sampled_projection(weight, bias, pix, maps):
+    """[B, R, 128] projected feature rows at the sampled pixels of one modality."""
+    return _SampledProjection.apply(weight, bias, pix, *maps)
+
+
+def fmap_losses_rows(rows1, rows2, feat3, S, coord_ind, coord_w, keep, joints_vis, use_depth, use_rgb, temperature):
+    """The three feature-map losses on already-sampled rows [B, S+J, 128] (first S: dense samples,
+    last J: joints).  The row matrix is handed to the same kernels as a [B,128,1,S+J] channels-last
+    "map" whose pixel index is the row position, so every gather is one 512-byte line."""
+    B, R, Cc = rows1.shape
+    dev = rows1.device
+    m1 = rows1.permute(0, 2, 1).unsqueeze(2)
+    m2 = rows2.permute(0, 2, 1).unsqueeze(2)
+    ar = torch.arange(R, device=dev, dtype=torch.int64).unsqueeze(0).expand(B, R)
+    gather_dense = ar[:, :S].contiguous()
+    gather_joint = ar[:, S:].contiguous()
+    return fmap_losses(m1, m2, feat3, gather_dense, keep, gather_joint, joints_vis, use_depth, use_rgb, temperature,
+                       coord_ind=coord_ind.contiguous(), coord_w=coord_w)
 
 
 # --------------------------------------------------------------------------- #

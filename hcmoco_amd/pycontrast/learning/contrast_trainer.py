@@ -61,6 +61,10 @@ class ContrastTrainer(BaseTrainer):
     def wrap_up(self, model, model_ema, optimizer):
         args = self.args
         model.to(self.device)
+        # engines that can project at the sampled pixels get the raw branch maps from the model
+        if (hasattr(self.engine, 'fmap_sampled') and hasattr(model, 'defer_projection') and self.graphed is None
+                and getattr(args, 'sampled_projection', 1)):
+            model.defer_projection = True
         if getattr(args, 'channels_last', False):
             model.to(memory_format=torch.channels_last)
         if isinstance(model_ema, torch.nn.Module):
@@ -201,10 +205,14 @@ class ContrastTrainer(BaseTrainer):
         if stage2:      # stage 2 hands only use_depth to the bank CE (contrast_trainer.py:965-967)
             total, losses, accs = self.engine.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
                                                    use_depth=use_depth)
-            fm_total, meters = self.engine.fmap(
-                aux['linear_merge1'], aux['linear_merge2'], _feat3, self._to_dev(data[7]),
-                self._to_dev(data[4]), self._to_dev(data[5]), use_depth, use_rgb,
-                args.pri3d_num_samples_per_image, args.temperature)
+            fm_args = (_feat3, self._to_dev(data[7]), self._to_dev(data[4]), self._to_dev(data[5]), use_depth,
+                       use_rgb, args.pri3d_num_samples_per_image, args.temperature)
+            if aux['linear_merge1'] is None:     # model.defer_projection: project at the sampled pixels only
+                net = self.unwrap(model)
+                fm_total, meters = self.engine.fmap_sampled(_feat1, _feat2, net.encoder1_linear,
+                                                            net.encoder2_linear, *fm_args)
+            else:
+                fm_total, meters = self.engine.fmap(aux['linear_merge1'], aux['linear_merge2'], *fm_args)
             loss = total + fm_total
             out['fmap'] = meters
         else:           # stage 1 (contrast_trainer.py:592-594)

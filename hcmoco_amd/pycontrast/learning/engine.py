@@ -47,3 +47,23 @@ class HipLossEngine(object):
         pix = hip_ops.joint_pixels(joints2d, h)
         ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=map1.device)
         return hip_ops.fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, ud, use_rgb, temperature)
+
+    # ---- rows 5-8 fused at the sampled pixels ---------------------------------
+    def fmap_sampled(self, branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
+                     use_depth, use_rgb, num_samples, temperature, sample_ind=None, keep=None):
+        """Same losses as ``fmap`` computed from the raw HRNet branch maps: the 1x1 projections
+        ``proj1/proj2`` (``encoder{1,2}_linear``) are applied only at the S+J pixels the losses read
+        (``hip_ops.sampled_projection``), so ``merge_all_res`` and the full-resolution projection
+        are never materialised."""
+        h, w = branches1[0].shape[-2:]
+        assert h == w
+        B = branches1[0].shape[0]
+        if sample_ind is None:
+            sample_ind, keep = self.dense_samples(depth_mask, h, w, num_samples, use_depth)
+        pix_j = hip_ops.joint_pixels(joints2d, h)
+        pix = torch.cat([sample_ind, pix_j], dim=1).contiguous()
+        rows1 = hip_ops.sampled_projection(proj1.weight, proj1.bias, pix, list(branches1))
+        rows2 = hip_ops.sampled_projection(proj2.weight, proj2.bias, pix, list(branches2))
+        ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=pix.device)
+        return hip_ops.fmap_losses_rows(rows1, rows2, feat3, sample_ind.shape[1], sample_ind, w, keep, joints_vis,
+                                        ud, use_rgb, temperature)

@@ -42,6 +42,10 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         if self.linear_feat_map:
             self.encoder1_linear = nn.Conv2d(dim_in, sgcn_dim, kernel_size=1, stride=1, bias=True)
             self.encoder2_linear = nn.Conv2d(dim_in, sgcn_dim, kernel_size=1, stride=1, bias=True)
+        # Set by a trainer whose loss engine projects only the sampled pixels (engine.fmap_sampled):
+        # ``return_fm`` then hands back the raw branch maps and skips merge_all_res + the full 1x1
+        # projections (aux entries are None).  Off by default = the reference data flow.
+        self.defer_projection = False
 
     @staticmethod
     def merge_all_res(maps):
@@ -69,6 +73,9 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         if not return_fm:
             return f
         if self.linear_feat_map:
+            if self.defer_projection:
+                return _feat1, _feat2, _feat3, f, {'merge1': None, 'merge2': None,
+                                                   'linear_merge1': None, 'linear_merge2': None}
             merge1, merge2 = self.merge_all_res(_feat1), self.merge_all_res(_feat2)
             return _feat1, _feat2, _feat3, f, {
                 'merge1': merge1, 'merge2': merge2,

@@ -97,6 +97,9 @@ BASE_FLAGS = [
     (('--synthetic_n_data',), dict(type=_I, default=131072)),
     (('--synthetic_size',), dict(type=_I, default=256)),
     (('--synthetic_steps',), dict(type=_I, default=50, help='batches per epoch in synthetic mode')),
+    (('--sampled_projection',), dict(type=_I, default=1,
+                                     help='1: apply merge_all_res + the 1x1 feature-map projection only at the '
+                                          'pixels the losses sample (same math, SURVEY 8f-1); 0: full maps')),
     (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
                              help='storage type of the memory banks (bf16: BASELINE config 5)')),
 ]

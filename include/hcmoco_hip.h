@@ -133,6 +133,15 @@ int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, in
                        float* out4, float* gmap1, float* gmap2,
                        void* workspace, size_t workspace_bytes, hcm_stream_t stream);
 
+/* Same, with the soft-target pixel coordinates decoupled from the gather index: coord_ind [B, S]
+ * (row*coord_w + col) feeds the distance target (:702-706) while sample_ind addresses the map.
+ * Used when the "map" is a matrix of already-sampled rows (hcm_sample_rows). */
+int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                              const int64_t* sample_ind, const int64_t* coord_ind, int coord_w,
+                              const int32_t* keep, int S, float temperature,
+                              float* out4, float* gmap1, float* gmap2,
+                              void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
 /* Row 6: _compute_joints_pri3d_loss_accuracy (:744-828).  pix [B, J] int64 flat pixel of each
  * joint (clamp(floor(j/4))), feat3 [B, J, C] contiguous, joints_vis [B, J] int32,
  * use_depth [B] int32 or NULL.  out4 = {loss_rgb, loss_d, acc_rgb, acc_d}.
@@ -165,6 +174,17 @@ int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho,
 /* Same op on channels-last memory: in [N,Hi,Wi,C] -> out [N,Ho,Wo,C]. */
 int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, int Ho, int Wo,
                                  float* out, hcm_stream_t stream);
+
+/* Row 8, sampled form: bilinear(x)[b, :, pix[b,r]] for one HRNet branch
+ * x [B, C, hi, wi] (strides st), evaluated on the finest grid (h0 x w0, align_corners=False), written
+ * to out[(b*R + r)*ldo + col0 + c].  Equals merge_all_res (build_backbone.py:247-254) restricted to
+ * the sampled pixels; the 1x1 projection then runs on the [B*R, sum C] matrix.  The _grad form
+ * scatter-adds (atomics) grad_rows back into gx (same strides as x, caller-zeroed). */
+int hcm_sample_rows(const float* x, hcm_strides4 st, int B, int C, int hi, int wi, int h0, int w0,
+                    const int64_t* pix, int R, float* out, int ldo, int col0, hcm_stream_t stream);
+int hcm_sample_rows_grad(const float* grad_rows, int ldo, int col0, hcm_strides4 st, int B, int C,
+                         int hi, int wi, int h0, int w0, const int64_t* pix, int R, float* gx,
+                         hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
