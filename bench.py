@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps):
+def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, sampled=1):
     from hcmoco_amd.pycontrast.options.train_options import TrainOptions
     argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18',
             '--in_channel_list', '3,3', '--linear_feat_map', '1', '--modality_missing', '1',
@@ -43,7 +43,8 @@ def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps):
             '--nce_m', '0.5', '--batch_size', str(batch_global), '--skeleton_meta_name', skeleton,
             '--learning_rate', '0.03', '--dist-backend', backend, '--synthetic',
             '--synthetic_n_data', str(n_data), '--synthetic_size', str(size), '--synthetic_steps', str(steps),
-            '--model_path', tmp, '--tb_path', tmp, '--seed', '0', '--print_freq', '1000000']
+            '--model_path', tmp, '--tb_path', tmp, '--seed', '0', '--print_freq', '1000000',
+            '--sampled_projection', str(sampled)]
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -132,6 +133,8 @@ def main():
     ap.add_argument('--cpu_budget_s', type=float, default=20.0)
     ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
     ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
+    ap.add_argument('--sampled_projection', type=int, default=1,
+                    help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '0')),
                     help='capture the encoder forward/backward as hipGraphs')
     a = ap.parse_args()
@@ -159,7 +162,7 @@ def main():
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     B = a.batch_per_gpu
     args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, 'nccl', tempfile.mkdtemp(),
-                     a.steps + a.warmup)
+                     a.steps + a.warmup, sampled=a.sampled_projection)
     args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
     args.channels_last = bool(a.channels_last)
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
@@ -222,7 +225,7 @@ def main():
                                    % (a.size, a.size, a.skeleton),
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
-                       'channels_last': bool(a.channels_last), 'hip_graphs': bool(a.graphs),
+                       'channels_last': bool(a.channels_last), 'hip_graphs': bool(a.graphs), 'sampled_projection': bool(a.sampled_projection),
                        'final_loss': round(loss, 4)},
             'roofline': {'kernel': 'bank_pass_kernel<2,fused> (gather + 6 logit sets + online softmax + d/dx)',
                          'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
