@@ -45,6 +45,7 @@ SIGNATURES = {
     'hcm_dense_soft_nce_coords': (_i, [_p, _p, Strides4, _i, _i, _i, _i, _p, _p, _i, _p, _i, _f, _p, _p, _p, _p, _sz, _p]),
     'hcm_sample_rows': (_i, [_p, Strides4, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
     'hcm_sample_rows_grad': (_i, [_p, _i, _i, Strides4, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    'hcm_sampling_matrix': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     'hcm_joint_nce_workspace_bytes': (_sz, [_i, _i, _i]),
     'hcm_joint_nce': (_i, [_p, _p, Strides4, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f,
                            _p, _p, _p, _p, _p, _sz, _p]),

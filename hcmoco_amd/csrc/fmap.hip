@@ -742,11 +742,29 @@ __global__ __launch_bounds__(kWG) void scatter_sample_rows_kernel(const float* _
   for (int c = lane; c < C; c += 64) {
     const float gv = g[(int64_t)r * ldo + col0 + c];
     const int64_t oc = c * st.sC;
-    atomicAdd(gx + o00 + oc, gv * t.hy * t.hx);
-    atomicAdd(gx + o01 + oc, gv * t.hy * t.lx);
-    atomicAdd(gx + o10 + oc, gv * t.ly * t.hx);
-    atomicAdd(gx + o11 + oc, gv * t.ly * t.lx);
+    // zero-weight taps (always 3 of 4 on the finest branch) are skipped
+    if (t.hy * t.hx != 0.f) atomicAdd(gx + o00 + oc, gv * t.hy * t.hx);
+    if (t.hy * t.lx != 0.f) atomicAdd(gx + o01 + oc, gv * t.hy * t.lx);
+    if (t.ly * t.hx != 0.f) atomicAdd(gx + o10 + oc, gv * t.ly * t.hx);
+    if (t.ly * t.lx != 0.f) atomicAdd(gx + o11 + oc, gv * t.ly * t.lx);
   }
+}
+
+// Dense form of the same linear map for the COARSE branches: S[b, r, q] = bilinear weight of coarse
+// pixel q for sampled pixel pix[b, r] (4 non-zeros per row, added in a fixed order so coinciding
+// border taps sum).  With S in hand, sampling is bmm(S, x) and its backward bmm(S^T, g): two small
+// library GEMMs, deterministic, no atomics.  S must be zero-filled by the caller.
+__global__ void sampling_matrix_kernel(const int64_t* __restrict__ pix, int nrows, int hi, int wi,
+                                       int h0, int w0, float* __restrict__ S) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int p = (int)pix[r];
+  const Taps t = bilinear_taps(p / w0, p % w0, hi, wi, (float)hi / (float)h0, (float)wi / (float)w0);
+  float* row = S + (int64_t)r * hi * wi;
+  row[t.y0 * wi + t.x0] += t.hy * t.hx;
+  row[t.y0 * wi + t.x1] += t.hy * t.lx;
+  row[t.y1 * wi + t.x0] += t.ly * t.hx;
+  row[t.y1 * wi + t.x1] += t.ly * t.lx;
 }
 
 // ---- workspace carving (all regions 16-byte aligned) --------------------------------------
@@ -986,6 +1004,14 @@ int hcm_sample_rows_grad(const float* grad_rows, int ldo, int col0, hcm_strides4
   const int nrows = B * R;
   scatter_sample_rows_kernel<<<(nrows + 3) / 4, kWG, 0, (hipStream_t)stream>>>(
       grad_rows, ldo, col0, st, C, hi, wi, h0, w0, pix, R, nrows, gx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_sampling_matrix(const int64_t* pix, int nrows, int hi, int wi, int h0, int w0, float* S,
+                        hcm_stream_t stream) {
+  if (nrows <= 0 || hi <= 0 || wi <= 0 || h0 <= 0 || w0 <= 0) return (int)hipErrorInvalidValue;
+  sampling_matrix_kernel<<<(nrows + 255) / 256, 256, 0, (hipStream_t)stream>>>(pix, nrows, hi, wi, h0, w0, S);
   HCM_CHECK_LAUNCH();
   return 0;
 }

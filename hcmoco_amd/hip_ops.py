@@ -368,63 +368,64 @@ def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth,
 # --------------------------------------------------------------------------- #
 # row 8, sampled form: project only the pixels the losses read
 # --------------------------------------------------------------------------- #
-class _SampledProjection(torch.autograd.Function):
+class _SampleRows(torch.autograd.Function):
+    """x[b, :, pix[b, r]] sampled bilinearly on the finest grid -> [B, R, C] (hcm_sample_rows);
+    backward scatter-adds with atomics (hcm_sample_rows_grad).  Used for the finest branch, whose
+    sampling matrix would be too large to materialise."""
+
+    @staticmethod
+    def forward(ctx, x, pix, h0, w0):
+        x = _dense_map(x)
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError('hcmoco_amd.sample_rows needs fp32 ROCm tensors (no CPU fallback exists)')
+        B, R = pix.shape
+        Cc = x.shape[1]
+        out = torch.empty(B * R, Cc, dtype=torch.float32, device=x.device)
+        check(_lib.lib().hcm_sample_rows(C.c_void_p(x.data_ptr()), _strides(x), B, Cc, x.shape[2], x.shape[3], h0, w0,
+                                         _dev(pix, torch.int64, 'sample_rows'), R, C.c_void_p(out.data_ptr()), Cc, 0,
+                                         _stream()), 'hcm_sample_rows')
+        ctx.save_for_backward(pix)
+        ctx.meta = (tuple(x.shape), x.is_contiguous(), h0, w0)
+        return out.view(B, R, Cc)
+
+    @staticmethod
+    def backward(ctx, g):
+        pix, = ctx.saved_tensors
+        shape, contig, h0, w0 = ctx.meta
+        B, R = pix.shape
+        g = g.reshape(B * R, shape[1]).contiguous()
+        gx = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        if not contig:
+            gx = gx.contiguous(memory_format=torch.channels_last)
+        check(_lib.lib().hcm_sample_rows_grad(C.c_void_p(g.data_ptr()), shape[1], 0, _strides(gx), B, shape[1], shape[2],
+                                              shape[3], h0, w0, _dev(pix, torch.int64, 'sample_rows'), R,
+                                              C.c_void_p(gx.data_ptr()), _stream()), 'hcm_sample_rows_grad')
+        return gx, None, None, None
+
+
+def sampling_matrix(pix, hi, wi, h0, w0):
+    """[B, R, hi*wi] dense bilinear sampling matrix of a coarse branch (no grad)."""
+    B, R = pix.shape
+    S = torch.zeros(B, R, hi * wi, dtype=torch.float32, device=pix.device)
+    check(_lib.lib().hcm_sampling_matrix(_dev(pix, torch.int64, 'sampling_matrix'), B * R, hi, wi, h0, w0,
+                                         C.c_void_p(S.data_ptr()), _stream()), 'hcm_sampling_matrix')
+    return S
+
+
+def sampled_projection(weight, bias, pix, maps, sampling=None):
     """rows[b, r] = W . [x0[p]; bilinear(x1)[p]; bilinear(x2)[p]; bilinear(x3)[p]] + bias at p = pix[b, r]
-    == ``encoder_linear(merge_all_res(maps))[b, :, p]`` (build_backbone.py:243-254), without the
-    270-channel concat or the full-resolution projection.  The bilinear sampling / its backward are
-    HIP kernels (hcm_sample_rows / _grad); the [B*R, 270] x [270, 128] product is one library GEMM."""
-
-    @staticmethod
-    def forward(ctx, weight, bias, pix, *maps):
-        B, R = pix.shape
-        h0, w0 = maps[0].shape[-2:]
-        ctot = sum(m.shape[1] for m in maps)
-        xs = torch.empty(B * R, ctot, dtype=torch.float32, device=pix.device)
-        maps = [_dense_map(m) for m in maps]
-        L = _lib.lib()
-        col = 0
-        for m in maps:
-            if not m.is_cuda or m.dtype != torch.float32:
-                raise RuntimeError('hcmoco_amd.sampled_projection needs fp32 ROCm tensors (no CPU fallback exists)')
-            check(L.hcm_sample_rows(C.c_void_p(m.data_ptr()), _strides(m), B, m.shape[1], m.shape[2], m.shape[3],
-                                    h0, w0, _dev(pix, torch.int64, 'sample_rows'), R,
-                                    C.c_void_p(xs.data_ptr()), ctot, col, _stream()), 'hcm_sample_rows')
-            col += m.shape[1]
-        w2 = weight.reshape(weight.shape[0], ctot)
-        rows = torch.addmm(bias, xs, w2.t())
-        ctx.save_for_backward(xs, weight, pix)
-        ctx.meta = [(tuple(m.shape), m.stride(), m.is_contiguous()) for m in maps]
-        ctx.h0w0 = (h0, w0)
-        return rows.view(B, R, weight.shape[0])
-
-    @staticmethod
-    def backward(ctx, grows):
-        xs, weight, pix = ctx.saved_tensors
-        B, R = pix.shape
-        ctot = xs.shape[1]
-        g2 = grows.reshape(B * R, -1).contiguous()
-        w2 = weight.reshape(weight.shape[0], ctot)
-        gxs = torch.mm(g2, w2)                                   # [B*R, ctot]
-        gw = torch.mm(g2.t(), xs).view_as(weight)
-        gb = g2.sum(0)
-        L = _lib.lib()
-        h0, w0 = ctx.h0w0
-        gmaps, col = [], 0
-        for shape, stride, contig in ctx.meta:
-            gm = torch.zeros(shape, dtype=torch.float32, device=grows.device)
-            if not contig:
-                gm = gm.contiguous(memory_format=torch.channels_last)
-            check(L.hcm_sample_rows_grad(C.c_void_p(gxs.data_ptr()), ctot, col, _strides(gm), B, shape[1], shape[2],
-                                         shape[3], h0, w0, _dev(pix, torch.int64, 'sample_rows'), R,
-                                         C.c_void_p(gm.data_ptr()), _stream()), 'hcm_sample_rows_grad')
-            gmaps.append(gm)
-            col += shape[1]
-        return (gw, gb, None) + tuple(gmaps)
-
-
-def sampled_projection(weight, bias, pix, maps):
-    """[B, R, 128] projected feature rows at the sampled pixels of one modality."""
-    return _SampledProjection.apply(weight, bias, pix, *maps)
+    == ``encoder_linear(merge_all_res(maps))[b, :, p]`` (build_backbone.py:243-254) without the
+    270-channel concat or the full-resolution projection.  Finest branch: HIP gather/scatter kernels;
+    coarse branches: ``bmm`` with their dense sampling matrices (deterministic, library GEMMs); the
+    projection itself is one ``[B*R, 270] x [270, 128]`` library GEMM.  ``sampling``: matrices from
+    ``sampling_matrix`` to share between the two modalities."""
+    h0, w0 = maps[0].shape[-2:]
+    parts = [_SampleRows.apply(maps[0], pix, h0, w0)]
+    for i, m in enumerate(maps[1:]):
+        S = sampling[i] if sampling is not None else sampling_matrix(pix, m.shape[2], m.shape[3], h0, w0)
+        parts.append(torch.bmm(S, m.flatten(2).transpose(1, 2)))
+    xs = torch.cat(parts, dim=2)
+    return torch.nn.functional.linear(xs, weight.reshape(weight.shape[0], -1), bias)
 
 
 def fmap_losses_rows(rows1, rows2, feat3, S, coord_ind, coord_w, keep, joints_vis, use_depth, use_rgb, temperature):

@@ -62,8 +62,9 @@ class HipLossEngine(object):
             sample_ind, keep = self.dense_samples(depth_mask, h, w, num_samples, use_depth)
         pix_j = hip_ops.joint_pixels(joints2d, h)
         pix = torch.cat([sample_ind, pix_j], dim=1).contiguous()
-        rows1 = hip_ops.sampled_projection(proj1.weight, proj1.bias, pix, list(branches1))
-        rows2 = hip_ops.sampled_projection(proj2.weight, proj2.bias, pix, list(branches2))
+        S = [hip_ops.sampling_matrix(pix, m.shape[2], m.shape[3], h, w) for m in branches1[1:]]   # shared
+        rows1 = hip_ops.sampled_projection(proj1.weight, proj1.bias, pix, list(branches1), S)
+        rows2 = hip_ops.sampled_projection(proj2.weight, proj2.bias, pix, list(branches2), S)
         ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=pix.device)
         return hip_ops.fmap_losses_rows(rows1, rows2, feat3, sample_ind.shape[1], sample_ind, w, keep, joints_vis,
                                         ud, use_rgb, temperature)

@@ -185,6 +185,11 @@ int hcm_sample_rows(const float* x, hcm_strides4 st, int B, int C, int hi, int w
 int hcm_sample_rows_grad(const float* grad_rows, int ldo, int col0, hcm_strides4 st, int B, int C,
                          int hi, int wi, int h0, int w0, const int64_t* pix, int R, float* gx,
                          hcm_stream_t stream);
+/* Dense sampling matrix of a coarse branch: S[r, q] (caller-zeroed, [nrows, hi*wi]) += bilinear
+ * weight of coarse pixel q for sampled pixel pix[r]; sampling is then bmm(S, x), its backward
+ * bmm(S^T, g) -- deterministic library GEMMs instead of atomics. */
+int hcm_sampling_matrix(const int64_t* pix, int nrows, int hi, int wi, int h0, int w0, float* S,
+                        hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
