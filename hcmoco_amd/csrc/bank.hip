@@ -106,6 +106,32 @@ __device__ __forceinline__ void load_rows(Row3<NV>& r, const bf16_t* __restrict_
   unpack8(q3, r.v[2][0], r.v[2][1]);
 }
 
+// A gathered row triple as it sits in the prefetch ring: still packed (bf16: 12 VGPRs instead of 24),
+// unpacked to fp32 only when its turn to be consumed comes.
+template <class T, int NV> struct Packed;
+template <int NV> struct Packed<float, NV> { Row3<NV> r; };
+template <> struct Packed<bf16_t, 2> { uint4 q[3]; };
+
+template <int NV>
+__device__ __forceinline__ void load_packed(Packed<float, NV>& p, const float* b1, const float* b2,
+                                            const float* b3, int64_t row, int t) {
+  load_rows<NV>(p.r, b1, b2, b3, row, t);
+}
+__device__ __forceinline__ void load_packed(Packed<bf16_t, 2>& p, const bf16_t* b1, const bf16_t* b2,
+                                            const bf16_t* b3, int64_t row, int t) {
+  const int64_t off = row * 128 + 8 * t;
+  p.q[0] = *reinterpret_cast<const uint4*>(b1 + off);
+  p.q[1] = *reinterpret_cast<const uint4*>(b2 + off);
+  p.q[2] = *reinterpret_cast<const uint4*>(b3 + off);
+}
+template <int NV>
+__device__ __forceinline__ void unpack(const Packed<float, NV>& p, Row3<NV>& r) { r = p.r; }
+__device__ __forceinline__ void unpack(const Packed<bf16_t, 2>& p, Row3<2>& r) {
+  unpack8(p.q[0], r.v[0][0], r.v[0][1]);
+  unpack8(p.q[1], r.v[1][0], r.v[1][1]);
+  unpack8(p.q[2], r.v[2][0], r.v[2][1]);
+}
+
 template <int NV>
 __device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[NV]) {
   float d = dot4(a[0], b[0]);
@@ -121,7 +147,7 @@ __device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[N
 //   kLogitsFwd : logits[p][b][k] = dot/T
 //   kLogitsBwd : acc[p] += (grad_logits[p][b][k]/T) * row  -> per-workgroup partials
 // ---------------------------------------------------------------------------------------
-template <class T, int NV, int MODE, int PF = 1, int MINW = 1>
+template <class T, int NV, int MODE, int NPF = 1, int MINW = 1>
 __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
     const T* __restrict__ b1, const T* __restrict__ b2, const T* __restrict__ b3,
     const int64_t* __restrict__ idx, const float* __restrict__ x1, const float* __restrict__ x2,
@@ -158,18 +184,29 @@ __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
     for (int v = 0; v < NV; ++v) acc[p][v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // software pipeline: row index two iterations ahead, row data one iteration ahead
+  // software pipeline: a ring of NPF gathered (still packed) row triples in flight per stream, row
+  // indices one further round ahead.  In-flight bytes per wave = NPF x 4 rows x 3 banks x row size:
+  // this is what Little's law prices.
   auto ld_idx = [&](int it) -> int64_t {
     const int k = kbeg + it * kStreams + s;
     return (it < niter && k < kend) ? idxb[k] : (int64_t)0;
   };
-  Row3<NV> cur, nxt;
-  int64_t r_next = ld_idx(1);
-  load_rows<NV>(cur, b1, b2, b3, ld_idx(0), t);
+  Packed<T, NV> ring[NPF];
+  int64_t ridx[NPF];
+#pragma unroll
+  for (int j = 0; j < NPF; ++j) load_packed(ring[j], b1, b2, b3, ld_idx(j), t);
+#pragma unroll
+  for (int j = 0; j < NPF; ++j) ridx[j] = ld_idx(NPF + j);
 
-  for (int it = 0; it < niter; ++it) {
-    const int64_t r_next2 = ld_idx(it + 2);
-    if (PF && it + 1 < niter) load_rows<NV>(nxt, b1, b2, b3, r_next, t);
+  for (int it0 = 0; it0 < niter; it0 += NPF) {
+#pragma unroll
+   for (int j = 0; j < NPF; ++j) {
+    const int it = it0 + j;
+    if (it >= niter) break;  // workgroup-uniform
+    Row3<NV> cur;
+    unpack(ring[j], cur);
+    if (it + NPF < niter) load_packed(ring[j], b1, b2, b3, ridx[j], t);
+    ridx[j] = ld_idx(it + 2 * NPF);
     const int k = kbeg + it * kStreams + s;
     const bool valid = k < kend;
 
@@ -221,9 +258,7 @@ __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
         for (int v = 0; v < NV; ++v) fma4(acc[p][v], wgt, cur.v[c][v]);
       }
     }
-    if (PF) cur = nxt;
-    else if (it + 1 < niter) load_rows<NV>(cur, b1, b2, b3, r_next, t);
-    r_next = r_next2;
+   }
   }
   if (MODE == kLogitsFwd) return;
 
@@ -660,14 +695,16 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
   ProfSpan span(st);  // brackets the dominant kernel only
   if (D == 128) {
     static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
-#define HCM_LAUNCH_PASS(PF, MINW)                                                                   \
-  bank_pass_kernel<T, 2, kFused, PF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
-                                                                 nullptr, B, K1, R, scale2, ws.part_m, \
-                                                                 ws.part_s, ws.part_acc, ws.l0, nullptr)
-    switch (variant) {  // tuning variants (tools/tune_bank.py); 0 is the measured best
-      case 1: HCM_LAUNCH_PASS(1, 3); break;
-      case 2: HCM_LAUNCH_PASS(0, 3); break;
-      case 4: HCM_LAUNCH_PASS(0, 2); break;
+#define HCM_LAUNCH_PASS(NPF, MINW)                                                                   \
+  bank_pass_kernel<T, 2, kFused, NPF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
+                                                                  nullptr, B, K1, R, scale2, ws.part_m, \
+                                                                  ws.part_s, ws.part_acc, ws.l0, nullptr)
+    // prefetch depth (row triples in flight per stream); variants for tools/tune_bank.py
+    switch (variant > 0 ? variant : (kBf16 ? 4 : 1)) {
+      case 2: HCM_LAUNCH_PASS(2, 1); break;
+      case 3: HCM_LAUNCH_PASS(3, 1); break;
+      case 4: HCM_LAUNCH_PASS(4, 1); break;
+      case 6: HCM_LAUNCH_PASS(6, 1); break;
       default: HCM_LAUNCH_PASS(1, 1); break;
     }
 #undef HCM_LAUNCH_PASS

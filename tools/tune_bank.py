@@ -14,23 +14,20 @@ if len(sys.argv) > 1 and sys.argv[1] == 'worker':
     d = torch.device('cuda:0')
     torch.manual_seed(0)
     nrm = torch.nn.functional.normalize
-    for n, K, B in [(131072, 16384, 32), (131072, 65536, 32)]:
+    for n, K, B in [(131072, 16384, 32), (131072, 131072, 32)]:
         D = 128
         banks = [nrm(torch.randn(n, D, device=d)) for _ in range(3)]
         xs = [nrm(torch.randn(B, D, device=d)) for _ in range(3)]
         idx = torch.randint(0, n, (B, K + 1), device=d)
-        hip_ops.prof_enable(True)
-        for _ in range(25):
-            hip_ops.bank_nce_fused_raw(banks, idx, xs, 0.07)
-        ms, cnt = hip_ops.prof_read()
-        hip_ops.prof_enable(False)
-        whole = hip_ops.bank_nce_fused_timed(banks, idx, xs, 0.07, 20)
-        by = 3 * B * (K + 1) * D * 4 + B * (K + 1) * 8 + 12 * B * D * 4
-        print('  K=%6d  pass %.1f us -> %.0f GB/s   whole op %.1f us' % (K, 1e3 * ms / cnt, by / (ms / cnt) / 1e6, 1e3 * whole),
-              flush=True)
+        for name, bk, sz in (('fp32', banks, 4), ('bf16', [b.bfloat16() for b in banks], 2)):
+            hip_ops.bank_nce_fused_timed(bk, idx, xs, 0.07, 3)
+            whole = hip_ops.bank_nce_fused_timed(bk, idx, xs, 0.07, 20)
+            by = 3 * B * (K + 1) * D * sz + B * (K + 1) * 8 + 12 * B * D * 4
+            print('  K=%6d %s whole op %.1f us  (%.0f GB/s algorithmic over the whole op)' % (K, name, 1e3 * whole, by / whole / 1e6),
+                  flush=True)
 else:
-    for variant in (0, 1, 2, 3, 4):
-        for rows in (0, 512, 1024):
+    for variant in (1, 2, 3, 4, 6):          # = prefetch depth NPF
+        for rows in (0,):
             env = dict(os.environ, HCM_BANK_VARIANT=str(variant), HCM_BANK_ROWS=str(rows))
             print('variant %d rows %d' % (variant, rows), flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), 'worker'], env=env)
