@@ -699,8 +699,10 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
   bank_pass_kernel<T, 2, kFused, NPF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
                                                                   nullptr, B, K1, R, scale2, ws.part_m, \
                                                                   ws.part_s, ws.part_acc, ws.l0, nullptr)
-    // prefetch depth (row triples in flight per stream); variants for tools/tune_bank.py
-    switch (variant > 0 ? variant : (kBf16 ? 4 : 1)) {
+    // prefetch depth (row triples in flight per stream).  Measured (tools/tune_bank.py and the
+    // in-bench hipEvents): fp32 3 > 2 > 1 (0.129 / 0.137 / 0.159 ms on the same box), bf16 best at 4;
+    // depth 4+ for fp32 drops to one wave per SIMD and loses.  HCM_BANK_VARIANT overrides for tuning.
+    switch (variant > 0 ? variant : (kBf16 ? 4 : 3)) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;
