@@ -65,3 +65,19 @@ class OracleLossEngine(object):
         total, meters = _Fmap.apply(map1, map2, feat3, sample_ind, keep, joints2d, joints_vis, use_depth, use_rgb,
                                     temperature)
         return total, meters.detach()
+
+
+    def fmap_sampled(self, branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
+                     use_depth, use_rgb, num_samples, temperature, sample_ind=None, keep=None):
+        """CPU counterpart of HipLossEngine.fmap_sampled: the reference data flow in plain torch
+        (merge_all_res + 1x1 projection of the full maps) followed by the oracle losses.  The
+        projection weights are used OUTSIDE model.forward here, exactly like in the product path,
+        which is what the world_size-2 test needs to exercise under DistributedDataParallel."""
+        import torch.nn.functional as F
+
+        def project(branches, conv):
+            size = branches[0].shape[-2:]
+            up = [branches[0]] + [F.interpolate(m, size=size, mode='bilinear', align_corners=False) for m in branches[1:]]
+            return conv(torch.cat(up, 1))
+        return self.fmap(project(branches1, proj1), project(branches2, proj2), feat3, depth_mask, joints2d,
+                         joints_vis, use_depth, use_rgb, num_samples, temperature, sample_ind, keep)

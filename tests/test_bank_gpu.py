@@ -258,3 +258,28 @@ def test_bf16_banks_fused_logits_and_update(B, K, n):
         err = (new.float() - ref).abs()
         assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all())                                       # <= 1 bf16 ulp
         assert float((new.float()[touched].norm(dim=1) - 1).abs().max()) < 1e-2
+
+
+def test_config3_size_k65536_properties():
+    """BASELINE config 3 size (K=65536): fused loss == CE over API-mode logits, and doubling the
+    negatives by repeating them raises every loss by exactly the log-sum-exp identity
+    lse(l ++ l_neg) = log(exp(lse(l)) + sum exp(l_neg))."""
+    torch.manual_seed(1)
+    d = dev()
+    B, K, n, D, T = 32, 65536, 131072, 128, 0.07
+    nrm = torch.nn.functional.normalize
+    banks = [nrm(torch.randn(n, D, device=d)) for _ in range(3)]
+    xs = [nrm(torch.randn(B, D, device=d)) for _ in range(3)]
+    idx = torch.randint(0, n, (B, K + 1), device=d)
+    l, a, gx = ops().bank_nce_fused_raw(banks, idx, xs, T)
+    lg = ops().bank_logits(xs, banks, idx, T)
+    tgt = torch.zeros(B, dtype=torch.long, device=d)
+    for p in range(6):
+        assert abs(float(l[p]) - float(torch.nn.functional.cross_entropy(lg[p].double(), tgt))) < 2e-5 * float(l[p])
+    idx2 = torch.cat([idx, idx[:, 1:]], dim=1).contiguous()               # negatives twice
+    l2, _, _ = ops().bank_nce_fused_raw(banks, idx2, xs, T)
+    for p in range(6):
+        lse1 = torch.logsumexp(lg[p].double(), 1)
+        lse_neg = torch.logsumexp(lg[p][:, 1:].double(), 1)
+        want = (torch.logaddexp(lse1, lse_neg) - lg[p][:, 0].double()).mean()
+        assert abs(float(l2[p]) - float(want)) < 2e-5 * float(want)
