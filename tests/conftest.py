@@ -12,6 +12,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # Built artefacts are git-ignored: on a fresh checkout compile the product library (hipcc
+    # cross-compiles gfx950 without a GPU) and the C oracle before any test imports them.
+    from hcmoco_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    from oracle import pointnet2_oracle
+    if not os.path.exists(pointnet2_oracle._SO):
+        pointnet2_oracle.build()
 
 
 def load_golden(name):
