@@ -200,13 +200,33 @@ __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
 // honours this order is bit-identical to the reference tree.
 // One workgroup of bs threads per cloud; thread t owns points t, t+bs, ... in registers.
 // ------------------------------------------------------------------------------------------
-struct Cand {
-  float v;
-  int tid;
-  int k;
-};
-__device__ __forceinline__ bool better(const Cand& a, const Cand& b) {  // a beats b ?
-  return a.v > b.v || (a.v == b.v && a.tid < b.tid);
+// Candidates are packed into ONE 64-bit unsigned key so that the whole arg-max is a max-reduction:
+//   high 32 bits: the distance's float bits (distances are >= +0, so their bit patterns order like
+//                 unsigned integers);
+//   low  32 bits: 0xFFFFFFFF - ((bitrev(tid) << 21) | j)  -> among equal distances the smaller
+//                 bit-reversed thread id wins; j (< 2^21) says which of the thread's points it was.
+// A serial round then costs 4 DPP steps + 2 cross-row shuffles + one LDS exchange and ONE barrier
+// (the per-wave results are double-buffered and every wave finishes the reduction redundantly).
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) {
+  return a > b ? a : b;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long row16_umax64(unsigned long long v) {
+  v = umax64(v, dpp_mov64<0xB1>(v));
+  v = umax64(v, dpp_mov64<0x4E>(v));
+  v = umax64(v, dpp_mov64<0x141>(v));
+  v = umax64(v, dpp_mov64<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int off) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64);
+  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 template <int PER>
@@ -215,18 +235,15 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
                                                    float* __restrict__ temp,
                                                    int* __restrict__ idxs) {
   extern __shared__ __attribute__((aligned(16))) float sxyz[];  // [n*3] when PER > 0
-  __shared__ float red_v[16];
-  __shared__ int red_tid[16], red_k[16];
-  __shared__ int s_old;
+  __shared__ unsigned long long red[2][16];
   if (m <= 0) return;
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* cloud = dataset + (int64_t)b * n * 3;
   float* tmp = temp + (int64_t)b * n;
   int* out = idxs + (int64_t)b * m;
   const bool active = tid < bs;
-  // tie-break key: bit-reversed virtual thread id; idle threads (tid >= bs) sort last
-  const int key = active ? (log2bs == 0 ? 0 : (int)(__brev((unsigned)tid) >> (32 - log2bs))) : 0x7ffffff0 + 0 * tid;
-  const int nwaves = (blockDim.x + 63) >> 6;
+  const unsigned key = (log2bs == 0) ? 0u : (__brev((unsigned)tid) >> (32 - log2bs));
+  const int wave = tid >> 6;
 
   float px[PER > 0 ? PER : 1], py[PER > 0 ? PER : 1], pz[PER > 0 ? PER : 1], pt[PER > 0 ? PER : 1];
   if (PER > 0) {
@@ -242,15 +259,17 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
       }
     }
   }
-  if (tid == 0) { out[0] = 0; s_old = 0; }
+  if (tid < 32) red[tid >> 4][tid & 15] = 0ull;  // slots of absent waves stay "lowest"
+  if (tid == 0) out[0] = 0;
   __syncthreads();
 
+  int old = 0;
   for (int r = 1; r < m; ++r) {
-    const int old = s_old;
     float ox, oy, oz;
     if (PER > 0) { ox = sxyz[3 * old]; oy = sxyz[3 * old + 1]; oz = sxyz[3 * old + 2]; }
     else { ox = cloud[3 * old]; oy = cloud[3 * old + 1]; oz = cloud[3 * old + 2]; }
-    Cand c{-1.f, key, 0};
+    float best = -1.f;
+    int bestj = 0;
     if (PER > 0) {
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
@@ -259,37 +278,34 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
           const float d = sqdist(px[j], py[j], pz[j], ox, oy, oz);
           const float d2 = fminf(d, pt[j]);
           pt[j] = d2;
-          if (d2 > c.v) { c.v = d2; c.k = k; }
+          if (d2 > best) { best = d2; bestj = j; }   // first strict maximum over ascending k
         }
       }
     } else if (active) {
-      for (int k = tid; k < n; k += bs) {
+      int j = 0;
+      for (int k = tid; k < n; k += bs, ++j) {
         const float d = sqdist(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
         const float d2 = fminf(d, tmp[k]);
         tmp[k] = d2;
-        if (d2 > c.v) { c.v = d2; c.k = k; }
+        if (d2 > best) { best = d2; bestj = j; }
       }
     }
-    // wave butterfly on (v, tid, k)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      Cand o{__shfl_xor(c.v, off, 64), __shfl_xor(c.tid, off, 64), __shfl_xor(c.k, off, 64)};
-      if (better(o, c)) c = o;
-    }
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) { red_v[wave] = c.v; red_tid[wave] = c.tid; red_k[wave] = c.k; }
+    unsigned long long c = 0ull;
+    if (active && best >= 0.f)
+      c = ((unsigned long long)__float_as_uint(best) << 32) | (0xFFFFFFFFu - ((key << 21) | (unsigned)bestj));
+    c = row16_umax64(c);
+    c = umax64(c, shfl_xor64(c, 16));
+    c = umax64(c, shfl_xor64(c, 32));
+    const int par = r & 1;
+    if ((tid & 63) == 0) red[par][wave] = c;
     __syncthreads();
-    if (tid < 64) {
-      Cand w{tid < nwaves ? red_v[tid] : -2.f, tid < nwaves ? red_tid[tid] : 0x7fffffff,
-             tid < nwaves ? red_k[tid] : 0};
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        Cand o{__shfl_xor(w.v, off, 64), __shfl_xor(w.tid, off, 64), __shfl_xor(w.k, off, 64)};
-        if (better(o, w)) w = o;
-      }
-      if (tid == 0) { s_old = w.k; out[r] = w.k; }
-    }
-    __syncthreads();
+    unsigned long long w = red[par][tid & 15];
+    w = row16_umax64(w);
+    const unsigned low = 0xFFFFFFFFu - (unsigned)w;
+    const unsigned wkey = low >> 21, wj = low & 0x1FFFFFu;
+    const unsigned wtid = (log2bs == 0) ? 0u : (__brev(wkey) >> (32 - log2bs));
+    old = (int)wtid + (int)wj * bs;
+    if (tid == 0) out[r] = old;
   }
   if (PER > 0) {
 #pragma unroll
