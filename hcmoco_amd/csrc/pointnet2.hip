@@ -12,6 +12,8 @@
 // and read it back as wave-wide broadcasts; gather/scatter kernels load each index once and walk
 // a block of channels with it (the reference re-reads the index for every channel); FPS keeps
 // the whole cloud and its running min-distances in registers/LDS for all m serial rounds.
+#include <cstdlib>
+
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
 
@@ -229,6 +231,9 @@ __device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Every point k has the unique key (distance, ~(bitrev(k % bs) << 21 | k / bs)); the global maximum
+// of that key IS the reference winner whatever physical thread evaluated the point, so the physical
+// workgroup size P is a pure performance choice (fewer waves = cheaper barrier, more points each).
 template <int PER>
 __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log2bs,
                                                    const float* __restrict__ dataset,
@@ -237,25 +242,31 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
   extern __shared__ __attribute__((aligned(16))) float sxyz[];  // [n*3] when PER > 0
   __shared__ unsigned long long red[2][16];
   if (m <= 0) return;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, P = blockDim.x;
   const float* cloud = dataset + (int64_t)b * n * 3;
   float* tmp = temp + (int64_t)b * n;
   int* out = idxs + (int64_t)b * m;
-  const bool active = tid < bs;
-  const unsigned key = (log2bs == 0) ? 0u : (__brev((unsigned)tid) >> (32 - log2bs));
   const int wave = tid >> 6;
+  const int shift = 32 - log2bs;
+  auto point_key = [&](int k) -> unsigned {   // low word of the candidate key of point k
+    const unsigned vt = (unsigned)k & (unsigned)(bs - 1);
+    const unsigned brev = (log2bs == 0) ? 0u : (__brev(vt) >> shift);
+    return 0xFFFFFFFFu - ((brev << 21) | (unsigned)(k >> log2bs));
+  };
 
   float px[PER > 0 ? PER : 1], py[PER > 0 ? PER : 1], pz[PER > 0 ? PER : 1], pt[PER > 0 ? PER : 1];
+  unsigned pk[PER > 0 ? PER : 1];
   if (PER > 0) {
-    for (int e = tid; e < n * 3; e += blockDim.x) sxyz[e] = cloud[e];
+    for (int e = tid; e < n * 3; e += P) sxyz[e] = cloud[e];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const int k = tid + j * bs;
-      if (active && k < n) {
+      const int k = tid + j * P;
+      if (k < n) {
         px[j] = cloud[3 * k]; py[j] = cloud[3 * k + 1]; pz[j] = cloud[3 * k + 2];
         pt[j] = tmp[k];
+        pk[j] = point_key(k);
       } else {
-        px[j] = py[j] = pz[j] = 0.f; pt[j] = 0.f;
+        px[j] = py[j] = pz[j] = 0.f; pt[j] = 0.f; pk[j] = 0u;
       }
     }
   }
@@ -268,31 +279,25 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
     float ox, oy, oz;
     if (PER > 0) { ox = sxyz[3 * old]; oy = sxyz[3 * old + 1]; oz = sxyz[3 * old + 2]; }
     else { ox = cloud[3 * old]; oy = cloud[3 * old + 1]; oz = cloud[3 * old + 2]; }
-    float best = -1.f;
-    int bestj = 0;
+    unsigned long long c = 0ull;
     if (PER > 0) {
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
-        const int k = tid + j * bs;
-        if (active && k < n) {
+        if (tid + j * P < n) {
           const float d = sqdist(px[j], py[j], pz[j], ox, oy, oz);
           const float d2 = fminf(d, pt[j]);
           pt[j] = d2;
-          if (d2 > best) { best = d2; bestj = j; }   // first strict maximum over ascending k
+          c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | pk[j]);
         }
       }
-    } else if (active) {
-      int j = 0;
-      for (int k = tid; k < n; k += bs, ++j) {
+    } else {
+      for (int k = tid; k < n; k += P) {
         const float d = sqdist(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
         const float d2 = fminf(d, tmp[k]);
         tmp[k] = d2;
-        if (d2 > best) { best = d2; bestj = j; }
+        c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | point_key(k));
       }
     }
-    unsigned long long c = 0ull;
-    if (active && best >= 0.f)
-      c = ((unsigned long long)__float_as_uint(best) << 32) | (0xFFFFFFFFu - ((key << 21) | (unsigned)bestj));
     c = row16_umax64(c);
     c = umax64(c, shfl_xor64(c, 16));
     c = umax64(c, shfl_xor64(c, 32));
@@ -303,15 +308,15 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
     w = row16_umax64(w);
     const unsigned low = 0xFFFFFFFFu - (unsigned)w;
     const unsigned wkey = low >> 21, wj = low & 0x1FFFFFu;
-    const unsigned wtid = (log2bs == 0) ? 0u : (__brev(wkey) >> (32 - log2bs));
-    old = (int)wtid + (int)wj * bs;
+    const unsigned wvt = (log2bs == 0) ? 0u : (__brev(wkey) >> shift);
+    old = (int)wvt + (int)(wj << log2bs);
     if (tid == 0) out[r] = old;
   }
   if (PER > 0) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const int k = tid + j * bs;
-      if (active && k < n) tmp[k] = pt[j];
+      const int k = tid + j * P;
+      if (k < n) tmp[k] = pt[j];
     }
   }
 }
@@ -391,9 +396,11 @@ int hcm_three_nn(int b, int n, int m, const float* unknown, const float* known, 
 int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
                                 hcm_stream_t stream) {
   if (b <= 0 || n <= 0 || m <= 0) return b < 0 || n < 0 || m < 0 ? (int)hipErrorInvalidValue : 0;
-  const int bs = opt_n_threads(n);
-  const int threads = bs < 64 ? 64 : bs;
-  const int per = (n + bs - 1) / bs;
+  const int bs = opt_n_threads(n);   // the reference's block size: defines the tie-break order only
+  static const int pt_env = getenv("HCM_FPS_THREADS") ? atoi(getenv("HCM_FPS_THREADS")) : 512;
+  int threads = bs < 64 ? 64 : bs;
+  if (threads > pt_env && pt_env >= 64) threads = pt_env;
+  const int per = (n + threads - 1) / threads;
   int log2bs = 0;
   while ((1 << log2bs) < bs) ++log2bs;
   const size_t lds = (size_t)n * 3 * sizeof(float);
@@ -402,12 +409,13 @@ int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float
   do {                                                                                      \
     hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P>),                        \
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-    fps_kernel<P><<<b, threads, lds, st>>>(n, m, bs, log2bs, dataset, temp, idxs);                   \
+    fps_kernel<P><<<b, threads, lds, st>>>(n, m, bs, log2bs, dataset, temp, idxs);           \
   } while (0)
   if (per <= 1 && lds <= 150 * 1024) HCM_FPS(1);
   else if (per <= 2 && lds <= 150 * 1024) HCM_FPS(2);
   else if (per <= 4 && lds <= 150 * 1024) HCM_FPS(4);
   else if (per <= 8 && lds <= 150 * 1024) HCM_FPS(8);
+  else if (per <= 16 && lds <= 150 * 1024) HCM_FPS(16);
   else fps_kernel<0><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
 #undef HCM_FPS
   HCM_CHECK_LAUNCH();
