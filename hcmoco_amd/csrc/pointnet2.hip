@@ -102,6 +102,114 @@ __global__ __launch_bounds__(kT) void three_interp_grad_kernel(int c, int n, int
 }
 
 // ------------------------------------------------------------------------------------------
+// Scatter-add backward WITHOUT float atomics.
+// group_points_grad / gather_points_grad / three_interpolate_grad are all
+//     grad_points[b, c, j] = sum over q with idx[b, q] == j of coef[b, q] * grad_out[b, c, src(q)]
+// The reference (and hcm_*_grad above, kept for ABI parity) issues one float atomicAdd per (c, q);
+// on MI355X contended float atomics run at ~120 GB/s (three_interpolate_grad of pts2depth: 35.6 ms,
+// tools/bench_pointnet2.py).  Here the index tensor is inverted ONCE (counting sort with integer
+// atomics: offsets[b, j], list[b, .]) and every (b, j) then gathers its own contributions for all
+// channels: no float atomics, coalesced stores.  Buckets up to kSortMax entries are sorted by q, so
+// their fp32 sums are order-deterministic (larger buckets keep the fill order).
+// ------------------------------------------------------------------------------------------
+constexpr int kSortMax = 192;
+
+__global__ __launch_bounds__(kT) void inv_count_kernel(const int* __restrict__ idx, int Q, int m,
+                                                       int* __restrict__ counts /*[B][m+1], zeroed*/) {
+  const int b = blockIdx.y;
+  for (int q = blockIdx.x * kT + threadIdx.x; q < Q; q += gridDim.x * kT)
+    atomicAdd(&counts[(int64_t)b * (m + 1) + idx[(int64_t)b * Q + q] + 1], 1);
+}
+
+// in-place inclusive scan of counts[b][1..m] (counts[b][0] == 0) -> offsets; one workgroup per batch
+__global__ __launch_bounds__(1024) void inv_scan_kernel(int m, int* __restrict__ offsets,
+                                                        int* __restrict__ cursor) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  int* off = offsets + (int64_t)blockIdx.x * (m + 1);
+  int* cur = cursor + (int64_t)blockIdx.x * m;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 1; base <= m; base += 1024) {
+    const int i = base + threadIdx.x;
+    int v = (i <= m) ? off[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+      const int add = threadIdx.x >= s ? sh[threadIdx.x - s] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int incl = sh[threadIdx.x] + carry;
+    if (i <= m) {
+      off[i] = incl;
+      cur[i - 1] = incl - v;   // start of bucket j = i-1
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kT) void inv_fill_kernel(const int* __restrict__ idx, int Q, int m,
+                                                      int* __restrict__ cursor, int* __restrict__ list) {
+  const int b = blockIdx.y;
+  for (int q = blockIdx.x * kT + threadIdx.x; q < Q; q += gridDim.x * kT) {
+    const int j = idx[(int64_t)b * Q + q];
+    const int pos = atomicAdd(&cursor[(int64_t)b * m + j], 1);
+    list[(int64_t)b * Q + pos] = q;
+  }
+}
+
+__global__ __launch_bounds__(kT) void inv_sort_kernel(const int* __restrict__ offsets, int Q, int m,
+                                                      int* __restrict__ list) {
+  const int b = blockIdx.y, j = blockIdx.x * kT + threadIdx.x;
+  if (j >= m) return;
+  const int lo = offsets[(int64_t)b * (m + 1) + j], hi = offsets[(int64_t)b * (m + 1) + j + 1];
+  if (hi - lo < 2 || hi - lo > kSortMax) return;
+  int* l = list + (int64_t)b * Q;
+  for (int i = lo + 1; i < hi; ++i) {   // insertion sort: buckets are short (avg Q/m)
+    const int v = l[i];
+    int k = i - 1;
+    while (k >= lo && l[k] > v) { l[k + 1] = l[k]; --k; }
+    l[k + 1] = v;
+  }
+}
+
+constexpr int kSegC = 4;  // channels per thread
+// block = 64 columns (j) x 4 channel groups; each thread owns kSegC channels of one j
+__global__ __launch_bounds__(kT) void segment_gather_kernel(const float* __restrict__ grad_out,
+                                                            const float* __restrict__ coef,
+                                                            const int* __restrict__ offsets,
+                                                            const int* __restrict__ list, int C,
+                                                            int Qsrc, int Q, int m, int div,
+                                                            float* __restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int c0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kSegC;
+  if (j >= m || c0 >= C) return;
+  const int lo = offsets[(int64_t)b * (m + 1) + j], hi = offsets[(int64_t)b * (m + 1) + j + 1];
+  const int* l = list + (int64_t)b * Q;
+  const float* cf = coef ? coef + (int64_t)b * Q : nullptr;
+  const float* g = grad_out + ((int64_t)b * C + c0) * Qsrc;
+  float acc[kSegC];
+#pragma unroll
+  for (int k = 0; k < kSegC; ++k) acc[k] = 0.f;
+  for (int e = lo; e < hi; ++e) {
+    const int q = l[e];
+    const float w = cf ? cf[q] : 1.f;
+    const int src = q / div;
+#pragma unroll
+    for (int k = 0; k < kSegC; ++k)
+      if (c0 + k < C) acc[k] += w * g[(int64_t)k * Qsrc + src];
+  }
+#pragma unroll
+  for (int k = 0; k < kSegC; ++k)
+    if (c0 + k < C) grad_points[((int64_t)b * C + c0 + k) * m + j] = acc[k];
+}
+
+// ------------------------------------------------------------------------------------------
 // ball query (ball_query_gpu.cu:9-45): first `nsample` points, in index order, with d2 < r^2;
 // the first hit pre-fills all nsample slots; centres with no hit keep the caller's zeros.
 // One thread per centre; the scanned cloud goes through LDS in tiles of kTile points.
@@ -393,6 +501,45 @@ int hcm_three_nn(int b, int n, int m, const float* unknown, const float* known, 
   HCM_CHECK_LAUNCH();
   return 0;
 }
+
+size_t hcm_inverse_index_workspace_bytes(int B, int Q, int m) {
+  (void)Q;
+  return (size_t)B * (size_t)m * sizeof(int);
+}
+
+int hcm_inverse_index_build(const int* idx, int B, int Q, int m, int* offsets, int* list,
+                            void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
+  if (B <= 0 || Q <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+  if (workspace == nullptr || workspace_bytes < hcm_inverse_index_workspace_bytes(B, Q, m))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  int* cursor = reinterpret_cast<int*>(workspace);
+  hipError_t e = hipMemsetAsync(offsets, 0, (size_t)B * (m + 1) * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (Q + kT - 1) / kT;
+  if (gx > 1024) gx = 1024;
+  inv_count_kernel<<<dim3(gx, B), kT, 0, st>>>(idx, Q, m, offsets);
+  HCM_CHECK_LAUNCH();
+  inv_scan_kernel<<<B, 1024, 0, st>>>(m, offsets, cursor);
+  HCM_CHECK_LAUNCH();
+  inv_fill_kernel<<<dim3(gx, B), kT, 0, st>>>(idx, Q, m, cursor, list);
+  HCM_CHECK_LAUNCH();
+  inv_sort_kernel<<<dim3((m + kT - 1) / kT, B), kT, 0, st>>>(offsets, Q, m, list);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* offsets,
+                           const int* list, int B, int C, int Qsrc, int Q, int m, int div,
+                           float* grad_points, hcm_stream_t stream) {
+  if (B <= 0 || C <= 0 || Q <= 0 || m <= 0 || div <= 0 || Qsrc <= 0) return (int)hipErrorInvalidValue;
+  dim3 grid((m + 63) / 64, (C + 4 * kSegC - 1) / (4 * kSegC), B);
+  segment_gather_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(grad_out, coef, offsets, list, C, Qsrc, Q,
+                                                             m, div, grad_points);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
 int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
                                 hcm_stream_t stream) {
   if (b <= 0 || n <= 0 || m <= 0) return b < 0 || n < 0 || m < 0 ? (int)hipErrorInvalidValue : 0;

@@ -14,6 +14,16 @@ from torch.autograd import Function
 from .... import pointnet2_hip as pointnet2
 
 
+def _scatter_backward(grad_out, idx, coef, m, div, legacy):
+    """Backward of the three gather-type ops.  The native module of this build offers an atomic-free
+    inverse-index path (``segment_grad``); a module with only the reference's nine functions (the
+    pybind original, or the CPU oracle shim used by tests) takes the ``*_grad_wrapper`` route."""
+    fn = getattr(pointnet2, 'segment_grad', None)
+    if fn is not None:
+        return fn(grad_out, idx, coef, m, div)
+    return legacy()
+
+
 class FurthestPointSampling(Function):
     @staticmethod
     def forward(ctx, xyz, npoint):
@@ -48,9 +58,13 @@ class GatherOperation(Function):
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
-        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
-        return grad_features, None
+        grad_out = grad_out.contiguous()
+
+        def legacy():
+            grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+            pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out, idx, grad_features)
+            return grad_features
+        return _scatter_backward(grad_out, idx, None, N, 1, legacy), None
 
 
 gather_operation = GatherOperation.apply
@@ -92,9 +106,13 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
-        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
-        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
-        return grad_features, None, None
+        grad_out = grad_out.contiguous()
+
+        def legacy():
+            grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
+            pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out, idx, weight, grad_features)
+            return grad_features
+        return _scatter_backward(grad_out, idx, weight, m, 3, legacy), None, None
 
 
 three_interpolate = ThreeInterpolate.apply
@@ -115,9 +133,13 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
-        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
-        return grad_features, None
+        grad_out = grad_out.contiguous()
+
+        def legacy():
+            grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+            pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out, idx, grad_features)
+            return grad_features
+        return _scatter_backward(grad_out.view(B, C, npoint * nsample), idx, None, N, 1, legacy), None
 
 
 grouping_operation = GroupingOperation.apply

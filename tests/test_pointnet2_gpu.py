@@ -117,3 +117,31 @@ def test_bad_arguments_raise_instead_of_exit():
     with pytest.raises(TypeError):
         mod().ball_query_wrapper(1, 4, 2, 0.1, 2, torch.zeros(1, 2, 3, device=d()), torch.zeros(1, 4, 3, device=d()),
                                  torch.zeros(1, 2, 2, dtype=torch.int64, device=d()))
+
+
+@pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1),
+                                         (2, 19, 3 * 5000, 257, 3), (1, 4, 4000, 3, 1)])
+def test_segment_grad_matches_the_atomic_kernels_and_is_deterministic(B, C, Q, m, div):
+    """The inverse-index backward == oracle scatter-add (group / three_interpolate forms), including
+    empty buckets, buckets beyond the sort limit (m=3) and repeated indices; bitwise repeatable."""
+    torch.manual_seed(Q + m)
+    idx = torch.randint(0, m, (B, Q), dtype=torch.int32)
+    idx[:, : Q // 4] = idx[:, :1]                                  # a hot bucket
+    if m > 8:
+        idx[idx == 5] = 6                                          # an empty bucket
+    g = torch.randn(B, C, Q // div)
+    if div == 3:
+        w = torch.rand(B, Q // 3, 3)
+        ref = P.three_interpolate_grad(g, idx.view(B, Q // 3, 3), w, m)
+        coef = w
+    else:
+        ref = P.group_points_grad(g.view(B, C, Q, 1), idx.view(B, Q, 1), m)
+        coef = None
+    a = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
+    b = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
+    assert torch.allclose(a.cpu(), ref, rtol=1e-4, atol=1e-4)
+    if Q // m <= 150:
+        assert torch.equal(a, b)
+    offsets, lst = mod().inverse_index(idx.to(d()), m)
+    assert int(offsets[:, -1].min()) == Q and int(offsets[:, 0].abs().max()) == 0
+    assert torch.equal(torch.sort(lst.cpu().long(), 1).values, torch.arange(Q).expand(B, Q))   # a permutation
