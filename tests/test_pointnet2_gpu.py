@@ -119,7 +119,7 @@ def test_bad_arguments_raise_instead_of_exit():
                                  torch.zeros(1, 2, 2, dtype=torch.int64, device=d()))
 
 
-@pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1),
+@pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1), (2, 9, 600, 40, 1),
                                          (2, 19, 3 * 5000, 257, 3), (1, 4, 4000, 3, 1)])
 def test_segment_grad_matches_the_atomic_kernels_and_is_deterministic(B, C, Q, m, div):
     """The inverse-index backward == oracle scatter-add (group / three_interpolate forms), including
@@ -140,7 +140,8 @@ def test_segment_grad_matches_the_atomic_kernels_and_is_deterministic(B, C, Q, m
     a = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
     b = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
     assert torch.allclose(a.cpu(), ref, rtol=1e-4, atol=1e-4)
-    if Q // m <= 150:
+    biggest = max(int(torch.bincount(idx[b_].long(), minlength=m).max()) for b_ in range(B))
+    if biggest <= 192:                     # buckets up to the sort limit sum in a fixed order
         assert torch.equal(a, b)
     offsets, lst = mod().inverse_index(idx.to(d()), m)
     assert int(offsets[:, -1].min()) == Q and int(offsets[:, 0].abs().max()) == 0
