@@ -109,10 +109,10 @@ __global__ __launch_bounds__(kT) void three_interp_grad_kernel(int c, int n, int
 // on MI355X contended float atomics run at ~120 GB/s (three_interpolate_grad of pts2depth: 35.6 ms,
 // tools/bench_pointnet2.py).  Here the index tensor is inverted ONCE (counting sort with integer
 // atomics: offsets[b, j], list[b, .]) and every (b, j) then gathers its own contributions for all
-// channels: no float atomics, coalesced stores.  Buckets up to kSortMax entries are sorted by q, so
-// their fp32 sums are order-deterministic (larger buckets keep the fill order).
+// channels, accumulating in LDS: no global float atomics, coalesced stores, and a work split that
+// does not care how skewed the buckets are (ball-query padding makes hub points with thousands of
+// references).
 // ------------------------------------------------------------------------------------------
-constexpr int kSortMax = 192;
 
 __global__ __launch_bounds__(kT) void inv_count_kernel(const int* __restrict__ idx, int Q, int m,
                                                        int* __restrict__ counts /*[B][m+1], zeroed*/) {
@@ -162,51 +162,41 @@ __global__ __launch_bounds__(kT) void inv_fill_kernel(const int* __restrict__ id
   }
 }
 
-__global__ __launch_bounds__(kT) void inv_sort_kernel(const int* __restrict__ offsets, int Q, int m,
-                                                      int* __restrict__ list) {
-  const int b = blockIdx.y, j = blockIdx.x * kT + threadIdx.x;
-  if (j >= m) return;
-  const int lo = offsets[(int64_t)b * (m + 1) + j], hi = offsets[(int64_t)b * (m + 1) + j + 1];
-  if (hi - lo < 2 || hi - lo > kSortMax) return;
-  int* l = list + (int64_t)b * Q;
-  for (int i = lo + 1; i < hi; ++i) {   // insertion sort: buckets are short (avg Q/m)
-    const int v = l[i];
-    int k = i - 1;
-    while (k >= lo && l[k] > v) { l[k + 1] = l[k]; --k; }
-    l[k + 1] = v;
-  }
-}
-
-constexpr int kSegC = 4;  // channels per thread
-// block = 64 columns (j) x 4 channel groups; each thread owns kSegC channels of one j
+constexpr int kSegCB = 16;  // channels per workgroup
+// One workgroup = 64 consecutive targets j (their entries are ONE contiguous range of the inverted
+// list) x kSegCB channels.  Threads walk the entries of that range -- perfectly balanced whatever
+// the bucket sizes -- and accumulate into an LDS tile with LDS float atomics (ds_add_f32; the order
+// of the adds inside a bucket is not fixed, as with the reference's global atomicAdd).
 __global__ __launch_bounds__(kT) void segment_gather_kernel(const float* __restrict__ grad_out,
                                                             const float* __restrict__ coef,
+                                                            const int* __restrict__ idx,
                                                             const int* __restrict__ offsets,
                                                             const int* __restrict__ list, int C,
                                                             int Qsrc, int Q, int m, int div,
                                                             float* __restrict__ grad_points) {
-  const int b = blockIdx.z;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int c0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kSegC;
-  if (j >= m || c0 >= C) return;
-  const int lo = offsets[(int64_t)b * (m + 1) + j], hi = offsets[(int64_t)b * (m + 1) + j + 1];
+  __shared__ float acc[kSegCB][64];
+  const int b = blockIdx.z, j0 = blockIdx.x * 64, c0 = blockIdx.y * kSegCB;
+  const int nc = min(kSegCB, C - c0);
+  for (int e = threadIdx.x; e < kSegCB * 64; e += kT) (&acc[0][0])[e] = 0.f;
+  __syncthreads();
+  const int lo = offsets[(int64_t)b * (m + 1) + j0];
+  const int hi = offsets[(int64_t)b * (m + 1) + min(j0 + 64, m)];
   const int* l = list + (int64_t)b * Q;
+  const int* ix = idx + (int64_t)b * Q;
   const float* cf = coef ? coef + (int64_t)b * Q : nullptr;
   const float* g = grad_out + ((int64_t)b * C + c0) * Qsrc;
-  float acc[kSegC];
-#pragma unroll
-  for (int k = 0; k < kSegC; ++k) acc[k] = 0.f;
-  for (int e = lo; e < hi; ++e) {
+  for (int e = lo + threadIdx.x; e < hi; e += kT) {
     const int q = l[e];
+    const int jl = ix[q] - j0;
     const float w = cf ? cf[q] : 1.f;
     const int src = q / div;
-#pragma unroll
-    for (int k = 0; k < kSegC; ++k)
-      if (c0 + k < C) acc[k] += w * g[(int64_t)k * Qsrc + src];
+    for (int k = 0; k < nc; ++k) atomicAdd(&acc[k][jl], w * g[(int64_t)k * Qsrc + src]);
   }
-#pragma unroll
-  for (int k = 0; k < kSegC; ++k)
-    if (c0 + k < C) grad_points[((int64_t)b * C + c0 + k) * m + j] = acc[k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < nc * 64; e += kT) {
+    const int k = e >> 6, jl = e & 63;
+    if (j0 + jl < m) grad_points[((int64_t)b * C + c0 + k) * m + j0 + jl] = acc[k][jl];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,18 +514,16 @@ int hcm_inverse_index_build(const int* idx, int B, int Q, int m, int* offsets, i
   HCM_CHECK_LAUNCH();
   inv_fill_kernel<<<dim3(gx, B), kT, 0, st>>>(idx, Q, m, cursor, list);
   HCM_CHECK_LAUNCH();
-  inv_sort_kernel<<<dim3((m + kT - 1) / kT, B), kT, 0, st>>>(offsets, Q, m, list);
-  HCM_CHECK_LAUNCH();
   return 0;
 }
 
-int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* offsets,
-                           const int* list, int B, int C, int Qsrc, int Q, int m, int div,
-                           float* grad_points, hcm_stream_t stream) {
+int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* idx,
+                           const int* offsets, const int* list, int B, int C, int Qsrc, int Q, int m,
+                           int div, float* grad_points, hcm_stream_t stream) {
   if (B <= 0 || C <= 0 || Q <= 0 || m <= 0 || div <= 0 || Qsrc <= 0) return (int)hipErrorInvalidValue;
-  dim3 grid((m + 63) / 64, (C + 4 * kSegC - 1) / (4 * kSegC), B);
-  segment_gather_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(grad_out, coef, offsets, list, C, Qsrc, Q,
-                                                             m, div, grad_points);
+  dim3 grid((m + 63) / 64, (C + kSegCB - 1) / kSegCB, B);
+  segment_gather_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(grad_out, coef, idx, offsets, list, C,
+                                                             Qsrc, Q, m, div, grad_points);
   HCM_CHECK_LAUNCH();
   return 0;
 }

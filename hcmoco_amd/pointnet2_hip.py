@@ -108,7 +108,7 @@ def segment_grad(grad_out, idx, coef, m, div=1):
     offsets, lst = inverse_index(idx2, m)
     out = torch.empty(B, Cc, m, dtype=torch.float32, device=grad_out.device)
     cf = C.c_void_p(0) if coef is None else _f(coef.reshape(B, -1).contiguous(), 'segment_grad')
-    check(_lib.lib().hcm_segment_gather_sum(_f(grad_out, 'segment_grad'), cf, _i(offsets, 'segment_grad'),
-                                            _i(lst, 'segment_grad'), B, Cc, qsrc, Q, m, div,
+    check(_lib.lib().hcm_segment_gather_sum(_f(grad_out, 'segment_grad'), cf, _i(idx2, 'segment_grad'),
+                                            _i(offsets, 'segment_grad'), _i(lst, 'segment_grad'), B, Cc, qsrc, Q, m, div,
                                             _f(out, 'segment_grad'), _stream()), 'hcm_segment_gather_sum')
     return out

@@ -230,16 +230,15 @@ int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
  * gather_points_grad: idx [B, npoints],         coef NULL, div 1, Qsrc = npoints
  * three_interpolate_grad: idx [B, n*3], coef = weight [B, n*3], div 3, Qsrc = n
  * Step 1 inverts the index once (offsets [B, m+1], list [B, Q], both int32, caller-allocated;
- * counting sort with integer atomics, buckets of <= 192 entries sorted by q); step 2 lets every
- * (b, j) gather its own contributions for all C channels and OVERWRITES grad_points [B, C, m].
- * No float atomics: order-deterministic sums and ~10x the throughput of the atomic kernels on
- * contended indices (tools/bench_pointnet2.py). */
+ * counting sort with integer atomics); step 2 gives every tile of 64 targets its contiguous range
+ * of the list, accumulates in LDS and OVERWRITES grad_points [B, C, m].  No global float atomics;
+ * like the reference's atomicAdd the order of the adds inside a bucket is not fixed. */
 size_t hcm_inverse_index_workspace_bytes(int B, int Q, int m);
 int hcm_inverse_index_build(const int* idx, int B, int Q, int m, int* offsets, int* list,
                             void* workspace, size_t workspace_bytes, hcm_stream_t stream);
-int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* offsets,
-                           const int* list, int B, int C, int Qsrc, int Q, int m, int div,
-                           float* grad_points, hcm_stream_t stream);
+int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* idx,
+                           const int* offsets, const int* list, int B, int C, int Qsrc, int Q, int m,
+                           int div, float* grad_points, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Measurement helper: launches `reps` back-to-back hcm_bank_nce_fused passes bracketed by

@@ -121,9 +121,9 @@ def test_bad_arguments_raise_instead_of_exit():
 
 @pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1), (2, 9, 600, 40, 1),
                                          (2, 19, 3 * 5000, 257, 3), (1, 4, 4000, 3, 1)])
-def test_segment_grad_matches_the_atomic_kernels_and_is_deterministic(B, C, Q, m, div):
+def test_segment_grad_matches_the_scatter_add_oracle(B, C, Q, m, div):
     """The inverse-index backward == oracle scatter-add (group / three_interpolate forms), including
-    empty buckets, buckets beyond the sort limit (m=3) and repeated indices; bitwise repeatable."""
+    empty buckets, hub buckets (m=3: a thousand references each) and repeated indices."""
     torch.manual_seed(Q + m)
     idx = torch.randint(0, m, (B, Q), dtype=torch.int32)
     idx[:, : Q // 4] = idx[:, :1]                                  # a hot bucket
@@ -140,9 +140,7 @@ def test_segment_grad_matches_the_atomic_kernels_and_is_deterministic(B, C, Q, m
     a = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
     b = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
     assert torch.allclose(a.cpu(), ref, rtol=1e-4, atol=1e-4)
-    biggest = max(int(torch.bincount(idx[b_].long(), minlength=m).max()) for b_ in range(B))
-    if biggest <= 192:                     # buckets up to the sort limit sum in a fixed order
-        assert torch.equal(a, b)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)          # (add order inside a bucket is not fixed)
     offsets, lst = mod().inverse_index(idx.to(d()), m)
     assert int(offsets[:, -1].min()) == Q and int(offsets[:, 0].abs().max()) == 0
     assert torch.equal(torch.sort(lst.cpu().long(), 1).values, torch.arange(Q).expand(B, Q))   # a permutation
