@@ -190,7 +190,15 @@ __global__ __launch_bounds__(kT) void segment_gather_kernel(const float* __restr
     const int jl = ix[q] - j0;
     const float w = cf ? cf[q] : 1.f;
     const int src = q / div;
-    for (int k = 0; k < nc; ++k) atomicAdd(&acc[k][jl], w * g[(int64_t)k * Qsrc + src]);
+    if (nc == kSegCB) {   // full channel block: issue all gathers first (independent loads), then add
+      float v[kSegCB];
+#pragma unroll
+      for (int k = 0; k < kSegCB; ++k) v[k] = g[(int64_t)k * Qsrc + src];
+#pragma unroll
+      for (int k = 0; k < kSegCB; ++k) atomicAdd(&acc[k][jl], w * v[k]);
+    } else {
+      for (int k = 0; k < nc; ++k) atomicAdd(&acc[k][jl], w * g[(int64_t)k * Qsrc + src]);
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < nc * 64; e += kT) {
