@@ -112,3 +112,15 @@ def segment_grad(grad_out, idx, coef, m, div=1):
                                             _i(offsets, 'segment_grad'), _i(lst, 'segment_grad'), B, Cc, qsrc, Q, m, div,
                                             _f(out, 'segment_grad'), _stream()), 'hcm_segment_gather_sum')
     return out
+
+
+def scatter_add_lds(grad_out, idx, coef, m, div=1):
+    """Same contract as ``segment_grad`` through the LDS-resident kernel (no index inversion)."""
+    B, Cc, qsrc = grad_out.shape
+    idx2 = idx.reshape(B, -1).contiguous()
+    out = torch.empty(B, Cc, m, dtype=torch.float32, device=grad_out.device)
+    cf = C.c_void_p(0) if coef is None else _f(coef.reshape(B, -1).contiguous(), 'scatter_add_lds')
+    check(_lib.lib().hcm_scatter_add_lds(_f(grad_out, 'scatter_add_lds'), cf, _i(idx2, 'scatter_add_lds'), B, Cc, qsrc,
+                                         idx2.shape[1], m, div, _f(out, 'scatter_add_lds'), _stream()),
+          'hcm_scatter_add_lds')
+    return out

@@ -233,6 +233,12 @@ int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
  * counting sort with integer atomics); step 2 gives every tile of 64 targets its contiguous range
  * of the list, accumulates in LDS and OVERWRITES grad_points [B, C, m].  No global float atomics;
  * like the reference's atomicAdd the order of the adds inside a bucket is not fixed. */
+/* Preferred form when the target row fits LDS (m * 4 B <= 140 KB, i.e. every PointNet++ level): one
+ * workgroup keeps grad_points[b, c0:c0+CBL, :] in LDS, streams grad_out / idx / coef once
+ * (coalesced), accumulates with LDS float atomics and OVERWRITES grad_points [B, C, m].  Returns
+ * hipErrorInvalidConfiguration when m is too large (then use the atomic kernels). */
+int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx, int B, int C,
+                        int Qsrc, int Q, int m, int div, float* grad_points, hcm_stream_t stream);
 size_t hcm_inverse_index_workspace_bytes(int B, int Q, int m);
 int hcm_inverse_index_build(const int* idx, int B, int Q, int m, int* offsets, int* list,
                             void* workspace, size_t workspace_bytes, hcm_stream_t stream);

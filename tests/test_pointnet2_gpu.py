@@ -140,6 +140,8 @@ def test_segment_grad_matches_the_scatter_add_oracle(B, C, Q, m, div):
     a = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
     b = mod().segment_grad(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
     assert torch.allclose(a.cpu(), ref, rtol=1e-4, atol=1e-4)
+    c = mod().scatter_add_lds(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
+    assert torch.allclose(c.cpu(), ref, rtol=1e-4, atol=1e-4)
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-3)          # (add order inside a bucket is not fixed)
     offsets, lst = mod().inverse_index(idx.to(d()), m)
     assert int(offsets[:, -1].min()) == Q and int(offsets[:, 0].abs().max()) == 0
