@@ -64,9 +64,6 @@ SIGNATURES = {
     'hcm_three_interpolate': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_three_interpolate_grad': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    'hcm_inverse_index_workspace_bytes': (_sz, [_i, _i, _i]),
-    'hcm_inverse_index_build': (_i, [_p, _i, _i, _i, _p, _p, _p, _sz, _p]),
-    'hcm_segment_gather_sum': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
 }

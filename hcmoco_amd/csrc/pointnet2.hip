@@ -102,112 +102,6 @@ __global__ __launch_bounds__(kT) void three_interp_grad_kernel(int c, int n, int
 }
 
 // ------------------------------------------------------------------------------------------
-// Scatter-add backward WITHOUT float atomics.
-// group_points_grad / gather_points_grad / three_interpolate_grad are all
-//     grad_points[b, c, j] = sum over q with idx[b, q] == j of coef[b, q] * grad_out[b, c, src(q)]
-// The reference (and hcm_*_grad above, kept for ABI parity) issues one float atomicAdd per (c, q);
-// on MI355X contended float atomics run at ~120 GB/s (three_interpolate_grad of pts2depth: 35.6 ms,
-// tools/bench_pointnet2.py).  Here the index tensor is inverted ONCE (counting sort with integer
-// atomics: offsets[b, j], list[b, .]) and every (b, j) then gathers its own contributions for all
-// channels, accumulating in LDS: no global float atomics, coalesced stores, and a work split that
-// does not care how skewed the buckets are (ball-query padding makes hub points with thousands of
-// references).
-// ------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(kT) void inv_count_kernel(const int* __restrict__ idx, int Q, int m,
-                                                       int* __restrict__ counts /*[B][m+1], zeroed*/) {
-  const int b = blockIdx.y;
-  for (int q = blockIdx.x * kT + threadIdx.x; q < Q; q += gridDim.x * kT)
-    atomicAdd(&counts[(int64_t)b * (m + 1) + idx[(int64_t)b * Q + q] + 1], 1);
-}
-
-// in-place inclusive scan of counts[b][1..m] (counts[b][0] == 0) -> offsets; one workgroup per batch
-__global__ __launch_bounds__(1024) void inv_scan_kernel(int m, int* __restrict__ offsets,
-                                                        int* __restrict__ cursor) {
-  __shared__ int sh[1024];
-  __shared__ int carry;
-  int* off = offsets + (int64_t)blockIdx.x * (m + 1);
-  int* cur = cursor + (int64_t)blockIdx.x * m;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 1; base <= m; base += 1024) {
-    const int i = base + threadIdx.x;
-    int v = (i <= m) ? off[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 1; s < 1024; s <<= 1) {
-      const int add = threadIdx.x >= s ? sh[threadIdx.x - s] : 0;
-      __syncthreads();
-      sh[threadIdx.x] += add;
-      __syncthreads();
-    }
-    const int incl = sh[threadIdx.x] + carry;
-    if (i <= m) {
-      off[i] = incl;
-      cur[i - 1] = incl - v;   // start of bucket j = i-1
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = incl;
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(kT) void inv_fill_kernel(const int* __restrict__ idx, int Q, int m,
-                                                      int* __restrict__ cursor, int* __restrict__ list) {
-  const int b = blockIdx.y;
-  for (int q = blockIdx.x * kT + threadIdx.x; q < Q; q += gridDim.x * kT) {
-    const int j = idx[(int64_t)b * Q + q];
-    const int pos = atomicAdd(&cursor[(int64_t)b * m + j], 1);
-    list[(int64_t)b * Q + pos] = q;
-  }
-}
-
-constexpr int kSegCB = 16;  // channels per workgroup
-// One workgroup = 64 consecutive targets j (their entries are ONE contiguous range of the inverted
-// list) x kSegCB channels.  Threads walk the entries of that range -- perfectly balanced whatever
-// the bucket sizes -- and accumulate into an LDS tile with LDS float atomics (ds_add_f32; the order
-// of the adds inside a bucket is not fixed, as with the reference's global atomicAdd).
-__global__ __launch_bounds__(kT) void segment_gather_kernel(const float* __restrict__ grad_out,
-                                                            const float* __restrict__ coef,
-                                                            const int* __restrict__ idx,
-                                                            const int* __restrict__ offsets,
-                                                            const int* __restrict__ list, int C,
-                                                            int Qsrc, int Q, int m, int div,
-                                                            float* __restrict__ grad_points) {
-  __shared__ float acc[kSegCB][64];
-  const int b = blockIdx.z, j0 = blockIdx.x * 64, c0 = blockIdx.y * kSegCB;
-  const int nc = min(kSegCB, C - c0);
-  for (int e = threadIdx.x; e < kSegCB * 64; e += kT) (&acc[0][0])[e] = 0.f;
-  __syncthreads();
-  const int lo = offsets[(int64_t)b * (m + 1) + j0];
-  const int hi = offsets[(int64_t)b * (m + 1) + min(j0 + 64, m)];
-  const int* l = list + (int64_t)b * Q;
-  const int* ix = idx + (int64_t)b * Q;
-  const float* cf = coef ? coef + (int64_t)b * Q : nullptr;
-  const float* g = grad_out + ((int64_t)b * C + c0) * Qsrc;
-  for (int e = lo + threadIdx.x; e < hi; e += kT) {
-    const int q = l[e];
-    const int jl = ix[q] - j0;
-    const float w = cf ? cf[q] : 1.f;
-    const int src = q / div;
-    if (nc == kSegCB) {   // full channel block: issue all gathers first (independent loads), then add
-      float v[kSegCB];
-#pragma unroll
-      for (int k = 0; k < kSegCB; ++k) v[k] = g[(int64_t)k * Qsrc + src];
-#pragma unroll
-      for (int k = 0; k < kSegCB; ++k) atomicAdd(&acc[k][jl], w * v[k]);
-    } else {
-      for (int k = 0; k < nc; ++k) atomicAdd(&acc[k][jl], w * g[(int64_t)k * Qsrc + src]);
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nc * 64; e += kT) {
-    const int k = e >> 6, jl = e & 63;
-    if (j0 + jl < m) grad_points[((int64_t)b * C + c0 + k) * m + j0 + jl] = acc[k][jl];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // LDS-resident scatter-add (preferred backward of group_points / gather_points / three_interpolate):
 //     grad_points[b, c, j] = sum_{q : idx[b, q] == j} coef[b, q] * grad_out[b, c, q / div]
 // The target axis is short in PointNet++ (m <= 4096 points), so a workgroup keeps the WHOLE target
@@ -550,42 +444,6 @@ int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx
   dim3 grid((C + cbl - 1) / cbl, B);
   lds_scatter_kernel<<<grid, kLdsScatterThreads, lds, (hipStream_t)stream>>>(grad_out, coef, idx, C, Qsrc,
                                                                             Q, m, div, cbl, grad_points);
-  HCM_CHECK_LAUNCH();
-  return 0;
-}
-
-size_t hcm_inverse_index_workspace_bytes(int B, int Q, int m) {
-  (void)Q;
-  return (size_t)B * (size_t)m * sizeof(int);
-}
-
-int hcm_inverse_index_build(const int* idx, int B, int Q, int m, int* offsets, int* list,
-                            void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
-  if (B <= 0 || Q <= 0 || m <= 0) return (int)hipErrorInvalidValue;
-  if (workspace == nullptr || workspace_bytes < hcm_inverse_index_workspace_bytes(B, Q, m))
-    return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  int* cursor = reinterpret_cast<int*>(workspace);
-  hipError_t e = hipMemsetAsync(offsets, 0, (size_t)B * (m + 1) * sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
-  int gx = (Q + kT - 1) / kT;
-  if (gx > 1024) gx = 1024;
-  inv_count_kernel<<<dim3(gx, B), kT, 0, st>>>(idx, Q, m, offsets);
-  HCM_CHECK_LAUNCH();
-  inv_scan_kernel<<<B, 1024, 0, st>>>(m, offsets, cursor);
-  HCM_CHECK_LAUNCH();
-  inv_fill_kernel<<<dim3(gx, B), kT, 0, st>>>(idx, Q, m, cursor, list);
-  HCM_CHECK_LAUNCH();
-  return 0;
-}
-
-int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* idx,
-                           const int* offsets, const int* list, int B, int C, int Qsrc, int Q, int m,
-                           int div, float* grad_points, hcm_stream_t stream) {
-  if (B <= 0 || C <= 0 || Q <= 0 || m <= 0 || div <= 0 || Qsrc <= 0) return (int)hipErrorInvalidValue;
-  dim3 grid((m + 63) / 64, (C + kSegCB - 1) / kSegCB, B);
-  segment_gather_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(grad_out, coef, idx, offsets, list, C,
-                                                             Qsrc, Q, m, div, grad_points);
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -83,39 +83,14 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
 
 
 # --------------------------------------------------------------------------------------------- #
-# Atomic-free backward shared by group_points / gather_points / three_interpolate (an addition of
+# LDS-resident backward shared by group_points / gather_points / three_interpolate (an addition of
 # this build; `pointnet2_cuda` has no counterpart).  See include/hcmoco_hip.h.
 # --------------------------------------------------------------------------------------------- #
-def inverse_index(idx, m):
-    """idx [B, Q] int32 with values in [0, m) -> (offsets [B, m+1], list [B, Q]) int32."""
-    B, Q = idx.shape
-    L = _lib.lib()
-    offsets = torch.empty(B, m + 1, dtype=torch.int32, device=idx.device)
-    lst = torch.empty(B, Q, dtype=torch.int32, device=idx.device)
-    nb = L.hcm_inverse_index_workspace_bytes(B, Q, m)
-    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=idx.device)
-    check(L.hcm_inverse_index_build(_i(idx, 'inverse_index'), B, Q, m, _i(offsets, 'inverse_index'),
-                                    _i(lst, 'inverse_index'), C.c_void_p(ws.data_ptr()), nb, _stream()),
-          'hcm_inverse_index_build')
-    return offsets, lst
-
-
-def segment_grad(grad_out, idx, coef, m, div=1):
-    """grad_points[b,c,j] = sum_{q: idx[b,q]==j} coef[b,q] * grad_out[b,c,q//div]  -> [B, C, m]."""
-    B, Cc, qsrc = grad_out.shape
-    idx2 = idx.reshape(B, -1).contiguous()
-    Q = idx2.shape[1]
-    offsets, lst = inverse_index(idx2, m)
-    out = torch.empty(B, Cc, m, dtype=torch.float32, device=grad_out.device)
-    cf = C.c_void_p(0) if coef is None else _f(coef.reshape(B, -1).contiguous(), 'segment_grad')
-    check(_lib.lib().hcm_segment_gather_sum(_f(grad_out, 'segment_grad'), cf, _i(idx2, 'segment_grad'),
-                                            _i(offsets, 'segment_grad'), _i(lst, 'segment_grad'), B, Cc, qsrc, Q, m, div,
-                                            _f(out, 'segment_grad'), _stream()), 'hcm_segment_gather_sum')
-    return out
+LDS_SCATTER_MAX_TARGETS = 140 * 1024 // 4
 
 
 def scatter_add_lds(grad_out, idx, coef, m, div=1):
-    """Same contract as ``segment_grad`` through the LDS-resident kernel (no index inversion)."""
+    """grad_points[b,c,j] = sum_{q: idx[b,q]==j} coef[b,q] * grad_out[b,c,q//div]  -> [B, C, m]."""
     B, Cc, qsrc = grad_out.shape
     idx2 = idx.reshape(B, -1).contiguous()
     out = torch.empty(B, Cc, m, dtype=torch.float32, device=grad_out.device)

@@ -14,22 +14,15 @@ from torch.autograd import Function
 from .... import pointnet2_hip as pointnet2
 
 
-import os
-
-# which backward each op takes when the native module offers both (tools/bench_pointnet2.py):
-# three_interpolate: inverse index + LDS accumulation is 2.4-5.6x faster than global float atomics at
-# every level (its buckets are balanced); group/gather: the two are within +-2x of each other and the
-# atomic kernels win on the hub-heavy ball-query indices, so they keep the reference-style path.
-_SEGMENT_OPS = set(os.environ.get('HCM_PN2_SEGMENT_GRAD', 'three_interpolate').split(','))
-
-
-def _scatter_backward(op, grad_out, idx, coef, m, div, legacy):
-    """Backward of the three gather-type ops.  The native module of this build offers, next to the
-    reference's ``*_grad_wrapper`` kernels (global float atomics), an inverse-index path
-    (``segment_grad``); a module with only the nine reference functions (the pybind original, or the
-    CPU oracle shim used by tests) always takes the ``*_grad_wrapper`` route."""
-    fn = getattr(pointnet2, 'segment_grad', None)
-    if fn is not None and op in _SEGMENT_OPS:
+def _scatter_backward(grad_out, idx, coef, m, div, legacy):
+    """Backward of the three gather-type ops.  Next to the reference's ``*_grad_wrapper`` kernels
+    (global float atomics) the native module of this build offers ``scatter_add_lds``: the target
+    row lives in LDS, inputs stream once -- 3-10x faster on MI355X at every PointNet++ level
+    (tools/bench_pointnet2.py).  A module with only the nine reference functions (the pybind
+    original, or the CPU oracle shim used by tests), or a target axis too long for LDS, takes the
+    ``*_grad_wrapper`` route."""
+    fn = getattr(pointnet2, 'scatter_add_lds', None)
+    if fn is not None and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0):
         return fn(grad_out, idx, coef, m, div)
     return legacy()
 
@@ -74,7 +67,7 @@ class GatherOperation(Function):
             grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
             pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out, idx, grad_features)
             return grad_features
-        return _scatter_backward('gather_points', grad_out, idx, None, N, 1, legacy), None
+        return _scatter_backward(grad_out, idx, None, N, 1, legacy), None
 
 
 gather_operation = GatherOperation.apply
@@ -122,7 +115,7 @@ class ThreeInterpolate(Function):
             grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
             pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out, idx, weight, grad_features)
             return grad_features
-        return _scatter_backward('three_interpolate', grad_out, idx, weight, m, 3, legacy), None, None
+        return _scatter_backward(grad_out, idx, weight, m, 3, legacy), None, None
 
 
 three_interpolate = ThreeInterpolate.apply
@@ -149,7 +142,7 @@ class GroupingOperation(Function):
             grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
             pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out, idx, grad_features)
             return grad_features
-        return _scatter_backward('group_points', grad_out.view(B, C, npoint * nsample), idx, None, N, 1, legacy), None
+        return _scatter_backward(grad_out.view(B, C, npoint * nsample), idx, None, N, 1, legacy), None
 
 
 grouping_operation = GroupingOperation.apply

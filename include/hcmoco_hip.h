@@ -224,27 +224,18 @@ int hcm_three_interpolate(int b, int c, int m, int n, const float* points, const
 int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
                                const float* weight, float* grad_points, hcm_stream_t stream);
 
-/* Atomic-free backward of the three scatter-add ops above (they share one algebraic form):
+/* LDS-resident backward of the three scatter-add ops above (they share one algebraic form):
  *   grad_points[b, c, j] = sum_{q : idx[b, q] == j} coef[b, q] * grad_out[b, c, q / div]
  * group_points_grad : idx [B, npoints*nsample], coef NULL, div 1, Qsrc = npoints*nsample
  * gather_points_grad: idx [B, npoints],         coef NULL, div 1, Qsrc = npoints
  * three_interpolate_grad: idx [B, n*3], coef = weight [B, n*3], div 3, Qsrc = n
- * Step 1 inverts the index once (offsets [B, m+1], list [B, Q], both int32, caller-allocated;
- * counting sort with integer atomics); step 2 gives every tile of 64 targets its contiguous range
- * of the list, accumulates in LDS and OVERWRITES grad_points [B, C, m].  No global float atomics;
- * like the reference's atomicAdd the order of the adds inside a bucket is not fixed. */
-/* Preferred form when the target row fits LDS (m * 4 B <= 140 KB, i.e. every PointNet++ level): one
- * workgroup keeps grad_points[b, c0:c0+CBL, :] in LDS, streams grad_out / idx / coef once
- * (coalesced), accumulates with LDS float atomics and OVERWRITES grad_points [B, C, m].  Returns
- * hipErrorInvalidConfiguration when m is too large (then use the atomic kernels). */
+ * One workgroup keeps grad_points[b, c0:c0+CBL, :] in LDS (m * 4 B <= 140 KB, i.e. every PointNet++
+ * level), streams grad_out / idx / coef once (coalesced), accumulates with LDS float atomics and
+ * OVERWRITES grad_points [B, C, m] (no zero-fill needed).  3-10x the reference-style global-atomic
+ * kernels on MI355X (tools/bench_pointnet2.py).  Returns hipErrorInvalidConfiguration when m is too
+ * large for LDS (then use the atomic kernels). */
 int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx, int B, int C,
                         int Qsrc, int Q, int m, int div, float* grad_points, hcm_stream_t stream);
-size_t hcm_inverse_index_workspace_bytes(int B, int Q, int m);
-int hcm_inverse_index_build(const int* idx, int B, int Q, int m, int* offsets, int* list,
-                            void* workspace, size_t workspace_bytes, hcm_stream_t stream);
-int hcm_segment_gather_sum(const float* grad_out, const float* coef, const int* idx,
-                           const int* offsets, const int* list, int B, int C, int Qsrc, int Q, int m,
-                           int div, float* grad_points, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Measurement helper: launches `reps` back-to-back hcm_bank_nce_fused passes bracketed by

@@ -63,8 +63,6 @@ for n, m, radii, nsamples, cin in levels:
         g = torch.zeros(B, cin, n, device=d)
         timeit('group_points_grad c=%d  [atomic, reference ABI]' % cin,
                lambda: pn.group_points_grad_wrapper(B, cin, n, m, ns, out, bidx, g), work=by, unit='GB/s')
-        timeit('group_points_grad c=%d  [inverse index + segment gather]' % cin,
-               lambda: pn.segment_grad(out.view(B, cin, m * ns), bidx.view(B, -1), None, n, 1), work=by, unit='GB/s')
         total += timeit('group_points_grad c=%d  [LDS-resident scatter]' % cin,
                         lambda: pn.scatter_add_lds(out.view(B, cin, m * ns), bidx.view(B, -1), None, n, 1), work=by, unit='GB/s')
     xyz = new_xyz
@@ -84,8 +82,6 @@ for n, m, c in [(256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (4096, 409
     g = torch.zeros(B, c, m, device=d)
     timeit('three_interpolate_grad c=%d  [atomic, reference ABI]' % c,
            lambda: pn.three_interpolate_grad_wrapper(B, c, n, m, out, idx, w, g), work=by, unit='GB/s')
-    timeit('three_interpolate_grad c=%d  [inverse index + segment gather]' % c,
-           lambda: pn.segment_grad(out, idx.view(B, -1), w, m, 3), work=by, unit='GB/s')
     total += timeit('three_interpolate_grad c=%d  [LDS-resident scatter]' % c,
                     lambda: pn.scatter_add_lds(out, idx.view(B, -1), w, m, 3), work=by, unit='GB/s')
 print('sum of one call each: %.2f ms' % total)
