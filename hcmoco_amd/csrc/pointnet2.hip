@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
                                                         const float* __restrict__ new_xyz,
                                                         const float* __restrict__ xyz,
                                                         int* __restrict__ idx) {
-  __shared__ float tile[kTile * 3];
+  __shared__ float4 tile[kTile];
   const int b = blockIdx.y, pt = blockIdx.x * kT + threadIdx.x;
   const bool live = pt < m;
   float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -160,11 +160,15 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
   for (int base = 0; base < n; base += kTile) {
     const int len = min(kTile, n - base);
     __syncthreads();
-    for (int e = threadIdx.x; e < len * 3; e += kT) tile[e] = cloud[(int64_t)base * 3 + e];
+    for (int e = threadIdx.x; e < len; e += kT) {
+      const float* c = cloud + (int64_t)(base + e) * 3;
+      tile[e] = make_float4(c[0], c[1], c[2], 0.f);
+    }
     __syncthreads();
     if (cnt < nsample) {
       for (int k = 0; k < len; ++k) {
-        const float d2 = sqdist(cx, cy, cz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
+        const float4 p = tile[k];
+        const float d2 = sqdist(cx, cy, cz, p.x, p.y, p.z);
         if (d2 < radius2) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) out[l] = base + k;
@@ -180,48 +184,79 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
 // ------------------------------------------------------------------------------------------
 // three_nn (interpolate_gpu.cu:9-52): three smallest squared distances, strict '<', first wins.
 // ------------------------------------------------------------------------------------------
+// Each thread owns TWO unknown points (halves the LDS traffic per distance) and the known cloud is
+// staged as float4 (x,y,z,-) so one ds_read_b128 broadcast feeds both.  The insertion cascade is
+// entered only when d beats the current third best.
+struct Top3 {
+  float b1, b2, b3;
+  int i1, i2, i3;
+  __device__ __forceinline__ void init() {
+    // The reference keeps the bests in doubles initialised to 1e40 and compares the float d against
+    // them: every finite d wins over 1e40, +inf / NaN never do, and an unset slot is stored back
+    // as +inf.  Float trackers initialised to +inf behave identically.
+    b1 = b2 = b3 = __builtin_inff();
+    i1 = i2 = i3 = 0;
+  }
+  __device__ __forceinline__ void push(float d, int k) {
+    if (d < b3) {
+      if (d < b1) {
+        b3 = b2; i3 = i2;
+        b2 = b1; i2 = i1;
+        b1 = d; i1 = k;
+      } else if (d < b2) {
+        b3 = b2; i3 = i2;
+        b2 = d; i2 = k;
+      } else {
+        b3 = d; i3 = k;
+      }
+    }
+  }
+};
+
 __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
                                                       const float* __restrict__ unknown,
                                                       const float* __restrict__ known,
                                                       float* __restrict__ dist2,
                                                       int* __restrict__ idx) {
-  __shared__ float tile[kTile * 3];
-  const int b = blockIdx.y, pt = blockIdx.x * kT + threadIdx.x;
-  const bool live = pt < n;
-  float ux = 0.f, uy = 0.f, uz = 0.f;
-  if (live) {
-    const float* u = unknown + ((int64_t)b * n + pt) * 3;
-    ux = u[0]; uy = u[1]; uz = u[2];
+  __shared__ float4 tile[kTile];
+  const int b = blockIdx.y;
+  const int pt0 = blockIdx.x * (2 * kT) + threadIdx.x, pt1 = pt0 + kT;
+  float ux0 = 0.f, uy0 = 0.f, uz0 = 0.f, ux1 = 0.f, uy1 = 0.f, uz1 = 0.f;
+  if (pt0 < n) {
+    const float* u = unknown + ((int64_t)b * n + pt0) * 3;
+    ux0 = u[0]; uy0 = u[1]; uz0 = u[2];
   }
-  // The reference keeps the bests in doubles initialised to 1e40 and compares the float d
-  // against them: every finite d wins over 1e40, +inf / NaN never do, and an unset slot is
-  // stored back as +inf.  Float trackers initialised to +inf behave identically.
-  float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
-  int i1 = 0, i2 = 0, i3 = 0;
+  if (pt1 < n) {
+    const float* u = unknown + ((int64_t)b * n + pt1) * 3;
+    ux1 = u[0]; uy1 = u[1]; uz1 = u[2];
+  }
+  Top3 t0, t1;
+  t0.init();
+  t1.init();
   const float* cloud = known + (int64_t)b * m * 3;
   for (int base = 0; base < m; base += kTile) {
     const int len = min(kTile, m - base);
     __syncthreads();
-    for (int e = threadIdx.x; e < len * 3; e += kT) tile[e] = cloud[(int64_t)base * 3 + e];
+    for (int e = threadIdx.x; e < len; e += kT) {
+      const float* c = cloud + (int64_t)(base + e) * 3;
+      tile[e] = make_float4(c[0], c[1], c[2], 0.f);
+    }
     __syncthreads();
     for (int k = 0; k < len; ++k) {
-      const float d = sqdist(ux, uy, uz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
-      if (d < b1) {
-        b3 = b2; i3 = i2;
-        b2 = b1; i2 = i1;
-        b1 = d; i1 = base + k;
-      } else if (d < b2) {
-        b3 = b2; i3 = i2;
-        b2 = d; i2 = base + k;
-      } else if (d < b3) {
-        b3 = d; i3 = base + k;
-      }
+      const float4 p = tile[k];
+      t0.push(sqdist(ux0, uy0, uz0, p.x, p.y, p.z), base + k);
+      t1.push(sqdist(ux1, uy1, uz1, p.x, p.y, p.z), base + k);
     }
   }
-  if (live) {
-    const int64_t o = ((int64_t)b * n + pt) * 3;
-    dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
-    idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+  if (pt0 < n) {
+    const int64_t o = ((int64_t)b * n + pt0) * 3;
+    dist2[o] = t0.b1; dist2[o + 1] = t0.b2; dist2[o + 2] = t0.b3;
+    idx[o] = t0.i1; idx[o + 1] = t0.i2; idx[o + 2] = t0.i3;
+  }
+  if (pt1 < n) {
+    const int64_t o = ((int64_t)b * n + pt1) * 3;
+    dist2[o] = t1.b1; dist2[o + 1] = t1.b2; dist2[o + 2] = t1.b3;
+    idx[o] = t1.i1; idx[o + 1] = t1.i2; idx[o + 2] = t1.i3;
   }
 }
 
@@ -422,7 +457,7 @@ int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* 
 int hcm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
                  int* idx, hcm_stream_t stream) {
   if (b <= 0 || n <= 0) return b < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
-  dim3 grid((n + kT - 1) / kT, b);
+  dim3 grid((n + 2 * kT - 1) / (2 * kT), b);
   three_nn_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
   HCM_CHECK_LAUNCH();
   return 0;
