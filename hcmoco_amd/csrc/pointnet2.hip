@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
                                                         const float* __restrict__ xyz,
                                                         int* __restrict__ idx) {
   __shared__ float4 tile[kTile];
-  const int b = blockIdx.y, pt = blockIdx.x * kT + threadIdx.x;
+  const int b = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = pt < m;
   float cx = 0.f, cy = 0.f, cz = 0.f;
   if (live) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
   for (int base = 0; base < n; base += kTile) {
     const int len = min(kTile, n - base);
     __syncthreads();
-    for (int e = threadIdx.x; e < len; e += kT) {
+    for (int e = threadIdx.x; e < len; e += blockDim.x) {
       const float* c = cloud + (int64_t)(base + e) * 3;
       tile[e] = make_float4(c[0], c[1], c[2], 0.f);
     }
@@ -449,8 +449,11 @@ int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
 int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
                    const float* xyz, int* idx, hcm_stream_t stream) {
   if (b <= 0 || m <= 0 || nsample <= 0) return b < 0 || m < 0 || nsample < 0 ? (int)hipErrorInvalidValue : 0;
-  dim3 grid((m + kT - 1) / kT, b);
-  ball_query_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
+  // one thread per centre: shrink the workgroup when there are too few centres to fill 256 CUs
+  int threads = kT;
+  while (threads > 64 && (long long)b * ((m + threads - 1) / threads) < 1024) threads >>= 1;
+  dim3 grid((m + threads - 1) / threads, b);
+  ball_query_kernel<<<grid, threads, 0, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
   HCM_CHECK_LAUNCH();
   return 0;
 }
