@@ -142,25 +142,29 @@ __global__ __launch_bounds__(kLdsScatterThreads) void lds_scatter_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kTile = 1024;
 
+// Hits are collected in LDS ([slot][thread], conflict-free) and written out once at the end: a global
+// store inside the scan loop is issued by ~half of all iterations (any of the 64 lanes hitting) and
+// paces the kernel otherwise.
 __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radius2, int nsample,
                                                         const float* __restrict__ new_xyz,
                                                         const float* __restrict__ xyz,
                                                         int* __restrict__ idx) {
   __shared__ float4 tile[kTile];
+  extern __shared__ __attribute__((aligned(16))) int hits[];  // [nsample][blockDim.x]
   const int b = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt = blockDim.x;
   const bool live = pt < m;
   float cx = 0.f, cy = 0.f, cz = 0.f;
   if (live) {
     const float* c = new_xyz + ((int64_t)b * m + pt) * 3;
     cx = c[0]; cy = c[1]; cz = c[2];
   }
-  int* out = idx + ((int64_t)b * m + (live ? pt : 0)) * nsample;
   const float* cloud = xyz + (int64_t)b * n * 3;
   int cnt = live ? 0 : nsample;
   for (int base = 0; base < n; base += kTile) {
     const int len = min(kTile, n - base);
     __syncthreads();
-    for (int e = threadIdx.x; e < len; e += blockDim.x) {
+    for (int e = threadIdx.x; e < len; e += nt) {
       const float* c = cloud + (int64_t)(base + e) * 3;
       tile[e] = make_float4(c[0], c[1], c[2], 0.f);
     }
@@ -170,14 +174,17 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
         const float4 p = tile[k];
         const float d2 = sqdist(cx, cy, cz, p.x, p.y, p.z);
         if (d2 < radius2) {
-          if (cnt == 0)
-            for (int l = 0; l < nsample; ++l) out[l] = base + k;
-          out[cnt] = base + k;
+          hits[cnt * nt + threadIdx.x] = base + k;
           if (++cnt >= nsample) break;
         }
       }
     }
     if (__syncthreads_count(cnt < nsample) == 0) break;
+  }
+  if (live && cnt > 0) {   // no hit: the caller's zeros survive (ball_query_gpu.cu: idx untouched)
+    int* out = idx + ((int64_t)b * m + pt) * nsample;
+    const int first = hits[threadIdx.x];
+    for (int l = 0; l < nsample; ++l) out[l] = l < cnt ? hits[l * nt + threadIdx.x] : first;
   }
 }
 
@@ -452,8 +459,14 @@ int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* 
   // one thread per centre: shrink the workgroup when there are too few centres to fill 256 CUs
   int threads = kT;
   while (threads > 64 && (long long)b * ((m + threads - 1) / threads) < 1024) threads >>= 1;
+  while (threads > 64 && (size_t)threads * nsample * sizeof(int) > 96 * 1024) threads >>= 1;
+  const size_t lds = (size_t)threads * nsample * sizeof(int);
+  if (lds > 128 * 1024) return (int)hipErrorInvalidValue;   // nsample > 512
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
   dim3 grid((m + threads - 1) / threads, b);
-  ball_query_kernel<<<grid, threads, 0, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
+  ball_query_kernel<<<grid, threads, lds, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
   HCM_CHECK_LAUNCH();
   return 0;
 }
