@@ -170,12 +170,21 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
     }
     __syncthreads();
     if (cnt < nsample) {
-      for (int k = 0; k < len; ++k) {
-        const float4 p = tile[k];
-        const float d2 = sqdist(cx, cy, cz, p.x, p.y, p.z);
-        if (d2 < radius2) {
-          hits[cnt * nt + threadIdx.x] = base + k;
-          if (++cnt >= nsample) break;
+      // chunks of 8: the LDS reads and distance evaluations of a chunk are independent (issued
+      // back to back); hits are then recorded strictly in index order, as the reference scans
+      for (int k0 = 0; k0 < len && cnt < nsample; k0 += 8) {
+        float d2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 p = tile[min(k0 + j, len - 1)];
+          d2[j] = (k0 + j < len) ? sqdist(cx, cy, cz, p.x, p.y, p.z) : __builtin_inff();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (d2[j] < radius2 && cnt < nsample) {
+            hits[cnt * nt + threadIdx.x] = base + k0 + j;
+            ++cnt;
+          }
         }
       }
     }
