@@ -35,9 +35,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, sampled=1):
+def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, sampled=1, arch='HRNet', width=18,
+              bank_dtype='fp32'):
     from hcmoco_amd.pycontrast.options.train_options import TrainOptions
-    argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18',
+    argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', arch, '--width', str(width),
+            '--bank_dtype', bank_dtype,
             '--in_channel_list', '3,3', '--linear_feat_map', '1', '--modality_missing', '1',
             '--pri3d_num_samples_per_image', '400', '--temperature', '0.07', '--nce_k', str(nce_k),
             '--nce_m', '0.5', '--batch_size', str(batch_global), '--skeleton_meta_name', skeleton,
@@ -133,6 +135,11 @@ def main():
     ap.add_argument('--cpu_budget_s', type=float, default=20.0)
     ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
     ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
+    ap.add_argument('--arch', type=str, default='HRNet', choices=['HRNet', 'HRNetPN'],
+                    help='HRNetPN = BASELINE config 4 (PointNet++ depth encoder); not the headline config')
+    ap.add_argument('--width', type=int, default=18, choices=[18, 32, 48])
+    ap.add_argument('--bank_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
+                    help='bf16 = BASELINE config 5 bank storage; not the headline config')
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '0')),
@@ -162,7 +169,8 @@ def main():
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     B = a.batch_per_gpu
     args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, 'nccl', tempfile.mkdtemp(),
-                     a.steps + a.warmup, sampled=a.sampled_projection)
+                     a.steps + a.warmup, sampled=a.sampled_projection, arch=a.arch, width=a.width,
+                     bank_dtype=a.bank_dtype)
     args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
     args.channels_last = bool(a.channels_last)
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
@@ -200,7 +208,8 @@ def main():
         K1, D = a.nce_k + 1, 128
         # algorithmic bytes of one gather pass: 3 gathered rows + the int64 row index
         # per (sample, negative), plus the 3 query rows and 3 gradient rows per sample
-        bytes_per_sample = 3 * K1 * D * 4 + K1 * 8 + 12 * D * 4
+        row_bytes = 2 if a.bank_dtype == 'bf16' else 4
+        bytes_per_sample = 3 * K1 * D * row_bytes + K1 * 8 + 12 * D * 4
         bytes_per_launch = B * bytes_per_sample
         avg_ms = kern_ms / max(kern_n, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None
@@ -210,7 +219,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bank_pass_pmc.json')))
             c = pmc['config']
-            if (c['B'], c['K'], c['n_data'], c['D']) == (B, a.nce_k, a.n_data, D):
+            if (c['B'], c['K'], c['n_data'], c['D']) == (B, a.nce_k, a.n_data, D) and a.bank_dtype == 'fp32':
                 traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_bank_pass_pmc.json'
         except (OSError, KeyError, ValueError):
             pass
@@ -221,8 +230,11 @@ def main():
             'ms_per_step': round(1e3 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'second-stage HCMoCo step (bank NCE + dense + joint + SCL losses, fwd+bwd+SGD+bank '
-                                   'update), HRNet-w18 x2 + SemGCN, %dx%d RGB+depth+%s keypoints'
-                                   % (a.size, a.size, a.skeleton),
+                                   'update), %s + SemGCN, %dx%d RGB+depth+%s keypoints'
+                                   % ('HRNet-w%d x2' % a.width if a.arch == 'HRNet' else
+                                      'HRNet-w%d (RGB) + PointNet++ MSG (depth cloud, 4096 pts)' % a.width,
+                                      a.size, a.size, a.skeleton),
+                       'arch': a.arch, 'width': a.width, 'bank_dtype': a.bank_dtype,
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
                        'channels_last': bool(a.channels_last), 'hip_graphs': bool(a.graphs), 'sampled_projection': bool(a.sampled_projection),
@@ -234,7 +246,7 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.arch == 'HRNet':
             out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton)
         else:
             out['cpu_baseline'] = None
