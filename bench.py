@@ -234,7 +234,7 @@ def main():
                                    % ('HRNet-w%d x2' % a.width if a.arch == 'HRNet' else
                                       'HRNet-w%d (RGB) + PointNet++ MSG (depth cloud, 4096 pts)' % a.width,
                                       a.size, a.size, a.skeleton),
-                       'arch': a.arch, 'width': a.width, 'bank_dtype': a.bank_dtype,
+                       'bank_dtype': a.bank_dtype,
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
                        'channels_last': bool(a.channels_last), 'hip_graphs': bool(a.graphs), 'sampled_projection': bool(a.sampled_projection),
