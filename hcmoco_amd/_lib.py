@@ -64,6 +64,8 @@ SIGNATURES = {
     'hcm_three_interpolate': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_three_interpolate_grad': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 5),
+    'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 6),
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
 }

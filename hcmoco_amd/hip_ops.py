@@ -480,3 +480,67 @@ class _UpsampleBilinear(torch.autograd.Function):
 def upsample_bilinear(x, size):
     """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for fp32 NCHW ROCm tensors."""
     return _UpsampleBilinear.apply(x, tuple(size))
+
+
+# --------------------------------------------------------------------------- #
+# SemGCN layer (SURVEY 8f-3): library GEMM + one fused kernel per direction
+# --------------------------------------------------------------------------- #
+class _SgcLayer(torch.autograd.Function):
+    """SemGraphConv [+ BatchNorm1d + ReLU] (networks/SGCN/sem_graph_conv.py:34-48, sem_gcn.py:8-28).
+    forward: H = X [W0|W1] (rocBLAS) -> hcm_sgc_forward ; backward: hcm_sgc_backward -> two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, e, bias, gamma, beta, running_mean, running_var, graph, has_bn, relu, training,
+                momentum, eps):
+        B, J, cin = x.shape
+        cout = W.shape[2]
+        x2 = x.reshape(B * J, cin)
+        wcat = W.permute(1, 0, 2).reshape(cin, 2 * cout)            # [W0 | W1]
+        H = torch.mm(x2, wcat)
+        E = e.numel()
+        dev = x.device
+        out = torch.empty(B * J, cout, dtype=torch.float32, device=dev)
+        xhat = torch.empty(B * J, cout, dtype=torch.float32, device=dev) if has_bn else out
+        invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+        A = torch.empty(E, dtype=torch.float32, device=dev)
+        nul = C.c_void_p(0)
+        p = lambda t: nul if t is None else C.c_void_p(t.data_ptr())
+        ec = e.reshape(-1).contiguous()
+        check(_lib.lib().hcm_sgc_forward(
+            p(H), _dev(ec, torch.float32, 'sgc'), p(graph[0]), p(graph[1]), p(graph[2]), p(graph[3]), p(graph[4]),
+            p(bias), p(gamma), p(beta), p(running_mean), p(running_var), B, J, cout, E, int(has_bn), int(relu),
+            int(training), float(momentum), float(eps), p(out), p(xhat), p(invstd), p(A), _stream()), 'hcm_sgc_forward')
+        ctx.save_for_backward(x2, wcat, H, out, xhat, invstd, A, gamma if gamma is not None else invstd)
+        ctx.graph, ctx.dims = graph, (B, J, cin, cout, E, int(has_bn), int(relu), int(training), bias is not None)
+        return out.view(B, J, cout)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, wcat, H, out, xhat, invstd, A, gamma = ctx.saved_tensors
+        B, J, cin, cout, E, has_bn, relu, training, has_bias = ctx.dims
+        graph = ctx.graph
+        dev = g.device
+        g = g.reshape(B * J, cout).contiguous()
+        dH = torch.empty(B * J, 2 * cout, dtype=torch.float32, device=dev)
+        small = torch.empty(3 * cout + E, dtype=torch.float32, device=dev)
+        dgamma, dbeta, dbias, de = small[:cout], small[cout:2 * cout], small[2 * cout:3 * cout], small[3 * cout:]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(_lib.lib().hcm_sgc_backward(
+            p(g), p(out), p(xhat), p(invstd), p(gamma), p(A), p(graph[0]), p(graph[1]), p(graph[2]), p(graph[3]),
+            p(graph[4]), p(H), B, J, cout, E, has_bn, relu, training, p(dH), p(dgamma), p(dbeta), p(dbias), p(de),
+            _stream()), 'hcm_sgc_backward')
+        dx = torch.mm(dH, wcat.t()).view(B, J, cin)
+        dW = torch.mm(x2.t(), dH).view(cin, 2, cout).permute(1, 0, 2)
+        return (dx, dW, de.view(1, E), dbias if has_bias else None, dgamma if has_bn else None,
+                dbeta if has_bn else None, None, None, None, None, None, None, None, None)
+
+
+def sgc_layer(x, W, e, bias, graph, bn=None, relu=False):
+    """One SemGCN layer on a ROCm tensor.  ``bn``: an ``nn.BatchNorm1d`` (its running statistics are
+    updated in place when it is in training mode) or None; ``graph``: the five int32 index tensors
+    of ``networks/sgcn.py:graph_index``."""
+    if bn is None:
+        return _SgcLayer.apply(x.contiguous(), W, e, bias, None, None, None, None, graph, False, relu, False, 0.0, 1e-5)
+    training = bn.training or bn.running_mean is None
+    return _SgcLayer.apply(x.contiguous(), W, e, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, graph,
+                           True, relu, training, bn.momentum if bn.momentum is not None else 0.1, bn.eps)

@@ -39,6 +39,24 @@ def adjacency(name):
     return a / a.sum(1, keepdim=True)
 
 
+def graph_index(adj):
+    """int32 CSR/CSC description of the skeleton edges (incl. self loops) in the row-major order of
+    ``adj[adj > 0]`` -- what the fused layer kernel (hcm_sgc_forward/backward) walks."""
+    mask = adj > 0
+    J = mask.shape[0]
+    rows, cols = mask.nonzero(as_tuple=True)                    # row-major
+    row_ptr = torch.zeros(J + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(mask.sum(1), 0).to(torch.int32)
+    order = torch.argsort(cols * J + rows)                       # by column, then row
+    csc_ptr = torch.zeros(J + 1, dtype=torch.int32)
+    csc_ptr[1:] = torch.cumsum(mask.sum(0), 0).to(torch.int32)
+    return [row_ptr, cols.to(torch.int32), csc_ptr, order.to(torch.int32), rows.to(torch.int32)]
+
+
+def _fusable(x, cout):
+    return x.is_cuda and x.dtype == torch.float32 and cout in (64, 128) and x.shape[1] <= 32
+
+
 class SemGraphConv(nn.Module):
     """sem_graph_conv.py:9-57: learned edge weights soft-maxed over the skeleton adjacency;
     self-loops use W[0], neighbours W[1]."""
@@ -54,6 +72,8 @@ class SemGraphConv(nn.Module):
         # indexing with them instead of the boolean mask avoids a device->host sync (nonzero) and
         # keeps the layer capturable in a hipGraph
         self.register_buffer('m_idx', (adj > 0).flatten().nonzero().flatten(), persistent=False)
+        for name, t in zip(('g_row_ptr', 'g_col_idx', 'g_csc_ptr', 'g_csc_edge', 'g_edge_row'), graph_index(adj)):
+            self.register_buffer(name, t, persistent=False)
         self.e = nn.Parameter(torch.ones(1, int((adj > 0).sum())))
         if bias:
             self.bias = nn.Parameter(torch.zeros(out_features))
@@ -68,7 +88,13 @@ class SemGraphConv(nn.Module):
         logits = logits.index_copy(0, self.m_idx, self.e.reshape(-1)).view(n, n)
         return F.softmax(logits, dim=1)
 
+    def graph(self):
+        return [self.g_row_ptr, self.g_col_idx, self.g_csc_ptr, self.g_csc_edge, self.g_edge_row]
+
     def forward(self, x):
+        if _fusable(x, self.out_features):          # MI355X: GEMM + one fused kernel
+            from ... import hip_ops
+            return hip_ops.sgc_layer(x, self.W, self.e, self.bias, self.graph())
         a = self.edge_weights()
         eye = torch.eye(a.shape[0], dtype=a.dtype, device=a.device)
         out = torch.matmul(a * eye, torch.matmul(x, self.W[0])) + torch.matmul(a * (1 - eye), torch.matmul(x, self.W[1]))
@@ -83,7 +109,13 @@ class _GraphConv(nn.Module):
         self.relu = nn.ReLU()
 
     def forward(self, x):
-        x = self.gconv(x).transpose(1, 2)
+        gc = self.gconv
+        if _fusable(x, gc.out_features):            # SemGraphConv + BatchNorm1d + ReLU in one kernel
+            from ... import hip_ops
+            if self.bn.training and self.bn.track_running_stats:
+                self.bn.num_batches_tracked.add_(1)
+            return hip_ops.sgc_layer(x, gc.W, gc.e, gc.bias, gc.graph(), bn=self.bn, relu=True)
+        x = gc(x).transpose(1, 2)
         return self.relu(self.bn(x).transpose(1, 2))
 
 

@@ -192,6 +192,30 @@ int hcm_sampling_matrix(const int64_t* pix, int nrows, int hi, int wi, int h0, i
                         hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * SemGCN layer: SemGraphConv (networks/SGCN/sem_graph_conv.py:34-48) [+ BatchNorm1d +
+ * ReLU, networks/SGCN/sem_gcn.py:8-28] after the library GEMM H = X [W0 | W1]  ([B*J, 2C]).
+ * Graph: edges in the row-major order of the reference's `adj[self.m]` as CSR (row_ptr [J+1],
+ * col_idx [E], edge_row [E]) and CSC (csc_ptr [J+1], csc_edge [E]); e [E] learned edge logits.
+ * forward : A = row-softmax(e); Y = A_diag (.) H0 + A_off H1 + bias; out = relu(bn(Y)) (batch
+ *           statistics when training, running statistics updated in place with `momentum`);
+ *           saves xhat [B*J, C], invstd [C], A_out [E] for the backward.
+ * backward: dH [B*J, 2C] (for dX = dH Wcat^T and dWcat = X^T dH), dgamma/dbeta/dbias [C], de [E].
+ * J <= 32, C in {64, 128}, E <= 256.  One 1024-thread workgroup per call: the layer is launch- and
+ * latency-bound, not throughput-bound (B*J*C ~ 70k outputs).
+ * ------------------------------------------------------------------------ */
+int hcm_sgc_forward(const float* H, const float* e, const int* row_ptr, const int* col_idx,
+                    const int* csc_ptr, const int* csc_edge, const int* edge_row, const float* bias,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    int B, int J, int C, int E, int has_bn, int relu, int training, float momentum,
+                    float eps, float* out, float* xhat, float* invstd, float* A_out,
+                    hcm_stream_t stream);
+int hcm_sgc_backward(const float* dOut, const float* out, const float* xhat, const float* invstd,
+                     const float* gamma, const float* A, const int* row_ptr, const int* col_idx,
+                     const int* csc_ptr, const int* csc_edge, const int* edge_row, const float* H, int B,
+                     int J, int C, int E, int has_bn, int relu, int training, float* dH, float* dgamma,
+                     float* dbeta, float* dbias, float* de, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
  * reference's C launcher layer (networks/pointnet2/src/<name>_gpu.h), which the pybind
  * module `pointnet2_cuda` (src/pointnet2_api.cpp:10-24) wraps: the caller allocates and
