@@ -46,10 +46,14 @@ def test_whole_encoder_matches_eager(skel, training, monkeypatch):
     g = torch.randn_like(yr)
     yr.backward(g); yf.backward(g)
     assert rel(xf.grad, xr.grad) < 2e-3
+    # a bias in front of a BatchNorm has an analytically ZERO gradient (the mean is subtracted):
+    # both implementations return round-off there, so errors are also allowed relative to the
+    # largest gradient of the net
+    scale = max(float(p.grad.norm()) for p in ref.parameters())
     for (n, pr), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
         assert pf.grad is not None, n
         err = float((pf.grad - pr.grad).norm())
-        assert err < 2e-3 * float(pr.grad.norm()) + 1e-5, (n, err, float(pr.grad.norm()))
+        assert err < 2e-3 * float(pr.grad.norm()) + 1e-5 * scale, (n, err, float(pr.grad.norm()), scale)
     for (n, br), (_, bf) in zip(ref.named_buffers(), fused.named_buffers()):
         if 'running' in n or 'num_batches' in n:
             assert torch.allclose(bf.float(), br.float(), rtol=1e-4, atol=1e-5), n
