@@ -6,6 +6,7 @@ math; the adjacency is built with plain torch instead of scipy.sparse.  ``coco17
 of this build (17-joint COCO skeleton used by the benchmark config).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -53,8 +54,11 @@ def graph_index(adj):
     return [row_ptr, cols.to(torch.int32), csc_ptr, order.to(torch.int32), rows.to(torch.int32)]
 
 
+_FUSED = os.environ.get('HCM_SGCN_FUSED', '1') != '0'      # A/B switch for measurements
+
+
 def _fusable(x, cout):
-    return x.is_cuda and x.dtype == torch.float32 and cout in (64, 128) and x.shape[1] <= 32
+    return _FUSED and x.is_cuda and x.dtype == torch.float32 and cout in (64, 128) and x.shape[1] <= 32
 
 
 class SemGraphConv(nn.Module):
