@@ -33,10 +33,9 @@ constexpr float kInvalid = -3.0e30f;  // logit of a padded row: exp2(kInvalid - 
 
 enum Mode { kFused = 0, kLogitsFwd = 1, kLogitsBwd = 2 };
 
-// pair p -> bank it gathers from (0:M1 1:M2 2:M3) and query modality (0:x1 1:x2 2:x3);
-// order 12,21,23,32,13,31 (mem_bank.py:186-191).
+// pair p -> bank it gathers from (0:M1 1:M2 2:M3); the query modality of the pairs is
+// x1: 0,4  x2: 1,2  x3: 3,5.  Order 12,21,23,32,13,31 (mem_bank.py:186-191).
 __device__ __constant__ const int kPairBank[6] = {1, 0, 2, 1, 2, 0};
-__device__ __constant__ const int kPairQuery[6] = {0, 1, 1, 2, 0, 2};
 
 __host__ __device__ inline int rows_per_wg(int B, int K1) {
 #ifndef __HIP_DEVICE_COMPILE__
@@ -362,10 +361,10 @@ __global__ __launch_bounds__(kWG) void bank_finish_kernel(
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // scale[nchunks][6]
   __shared__ float sM[6], sS[6];
   __shared__ float sG[6][D];
-  __shared__ int sCntSel, sCntAll;
+  __shared__ int sCntSel;
   const int b = blockIdx.x, tid = threadIdx.x;
 
-  if (tid == 0) { sCntSel = 0; sCntAll = 0; }
+  if (tid == 0) sCntSel = 0;
   __syncthreads();
   {
     int sel = 0;

@@ -14,8 +14,6 @@ Parity is PINNED: every function below is checked against golden vectors that
 Reference citations are relative to ``/root/reference/pycontrast``.
 All floating point is fp32 unless ``dtype`` says otherwise.
 """
-import math
-
 import numpy as np
 import torch
 import torch.nn.functional as F

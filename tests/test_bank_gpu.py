@@ -1,7 +1,6 @@
 """GPU parity of the memory-bank kernels through the C ABI:
 HIP vs the CPU oracle on seeded inputs, vs the committed golden vectors generated from the
 reference, and size-independent properties at BASELINE sizes."""
-import numpy as np
 import pytest
 import torch
 
