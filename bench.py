@@ -142,6 +142,9 @@ def main():
                     help='bf16 = BASELINE config 5 bank storage; not the headline config')
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
+    ap.add_argument('--backend', type=str, default='nccl',
+                    help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '
+                         'multi-rank control flow be exercised on a single-GPU box')
     ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '0')),
                     help='capture the encoder forward/backward as hipGraphs')
     a = ap.parse_args()
@@ -162,13 +165,13 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.device('cuda', torch.cuda.current_device())
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world)        # RCCL over xGMI
+        dist.init_process_group(a.backend, rank=rank, world_size=world)      # nccl = RCCL over xGMI
 
     import tempfile
     from hcmoco_amd import hip_ops
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     B = a.batch_per_gpu
-    args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, 'nccl', tempfile.mkdtemp(),
+    args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, a.backend, tempfile.mkdtemp(),
                      a.steps + a.warmup, sampled=a.sampled_projection, arch=a.arch, width=a.width,
                      bank_dtype=a.bank_dtype)
     args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
