@@ -5,6 +5,8 @@ Reference: /root/reference/pycontrast/networks/build_backbone.py:186-303 (RGBD2S
 'Sin')``; constructors take the same positional arguments; ``state_dict`` top-level names are
 ``encoder1, encoder2, encoder3, head1-3, encoder1_linear, encoder2_linear``.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -46,6 +48,27 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # ``return_fm`` then hands back the raw branch maps and skips merge_all_res + the full 1x1
         # projections (aux entries are None).  Off by default = the reference data flow.
         self.defer_projection = False
+        # The two HRNets are independent until the heads: on the GPU they are issued on two HIP
+        # streams so their (small, low-occupancy) kernels overlap -- forward, and backward too
+        # (autograd replays every node on the stream its forward ran on).  HCM_TWO_STREAMS=0 disables.
+        self.two_streams = os.environ.get('HCM_TWO_STREAMS', '1') != '0'
+        self._side_stream = None
+
+    def _encode_pair(self, x1, x2):
+        if not (self.two_streams and x1.is_cuda):
+            return self.encoder1(x1), self.encoder2(x2)
+        main = torch.cuda.current_stream(x1.device)
+        if self._side_stream is None or self._side_stream.device != x1.device:
+            self._side_stream = torch.cuda.Stream(device=x1.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            feat2 = self.encoder2(x2)
+        feat1 = self.encoder1(x1)
+        main.wait_stream(side)
+        for t in feat2:                      # consumed on the main stream from here on
+            t.record_stream(main)
+        return feat1, feat2
 
     @staticmethod
     def merge_all_res(maps):
@@ -61,8 +84,7 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
     def forward(self, x, s, mode=0, return_fm=False):
         """mode 0/1: projected + L2-normalised features; 2: raw pooled features (:256-303)."""
         x1, x2 = torch.split(x, self.in_channel_list, dim=1)
-        _feat1 = self.encoder1(x1)
-        _feat2 = self.encoder2(x2)
+        _feat1, _feat2 = self._encode_pair(x1, x2)
         _feat3 = self.encoder3(s)
         avg1, avg2, avg3 = self._pool(_feat1), self._pool(_feat2), _feat3.mean(1)
         if mode in (0, 1):
