@@ -66,6 +66,9 @@ SIGNATURES = {
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 5),
     'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 6),
+    'hcm_bn_act_stats_floats': (C.c_size_t, [_i, _i, _i]),
+    'hcm_bn_act_forward': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3),
+    'hcm_bn_act_backward': (_i, [_p] * 5 + [_i] * 4 + [_p] * 4),
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
 }

@@ -1,0 +1,252 @@
+// Fused BatchNorm2d (+ residual add) (+ ReLU) for the HRNet encoders, gfx950.
+//
+// Every convolution of the two HRNets (pycontrast/networks/official_hrnet/official_hrnet.py:40-105
+// BasicBlock / Bottleneck, :287-347 transitions, :161-207 fuse layers) is followed by
+// BatchNorm2d, usually a residual add, usually a ReLU: 618 normalisations per step on activations of
+// 0.3-134 MB.  The stock path runs them as 3 kernels forward and 3 backward, and the library's
+// spatial batch-norm assigns ONE workgroup per channel -- with C = 18 channels (the high-resolution
+// branch) that is 18 workgroups on a 256-CU part (r01 profile: 19-21 us per launch for a 9.4 MB map).
+//
+// Here a layer is two kernels per direction, both on a (channel, slice) grid so that even C = 18 is
+// several hundred workgroups, and the second kernel of a pair re-reads exactly the slice its
+// twin just streamed (same blockIdx -> same XCD -> L2 hit):
+//   forward : stats  (per-slice shifted sums  S1 = sum(x-k), S2 = sum((x-k)^2), k = x[0,c,0,0])
+//             apply  (merge slices in fixed order -> mean, invstd, running stats;
+//                     y = relu(x*sc + sh + residual))
+//   backward: reduce (dz = dy * [y > 0]; per-slice sum(dz), sum(dz*(x-mean)); dz doubles as d residual)
+//             apply  (dgamma, dbeta; dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)))
+// Sums are plain additions of per-slice partials in slice order: deterministic, no atomics.
+// HBM-bound: forward moves 3 (4 with residual) tensor passes, backward 7; see DESIGN.md 4.7.
+#include "hcm_common.h"
+#include "../../include/hcmoco_hip.h"
+
+namespace {
+
+using namespace hcm;
+
+constexpr int kBT = 256;          // threads per workgroup
+constexpr int kVec = kBT * 4;     // floats per workgroup iteration
+constexpr int kMaxSplit = 64;     // slices per channel (merged by one wave)
+
+struct Geo {
+  int C, HW, M;      // M = N*HW elements per channel
+  int per, split;    // slice length (multiple of kVec) and slice count
+  int shift;         // log2(HW) or -1
+};
+
+Geo make_geo(int N, int C, int HW) {
+  Geo g;
+  g.C = C; g.HW = HW; g.M = N * HW;
+  int want = 1024 / C;
+  if (want < 1) want = 1;
+  if (want > kMaxSplit) want = kMaxSplit;
+  int per = (g.M + want - 1) / want;
+  per = ((per + kVec - 1) / kVec) * kVec;
+  g.per = per;
+  g.split = (g.M + per - 1) / per;
+  g.shift = -1;
+  if ((HW & (HW - 1)) == 0) { int s = 0; while ((1 << s) < HW) ++s; g.shift = s; }
+  return g;
+}
+
+__device__ __forceinline__ size_t elem_offset(const Geo& g, int c, int f) {
+  const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+  return ((size_t)n * g.C + c) * (size_t)g.HW + (size_t)(f - n * g.HW);
+}
+
+// Sum two values over the workgroup; result valid in every thread.
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+  __shared__ float sh[2][kBT / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+  b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+}
+
+// Merge the per-slice partials of channel c (slice order, one lane per slice).
+__device__ __forceinline__ void merge_partials(const float* part, const Geo& g, int c, float& p1, float& p2) {
+  const int lane = threadIdx.x & 63;
+  p1 = lane < g.split ? part[(size_t)(2 * lane) * g.C + c] : 0.f;
+  p2 = lane < g.split ? part[(size_t)(2 * lane + 1) * g.C + c] : 0.f;
+  p1 = wave_sum(p1);
+  p2 = wave_sum(p2);
+}
+
+__global__ __launch_bounds__(kBT) void bn_stats_kernel(const float* __restrict__ x, Geo g,
+                                                       float* __restrict__ part) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  const float k = x[(size_t)c * g.HW];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const float4 v = *reinterpret_cast<const float4*>(x + elem_offset(g, c, f));
+    const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
+    s1 += (a + b) + (cc + d);
+    s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(cc, cc, s2); s2 = fmaf(d, d, s2);
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * s) * g.C + c] = s1;
+    part[(size_t)(2 * s + 1) * g.C + c] = s2;
+  }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(kBT) void bn_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ part, Geo g, float eps, float momentum,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float p1, p2;
+  merge_partials(part, g, c, p1, p2);
+  const float k = x[(size_t)c * g.HW];
+  const float invM = 1.f / (float)g.M;
+  const float m1 = p1 * invM;
+  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+  const float mean = k + m1;
+  const float invstd = 1.f / sqrtf(var + eps);
+  if (s == 0 && threadIdx.x == 0) {
+    stats[c] = mean;
+    stats[g.C + c] = invstd;
+    if (rmean != nullptr) {
+      const float unbiased = g.M > 1 ? var * ((float)g.M / (float)(g.M - 1)) : var;
+      rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+      rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+    }
+  }
+  const float sc = gamma[c] * invstd;
+  const float sh = fmaf(-mean, sc, beta[c]);
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+#pragma unroll 4
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const size_t o = elem_offset(g, c, f);
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    float4 r = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
+    if (RES) {
+      const float4 q = *reinterpret_cast<const float4*>(res + o);
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *reinterpret_cast<float4*>(y + o) = r;
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ stats, Geo g, float* __restrict__ dz, float* __restrict__ part) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  const float mean = stats[c];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const size_t o = elem_offset(g, c, f);
+    float4 d = *reinterpret_cast<const float4*>(dy + o);
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    if (RELU) {
+      const float4 out = *reinterpret_cast<const float4*>(y + o);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      *reinterpret_cast<float4*>(dz + o) = d;
+    }
+    s1 += (d.x + d.y) + (d.z + d.w);
+    s2 = fmaf(d.x, v.x - mean, s2); s2 = fmaf(d.y, v.y - mean, s2);
+    s2 = fmaf(d.z, v.z - mean, s2); s2 = fmaf(d.w, v.w - mean, s2);
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * s) * g.C + c] = s1;
+    part[(size_t)(2 * s + 1) * g.C + c] = s2;
+  }
+}
+
+__global__ __launch_bounds__(kBT) void bn_bwd_apply_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ stats, const float* __restrict__ part, Geo g, float* __restrict__ gstats,
+    float* __restrict__ dx) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float p1, p2;
+  merge_partials(part, g, c, p1, p2);
+  const float mean = stats[c], invstd = stats[g.C + c];
+  if (s == 0 && threadIdx.x == 0) {
+    gstats[c] = p2 * invstd;     // d gamma
+    gstats[g.C + c] = p1;        // d beta
+  }
+  if (dx == nullptr) return;
+  const float invM = 1.f / (float)g.M;
+  const float a = gamma[c] * invstd;
+  const float b = p1 * invM;
+  const float q = p2 * invstd * invstd * invM;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+#pragma unroll 4
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const size_t o = elem_offset(g, c, f);
+    const float4 d = *reinterpret_cast<const float4*>(dz + o);
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    float4 r;
+    r.x = a * (d.x - b - (v.x - mean) * q);
+    r.y = a * (d.y - b - (v.y - mean) * q);
+    r.z = a * (d.z - b - (v.z - mean) * q);
+    r.w = a * (d.w - b - (v.w - mean) * q);
+    *reinterpret_cast<float4*>(dx + o) = r;
+  }
+}
+
+bool bad_shape(int N, int C, int HW) {
+  return N <= 0 || C <= 0 || HW <= 0 || (HW & 3) != 0 || (long long)N * HW > 0x7fffffffLL - kVec ||
+         C > 65535;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hcm_bn_act_stats_floats(int N, int C, int HW) {
+  if (bad_shape(N, C, HW)) return 0;
+  const Geo g = make_geo(N, C, HW);
+  return (size_t)(2 + 2 * g.split) * (size_t)C;
+}
+
+int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, int relu,
+                       int N, int C, int HW, float* y, float* stats, hcm_stream_t stream) {
+  if (bad_shape(N, C, HW) || !x || !gamma || !beta || !y || !stats || (running_mean == nullptr) != (running_var == nullptr))
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(N, C, HW);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(C, g.split);
+  float* part = stats + 2 * (size_t)C;
+  bn_stats_kernel<<<grid, kBT, 0, st>>>(x, g, part);
+  HCM_CHECK_LAUNCH();
+#define HCM_BN_APPLY(R, S)                                                                           \
+  bn_apply_kernel<R, S><<<grid, kBT, 0, st>>>(x, residual, gamma, beta, part, g, eps, momentum,      \
+                                              running_mean, running_var, stats, y)
+  if (relu) { if (residual) HCM_BN_APPLY(true, true); else HCM_BN_APPLY(true, false); }
+  else      { if (residual) HCM_BN_APPLY(false, true); else HCM_BN_APPLY(false, false); }
+#undef HCM_BN_APPLY
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma,
+                        const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
+                        float* gstats, hcm_stream_t stream) {
+  if (bad_shape(N, C, HW) || !dy || !x || !gamma || !stats || !gstats || (relu && (!y || !dz)))
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(N, C, HW);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(C, g.split);
+  float* part = gstats + 2 * (size_t)C;
+  if (relu) bn_bwd_reduce_kernel<true><<<grid, kBT, 0, st>>>(dy, x, y, stats, g, dz, part);
+  else      bn_bwd_reduce_kernel<false><<<grid, kBT, 0, st>>>(dy, x, nullptr, stats, g, nullptr, part);
+  HCM_CHECK_LAUNCH();
+  bn_bwd_apply_kernel<<<grid, kBT, 0, st>>>(relu ? dz : dy, x, gamma, stats, part, g, gstats, dx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

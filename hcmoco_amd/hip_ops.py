@@ -544,3 +544,80 @@ def sgc_layer(x, W, e, bias, graph, bn=None, relu=False):
     training = bn.training or bn.running_mean is None
     return _SgcLayer.apply(x.contiguous(), W, e, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, graph,
                            True, relu, training, bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+
+
+# --------------------------------------------------------------------------- #
+# encoder normalisation: BatchNorm2d [+ residual] [+ ReLU], two kernels per direction
+# --------------------------------------------------------------------------- #
+_BN_STATS_FLOATS = {}
+
+
+def _bn_stats_floats(N, Cc, HW):
+    key = (N, Cc, HW)
+    n = _BN_STATS_FLOATS.get(key)
+    if n is None:
+        n = int(_lib.lib().hcm_bn_act_stats_floats(N, Cc, HW))
+        if n == 0:
+            raise ValueError('bn_act: unsupported shape N=%d C=%d HW=%d (HW must be a multiple of 4)' % key)
+        _BN_STATS_FLOATS[key] = n
+    return n
+
+
+def bn_act_supported(x):
+    """Shapes/dtypes hcm_bn_act_* covers: fp32 NCHW-contiguous ROCm maps with H*W % 4 == 0."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[1] <= 65535)
+
+
+class _BnAct(torch.autograd.Function):
+    """Training-mode BatchNorm2d [+ residual] [+ ReLU] (official_hrnet.py:40-105 block tails).
+    forward: hcm_bn_act_forward (stats + apply); backward: hcm_bn_act_backward (reduce + apply)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
+        if not bn_act_supported(x):
+            raise RuntimeError('hcmoco_amd.bn_act needs fp32 NCHW-contiguous ROCm maps with H*W % 4 == 0 '
+                               '(no CPU fallback exists)')
+        N, Cc, H, W = x.shape
+        HW = H * W
+        if residual is not None and (residual.shape != x.shape or not residual.is_contiguous()
+                                     or residual.dtype != torch.float32):
+            residual = residual.to(torch.float32).expand_as(x).contiguous()
+        y = torch.empty_like(x)
+        stats = torch.empty(_bn_stats_floats(N, Cc, HW), dtype=torch.float32, device=x.device)
+        check(_lib.lib().hcm_bn_act_forward(
+            x.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+            None if running_mean is None else running_mean.data_ptr(),
+            None if running_var is None else running_var.data_ptr(),
+            float(momentum), float(eps), int(relu), N, Cc, HW, y.data_ptr(), stats.data_ptr(), _stream()),
+            'hcm_bn_act_forward')
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        if relu:
+            ctx.save_for_backward(x, weight, stats, y)
+        else:
+            ctx.save_for_backward(x, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.relu:
+            x, weight, stats, y = ctx.saved_tensors
+        else:
+            (x, weight, stats), y = ctx.saved_tensors, None
+        N, Cc, H, W = x.shape
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dz = torch.empty_like(x) if ctx.relu else None
+        gstats = torch.empty(stats.numel(), dtype=torch.float32, device=x.device)
+        check(_lib.lib().hcm_bn_act_backward(
+            g.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), weight.data_ptr(), stats.data_ptr(),
+            int(ctx.relu), N, Cc, H * W, None if dz is None else dz.data_ptr(),
+            None if dx is None else dx.data_ptr(), gstats.data_ptr(), _stream()), 'hcm_bn_act_backward')
+        dres = (dz if ctx.relu else g) if ctx.has_res else None
+        return dx, dres, gstats[:Cc], gstats[Cc:2 * Cc], None, None, None, None, None
+
+
+def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
+    """relu?(batch_norm(x; batch statistics) + residual?) with the running statistics updated in place."""
+    return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)

@@ -51,8 +51,11 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # The two HRNets are independent until the heads: on the GPU they are issued on two HIP
         # streams so their (small, low-occupancy) kernels overlap -- forward, and backward too
         # (autograd replays every node on the stream its forward ran on).  HCM_TWO_STREAMS=0 disables.
-        self.two_streams = os.environ.get('HCM_TWO_STREAMS', '1') != '0'
+        # HCM_TWO_STREAMS=2 additionally issues encoder2 from a helper thread: ATen releases the GIL
+        # inside every op, so the two ~1250-op forward passes overlap on the host as well.
+        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '1'))
         self._side_stream = None
+        self._helper = None
 
     def _encode_pair(self, x1, x2):
         if not (self.two_streams and x1.is_cuda):
@@ -62,9 +65,21 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
             self._side_stream = torch.cuda.Stream(device=x1.device)
         side = self._side_stream
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            feat2 = self.encoder2(x2)
-        feat1 = self.encoder1(x1)
+
+        def run_side():
+            with torch.cuda.stream(side):
+                return self.encoder2(x2)
+
+        if self.two_streams >= 2 and torch.is_grad_enabled():
+            if self._helper is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix='hcm-enc2')
+            pending = self._helper.submit(run_side)
+            feat1 = self.encoder1(x1)
+            feat2 = pending.result()
+        else:
+            feat2 = run_side()
+            feat1 = self.encoder1(x1)
         main.wait_stream(side)
         for t in feat2:                      # consumed on the main stream from here on
             t.record_stream(main)

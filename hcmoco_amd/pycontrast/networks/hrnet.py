@@ -7,11 +7,19 @@ names (``state_dict`` keys) and initialisation follow the reference
 files), so ImageNet / first-stage checkpoints load unchanged.  The topology is a Python table
 here instead of a yacs config read from a cwd-relative yaml path (official_hrnet.py:498-503).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 BN_MOMENTUM = 0.01                                           # official_hrnet.py:23
+FUSED_BN = os.environ.get('HCM_FUSED_BN', '1') != '0'        # hcm_bn_act_* on the GPU (0: stock ops)
+
+
+def bn_act_supported(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and (x.shape[2] * x.shape[3]) % 4 == 0)
 
 
 def upsample_bilinear(x, size):
@@ -38,20 +46,38 @@ class BatchNorm2d(nn.BatchNorm2d):
     each per step).  ``HighResolutionNet.forward`` advances all counters with ONE foreach launch, so
     the buffers (and checkpoints) evolve exactly as in the reference."""
 
-    def forward(self, x):
-        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
-                            self.training or not self.track_running_stats, self.momentum, self.eps)
+    def forward(self, x, residual=None, relu=False):
+        """``relu?(bn(x) + residual?)``.  Training steps on the MI355X run it as ONE fused op
+        (``hcm_bn_act_forward/backward``, a (channel, slice) grid instead of the library's one
+        workgroup per channel); everything else is the stock composition."""
+        if FUSED_BN and self.training and bn_act_supported(x):
+            from ... import hip_ops
+            return hip_ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                  self.momentum, self.eps, residual=residual, relu=relu)
+        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                         self.training or not self.track_running_stats, self.momentum, self.eps)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y, inplace=True) if relu else y
 
 
 def _bn(c):
     return BatchNorm2d(c, momentum=BN_MOMENTUM)
 
 
+class ConvBn(nn.Sequential):
+    """conv -> bn [-> relu] with the reference's Sequential child names ('0', '1', ['2']); the
+    normalisation, the optional residual and the ReLU run as one op."""
+
+    def forward(self, x, residual=None):
+        return self[1](self[0](x), residual=residual, relu=len(self) == 3)
+
+
 def _conv_bn(cin, cout, k, stride=1, relu=False):
     layers = [nn.Conv2d(cin, cout, k, stride, k // 2, bias=False), _bn(cout)]
     if relu:
         layers.append(nn.ReLU(inplace=True))
-    return nn.Sequential(*layers)
+    return ConvBn(*layers)
 
 
 class BasicBlock(nn.Module):
@@ -68,9 +94,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu(y + skip)
+        y = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(y), residual=skip, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -89,16 +114,15 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + skip)
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
+        return self.bn3(self.conv3(y), residual=skip, relu=True)
 
 
 def _block_chain(block, cin, planes, n):
     down = None
     if cin != planes * block.expansion:
-        down = nn.Sequential(nn.Conv2d(cin, planes * block.expansion, 1, bias=False), _bn(planes * block.expansion))
+        down = ConvBn(nn.Conv2d(cin, planes * block.expansion, 1, bias=False), _bn(planes * block.expansion))
     layers = [block(cin, planes, 1, down)]
     layers += [block(planes * block.expansion, planes) for _ in range(n - 1)]
     return nn.Sequential(*layers)
@@ -143,8 +167,11 @@ class HighResolutionModule(nn.Module):
                     y = y + xs[j]
                 elif j > i:
                     y = y + upsample_bilinear(row[j](xs[j]), xs[i].shape[-2:])
-                else:
-                    y = y + row[j](xs[j])
+                else:                          # the last conv-bn of the chain adds the running sum itself
+                    t = xs[j]
+                    for step in row[j][:-1]:
+                        t = step(t)
+                    y = row[j][-1](t, residual=y)
             outs.append(self.relu(y))
         return outs
 
@@ -203,8 +230,8 @@ class HighResolutionNet(nn.Module):
     def forward(self, x):
         if self.training:
             self._count_batch()
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
         x = self.layer1(x)
         ys = [x]
         for s in (2, 3, 4):

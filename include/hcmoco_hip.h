@@ -216,6 +216,27 @@ int hcm_sgc_backward(const float* dOut, const float* out, const float* xhat, con
                      float* dbeta, float* dbias, float* de, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * Encoder normalisation: training-mode BatchNorm2d [+ residual add] [+ ReLU] on fp32 NCHW maps
+ * (torch.nn.BatchNorm2d + `out += residual` + ReLU in networks/official_hrnet/official_hrnet.py:40-105,
+ * :161-207, :287-347).  x, residual, y, dy, dz, dx: [N, C, HW] contiguous, HW % 4 == 0.
+ * `stats` / `gstats`: caller-owned, hcm_bn_act_stats_floats(N, C, HW) floats each;
+ *   stats  = [mean C][invstd C][scratch]   (written by forward, read by backward)
+ *   gstats = [dgamma C][dbeta C][scratch]  (written by backward)
+ * forward : y = relu?(gamma * (x - mean) * invstd + beta + residual?), biased batch variance;
+ *           running_mean/var (nullable pair) <- (1 - momentum) * running + momentum * {mean, unbiased var}.
+ * backward: dz = dy * [y > 0] when relu (dz is also the gradient of `residual`; without relu that
+ *           gradient is dy itself and y, dz may be NULL); dx (NULL to skip), dgamma, dbeta.
+ * Deterministic (fixed-order partial sums, no atomics).
+ * ------------------------------------------------------------------------ */
+size_t hcm_bn_act_stats_floats(int N, int C, int HW);
+int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, int relu,
+                       int N, int C, int HW, float* y, float* stats, hcm_stream_t stream);
+int hcm_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma,
+                        const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
+                        float* gstats, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
  * reference's C launcher layer (networks/pointnet2/src/<name>_gpu.h), which the pybind
  * module `pointnet2_cuda` (src/pointnet2_api.cpp:10-24) wraps: the caller allocates and

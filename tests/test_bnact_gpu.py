@@ -1,0 +1,119 @@
+"""hcm_bn_act_* (fused BatchNorm2d [+ residual] [+ ReLU]) against torch's own ops in float64.
+
+A floating-point kernel: the reference here is torch (F.batch_norm + add + relu), which is what
+official_hrnet.py:40-105 composes.  Tolerances: 2e-5 relative to the tensor's scale (fp32 sums over up
+to 5e5 elements), running statistics 1e-5.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(32, 18, 64, 64), (4, 36, 32, 32), (3, 72, 16, 16), (2, 144, 8, 8), (2, 5, 6, 6), (1, 3, 2, 2),
+          (8, 64, 128, 128), (5, 7, 12, 20)]
+
+
+def _ref(x, res, w, b, rm, rv, mom, eps, relu):
+    y = F.batch_norm(x, rm, rv, w, b, True, mom, eps)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_bn_act_matches_torch(shape, relu, with_res):
+    from hcmoco_amd import hip_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(hash((shape, relu, with_res)) % (2 ** 31))
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 2.0 + 3.0 * torch.randn(1, C, 1, 1, generator=g)).to(dev)
+    res = torch.randn(shape, generator=g).to(dev) if with_res else None
+    w = (torch.rand(C, generator=g) + 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    rm = torch.randn(C, generator=g).to(dev)
+    rv = (torch.rand(C, generator=g) + 0.5).to(dev)
+    gy = torch.randn(shape, generator=g).to(dev)
+    mom, eps = 0.01, 1e-5
+
+    xs, ws, bs = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    rs = res.clone().requires_grad_() if with_res else None
+    rm1, rv1 = rm.clone(), rv.clone()
+    y = hip_ops.bn_act(xs, ws, bs, rm1, rv1, mom, eps, residual=rs, relu=relu)
+    y.backward(gy)
+
+    xd, wd, bd = (t.double().detach().requires_grad_() for t in (x, w, b))
+    rd = res.double().requires_grad_() if with_res else None
+    rm2, rv2 = rm.double(), rv.double()
+    yd = _ref(xd, rd, wd, bd, rm2, rv2, mom, eps, relu)
+    yd.backward(gy.double())
+
+    def close(a, ref, tol=2e-5):
+        scale = ref.abs().max().item() + 1e-12
+        err = (a.double() - ref).abs().max().item()
+        assert err <= tol * scale, (err, scale)
+
+    close(y, yd)
+    close(rm1, rm2, 1e-5)
+    close(rv1, rv2, 1e-5)
+    # elements whose pre-activation is within rounding of zero may flip the ReLU mask: compare the
+    # gradients only where the float64 pre-activation is clearly away from zero
+    if relu:
+        pre = _ref(xd, rd, wd, bd, rm.double(), rv.double(), mom, eps, False)
+        assert (pre.abs() < 1e-4).float().mean().item() < 1e-3
+    close(xs.grad, xd.grad, 1e-4 if relu else 2e-5)
+    close(ws.grad, wd.grad, 1e-4)
+    close(bs.grad, bd.grad, 1e-4)
+    if with_res:
+        close(rs.grad, rd.grad, 1e-4 if relu else 2e-5)
+
+
+def test_bn_act_is_deterministic_and_rejects_bad_input():
+    from hcmoco_amd import hip_ops
+    dev = torch.device('cuda:0')
+    x = torch.randn(8, 18, 32, 32, device=dev)
+    w, b = torch.ones(18, device=dev), torch.zeros(18, device=dev)
+    outs = []
+    for _ in range(3):
+        xs = x.clone().requires_grad_()
+        y = hip_ops.bn_act(xs, w, b, None, None, 0.1, 1e-5, relu=True)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), xs.grad.clone()))
+    for y, gx in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(gx, outs[0][1])
+    with pytest.raises(RuntimeError):
+        hip_ops.bn_act(torch.randn(2, 3, 3, 3, device=dev), w[:3], b[:3], None, None, 0.1, 1e-5)   # HW % 4 != 0
+    with pytest.raises(RuntimeError):
+        hip_ops.bn_act(torch.randn(2, 3, 4, 4), w[:3].cpu(), b[:3].cpu(), None, None, 0.1, 1e-5)  # CPU tensor
+
+
+def test_hrnet_fused_bn_matches_stock_ops():
+    """One HRNet-w18 forward/backward with the fused normalisation against the stock composition."""
+    from hcmoco_amd.pycontrast.networks import hrnet
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    net = hrnet.get_hrnet_w18_backbone().to(dev).train()
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    res = {}
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    for fused in (True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        hrnet.FUSED_BN = fused
+        try:
+            ys = net(x)
+            sum(y.square().mean() for y in ys).backward()
+        finally:
+            hrnet.FUSED_BN = True
+        res[fused] = ([y.detach().clone() for y in ys],
+                      {n: p.grad.clone() for n, p in net.named_parameters()},
+                      {n: b.clone() for n, b in net.named_buffers()})
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item()
+    gscale = max(v.abs().max().item() for v in res[False][1].values())
+    for n, gb in res[False][1].items():
+        assert (res[True][1][n] - gb).abs().max().item() <= 2e-2 * max(gb.abs().max().item(), 1e-3 * gscale), n
+    for n, bb in res[False][2].items():
+        assert torch.allclose(res[True][2][n].float(), bb.float(), rtol=1e-3, atol=1e-5), n
