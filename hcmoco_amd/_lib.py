@@ -10,6 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libhcmoco_hip.so')
+GLUE_PATH = os.path.join(CSRC, 'libhcmoco_torch.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hcmoco_hip.h')
 
 
@@ -82,7 +83,9 @@ _lib = None
 
 def build(verbose=False):
     """Compile csrc/*.hip for gfx950 into csrc/libhcmoco_hip.so (in-tree, via make + hipcc)."""
-    res = subprocess.run(['make', '-C', CSRC, '-j', '4'], capture_output=True, text=True)
+    import torch
+    res = subprocess.run(['make', '-C', CSRC, '-j', '4', 'TORCH_DIR=' + os.path.dirname(torch.__file__)],
+                         capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-8000:])
@@ -110,6 +113,24 @@ def lib():
             raise ImportError('libhcmoco_hip.so ABI version mismatch')
         _lib = handle
     return _lib
+
+
+_glue_loaded = False
+
+
+def torch_glue():
+    """Load csrc/libhcmoco_torch.so (registers torch.ops.hcmoco.*: C++ autograd nodes over the C ABI).
+    Raises if it has not been built -- there is no fallback implementation."""
+    global _glue_loaded
+    if not _glue_loaded:
+        lib()
+        if not os.path.exists(GLUE_PATH):
+            raise ImportError('libhcmoco_torch.so is missing (%s); build it with `make -C hcmoco_amd/csrc`' % GLUE_PATH)
+        import torch
+        torch.ops.load_library(GLUE_PATH)
+        _glue_loaded = True
+    import torch
+    return torch.ops.hcmoco
 
 
 def check(rc, what):

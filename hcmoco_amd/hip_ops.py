@@ -6,6 +6,7 @@ the C entry points of ``include/hcmoco_hip.h`` and wraps the result in a
 CPU tensors raise ``RuntimeError`` and a missing library raises ``ImportError``.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -618,6 +619,14 @@ class _BnAct(torch.autograd.Function):
         return dx, dres, gstats[:Cc], gstats[Cc:2 * Cc], None, None, None, None, None
 
 
+_BN_GLUE = os.environ.get('HCM_BN_GLUE', '1') != '0'
+
+
 def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
-    """relu?(batch_norm(x; batch statistics) + residual?) with the running statistics updated in place."""
+    """relu?(batch_norm(x; batch statistics) + residual?) with the running statistics updated in place.
+    Runs as a C++ autograd node (csrc/torch_glue, torch.ops.hcmoco.bn_act) over hcm_bn_act_*;
+    HCM_BN_GLUE=0 selects the Python autograd.Function over the same two C entry points."""
+    if _BN_GLUE:
+        return _lib.torch_glue().bn_act(x, residual, weight, bias, running_mean, running_var,
+                                        float(momentum), float(eps), bool(relu))
     return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
