@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 BN_MOMENTUM = 0.01                                           # official_hrnet.py:23
 FUSED_BN = os.environ.get('HCM_FUSED_BN', '1') != '0'        # hcm_bn_act_* on the GPU (0: stock ops)
+CONV_GLUE = os.environ.get('HCM_CONV_GLUE', '1') != '0'      # torch.ops.hcmoco.conv2d (0: ATen)
 
 
 def bn_act_supported(x):
@@ -38,6 +39,21 @@ STAGES = {
     'stage3': dict(modules=4, branches=3, blocks=4, kind='basic'),
     'stage4': dict(modules=3, branches=4, blocks=4, kind='basic'),
 }
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (bias-free, groups = dilation = 1) whose ROCm path is ``torch.ops.hcmoco.conv2d``:
+    the same MIOpen kernels ATen would pick, issued from one C++ autograd node with cached
+    descriptors/algorithms (ATen spends ~125 us of host time per layer and step on a 25 us kernel;
+    csrc/torch_glue/hcm_torch_glue.cpp).  HCM_CONV_GLUE=0 or any other configuration: stock ATen."""
+
+    def forward(self, x):
+        if (CONV_GLUE and x.is_cuda and x.dtype == torch.float32 and self.bias is None and self.groups == 1
+                and self.dilation == (1, 1) and self.stride[0] == self.stride[1]
+                and self.padding[0] == self.padding[1] and self.padding_mode == 'zeros'):
+            from ... import _lib
+            return _lib.torch_glue().conv2d(x, self.weight, self.stride[0], self.padding[0])
+        return super().forward(x)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -74,7 +90,7 @@ class ConvBn(nn.Sequential):
 
 
 def _conv_bn(cin, cout, k, stride=1, relu=False):
-    layers = [nn.Conv2d(cin, cout, k, stride, k // 2, bias=False), _bn(cout)]
+    layers = [Conv2d(cin, cout, k, stride, k // 2, bias=False), _bn(cout)]
     if relu:
         layers.append(nn.ReLU(inplace=True))
     return ConvBn(*layers)
@@ -85,10 +101,10 @@ class BasicBlock(nn.Module):
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.conv1 = Conv2d(cin, planes, 3, stride, 1, bias=False)
         self.bn1 = _bn(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = _bn(planes)
         self.downsample = downsample
 
@@ -103,11 +119,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.conv1 = Conv2d(cin, planes, 1, bias=False)
         self.bn1 = _bn(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, stride, 1, bias=False)
         self.bn2 = _bn(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = _bn(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -122,7 +138,7 @@ class Bottleneck(nn.Module):
 def _block_chain(block, cin, planes, n):
     down = None
     if cin != planes * block.expansion:
-        down = ConvBn(nn.Conv2d(cin, planes * block.expansion, 1, bias=False), _bn(planes * block.expansion))
+        down = ConvBn(Conv2d(cin, planes * block.expansion, 1, bias=False), _bn(planes * block.expansion))
     layers = [block(cin, planes, 1, down)]
     layers += [block(planes * block.expansion, planes) for _ in range(n - 1)]
     return nn.Sequential(*layers)
@@ -180,9 +196,9 @@ class HighResolutionNet(nn.Module):
     def __init__(self, width=18):
         super().__init__()
         self.width = width
-        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.conv1 = Conv2d(3, 64, 3, 2, 1, bias=False)
         self.bn1 = _bn(64)
-        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.conv2 = Conv2d(64, 64, 3, 2, 1, bias=False)
         self.bn2 = _bn(64)
         self.relu = nn.ReLU(inplace=True)
         self.layer1 = _block_chain(Bottleneck, 64, 64, 4)

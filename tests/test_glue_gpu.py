@@ -1,0 +1,81 @@
+"""torch.ops.hcmoco.conv2d (MIOpen issued from the C++ glue with cached plans) against ATen's conv2d.
+
+Floating point: both sides run MIOpen fp32 kernels but may pick different algorithms (Winograd vs
+implicit GEMM), so the bound is 1e-3 of the tensor's scale."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # N, C, H, W, K, R, stride, pad
+    (32, 18, 64, 64, 18, 3, 1, 1), (8, 36, 32, 32, 36, 3, 1, 1), (4, 144, 8, 8, 144, 3, 1, 1),
+    (8, 18, 64, 64, 36, 3, 2, 1), (8, 64, 32, 32, 256, 1, 1, 0), (4, 3, 64, 64, 64, 3, 2, 1),
+    (2, 72, 16, 16, 18, 1, 1, 0), (3, 5, 9, 11, 7, 3, 1, 1),
+]
+
+
+def _close(a, b, tol=1e-3):
+    scale = b.abs().max().item() + 1e-12
+    assert (a - b).abs().max().item() <= tol * scale, ((a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_matches_aten(case):
+    from hcmoco_amd import _lib
+    ops = _lib.torch_glue()
+    N, C, H, W, K, R, stride, pad = case
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    w = (torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5).to(dev)
+    for rep in range(2):              # second pass runs from the cached plan
+        xa, wa = x.clone().requires_grad_(), w.clone().requires_grad_()
+        xb, wb = x.clone().requires_grad_(), w.clone().requires_grad_()
+        ya = ops.conv2d(xa, wa, stride, pad)
+        yb = F.conv2d(xb, wb, None, stride, pad)
+        gy = torch.randn(yb.shape, generator=g).to(dev)
+        ya.backward(gy)
+        yb.backward(gy)
+        _close(ya, yb)
+        _close(xa.grad, xb.grad)
+        _close(wa.grad, wb.grad)
+
+
+def test_conv2d_skips_unneeded_gradients_and_rejects_cpu():
+    from hcmoco_amd import _lib
+    ops = _lib.torch_glue()
+    dev = torch.device('cuda:0')
+    x = torch.randn(2, 4, 8, 8, device=dev)                      # no grad for the input (first layer)
+    w = torch.randn(6, 4, 3, 3, device=dev, requires_grad=True)
+    y = ops.conv2d(x, w, 1, 1)
+    y.sum().backward()
+    ref = torch.autograd.grad(F.conv2d(x, w, None, 1, 1).sum(), w)[0]
+    _close(w.grad, ref)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x.cpu(), w.detach().cpu(), 1, 1)
+
+
+def test_hrnet_glue_conv_matches_aten():
+    from hcmoco_amd.pycontrast.networks import hrnet
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    net = hrnet.get_hrnet_w18_backbone().to(dev).train()
+    x = torch.randn(8, 3, 128, 128, device=dev)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = {}
+    for glue in (True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        hrnet.CONV_GLUE = glue
+        try:
+            ys = net(x)
+            sum(y.square().mean() for y in ys).backward()
+        finally:
+            hrnet.CONV_GLUE = True
+        res[glue] = ([y.detach().clone() for y in ys], {n: p.grad.clone() for n, p in net.named_parameters()})
+    for a, b in zip(res[True][0], res[False][0]):
+        _close(a, b, 1e-2)
+    gscale = max(v.abs().max().item() for v in res[False][1].values())
+    for n, gb in res[False][1].items():
+        assert (res[True][1][n] - gb).abs().max().item() <= 5e-2 * max(gb.abs().max().item(), 1e-3 * gscale), n

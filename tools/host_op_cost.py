@@ -28,3 +28,19 @@ for name, layer in variants.items():
         y.sum().backward(); t2 = time.perf_counter()
         torch.cuda.synchronize(); t3 = time.perf_counter()
     print(f'{name}: fwd {1e6*(t1-t0)/N:.1f} us/layer  bwd {1e6*(t2-t1)/N:.1f} us/layer  total wall {1e3*(t3-t0):.1f} ms')
+
+# the convolutions either side of the normalisation (MIOpen through ATen)
+for cin, hw, k in ((18, 64, 3), (36, 32, 3), (144, 8, 3), (64, 64, 1)):
+    conv = nn.Conv2d(cin, cin, k, 1, k // 2, bias=False).to(dev)
+    xc = torch.randn(32, cin, hw, hw, device=dev, requires_grad=True)
+    def chain_conv():
+        x = xc
+        for _ in range(N):
+            x = conv(x)
+        return x
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = chain_conv(); t1 = time.perf_counter()
+        y.sum().backward(); t2 = time.perf_counter()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f'conv{k}x{k} {cin}ch @{hw}: fwd {1e6*(t1-t0)/N:.1f} us/layer  bwd {1e6*(t2-t1)/N:.1f} us/layer  total wall {1e3*(t3-t0):.1f} ms')
