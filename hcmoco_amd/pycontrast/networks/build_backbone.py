@@ -48,42 +48,59 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # ``return_fm`` then hands back the raw branch maps and skips merge_all_res + the full 1x1
         # projections (aux entries are None).  Off by default = the reference data flow.
         self.defer_projection = False
-        # The two HRNets are independent until the heads: on the GPU they are issued on two HIP
-        # streams so their (small, low-occupancy) kernels overlap -- forward, and backward too
-        # (autograd replays every node on the stream its forward ran on).  HCM_TWO_STREAMS=0 disables.
-        # HCM_TWO_STREAMS=2 additionally issues encoder2 from a helper thread: ATen releases the GIL
-        # inside every op, so the two ~1250-op forward passes overlap on the host as well.
+        # The three encoders are independent until the heads.  HCM_TWO_STREAMS is a bit mask:
+        #   1 (default)  SemGCN on a side HIP stream, issued first: its single-workgroup kernels
+        #                (3.5 ms per step, one CU) run underneath the HRNets instead of in line;
+        #   2            encoder2 on a second side stream (small HRNet kernels overlap);
+        #   4            with 2: encoder2 is also issued from a helper thread.
+        # Backward follows automatically: autograd replays every node on its forward stream.
         self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '1'))
-        self._side_stream = None
+        self._side_streams = {}
         self._helper = None
 
-    def _encode_pair(self, x1, x2):
-        if not (self.two_streams and x1.is_cuda):
-            return self.encoder1(x1), self.encoder2(x2)
+    def _side(self, idx, device):
+        st = self._side_streams.get((idx, device))
+        if st is None:
+            st = self._side_streams[(idx, device)] = torch.cuda.Stream(device=device)
+        return st
+
+    def _encode(self, x1, x2, s):
+        """(feat1 maps, feat2 maps, feat3) with the stream placement described in __init__."""
+        mode = self.two_streams if x1.is_cuda else 0
+        if not mode:
+            return self.encoder1(x1), self.encoder2(x2), self.encoder3(s)
         main = torch.cuda.current_stream(x1.device)
-        if self._side_stream is None or self._side_stream.device != x1.device:
-            self._side_stream = torch.cuda.Stream(device=x1.device)
-        side = self._side_stream
-        side.wait_stream(main)
+        joined = []
 
-        def run_side():
+        def on_side(idx, fn):
+            side = self._side(idx, x1.device)
+            side.wait_stream(main)
             with torch.cuda.stream(side):
-                return self.encoder2(x2)
+                out = fn()
+            joined.append((side, out))
+            return out
 
-        if self.two_streams >= 2 and torch.is_grad_enabled():
-            if self._helper is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix='hcm-enc2')
-            pending = self._helper.submit(run_side)
-            feat1 = self.encoder1(x1)
-            feat2 = pending.result()
+        feat3 = on_side(0, lambda: self.encoder3(s)) if mode & 1 else None
+        if mode & 2:
+            if mode & 4 and torch.is_grad_enabled():
+                if self._helper is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix='hcm-enc2')
+                pending = self._helper.submit(on_side, 1, lambda: self.encoder2(x2))
+                feat1 = self.encoder1(x1)
+                feat2 = pending.result()
+            else:
+                feat2 = on_side(1, lambda: self.encoder2(x2))
+                feat1 = self.encoder1(x1)
         else:
-            feat2 = run_side()
-            feat1 = self.encoder1(x1)
-        main.wait_stream(side)
-        for t in feat2:                      # consumed on the main stream from here on
-            t.record_stream(main)
-        return feat1, feat2
+            feat1, feat2 = self.encoder1(x1), self.encoder2(x2)
+        if feat3 is None:
+            feat3 = self.encoder3(s)
+        for side, out in joined:             # consumed on the main stream from here on
+            main.wait_stream(side)
+            for t in (out if isinstance(out, (list, tuple)) else (out,)):
+                t.record_stream(main)
+        return feat1, feat2, feat3
 
     @staticmethod
     def merge_all_res(maps):
@@ -99,8 +116,7 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
     def forward(self, x, s, mode=0, return_fm=False):
         """mode 0/1: projected + L2-normalised features; 2: raw pooled features (:256-303)."""
         x1, x2 = torch.split(x, self.in_channel_list, dim=1)
-        _feat1, _feat2 = self._encode_pair(x1, x2)
-        _feat3 = self.encoder3(s)
+        _feat1, _feat2, _feat3 = self._encode(x1, x2, s)
         avg1, avg2, avg3 = self._pool(_feat1), self._pool(_feat2), _feat3.mean(1)
         if mode in (0, 1):
             feat1, feat2, feat3 = self.head1(avg1), self.head2(avg2), self.head3(avg3)

@@ -41,6 +41,18 @@ STAGES = {
 }
 
 
+_GLUE_OPS = {}
+
+
+def _glue_op(name):
+    """torch.ops.hcmoco.<name>.default, resolved once (the packet lookup costs microseconds per call)."""
+    op = _GLUE_OPS.get(name)
+    if op is None:
+        from ... import _lib
+        op = _GLUE_OPS[name] = getattr(_lib.torch_glue(), name).default
+    return op
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (bias-free, groups = dilation = 1) whose ROCm path is ``torch.ops.hcmoco.conv2d``:
     the same MIOpen kernels ATen would pick, issued from one C++ autograd node with cached
@@ -51,8 +63,7 @@ class Conv2d(nn.Conv2d):
         if (CONV_GLUE and x.is_cuda and x.dtype == torch.float32 and self.bias is None and self.groups == 1
                 and self.dilation == (1, 1) and self.stride[0] == self.stride[1]
                 and self.padding[0] == self.padding[1] and self.padding_mode == 'zeros'):
-            from ... import _lib
-            return _lib.torch_glue().conv2d(x, self.weight, self.stride[0], self.padding[0])
+            return _glue_op('conv2d')(x, self.weight, self.stride[0], self.padding[0])
         return super().forward(x)
 
 
@@ -67,9 +78,8 @@ class BatchNorm2d(nn.BatchNorm2d):
         (``hcm_bn_act_forward/backward``, a (channel, slice) grid instead of the library's one
         workgroup per channel); everything else is the stock composition."""
         if FUSED_BN and self.training and bn_act_supported(x):
-            from ... import hip_ops
-            return hip_ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                  self.momentum, self.eps, residual=residual, relu=relu)
+            return _glue_op('bn_act')(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
+                                      self.momentum, self.eps, relu)
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                          self.training or not self.track_running_stats, self.momentum, self.eps)
         if residual is not None:

@@ -77,5 +77,6 @@ def test_hrnet_glue_conv_matches_aten():
     for a, b in zip(res[True][0], res[False][0]):
         _close(a, b, 1e-2)
     gscale = max(v.abs().max().item() for v in res[False][1].values())
-    for n, gb in res[False][1].items():
-        assert (res[True][1][n] - gb).abs().max().item() <= 5e-2 * max(gb.abs().max().item(), 1e-3 * gscale), n
+    worst = max(((res[True][1][n] - gb).abs().max().item() / max(gb.abs().max().item(), 1e-3 * gscale), n)
+                for n, gb in res[False][1].items())
+    assert worst[0] <= 5e-2, worst

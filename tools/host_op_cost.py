@@ -43,4 +43,18 @@ for cin, hw, k in ((18, 64, 3), (36, 32, 3), (144, 8, 3), (64, 64, 1)):
         y = chain_conv(); t1 = time.perf_counter()
         y.sum().backward(); t2 = time.perf_counter()
         torch.cuda.synchronize(); t3 = time.perf_counter()
-    print(f'conv{k}x{k} {cin}ch @{hw}: fwd {1e6*(t1-t0)/N:.1f} us/layer  bwd {1e6*(t2-t1)/N:.1f} us/layer  total wall {1e3*(t3-t0):.1f} ms')
+    print(f'ATen conv{k}x{k} {cin}ch @{hw}: fwd {1e6*(t1-t0)/N:.1f} us/layer  bwd {1e6*(t2-t1)/N:.1f} us/layer  total wall {1e3*(t3-t0):.1f} ms')
+
+    op = hip_ops._lib.torch_glue().conv2d.default
+    w = conv.weight
+    def chain_glue():
+        x = xc
+        for _ in range(N):
+            x = op(x, w, 1, k // 2)
+        return x
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = chain_glue(); t1 = time.perf_counter()
+        y.sum().backward(); t2 = time.perf_counter()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f'glue conv{k}x{k} {cin}ch @{hw}: fwd {1e6*(t1-t0)/N:.1f} us/layer  bwd {1e6*(t2-t1)/N:.1f} us/layer  total wall {1e3*(t3-t0):.1f} ms')
