@@ -34,59 +34,79 @@ inline void check_rc(int rc, const char* what) {
 
 inline float* fptr(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 
-// relu?(batch_norm(x; batch statistics) + residual?)   -- official_hrnet.py:40-105 block tails
+// ------------------------------------------------------------------------------------------------
+// Normalisation: relu?(batch_norm(x; batch statistics) + residual?)  -- official_hrnet.py:40-105
+// ------------------------------------------------------------------------------------------------
+struct BnOut { Tensor y, stats; };
+
+BnOut bn_forward_raw(const Tensor& x, const Tensor& res, const Tensor& weight, const Tensor& bias, const Tensor& rm,
+                     const Tensor& rv, double momentum, double eps, bool relu) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && x.is_contiguous(),
+              "hcmoco::bn_act needs fp32 NCHW-contiguous ROCm maps (no CPU fallback exists)");
+  TORCH_CHECK(weight.defined() && bias.defined() && weight.is_contiguous() && bias.is_contiguous() &&
+                  weight.scalar_type() == at::kFloat && bias.scalar_type() == at::kFloat &&
+                  weight.numel() == x.size(1) && bias.numel() == x.size(1),
+              "hcmoco::bn_act: affine parameters must be fp32 [C]");
+  const int N = (int)x.size(0), C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
+  const size_t nf = hcm_bn_act_stats_floats(N, C, HW);
+  TORCH_CHECK(nf > 0, "hcmoco::bn_act: unsupported shape (H*W must be a multiple of 4)");
+  if (res.defined())
+    TORCH_CHECK(res.sizes() == x.sizes() && res.scalar_type() == at::kFloat && res.is_contiguous(),
+                "hcmoco::bn_act: residual must be a contiguous fp32 tensor shaped like x");
+  BnOut o;
+  o.y = at::empty_like(x);
+  o.stats = at::empty({(int64_t)nf}, x.options());
+  check_rc(hcm_bn_act_forward(x.data_ptr<float>(), fptr(res), weight.data_ptr<float>(), bias.data_ptr<float>(),
+                              fptr(rm), fptr(rv), (float)momentum, (float)eps, relu ? 1 : 0, N, C, HW,
+                              o.y.data_ptr<float>(), o.stats.data_ptr<float>(), current_stream(x)),
+           "hcm_bn_act_forward");
+  return o;
+}
+
+struct BnGrads { Tensor dx, dres, dgamma, dbeta; };
+
+// g must be contiguous.  dres aliases dz (relu) or g (no relu).
+BnGrads bn_backward_raw(const Tensor& g, const Tensor& x, const Tensor& y, const Tensor& weight, const Tensor& stats,
+                        bool relu, bool has_res, bool need_dx) {
+  const int N = (int)x.size(0), C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
+  BnGrads o;
+  if (need_dx) o.dx = at::empty_like(x);
+  Tensor dz = relu ? at::empty_like(x) : Tensor();
+  Tensor gstats = at::empty_like(stats);
+  check_rc(hcm_bn_act_backward(g.data_ptr<float>(), x.data_ptr<float>(), fptr(y), weight.data_ptr<float>(),
+                               stats.data_ptr<float>(), relu ? 1 : 0, N, C, HW, fptr(dz), fptr(o.dx),
+                               gstats.data_ptr<float>(), current_stream(x)),
+           "hcm_bn_act_backward");
+  if (has_res) o.dres = relu ? dz : g;
+  o.dgamma = gstats.narrow(0, 0, C);
+  o.dbeta = gstats.narrow(0, C, C);
+  return o;
+}
+
+inline Tensor opt_tensor(const c10::optional<Tensor>& t) { return t.has_value() ? *t : Tensor(); }
+inline Tensor opt_contig(const c10::optional<Tensor>& t) {
+  return (t.has_value() && t->defined()) ? t->contiguous() : Tensor();
+}
+
 struct BnAct : public torch::autograd::Function<BnAct> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, const c10::optional<Tensor>& residual,
                         const Tensor& weight, const Tensor& bias, const c10::optional<Tensor>& running_mean,
                         const c10::optional<Tensor>& running_var, double momentum, double eps, bool relu) {
-    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && x.is_contiguous(),
-                "hcmoco::bn_act needs fp32 NCHW-contiguous ROCm maps (no CPU fallback exists)");
-    TORCH_CHECK(weight.defined() && bias.defined() && weight.is_contiguous() && bias.is_contiguous() &&
-                    weight.scalar_type() == at::kFloat && bias.scalar_type() == at::kFloat &&
-                    weight.numel() == x.size(1) && bias.numel() == x.size(1),
-                "hcmoco::bn_act: affine parameters must be fp32 [C]");
-    const int N = (int)x.size(0), C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
-    const size_t nf = hcm_bn_act_stats_floats(N, C, HW);
-    TORCH_CHECK(nf > 0, "hcmoco::bn_act: unsupported shape (H*W must be a multiple of 4)");
-    Tensor res;
-    if (residual.has_value() && residual->defined()) {
-      TORCH_CHECK(residual->sizes() == x.sizes() && residual->scalar_type() == at::kFloat,
-                  "hcmoco::bn_act: residual must match x");
-      res = residual->contiguous();
-    }
-    Tensor rm = running_mean.has_value() ? *running_mean : Tensor();
-    Tensor rv = running_var.has_value() ? *running_var : Tensor();
-    Tensor y = at::empty_like(x);
-    Tensor stats = at::empty({(int64_t)nf}, x.options());
-    check_rc(hcm_bn_act_forward(x.data_ptr<float>(), fptr(res), weight.data_ptr<float>(), bias.data_ptr<float>(),
-                                fptr(rm), fptr(rv), (float)momentum, (float)eps, relu ? 1 : 0, N, C, HW,
-                                y.data_ptr<float>(), stats.data_ptr<float>(), current_stream(x)),
-             "hcm_bn_act_forward");
+    Tensor res = opt_contig(residual);
+    BnOut o = bn_forward_raw(x, res, weight, bias, opt_tensor(running_mean), opt_tensor(running_var), momentum, eps, relu);
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["has_res"] = res.defined();
-    ctx->save_for_backward({x, weight, stats, relu ? y : Tensor()});
-    return y;
+    ctx->save_for_backward({x, weight, o.stats, relu ? o.y : Tensor()});
+    return o.y;
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
-    const Tensor& x = saved[0];
-    const Tensor& weight = saved[1];
-    const Tensor& stats = saved[2];
-    const Tensor& y = saved[3];
     const bool relu = ctx->saved_data["relu"].toBool();
     const bool has_res = ctx->saved_data["has_res"].toBool();
-    const int N = (int)x.size(0), C = (int)x.size(1), HW = (int)(x.size(2) * x.size(3));
-    Tensor g = grads[0].contiguous();
-    Tensor dx = ctx->needs_input_grad(0) ? at::empty_like(x) : Tensor();
-    Tensor dz = relu ? at::empty_like(x) : Tensor();
-    Tensor gstats = at::empty_like(stats);
-    check_rc(hcm_bn_act_backward(g.data_ptr<float>(), x.data_ptr<float>(), fptr(y), weight.data_ptr<float>(),
-                                 stats.data_ptr<float>(), relu ? 1 : 0, N, C, HW, fptr(dz), fptr(dx),
-                                 gstats.data_ptr<float>(), current_stream(x)),
-             "hcm_bn_act_backward");
-    Tensor dres = has_res ? (relu ? dz : g) : Tensor();
-    return {dx, dres, gstats.narrow(0, 0, C), gstats.narrow(0, C, C), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    BnGrads o = bn_backward_raw(grads[0].contiguous(), saved[0], saved[3], saved[1], saved[2], relu, has_res,
+                                ctx->needs_input_grad(0));
+    return {o.dx, o.dres, o.dgamma, o.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -129,7 +149,6 @@ struct ConvPlan {
   miopenTensorDescriptor_t xd = nullptr, wd = nullptr, yd = nullptr;
   miopenConvolutionDescriptor_t cd = nullptr;
   int Ho = 0, Wo = 0;
-  bool has_fwd = false, has_bd = false, has_bw = false;
   miopenConvFwdAlgorithm_t fwd_algo{};
   miopenConvBwdDataAlgorithm_t bd_algo{};
   miopenConvBwdWeightsAlgorithm_t bw_algo{};
@@ -172,6 +191,17 @@ miopenHandle_t thread_handle(int dev, hipStream_t stream) {
   return it->second;
 }
 
+// MIOpen registers the kernels of a Find with the handle that ran it, so "found" is tracked per
+// (thread-local handle, plan, direction); the algorithm choice itself is kept in the shared plan.
+enum : unsigned { kFoundFwd = 1, kFoundBwdData = 2, kFoundBwdWeights = 4 };
+bool found_here(ConvPlan* p, unsigned dir) {
+  thread_local std::unordered_map<ConvPlan*, unsigned> found;
+  unsigned& m = found[p];
+  const bool had = (m & dir) != 0;
+  m |= dir;
+  return had;
+}
+
 inline Tensor workspace(size_t bytes, const Tensor& like) {
   return at::empty({(int64_t)(bytes ? bytes : 1)}, like.options().dtype(at::kByte));
 }
@@ -181,94 +211,168 @@ ConvKey key_of(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
                  (int)w.size(0), (int)w.size(2), (int)w.size(3), (int)stride, (int)pad};
 }
 
-struct Conv2d : public torch::autograd::Function<Conv2d> {
-  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, int64_t stride, int64_t pad) {
-    TORCH_CHECK(x_in.is_cuda() && x_in.scalar_type() == at::kFloat && x_in.dim() == 4 && w_in.is_cuda() &&
-                    w_in.scalar_type() == at::kFloat && w_in.dim() == 4 && w_in.size(1) == x_in.size(1),
-                "hcmoco::conv2d needs fp32 ROCm tensors x [N,C,H,W], w [K,C,R,S] (groups = dilation = 1, no bias)");
-    Tensor x = x_in.contiguous(), w = w_in.contiguous();
-    const ConvKey k = key_of(x, w, stride, pad);
-    ConvPlan* p = get_plan(k);
-    hipStream_t st = (hipStream_t)current_stream(x);
-    miopenHandle_t h = thread_handle(k.dev, st);
-    Tensor y = at::empty({k.N, k.K, p->Ho, p->Wo}, x.options());
-    if (!p->has_fwd) {
+Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
+                  w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
+                  w.is_contiguous(),
+              "hcmoco::conv2d needs contiguous fp32 ROCm tensors x [N,C,H,W], w [K,C,R,S] (groups = dilation = 1, no bias)");
+  const ConvKey k = key_of(x, w, stride, pad);
+  ConvPlan* p = get_plan(k);
+  hipStream_t st = (hipStream_t)current_stream(x);
+  miopenHandle_t h = thread_handle(k.dev, st);
+  Tensor y = at::empty({k.N, k.K, p->Ho, p->Wo}, x.options());
+  if (!found_here(p, kFoundFwd)) {
+    size_t need = 0;
+    HCM_MIOPEN(miopenConvolutionForwardGetWorkSpaceSize(h, p->wd, p->xd, p->cd, p->yd, &need));
+    Tensor ws = workspace(need, x);
+    miopenConvAlgoPerf_t perf; int got = 0;
+    HCM_MIOPEN(miopenFindConvolutionForwardAlgorithm(h, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->yd,
+                                                     y.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
+    TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no forward algorithm");
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    p->fwd_algo = perf.fwd_algo; p->fwd_ws = perf.memory;
+  }
+  Tensor ws = workspace(p->fwd_ws, x);
+  const float one = 1.f, zero = 0.f;
+  HCM_MIOPEN(miopenConvolutionForward(h, &one, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->fwd_algo, &zero,
+                                      p->yd, y.data_ptr(), ws.data_ptr(), p->fwd_ws));
+  return y;
+}
+
+struct ConvGrads { Tensor dx, dw; };
+
+// g must be contiguous.
+ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool need_dx,
+                            bool need_dw) {
+  const ConvKey k = key_of(x, w, stride, pad);
+  ConvPlan* p = get_plan(k);
+  hipStream_t st = (hipStream_t)current_stream(x);
+  miopenHandle_t h = thread_handle(k.dev, st);
+  const float one = 1.f, zero = 0.f;
+  ConvGrads o;
+  if (need_dx) {
+    o.dx = at::empty_like(x);
+    if (!found_here(p, kFoundBwdData)) {
       size_t need = 0;
-      HCM_MIOPEN(miopenConvolutionForwardGetWorkSpaceSize(h, p->wd, p->xd, p->cd, p->yd, &need));
+      HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
       Tensor ws = workspace(need, x);
       miopenConvAlgoPerf_t perf; int got = 0;
-      HCM_MIOPEN(miopenFindConvolutionForwardAlgorithm(h, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->yd,
-                                                       y.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
-      TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no forward algorithm");
+      HCM_MIOPEN(miopenFindConvolutionBackwardDataAlgorithm(h, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->xd,
+                                                            o.dx.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
+      TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no backward-data algorithm");
       std::lock_guard<std::mutex> lock(g_plan_mutex);
-      p->fwd_algo = perf.fwd_algo; p->fwd_ws = perf.memory; p->has_fwd = true;
+      p->bd_algo = perf.bwd_data_algo; p->bd_ws = perf.memory;
     }
-    Tensor ws = workspace(p->fwd_ws, x);
-    const float one = 1.f, zero = 0.f;
-    HCM_MIOPEN(miopenConvolutionForward(h, &one, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->fwd_algo, &zero,
-                                        p->yd, y.data_ptr(), ws.data_ptr(), p->fwd_ws));
+    Tensor ws = workspace(p->bd_ws, x);
+    HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->bd_algo, &zero,
+                                             p->xd, o.dx.data_ptr(), ws.data_ptr(), p->bd_ws));
+  }
+  if (need_dw) {
+    o.dw = at::empty_like(w);
+    if (!found_here(p, kFoundBwdWeights)) {
+      size_t need = 0;
+      HCM_MIOPEN(miopenConvolutionBackwardWeightsGetWorkSpaceSize(h, p->yd, p->xd, p->cd, p->wd, &need));
+      Tensor ws = workspace(need, x);
+      miopenConvAlgoPerf_t perf; int got = 0;
+      HCM_MIOPEN(miopenFindConvolutionBackwardWeightsAlgorithm(h, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, p->wd,
+                                                               o.dw.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
+      TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no backward-weights algorithm");
+      std::lock_guard<std::mutex> lock(g_plan_mutex);
+      p->bw_algo = perf.bwd_weights_algo; p->bw_ws = perf.memory;
+    }
+    Tensor ws = workspace(p->bw_ws, x);
+    HCM_MIOPEN(miopenConvolutionBackwardWeights(h, &one, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, p->bw_algo, &zero,
+                                                p->wd, o.dw.data_ptr(), ws.data_ptr(), p->bw_ws));
+  }
+  return o;
+}
+
+struct Conv2d : public torch::autograd::Function<Conv2d> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, int64_t stride, int64_t pad) {
+    Tensor x = x_in.contiguous(), w = w_in.contiguous();
+    Tensor y = conv_forward_raw(x, w, stride, pad);
     ctx->save_for_backward({x, w});
     ctx->saved_data["stride"] = stride;
     ctx->saved_data["pad"] = pad;
     return y;
   }
-
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
-    const Tensor& x = saved[0];
-    const Tensor& w = saved[1];
-    const int64_t stride = ctx->saved_data["stride"].toInt(), pad = ctx->saved_data["pad"].toInt();
-    const ConvKey k = key_of(x, w, stride, pad);
-    ConvPlan* p = get_plan(k);
-    hipStream_t st = (hipStream_t)current_stream(x);
-    miopenHandle_t h = thread_handle(k.dev, st);
-    Tensor g = grads[0].contiguous();
-    const float one = 1.f, zero = 0.f;
-    Tensor dx, dw;
-    if (ctx->needs_input_grad(0)) {
-      dx = at::empty_like(x);
-      if (!p->has_bd) {
-        size_t need = 0;
-        HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
-        Tensor ws = workspace(need, x);
-        miopenConvAlgoPerf_t perf; int got = 0;
-        HCM_MIOPEN(miopenFindConvolutionBackwardDataAlgorithm(h, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->xd,
-                                                              dx.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
-        TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no backward-data algorithm");
-        std::lock_guard<std::mutex> lock(g_plan_mutex);
-        p->bd_algo = perf.bwd_data_algo; p->bd_ws = perf.memory; p->has_bd = true;
-      }
-      Tensor ws = workspace(p->bd_ws, x);
-      HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->bd_algo, &zero,
-                                               p->xd, dx.data_ptr(), ws.data_ptr(), p->bd_ws));
-    }
-    if (ctx->needs_input_grad(1)) {
-      dw = at::empty_like(w);
-      if (!p->has_bw) {
-        size_t need = 0;
-        HCM_MIOPEN(miopenConvolutionBackwardWeightsGetWorkSpaceSize(h, p->yd, p->xd, p->cd, p->wd, &need));
-        Tensor ws = workspace(need, x);
-        miopenConvAlgoPerf_t perf; int got = 0;
-        HCM_MIOPEN(miopenFindConvolutionBackwardWeightsAlgorithm(h, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, p->wd,
-                                                                 dw.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
-        TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no backward-weights algorithm");
-        std::lock_guard<std::mutex> lock(g_plan_mutex);
-        p->bw_algo = perf.bwd_weights_algo; p->bw_ws = perf.memory; p->has_bw = true;
-      }
-      Tensor ws = workspace(p->bw_ws, x);
-      HCM_MIOPEN(miopenConvolutionBackwardWeights(h, &one, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, p->bw_algo, &zero,
-                                                  p->wd, dw.data_ptr(), ws.data_ptr(), p->bw_ws));
-    }
-    return {dx, dw, Tensor(), Tensor()};
+    ConvGrads o = conv_backward_raw(grads[0].contiguous(), saved[0], saved[1], ctx->saved_data["stride"].toInt(),
+                                    ctx->saved_data["pad"].toInt(), ctx->needs_input_grad(0), ctx->needs_input_grad(1));
+    return {o.dx, o.dw, Tensor(), Tensor()};
   }
 };
 
 Tensor conv2d(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) { return Conv2d::apply(x, w, stride, pad); }
 
+// conv -> bn [+ residual] [-> relu] as ONE autograd node (one node per layer in the backward walk).
+struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, int64_t stride, int64_t pad,
+                        const c10::optional<Tensor>& residual, const Tensor& gamma, const Tensor& beta,
+                        const c10::optional<Tensor>& running_mean, const c10::optional<Tensor>& running_var,
+                        double momentum, double eps, bool relu) {
+    Tensor x = x_in.contiguous(), w = w_in.contiguous();
+    Tensor z = conv_forward_raw(x, w, stride, pad);
+    Tensor res = opt_contig(residual);
+    BnOut o = bn_forward_raw(z, res, gamma, beta, opt_tensor(running_mean), opt_tensor(running_var), momentum, eps, relu);
+    ctx->saved_data["stride"] = stride;
+    ctx->saved_data["pad"] = pad;
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["has_res"] = res.defined();
+    ctx->save_for_backward({x, w, z, gamma, o.stats, relu ? o.y : Tensor()});
+    return o.y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const bool relu = ctx->saved_data["relu"].toBool();
+    const bool has_res = ctx->saved_data["has_res"].toBool();
+    BnGrads b = bn_backward_raw(grads[0].contiguous(), saved[2], saved[5], saved[3], saved[4], relu, has_res, true);
+    ConvGrads c = conv_backward_raw(b.dx, saved[0], saved[1], ctx->saved_data["stride"].toInt(),
+                                    ctx->saved_data["pad"].toInt(), ctx->needs_input_grad(0), ctx->needs_input_grad(1));
+    return {c.dx, c.dw, Tensor(), Tensor(), b.dres, b.dgamma, b.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor conv_bn_act(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, const c10::optional<Tensor>& residual,
+                   const Tensor& gamma, const Tensor& beta, const c10::optional<Tensor>& running_mean,
+                   const c10::optional<Tensor>& running_var, double momentum, double eps, bool relu) {
+  return ConvBnAct::apply(x, w, stride, pad, residual, gamma, beta, running_mean, running_var, momentum, eps, relu);
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) on NCHW maps: forward hcm_upsample_bilinear2d,
+// backward ATen's kernel (official_hrnet.py:231-236, build_backbone.py:247-254).
+struct Upsample : public torch::autograd::Function<Upsample> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, int64_t Ho, int64_t Wo) {
+    TORCH_CHECK(x_in.is_cuda() && x_in.scalar_type() == at::kFloat && x_in.dim() == 4,
+                "hcmoco::upsample_bilinear needs fp32 ROCm maps (no CPU fallback exists)");
+    Tensor x = x_in.contiguous();
+    const int64_t N = x.size(0), C = x.size(1), Hi = x.size(2), Wi = x.size(3);
+    Tensor y = at::empty({N, C, Ho, Wo}, x.options());
+    check_rc(hcm_upsample_bilinear2d(x.data_ptr<float>(), (int)(N * C), (int)Hi, (int)Wi, (int)Ho, (int)Wo,
+                                     y.data_ptr<float>(), current_stream(x)),
+             "hcm_upsample_bilinear2d");
+    ctx->saved_data["in"] = std::vector<int64_t>{N, C, Hi, Wi};
+    ctx->saved_data["out"] = std::vector<int64_t>{Ho, Wo};
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto in = ctx->saved_data["in"].toIntVector();
+    const auto out = ctx->saved_data["out"].toIntVector();
+    Tensor gi = at::upsample_bilinear2d_backward(grads[0].contiguous(), out, in, false, c10::nullopt, c10::nullopt);
+    return {gi, Tensor(), Tensor()};
+  }
+};
+
+Tensor upsample_bilinear(const Tensor& x, int64_t Ho, int64_t Wo) { return Upsample::apply(x, Ho, Wo); }
+
 }  // namespace
 
 TORCH_LIBRARY(hcmoco, m) {
   m.def("conv2d(Tensor x, Tensor weight, int stride, int pad) -> Tensor", &conv2d);
+  m.def("conv_bn_act(Tensor x, Tensor weight, int stride, int pad, Tensor? residual, Tensor gamma, Tensor beta, "
+        "Tensor? running_mean, Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &conv_bn_act);
+  m.def("upsample_bilinear(Tensor x, int out_h, int out_w) -> Tensor", &upsample_bilinear);
   m.def("bn_act(Tensor x, Tensor? residual, Tensor weight, Tensor bias, Tensor? running_mean, "
         "Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &bn_act);
 }

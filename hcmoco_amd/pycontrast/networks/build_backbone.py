@@ -49,12 +49,12 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # projections (aux entries are None).  Off by default = the reference data flow.
         self.defer_projection = False
         # The three encoders are independent until the heads.  HCM_TWO_STREAMS is a bit mask:
-        #   1 (default)  SemGCN on a side HIP stream, issued first: its single-workgroup kernels
+        #   1            SemGCN on a side HIP stream, issued first: its single-workgroup kernels
         #                (3.5 ms per step, one CU) run underneath the HRNets instead of in line;
-        #   2            encoder2 on a second side stream (small HRNet kernels overlap);
+        #   2            encoder2 on a second side stream (small HRNet kernels overlap); default 3 = 1|2
         #   4            with 2: encoder2 is also issued from a helper thread.
         # Backward follows automatically: autograd replays every node on its forward stream.
-        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '1'))
+        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '3'))
         self._side_streams = {}
         self._helper = None
 

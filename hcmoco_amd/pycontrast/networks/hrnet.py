@@ -28,6 +28,8 @@ def upsample_bilinear(x, size):
     runs in ``hcm_upsample_bilinear2d`` (ATen's NCHW forward is the single largest kernel of the
     step there, profiles/r01_bench_one_step_summary.csv); CPU tensors use ATen."""
     if x.is_cuda and x.dtype == torch.float32:
+        if x.is_contiguous():
+            return _glue_op('upsample_bilinear')(x, int(size[0]), int(size[1]))
         from ... import hip_ops
         return hip_ops.upsample_bilinear(x, size)
     return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
@@ -59,12 +61,30 @@ class Conv2d(nn.Conv2d):
     descriptors/algorithms (ATen spends ~125 us of host time per layer and step on a 25 us kernel;
     csrc/torch_glue/hcm_torch_glue.cpp).  HCM_CONV_GLUE=0 or any other configuration: stock ATen."""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.glue_ok = (self.bias is None and self.groups == 1 and self.dilation == (1, 1)
+                        and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]
+                        and isinstance(self.padding, tuple) and self.padding_mode == 'zeros')
+
     def forward(self, x):
-        if (CONV_GLUE and x.is_cuda and x.dtype == torch.float32 and self.bias is None and self.groups == 1
-                and self.dilation == (1, 1) and self.stride[0] == self.stride[1]
-                and self.padding[0] == self.padding[1] and self.padding_mode == 'zeros'):
+        if CONV_GLUE and self.glue_ok and x.is_cuda and x.dtype == torch.float32:
             return _glue_op('conv2d')(x, self.weight, self.stride[0], self.padding[0])
         return super().forward(x)
+
+
+def conv_bn(conv, bn, x, residual=None, relu=False):
+    """``relu?(bn(conv(x)) + residual?)``; a training step on the MI355X runs it as ONE autograd node
+    (torch.ops.hcmoco.conv_bn_act: MIOpen convolution + hcm_bn_act_*), anything else as the stock
+    composition of the two modules."""
+    if (CONV_GLUE and FUSED_BN and bn.training and conv.glue_ok and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4):
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        ho, wo = (x.shape[2] + 2 * p - k) // s + 1, (x.shape[3] + 2 * p - conv.kernel_size[1]) // s + 1
+        if (ho * wo) % 4 == 0:
+            return _glue_op('conv_bn_act')(x, conv.weight, s, p, residual, bn.weight, bn.bias, bn.running_mean,
+                                           bn.running_var, bn.momentum, bn.eps, relu)
+    return bn(conv(x), residual=residual, relu=relu)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -96,7 +116,7 @@ class ConvBn(nn.Sequential):
     normalisation, the optional residual and the ReLU run as one op."""
 
     def forward(self, x, residual=None):
-        return self[1](self[0](x), residual=residual, relu=len(self) == 3)
+        return conv_bn(self[0], self[1], x, residual, len(self) == 3)
 
 
 def _conv_bn(cin, cout, k, stride=1, relu=False):
@@ -120,8 +140,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
-        y = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(y), residual=skip, relu=True)
+        y = conv_bn(self.conv1, self.bn1, x, None, True)
+        return conv_bn(self.conv2, self.bn2, y, skip, True)
 
 
 class Bottleneck(nn.Module):
@@ -140,9 +160,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         skip = x if self.downsample is None else self.downsample(x)
-        y = self.bn1(self.conv1(x), relu=True)
-        y = self.bn2(self.conv2(y), relu=True)
-        return self.bn3(self.conv3(y), residual=skip, relu=True)
+        y = conv_bn(self.conv1, self.bn1, x, None, True)
+        y = conv_bn(self.conv2, self.bn2, y, None, True)
+        return conv_bn(self.conv3, self.bn3, y, skip, True)
 
 
 def _block_chain(block, cin, planes, n):
@@ -256,8 +276,8 @@ class HighResolutionNet(nn.Module):
     def forward(self, x):
         if self.training:
             self._count_batch()
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, None, True)
+        x = conv_bn(self.conv2, self.bn2, x, None, True)
         x = self.layer1(x)
         ys = [x]
         for s in (2, 3, 4):

@@ -80,3 +80,46 @@ def test_hrnet_glue_conv_matches_aten():
     worst = max(((res[True][1][n] - gb).abs().max().item() / max(gb.abs().max().item(), 1e-3 * gscale), n)
                 for n, gb in res[False][1].items())
     assert worst[0] <= 5e-2, worst
+
+
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_conv_bn_act_node_equals_its_two_parts(relu, with_res):
+    """The single node must issue exactly the launches of conv2d followed by bn_act: bit-identical."""
+    from hcmoco_amd import _lib
+    ops = _lib.torch_glue()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 18, 32, 32, generator=g).to(dev)
+    w = (torch.randn(36, 18, 3, 3, generator=g) / 13.0).to(dev)
+    res = torch.randn(8, 36, 16, 16, generator=g).to(dev) if with_res else None
+    gamma, beta = (torch.rand(36, generator=g) + 0.5).to(dev), torch.randn(36, generator=g).to(dev)
+    gy = torch.randn(8, 36, 16, 16, generator=g).to(dev)
+    outs = []
+    for fused in (True, False):
+        xs, ws, gs, bs = (t.clone().requires_grad_() for t in (x, w, gamma, beta))
+        rs = res.clone().requires_grad_() if with_res else None
+        rm, rv = torch.zeros(36, device=dev), torch.ones(36, device=dev)
+        if fused:
+            y = ops.conv_bn_act(xs, ws, 2, 1, rs, gs, bs, rm, rv, 0.01, 1e-5, relu)
+        else:
+            y = ops.bn_act(ops.conv2d(xs, ws, 2, 1), rs, gs, bs, rm, rv, 0.01, 1e-5, relu)
+        y.backward(gy)
+        outs.append([y.detach(), xs.grad, ws.grad, gs.grad, bs.grad, rm, rv] + ([rs.grad] if with_res else []))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_upsample_node_matches_interpolate():
+    from hcmoco_amd import _lib
+    ops = _lib.torch_glue()
+    dev = torch.device('cuda:0')
+    x = torch.randn(4, 36, 16, 16, device=dev)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = ops.upsample_bilinear(xa, 64, 64)
+    yb = F.interpolate(xb, size=(64, 64), mode='bilinear', align_corners=False)
+    gy = torch.randn_like(yb)
+    ya.backward(gy)
+    yb.backward(gy)
+    _close(ya, yb, 1e-6)
+    _close(xa.grad, xb.grad, 1e-6)
