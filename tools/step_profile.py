@@ -25,14 +25,27 @@ for s, e, n in win:
     agg[n][0] += 1
     agg[n][1] += e - s
     busy += e - s
+# union of the kernel intervals: with several HIP streams kernels overlap, so "some kernel is running"
+# (the GPU-bound floor of the step) is less than the sum of durations
+active, cur_s, cur_e = 0, None, None
+for s, e, _ in win:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None:
+            active += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+if cur_e is not None:
+    active += cur_e - cur_s
 items = sorted(agg.items(), key=lambda kv: -kv[1][1])
 with open(out, 'w') as f:
     w = csv.writer(f)
     w.writerow(['# one steady-state step: window between the last two launches of', marker])
-    w.writerow(['# wall_ms', round(wall / 1e6, 3), 'gpu_busy_ms', round(busy / 1e6, 3), 'kernel_launches', len(win)])
+    w.writerow(['# wall_ms', round(wall / 1e6, 3), 'gpu_busy_ms', round(busy / 1e6, 3), 'kernel_launches', len(win),
+                'gpu_active_ms (union over streams)', round(active / 1e6, 3)])
     w.writerow(['Name', 'Calls', 'TotalDurationUs', 'AverageUs', 'PercentOfBusy'])
     for n, (c, t) in items:
         w.writerow([n[:160], c, round(t / 1e3, 2), round(t / 1e3 / c, 2), round(100.0 * t / busy, 2)])
-print('step wall %.2f ms, gpu busy %.2f ms, %d launches' % (wall / 1e6, busy / 1e6, len(win)))
+print('step wall %.2f ms, gpu busy (sum) %.2f ms, gpu active (union) %.2f ms, %d launches' % (wall / 1e6, busy / 1e6, active / 1e6, len(win)))
 for n, (c, t) in items[:14]:
     print('%8.2f ms %6d  %s' % (t / 1e6, c, n[:110]))
