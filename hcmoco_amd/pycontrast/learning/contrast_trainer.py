@@ -31,6 +31,7 @@ class ContrastTrainer(BaseTrainer):
         self.engine = engine if engine is not None else HipLossEngine()
         self.graphed = None          # GraphedEncoder once enable_graphs() ran
         self.manual_allreduce = False
+        self.async_wgrad = None      # torch.ops.hcmoco namespace once deferred weight gradients are on
 
     def enable_graphs(self, model, sample_batch, stage2=True):
         """Capture the encoder forward/backward as hipGraphs (learning/graphed.py).  Call BEFORE
@@ -71,7 +72,21 @@ class ContrastTrainer(BaseTrainer):
             model_ema.to(self.device)
         if args.amp:
             raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
-        if dist.is_initialized() and dist.get_world_size() > 1 and self.graphed is None:
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        if self.device.type == 'cuda' and self.graphed is None and os.environ.get('HCM_ASYNC_WGRAD', '1') != '0':
+            # Deferred weight gradients (csrc/torch_glue): a helper thread issues the 620 MIOpen
+            # backward-weights calls while the autograd thread walks on.  Its contract -- gradients reset
+            # with set_to_none, nothing reads .grad before wgrad_join() -- rules out
+            # DistributedDataParallel's in-backward bucket copies, so N > 1 uses the single flat RCCL
+            # all-reduce after the join (78 MB over xGMI: well under a millisecond of a ~60 ms step).
+            from ... import _lib
+            self.async_wgrad = _lib.torch_glue()
+            self.async_wgrad.set_async_wgrad(True)
+            if multi:
+                from .graphed import broadcast_model
+                broadcast_model(model)
+                self.manual_allreduce = True
+        if multi and self.graphed is None and not self.manual_allreduce:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # stage 1 never touches the 1x1 feature-map projections when --linear_feat_map 1 is set
             unused = args.mem == 'bank' and bool(getattr(args, 'linear_feat_map', 0))
@@ -221,6 +236,8 @@ class ContrastTrainer(BaseTrainer):
             loss = total
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.async_wgrad is not None:
+            self.async_wgrad.wgrad_join()
         if self.manual_allreduce:
             from .graphed import allreduce_grads
             allreduce_grads([p for g in optimizer.param_groups for p in g['params']], dist.get_world_size())

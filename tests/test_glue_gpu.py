@@ -134,3 +134,31 @@ def test_upsample_node_matches_interpolate():
     yb.backward(gy)
     _close(ya, yb, 1e-6)
     _close(xa.grad, xb.grad, 1e-6)
+
+
+def test_deferred_weight_gradients_equal_inline_ones():
+    """set_async_wgrad(True): dW calls are issued by the helper thread on the same stream; after
+    wgrad_join() every gradient equals the inline run (to the rounding of MIOpen's atomic reduction)."""
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.networks import hrnet
+    ops = _lib.torch_glue()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    net = hrnet.get_hrnet_w18_backbone().to(dev).train()
+    x = torch.randn(8, 3, 128, 128, device=dev)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    runs = []
+    for deferred in (False, True, True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        ops.set_async_wgrad(deferred)
+        try:
+            ys = net(x)
+            sum(y.square().mean() for y in ys).backward()
+            ops.wgrad_join()
+        finally:
+            ops.set_async_wgrad(False)
+        runs.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    for other in runs[1:]:
+        for n, g in runs[0].items():
+            _close(other[n], g, 1e-4)

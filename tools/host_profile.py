@@ -15,7 +15,7 @@ it = iter(data)
 for _ in range(5):
     tr.train_step(next(it), model, contrast, opt, True)
 torch.cuda.synchronize()
-T = dict(fwd=0.0, gather=0.0, bank=0.0, fmap=0.0, bwd=0.0, opt=0.0)
+T = dict(fwd=0.0, gather=0.0, bank=0.0, fmap=0.0, bwd=0.0, join=0.0, opt=0.0)
 N = 15
 for _ in range(N):
     d = next(it)
@@ -33,9 +33,12 @@ for _ in range(N):
     opt.zero_grad(set_to_none=True)
     (total + ft).backward()
     t5 = time.perf_counter()
+    if tr.async_wgrad is not None:
+        tr.async_wgrad.wgrad_join()
+    t5b = time.perf_counter()
     opt.step()
     t6 = time.perf_counter()
-    for k, v in zip(T, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+    for k, v in zip(T, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5b - t5, t6 - t5b)):
         T[k] += v
     torch.cuda.synchronize()
 print('host enqueue ms per step:', {k: round(1e3 * v / N, 2) for k, v in T.items()}, 'sum', round(1e3 * sum(T.values()) / N, 2))

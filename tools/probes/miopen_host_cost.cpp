@@ -65,6 +65,28 @@ int main(int argc, char** argv) {
     double t3 = now(); CK(hipStreamSynchronize(st)); double t4 = now();
     if (rep) printf("immediate API  C=%d H=%d: host us/call fwd %.1f  bwd-data %.1f  bwd-weights %.1f   (drain %.1f ms)\n", C, H, (t1 - t0) / IT * 1e6, (t2 - t1) / IT * 1e6, (t3 - t2) / IT * 1e6, (t4 - t3) * 1e3);
   }
+  // every backward-weights / backward-data / forward solution MIOpen offers: host enqueue vs GPU time
+  {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (size_t i = 0; i < sw.size() && i < 12; ++i) {
+      if (sw[i].workspace_size > wsz) continue;
+      if (miopenConvolutionBackwardWeightsCompileSolution(h, yd, xd, cd, wd, sw[i].solution_id) != 0) continue;
+      for (int k = 0; k < 3; ++k) miopenConvolutionBackwardWeightsImmediate(h, yd, y, xd, x, cd, wd, dw, ws, wsz, sw[i].solution_id);
+      CK(hipStreamSynchronize(st)); double t0 = now(); CK(hipEventRecord(e0, st));
+      for (int k = 0; k < 100; ++k) miopenConvolutionBackwardWeightsImmediate(h, yd, y, xd, x, cd, wd, dw, ws, wsz, sw[i].solution_id);
+      double t1 = now(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("  wrw solution %llu algo %d: est %.3f ms, ws %zu  host %.1f us/call  wall %.1f us/call\n", (unsigned long long)sw[i].solution_id, (int)sw[i].algorithm, sw[i].time, sw[i].workspace_size, (t1 - t0) * 1e4, ms * 10);
+    }
+    for (size_t i = 0; i < sol.size() && i < 8; ++i) {
+      if (sol[i].workspace_size > wsz) continue;
+      if (miopenConvolutionForwardCompileSolution(h, wd, xd, cd, yd, sol[i].solution_id) != 0) continue;
+      for (int k = 0; k < 3; ++k) miopenConvolutionForwardImmediate(h, wd, w, xd, x, cd, yd, y, ws, wsz, sol[i].solution_id);
+      CK(hipStreamSynchronize(st)); double t0 = now(); CK(hipEventRecord(e0, st));
+      for (int k = 0; k < 100; ++k) miopenConvolutionForwardImmediate(h, wd, w, xd, x, cd, yd, y, ws, wsz, sol[i].solution_id);
+      double t1 = now(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("  fwd solution %llu algo %d: est %.3f ms, ws %zu  host %.1f us/call  wall %.1f us/call\n", (unsigned long long)sol[i].solution_id, (int)sol[i].algorithm, sol[i].time, sol[i].workspace_size, (t1 - t0) * 1e4, ms * 10);
+    }
+  }
   // GPU time per call of each (events)
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); float ms;
   CK(hipEventRecord(a, st)); for (int i = 0; i < 100; ++i) CK(miopenConvolutionForwardImmediate(h, wd, w, xd, x, cd, yd, y, ws, wsz, sol[0].solution_id));
