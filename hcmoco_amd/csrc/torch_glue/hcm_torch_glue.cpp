@@ -20,6 +20,7 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <vector>
 
 #include "hcmoco_hip.h"
 
@@ -270,15 +271,33 @@ class WgradWorker {
     {
       std::lock_guard<std::mutex> lk(m_);
       if (!started_) { th_ = std::thread([this] { loop(); }); th_.detach(); started_ = true; }
+      bool seen = false;
+      for (const auto& s : used_) seen = seen || s == t.stream;
+      if (!seen) used_.push_back(t.stream);
       q_.emplace_back(std::move(t));
       ++pending_;
     }
     cv_.notify_one();
   }
+  // Blocks until every queued call is in its stream, then orders the caller's current stream behind
+  // the streams those calls went to (autograd's own end-of-backward stream sync ran before them).
   void join() {
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
-    if (!error_.empty()) { std::string e; e.swap(error_); TORCH_CHECK(false, "deferred weight gradient failed: ", e); }
+    std::vector<c10::hip::HIPStream> used;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      done_.wait(lk, [this] { return pending_ == 0; });
+      used.swap(used_);
+      if (!error_.empty()) { std::string e; e.swap(error_); TORCH_CHECK(false, "deferred weight gradient failed: ", e); }
+    }
+    for (const auto& s : used) {
+      const auto cur = c10::hip::getCurrentHIPStream(s.device_index());
+      if (cur == s) continue;
+      hipEvent_t ev;
+      TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+      TORCH_CHECK(hipEventRecord(ev, s.stream()) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
+      (void)hipEventDestroy(ev);
+    }
   }
 
  private:
@@ -293,7 +312,7 @@ class WgradWorker {
       }
       try {
         c10::hip::HIPStreamGuard guard(t.stream);   // device + current stream of this thread
-        run_wgrad(t.plan, t.g, t.x, t.dw, t.w, &ws_);
+        run_wgrad(t.plan, t.g, t.x, t.dw, t.w, &ws_[t.stream.stream()]);
       } catch (const std::exception& e) {
         std::lock_guard<std::mutex> lk(m_);
         error_ = e.what();
@@ -312,7 +331,8 @@ class WgradWorker {
   bool started_ = false;
   std::thread th_;
   std::string error_;
-  Tensor ws_;   // grown to the largest workspace seen; only ever used on the task's stream, in order
+  std::vector<c10::hip::HIPStream> used_;            // streams written to since the last join
+  std::unordered_map<hipStream_t, Tensor> ws_;       // per stream, grown to the largest workspace seen, used in order
 };
 
 // leaked on purpose: the helper thread may still be parked in wait() when static destructors run

@@ -137,28 +137,61 @@ def test_upsample_node_matches_interpolate():
 
 
 def test_deferred_weight_gradients_equal_inline_ones():
-    """set_async_wgrad(True): dW calls are issued by the helper thread on the same stream; after
-    wgrad_join() every gradient equals the inline run (to the rounding of MIOpen's atomic reduction)."""
+    """set_async_wgrad(True): dW calls are issued by the helper thread on the stream of their node; after
+    wgrad_join() every gradient equals the inline run (to the rounding of MIOpen's atomic reduction).
+    A well-conditioned 8-layer chain on two streams for the element-wise check (a whole HRNet is
+    chaotic run to run, see _grads_agree), then the HRNet by gradient direction."""
     from hcmoco_amd import _lib
     from hcmoco_amd.pycontrast.networks import hrnet
     ops = _lib.torch_glue()
     dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(16, 18, 32, 32, generator=g).to(dev)
+    ws = [(torch.randn(18, 18, 3, 3, generator=g) / 12.7).to(dev).requires_grad_() for _ in range(16)]
+    gam = [(torch.rand(18, generator=g) + 0.5).to(dev).requires_grad_() for _ in range(16)]
+    bet = [torch.randn(18, generator=g).to(dev).requires_grad_() for _ in range(16)]
+    side = torch.cuda.Stream()
+
+    def chain(lo, hi):
+        y = x
+        for i in range(lo, hi):
+            y = ops.conv_bn_act(y, ws[i], 1, 1, y if i % 2 else None, gam[i], bet[i], None, None, 0.1, 1e-5, True)
+        return y
+
+    runs = []
+    for deferred in (False, True, True):
+        for t in ws + gam + bet:
+            t.grad = None
+        ops.set_async_wgrad(deferred)
+        try:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                b = chain(8, 16)
+            a = chain(0, 8)
+            torch.cuda.current_stream().wait_stream(side)
+            (a.square().mean() + b.square().mean()).backward()
+            ops.wgrad_join()
+        finally:
+            ops.set_async_wgrad(False)
+        runs.append([t.grad.clone() for t in ws + gam + bet])
+    for other in runs[1:]:
+        for a, b in zip(other, runs[0]):
+            _close(a, b, 1e-4)
+
     torch.manual_seed(0)
     net = hrnet.get_hrnet_w18_backbone().to(dev).train()
-    x = torch.randn(8, 3, 128, 128, device=dev)
+    xi = torch.randn(8, 3, 128, 128, device=dev)
     state = {k: v.clone() for k, v in net.state_dict().items()}
-    runs = []
-    for deferred in (False, True, True, False):
+    grads = []
+    for deferred in (False, True):
         net.load_state_dict(state)
         net.zero_grad(set_to_none=True)
         ops.set_async_wgrad(deferred)
         try:
-            ys = net(x)
+            ys = net(xi)
             sum(y.square().mean() for y in ys).backward()
             ops.wgrad_join()
         finally:
             ops.set_async_wgrad(False)
-        runs.append({n: p.grad.clone() for n, p in net.named_parameters()})
-    for other in runs[1:]:
-        for n, g in runs[0].items():
-            _close(other[n], g, 1e-4)
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    _grads_agree(grads[1], grads[0])
