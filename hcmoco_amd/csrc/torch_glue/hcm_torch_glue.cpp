@@ -238,10 +238,11 @@ Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     p->fwd_algo = perf.fwd_algo; p->fwd_ws = perf.memory;
   }
-  Tensor ws = workspace(p->fwd_ws, x);
+  Tensor ws;                                   // the Winograd kernels HRNet mostly gets need none
+  if (p->fwd_ws) ws = workspace(p->fwd_ws, x);
   const float one = 1.f, zero = 0.f;
   HCM_MIOPEN(miopenConvolutionForward(h, &one, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->fwd_algo, &zero,
-                                      p->yd, y.data_ptr(), ws.data_ptr(), p->fwd_ws));
+                                      p->yd, y.data_ptr(), p->fwd_ws ? ws.data_ptr() : nullptr, p->fwd_ws));
   return y;
 }
 
@@ -363,9 +364,10 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
       std::lock_guard<std::mutex> lock(g_plan_mutex);
       p->bd_algo = perf.bwd_data_algo; p->bd_ws = perf.memory;
     }
-    Tensor ws = workspace(p->bd_ws, x);
+    Tensor ws;
+    if (p->bd_ws) ws = workspace(p->bd_ws, x);
     HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->bd_algo, &zero,
-                                             p->xd, o.dx.data_ptr(), ws.data_ptr(), p->bd_ws));
+                                             p->xd, o.dx.data_ptr(), p->bd_ws ? ws.data_ptr() : nullptr, p->bd_ws));
   }
   if (need_dw) {
     o.dw = at::empty_like(w);

@@ -73,7 +73,10 @@ class ContrastTrainer(BaseTrainer):
         if args.amp:
             raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
         multi = dist.is_initialized() and dist.get_world_size() > 1
-        if self.device.type == 'cuda' and self.graphed is None and os.environ.get('HCM_ASYNC_WGRAD', '1') != '0':
+        sync = getattr(args, 'grad_sync', 'auto')
+        deferred = (self.device.type == 'cuda' and self.graphed is None and sync != 'ddp'
+                    and os.environ.get('HCM_ASYNC_WGRAD', '1') != '0')
+        if deferred:
             # Deferred weight gradients (csrc/torch_glue): a helper thread issues the 620 MIOpen
             # backward-weights calls while the autograd thread walks on.  Its contract -- gradients reset
             # with set_to_none, nothing reads .grad before wgrad_join() -- rules out
@@ -82,10 +85,10 @@ class ContrastTrainer(BaseTrainer):
             from ... import _lib
             self.async_wgrad = _lib.torch_glue()
             self.async_wgrad.set_async_wgrad(True)
-            if multi:
-                from .graphed import broadcast_model
-                broadcast_model(model)
-                self.manual_allreduce = True
+        if multi and self.graphed is None and (deferred or sync == 'flat'):
+            from .graphed import broadcast_model
+            broadcast_model(model)
+            self.manual_allreduce = True
         if multi and self.graphed is None and not self.manual_allreduce:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # stage 1 never touches the 1x1 feature-map projections when --linear_feat_map 1 is set

@@ -129,7 +129,7 @@ argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNe
         '--in_channel_list', '3,3', '--batch_size', '4', '--nce_k', '32', '--dist-backend', 'gloo', '--synthetic',
         '--synthetic_n_data', '128', '--synthetic_size', '64', '--synthetic_steps', '2', '--epochs', '1',
         '--linear_feat_map', '1', '--modality_missing', '1', '--pri3d_num_samples_per_image', '8',
-        '--model_path', tmp, '--tb_path', tmp, '--seed', '5', '--print_freq', '100']
+        '--model_path', tmp, '--tb_path', tmp, '--seed', '5', '--print_freq', '100', '--grad_sync', %r]
 outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
 # parameters only: BatchNorm running statistics are per-replica by design (local batches)
 w = torch.cat([p.detach().flatten().double() for p in trainer.unwrap(model).parameters()])
@@ -138,13 +138,11 @@ torch.save({'bank': [b.clone() for b in contrast.banks()], 'wsum': w.sum(), 'wab
 '''
 
 
-def test_world_size_2_gloo_replicas_stay_identical():
-    """N>1 path on CPU: packed all-gather -> the SAME rank-major bank update on every replica,
-    all three banks broadcast at start, DDP-averaged gradients -> identical weights."""
+def _run_two_ranks(grad_sync):
     out = tempfile.mkdtemp()
     script = os.path.join(out, 'worker.py')
     with open(script, 'w') as f:
-        f.write(WORKER % (ROOT, out))
+        f.write(WORKER % (ROOT, grad_sync, out))
     port = str(20000 + os.getpid() % 20000)
     env = dict(os.environ, OMP_NUM_THREADS='2')
     res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
@@ -155,6 +153,20 @@ def test_world_size_2_gloo_replicas_stay_identical():
     for b0, b1 in zip(r0['bank'], r1['bank']):
         assert torch.equal(b0, b1)                                     # replicated banks stay bit-identical
     assert float(r0['wsum']) == float(r1['wsum']) and float(r0['wabs']) == float(r1['wabs'])
+    return r0
+
+
+def test_world_size_2_gloo_replicas_stay_identical():
+    """N>1 path on CPU: packed all-gather -> the SAME rank-major bank update on every replica,
+    all three banks broadcast at start, averaged gradients -> identical weights; the bucketed
+    (DistributedDataParallel) and the flat (one all-reduce after backward, the ROCm default) gradient
+    averaging give the same model."""
+    ddp = _run_two_ranks('ddp')
+    flat = _run_two_ranks('flat')
+    for b0, b1 in zip(ddp['bank'], flat['bank']):
+        assert torch.allclose(b0, b1, rtol=1e-5, atol=1e-6)
+    assert abs(float(ddp['wsum']) - float(flat['wsum'])) <= 1e-6 * float(ddp['wabs'])
+    assert abs(float(ddp['wabs']) - float(flat['wabs'])) <= 1e-6 * float(ddp['wabs'])
 
 
 def test_pretrain_handoff_stage1_to_stage2(capsys):
