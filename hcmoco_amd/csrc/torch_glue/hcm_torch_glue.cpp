@@ -10,6 +10,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
+#include <torch/custom_class.h>
 #include <torch/library.h>
 
 #include <miopen/miopen.h>
@@ -17,6 +18,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -259,85 +261,91 @@ Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_
 // ------------------------------------------------------------------------------------------------
 void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Tensor& like_w, Tensor* cached_ws);
 
-struct WgradTask {
-  ConvPlan* plan;
-  Tensor g, x, w;     // w: options/shape only; dw is a raw pointer so that AccumulateGrad can steal the tensor
-  void* dw;
-  c10::hip::HIPStream stream;
-};
-
-class WgradWorker {
+// One helper thread per HIP stream; tasks run in push order with that stream current.
+class StreamWorker {
  public:
-  void push(WgradTask&& t) {
+  explicit StreamWorker(c10::hip::HIPStream stream) : stream_(stream) {
+    std::thread([this] { loop(); }).detach();
+  }
+  void push(std::function<void(Tensor*)>&& fn) {
     {
       std::lock_guard<std::mutex> lk(m_);
-      if (!started_) { th_ = std::thread([this] { loop(); }); th_.detach(); started_ = true; }
-      bool seen = false;
-      for (const auto& s : used_) seen = seen || s == t.stream;
-      if (!seen) used_.push_back(t.stream);
-      q_.emplace_back(std::move(t));
+      q_.emplace_back(std::move(fn));
       ++pending_;
     }
     cv_.notify_one();
   }
-  // Blocks until every queued call is in its stream, then orders the caller's current stream behind
-  // the streams those calls went to (autograd's own end-of-backward stream sync ran before them).
-  void join() {
-    std::vector<c10::hip::HIPStream> used;
-    {
-      std::unique_lock<std::mutex> lk(m_);
-      done_.wait(lk, [this] { return pending_ == 0; });
-      used.swap(used_);
-      if (!error_.empty()) { std::string e; e.swap(error_); TORCH_CHECK(false, "deferred weight gradient failed: ", e); }
-    }
-    for (const auto& s : used) {
-      const auto cur = c10::hip::getCurrentHIPStream(s.device_index());
-      if (cur == s) continue;
-      hipEvent_t ev;
-      TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
-      TORCH_CHECK(hipEventRecord(ev, s.stream()) == hipSuccess, "hipEventRecord failed");
-      TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
-      (void)hipEventDestroy(ev);
-    }
+  void wait_idle() {
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    if (!error_.empty()) { std::string e; e.swap(error_); TORCH_CHECK(false, "deferred work failed: ", e); }
   }
+  c10::hip::HIPStream stream() const { return stream_; }
 
  private:
   void loop() {
     for (;;) {
-      WgradTask t{nullptr, Tensor(), Tensor(), Tensor(), nullptr, c10::hip::getDefaultHIPStream()};
+      std::function<void(Tensor*)> fn;
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return !q_.empty(); });
-        t = std::move(q_.front());
+        fn = std::move(q_.front());
         q_.pop_front();
       }
       try {
-        c10::hip::HIPStreamGuard guard(t.stream);   // device + current stream of this thread
-        run_wgrad(t.plan, t.g, t.x, t.dw, t.w, &ws_[t.stream.stream()]);
+        c10::hip::HIPStreamGuard guard(stream_);   // device + current stream of this thread
+        fn(&ws_);
       } catch (const std::exception& e) {
         std::lock_guard<std::mutex> lk(m_);
         error_ = e.what();
       }
-      t = WgradTask{nullptr, Tensor(), Tensor(), Tensor(), nullptr, c10::hip::getDefaultHIPStream()};   // drop g, x
+      fn = nullptr;                                // drop captured tensors before reporting idle
       {
         std::lock_guard<std::mutex> lk(m_);
         if (--pending_ == 0) done_.notify_all();
       }
     }
   }
+  c10::hip::HIPStream stream_;
   std::mutex m_;
   std::condition_variable cv_, done_;
-  std::deque<WgradTask> q_;
+  std::deque<std::function<void(Tensor*)>> q_;
   size_t pending_ = 0;
-  bool started_ = false;
-  std::thread th_;
   std::string error_;
-  std::vector<c10::hip::HIPStream> used_;            // streams written to since the last join
-  std::unordered_map<hipStream_t, Tensor> ws_;       // per stream, grown to the largest workspace seen, used in order
+  Tensor ws_;   // MIOpen workspace of this stream, grown to the largest size seen, used in order
 };
 
-// leaked on purpose: the helper thread may still be parked in wait() when static destructors run
-WgradWorker& wgrad_worker() { static WgradWorker* w = new WgradWorker(); return *w; }
+std::mutex g_workers_mutex;
+std::unordered_map<hipStream_t, StreamWorker*> g_workers;   // leaked on purpose (threads outlive static dtors)
+
+StreamWorker& worker_for(c10::hip::HIPStream stream) {
+  std::lock_guard<std::mutex> lk(g_workers_mutex);
+  auto it = g_workers.find(stream.stream());
+  if (it == g_workers.end()) it = g_workers.emplace(stream.stream(), new StreamWorker(stream)).first;
+  return *it->second;
+}
+
+// Blocks until every queued task is in its stream, then orders the caller's current stream behind
+// the streams the tasks went to (autograd's own end-of-backward stream sync ran before them).
+void join_workers() {
+  std::vector<StreamWorker*> all;
+  {
+    std::lock_guard<std::mutex> lk(g_workers_mutex);
+    for (auto& kv : g_workers) all.push_back(kv.second);
+  }
+  for (StreamWorker* w : all) {
+    w->wait_idle();
+    const auto s = w->stream();
+    const auto cur = c10::hip::getCurrentHIPStream(s.device_index());
+    if (cur == s) continue;
+    hipEvent_t ev;
+    TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    TORCH_CHECK(hipEventRecord(ev, s.stream()) == hipSuccess, "hipEventRecord failed");
+    TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    (void)hipEventDestroy(ev);
+  }
+}
+
 std::atomic<bool> g_async_wgrad{false};
 
 struct ConvGrads { Tensor dx, dw; };
@@ -371,9 +379,11 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   }
   if (need_dw) {
     o.dw = at::empty_like(w);
-    if (g_async_wgrad.load(std::memory_order_relaxed))
-      wgrad_worker().push(WgradTask{p, g, x, w, o.dw.data_ptr(), c10::hip::getCurrentHIPStream(k.dev)});
-    else
+    if (g_async_wgrad.load(std::memory_order_relaxed)) {
+      // dw travels as a raw pointer so that AccumulateGrad can steal the tensor (use_count == 1)
+      void* dw = o.dw.data_ptr();
+      worker_for(c10::hip::getCurrentHIPStream(k.dev)).push([p, g, x, w, dw](Tensor* ws) { run_wgrad(p, g, x, dw, w, ws); });
+    } else
       run_wgrad(p, g, x, o.dw.data_ptr(), w, nullptr);
   }
   return o;
@@ -403,10 +413,10 @@ void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Te
 }
 
 void set_async_wgrad(bool on) {
-  if (!on) wgrad_worker().join();
+  if (!on) join_workers();
   g_async_wgrad.store(on);
 }
-void wgrad_join() { wgrad_worker().join(); }
+void wgrad_join() { join_workers(); }
 
 struct Conv2d : public torch::autograd::Function<Conv2d> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, int64_t stride, int64_t pad) {
@@ -487,6 +497,252 @@ struct Upsample : public torch::autograd::Function<Upsample> {
 
 Tensor upsample_bilinear(const Tensor& x, int64_t Ho, int64_t Wo) { return Upsample::apply(x, Ho, Wo); }
 
+// ------------------------------------------------------------------------------------------------
+// Encoder programs.  An HRNet is ~330 instructions of four kinds (conv+bn[+residual][+relu], add,
+// relu, bilinear up-sampling) on value slots; networks/hrnet.py compiles the module tree into that
+// list once per input size.  run_encoder executes it as ONE autograd node:
+//   * forward: a C++ loop over the raw calls above -- no Python, no dispatcher, no per-layer node;
+//   * backward: the reverse loop with its own gradient slots.  The encoder's input is an image
+//     (no gradient), so nothing on autograd's dependency chain waits for this node: with
+//     set_async_wgrad(true) the WHOLE reverse loop is queued on the helper thread of the node's stream
+//     and autograd moves on -- the two HRNets' backward passes are issued by two threads in parallel.
+//     Parameter gradients are views of one flat buffer allocated up front; wgrad_join() as before.
+//   * encoder_forward_async/_wait run the forward on the helper thread of the current stream as well,
+//     so the caller can issue the other encoder meanwhile.
+// ------------------------------------------------------------------------------------------------
+enum : int64_t { kOpConvBn = 0, kOpAdd = 1, kOpRelu = 2, kOpUpsample = 3 };
+constexpr int kInstrInts = 12;   // op dst a b layer stride pad relu out_h out_w 0 0
+
+struct Tape : torch::CustomClassHolder {
+  std::vector<int64_t> prog;
+  std::vector<Tensor> val;            // value slots (outputs held as detached aliases: no cycle with the node)
+  std::vector<Tensor> z, stats;       // per conv+bn layer
+  std::vector<Tensor> w, gamma;       // parameters the backward reads
+  std::vector<int64_t> layer_off;     // offset of layer L's [dw | dgamma dbeta scratch] block in the flat gradient buffer
+  int64_t flat_numel = 0;
+  bool need_dx0 = false;
+};
+
+Tensor upsample_forward_raw(const Tensor& x, int64_t Ho, int64_t Wo) {
+  const int64_t N = x.size(0), C = x.size(1), Hi = x.size(2), Wi = x.size(3);
+  Tensor y = at::empty({N, C, Ho, Wo}, x.options());
+  check_rc(hcm_upsample_bilinear2d(x.data_ptr<float>(), (int)(N * C), (int)Hi, (int)Wi, (int)Ho, (int)Wo,
+                                   y.data_ptr<float>(), current_stream(x)),
+           "hcm_upsample_bilinear2d");
+  return y;
+}
+
+struct GradSlot { Tensor t; bool owned = false; };
+inline void accumulate(GradSlot& s, const Tensor& t, bool owned) {
+  if (!s.t.defined()) { s.t = t; s.owned = owned; }
+  else if (s.owned) s.t.add_(t);
+  else { s.t = s.t + t; s.owned = true; }
+}
+
+// Reverse pass of a tape.  out_grads: gradients of the output slots; flat: the parameter-gradient buffer.
+void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vector<int64_t>& out_slots,
+                          std::vector<Tensor> out_grads, Tensor flat, Tensor* ws) {
+  at::NoGradGuard no_grad;
+  Tape& T = *tape;
+  std::vector<GradSlot> G(T.val.size());
+  for (size_t i = 0; i < out_slots.size(); ++i)
+    if (out_grads[i].defined()) accumulate(G[out_slots[i]], out_grads[i], false);
+  out_grads.clear();
+  float* fbase = flat.data_ptr<float>();
+  const int64_t n = (int64_t)T.prog.size() / kInstrInts;
+  for (int64_t i = n - 1; i >= 0; --i) {
+    const int64_t* I = &T.prog[i * kInstrInts];
+    const int64_t op = I[0], dst = I[1], a = I[2], b = I[3];
+    GradSlot gs = std::move(G[dst]);
+    G[dst] = GradSlot();
+    if (!gs.t.defined()) continue;                       // value does not reach the outputs
+    Tensor g = gs.t.contiguous();
+    if (op == kOpConvBn) {
+      const int64_t L = I[4];
+      const bool relu = I[7] != 0, has_res = b >= 0;
+      const Tensor& z = T.z[L];
+      const int N = (int)z.size(0), C = (int)z.size(1), HW = (int)(z.size(2) * z.size(3));
+      Tensor dzc = at::empty_like(z);
+      Tensor dz = relu ? at::empty_like(z) : Tensor();
+      float* gstats = fbase + T.layer_off[L] + T.w[L].numel();
+      check_rc(hcm_bn_act_backward(g.data_ptr<float>(), z.data_ptr<float>(), relu ? T.val[dst].data_ptr<float>() : nullptr,
+                                   T.gamma[L].data_ptr<float>(), T.stats[L].data_ptr<float>(), relu ? 1 : 0, N, C, HW,
+                                   fptr(dz), dzc.data_ptr<float>(), gstats, current_stream(z)),
+               "hcm_bn_act_backward");
+      if (has_res) accumulate(G[b], relu ? dz : g, relu);
+      const Tensor& x = T.val[a];
+      const bool need_dx = a != 0 || T.need_dx0;
+      ConvPlan* p = get_plan(key_of(x, T.w[L], I[5], I[6]));
+      if (need_dx) {
+        hipStream_t st = (hipStream_t)current_stream(x);
+        miopenHandle_t h = thread_handle((int)x.get_device(), st);
+        Tensor dx = at::empty_like(x);
+        const float one = 1.f, zero = 0.f;
+        if (!found_here(p, kFoundBwdData)) {
+          size_t need = 0;
+          HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
+          Tensor fws = workspace(need, x);
+          miopenConvAlgoPerf_t perf; int got = 0;
+          HCM_MIOPEN(miopenFindConvolutionBackwardDataAlgorithm(h, p->yd, dzc.data_ptr(), p->wd, T.w[L].data_ptr(), p->cd, p->xd,
+                                                                dx.data_ptr(), 1, &got, &perf, fws.data_ptr(), need, false));
+          TORCH_CHECK(got >= 1, "hcmoco: MIOpen found no backward-data algorithm");
+          std::lock_guard<std::mutex> lock(g_plan_mutex);
+          p->bd_algo = perf.bwd_data_algo; p->bd_ws = perf.memory;
+        }
+        Tensor bws;
+        if (p->bd_ws) bws = workspace(p->bd_ws, x);
+        HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, dzc.data_ptr(), p->wd, T.w[L].data_ptr(), p->cd, p->bd_algo,
+                                                 &zero, p->xd, dx.data_ptr(), p->bd_ws ? bws.data_ptr() : nullptr, p->bd_ws));
+        accumulate(G[a], dx, true);
+      }
+      run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], ws);
+      T.z[L] = Tensor(); T.stats[L] = Tensor();           // release activations as the walk passes them
+    } else if (op == kOpAdd) {
+      accumulate(G[a], g, false);
+      accumulate(G[b], g, false);
+    } else if (op == kOpRelu) {
+      accumulate(G[a], at::threshold_backward(g, T.val[dst], 0), true);
+    } else if (op == kOpUpsample) {
+      const Tensor& x = T.val[a];
+      accumulate(G[a], at::upsample_bilinear2d_backward(g, {I[8], I[9]}, x.sizes(), false, c10::nullopt, c10::nullopt), true);
+    }
+    T.val[dst] = Tensor();
+  }
+}
+
+struct EncoderFn : public torch::autograd::Function<EncoderFn> {
+  // params: 3 per layer (w, gamma, beta); buffers: 2 per layer (running_mean, running_var)
+  static variable_list forward(AutogradContext* ctx, const Tensor& x_in, at::TensorList params, at::TensorList buffers,
+                               std::vector<int64_t> prog, std::vector<int64_t> out_slots, int64_t n_values,
+                               double momentum, double eps) {
+    TORCH_CHECK(prog.size() % kInstrInts == 0 && params.size() % 3 == 0 && buffers.size() * 3 == params.size() * 2,
+                "hcmoco::run_encoder: malformed program");
+    auto tape = c10::make_intrusive<Tape>();
+    Tape& T = *tape;
+    const int64_t layers = (int64_t)params.size() / 3;
+    T.val.resize(n_values);
+    T.z.resize(layers); T.stats.resize(layers); T.w.resize(layers); T.gamma.resize(layers); T.layer_off.resize(layers);
+    T.val[0] = x_in.contiguous();
+    T.need_dx0 = x_in.requires_grad();
+    const int64_t n = (int64_t)prog.size() / kInstrInts;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t* I = &prog[i * kInstrInts];
+      const int64_t op = I[0], dst = I[1], a = I[2], b = I[3];
+      if (op == kOpConvBn) {
+        const int64_t L = I[4];
+        const Tensor& w = params[3 * L];
+        Tensor z = conv_forward_raw(T.val[a], w, I[5], I[6]);
+        BnOut o = bn_forward_raw(z, b >= 0 ? T.val[b] : Tensor(), params[3 * L + 1], params[3 * L + 2], buffers[2 * L],
+                                 buffers[2 * L + 1], momentum, eps, I[7] != 0);
+        T.val[dst] = o.y; T.z[L] = z; T.stats[L] = o.stats; T.w[L] = w; T.gamma[L] = params[3 * L + 1];
+        T.layer_off[L] = T.flat_numel;
+        T.flat_numel += w.numel() + o.stats.numel();
+      } else if (op == kOpAdd) {
+        T.val[dst] = at::add(T.val[a], T.val[b]);
+      } else if (op == kOpRelu) {
+        T.val[dst] = at::relu(T.val[a]);
+      } else if (op == kOpUpsample) {
+        T.val[dst] = upsample_forward_raw(T.val[a], I[8], I[9]);
+      } else {
+        TORCH_CHECK(false, "hcmoco::run_encoder: unknown opcode ", op);
+      }
+    }
+    variable_list outs;
+    for (int64_t s : out_slots) {
+      outs.push_back(T.val[s]);
+      T.val[s] = T.val[s].detach();       // the tape keeps an alias without autograd history
+    }
+    T.val[0] = T.val[0].detach();
+    T.prog = std::move(prog);
+    ctx->saved_data["tape"] = c10::IValue::make_capsule(tape);
+    ctx->saved_data["outs"] = out_slots;
+    ctx->saved_data["layers"] = layers;
+    return outs;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto tape = c10::static_intrusive_pointer_cast<Tape>(ctx->saved_data["tape"].toCapsule());
+    std::vector<int64_t> out_slots = ctx->saved_data["outs"].toIntVector();
+    const int64_t layers = ctx->saved_data["layers"].toInt();
+    ctx->saved_data.erase("tape");
+    Tape& T = *tape;
+    Tensor flat = at::empty({T.flat_numel}, T.w[0].options());
+    variable_list out(1 + 5 * layers + 5);           // x, params, buffers, then the five non-tensor arguments
+    for (int64_t L = 0; L < layers; ++L) {
+      const int64_t C = T.gamma[L].numel(), off = T.layer_off[L], wn = T.w[L].numel();
+      out[1 + 3 * L] = flat.narrow(0, off, wn).view(T.w[L].sizes());
+      out[1 + 3 * L + 1] = flat.narrow(0, off + wn, C);
+      out[1 + 3 * L + 2] = flat.narrow(0, off + wn + C, C);
+    }
+    for (auto& g : grads) if (g.defined()) g = g.contiguous();
+    auto stream = c10::hip::getCurrentHIPStream(T.val[0].get_device());
+    if (g_async_wgrad.load(std::memory_order_relaxed) && !T.need_dx0) {
+      worker_for(stream).push([tape, out_slots, grads, flat](Tensor* ws) mutable {
+        run_encoder_backward(tape, out_slots, std::move(grads), flat, ws);
+      });
+    } else {
+      Tensor ws;
+      run_encoder_backward(tape, out_slots, std::move(grads), flat, &ws);
+    }
+    return out;
+  }
+};
+
+std::vector<Tensor> run_encoder(const Tensor& x, at::TensorList params, at::TensorList buffers, std::vector<int64_t> prog,
+                                std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps) {
+  return EncoderFn::apply(x, params, buffers, std::move(prog), std::move(out_slots), n_values, momentum, eps);
+}
+
+// Forward on the helper thread of the current stream; the caller collects the outputs with _wait.
+struct PendingForward { std::mutex m; std::condition_variable cv; bool done = false; std::vector<Tensor> outs; std::string error; };
+std::mutex g_pending_mutex;
+std::unordered_map<int64_t, std::shared_ptr<PendingForward>> g_pending;
+int64_t g_pending_next = 1;
+
+int64_t encoder_forward_async(const Tensor& x, at::TensorList params, at::TensorList buffers, std::vector<int64_t> prog,
+                              std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps) {
+  auto pend = std::make_shared<PendingForward>();
+  int64_t id;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mutex);
+    id = g_pending_next++;
+    g_pending[id] = pend;
+  }
+  std::vector<Tensor> pv(params.begin(), params.end()), bv(buffers.begin(), buffers.end());
+  const bool grad = at::GradMode::is_enabled();
+  worker_for(c10::hip::getCurrentHIPStream(x.get_device())).push(
+      [pend, x, pv, bv, prog, out_slots, n_values, momentum, eps, grad](Tensor*) mutable {
+        std::vector<Tensor> outs;
+        std::string err;
+        try {
+          at::AutoGradMode mode(grad);
+          outs = EncoderFn::apply(x, at::TensorList(pv), at::TensorList(bv), std::move(prog), std::move(out_slots), n_values,
+                                  momentum, eps);
+        } catch (const std::exception& e) { err = e.what(); }
+        {
+          std::lock_guard<std::mutex> lk(pend->m);
+          pend->outs = std::move(outs); pend->error = err; pend->done = true;
+        }
+        pend->cv.notify_all();
+      });
+  return id;
+}
+
+std::vector<Tensor> encoder_forward_wait(int64_t id) {
+  std::shared_ptr<PendingForward> pend;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mutex);
+    auto it = g_pending.find(id);
+    TORCH_CHECK(it != g_pending.end(), "hcmoco::encoder_forward_wait: unknown handle ", id);
+    pend = it->second;
+    g_pending.erase(it);
+  }
+  std::unique_lock<std::mutex> lk(pend->m);
+  pend->cv.wait(lk, [&] { return pend->done; });
+  TORCH_CHECK(pend->error.empty(), "hcmoco::encoder_forward_async failed: ", pend->error);
+  return std::move(pend->outs);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(hcmoco, m) {
@@ -494,6 +750,11 @@ TORCH_LIBRARY(hcmoco, m) {
   m.def("conv_bn_act(Tensor x, Tensor weight, int stride, int pad, Tensor? residual, Tensor gamma, Tensor beta, "
         "Tensor? running_mean, Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &conv_bn_act);
   m.def("upsample_bilinear(Tensor x, int out_h, int out_w) -> Tensor", &upsample_bilinear);
+  m.def("run_encoder(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
+        "float momentum, float eps) -> Tensor[]", &run_encoder);
+  m.def("encoder_forward_async(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
+        "float momentum, float eps) -> int", &encoder_forward_async);
+  m.def("encoder_forward_wait(int handle) -> Tensor[]", &encoder_forward_wait);
   m.def("set_async_wgrad(bool on) -> ()", &set_async_wgrad);
   m.def("wgrad_join() -> ()", &wgrad_join);
   m.def("bn_act(Tensor x, Tensor? residual, Tensor weight, Tensor bias, Tensor? running_mean, "

@@ -82,6 +82,15 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
 
         feat3 = on_side(0, lambda: self.encoder3(s)) if mode & 1 else None
         if mode & 2:
+            # encoder2 on its own stream; when it runs as a compiled program (networks/hrnet.py) its
+            # forward is issued by that stream's C++ helper thread while this thread issues encoder1
+            handle = []
+
+            def start():
+                h = self.encoder2.forward_async(x2) if hasattr(self.encoder2, 'forward_async') else None
+                handle.append(h)
+                return [] if h is not None else self.encoder2(x2)
+
             if mode & 4 and torch.is_grad_enabled():
                 if self._helper is None:
                     from concurrent.futures import ThreadPoolExecutor
@@ -90,8 +99,10 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
                 feat1 = self.encoder1(x1)
                 feat2 = pending.result()
             else:
-                feat2 = on_side(1, lambda: self.encoder2(x2))
+                feat2 = on_side(1, start)
                 feat1 = self.encoder1(x1)
+                if handle[0] is not None:
+                    feat2.extend(self.encoder2.forward_wait(handle[0]))
         else:
             feat1, feat2 = self.encoder1(x1), self.encoder2(x2)
         if feat3 is None:

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 BN_MOMENTUM = 0.01                                           # official_hrnet.py:23
 FUSED_BN = os.environ.get('HCM_FUSED_BN', '1') != '0'        # hcm_bn_act_* on the GPU (0: stock ops)
 CONV_GLUE = os.environ.get('HCM_CONV_GLUE', '1') != '0'      # torch.ops.hcmoco.conv2d (0: ATen)
+ENCODER_PROGRAM = os.environ.get('HCM_ENCODER_PROGRAM', '1') != '0'   # whole encoder as one C++-executed program
 
 
 def bn_act_supported(x):
@@ -118,12 +119,66 @@ class ConvBn(nn.Sequential):
     def forward(self, x, residual=None):
         return conv_bn(self[0], self[1], x, residual, len(self) == 3)
 
+    def emit(self, pb, a, res=-1):
+        return pb.conv_bn(self[0], self[1], a, res, len(self) == 3)
+
 
 def _conv_bn(cin, cout, k, stride=1, relu=False):
     layers = [Conv2d(cin, cout, k, stride, k // 2, bias=False), _bn(cout)]
     if relu:
         layers.append(nn.ReLU(inplace=True))
     return ConvBn(*layers)
+
+
+class ProgramBuilder(object):
+    """Flattens the module tree into the instruction list ``torch.ops.hcmoco.run_encoder`` executes
+    (csrc/torch_glue: one autograd node for the whole encoder, C++ forward loop, reverse loop that can run
+    on a helper thread).  Instructions are 12 ints ``op dst a b layer stride pad relu out_h out_w 0 0``
+    over value slots; slot 0 is the input image.  ``ok`` turns False when a layer falls outside what the
+    kernels cover (then the module-by-module path runs)."""
+    CONV_BN, ADD, RELU, UPSAMPLE = 0, 1, 2, 3
+
+    def __init__(self, in_shape):
+        self.instr, self.params, self.buffers = [], [], []
+        self.shapes = [tuple(in_shape)]          # (C, H, W) per slot
+        self.ok = True
+
+    def _new(self, shape):
+        self.shapes.append(tuple(shape))
+        return len(self.shapes) - 1
+
+    def conv_bn(self, conv, bn, a, res=-1, relu=False):
+        _, h, w = self.shapes[a]
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - conv.kernel_size[1]) // s + 1
+        if not conv.glue_ok or (ho * wo) % 4 != 0 or not bn.affine or not bn.track_running_stats:
+            self.ok = False
+        layer = len(self.params) // 3
+        self.params += [conv.weight, bn.weight, bn.bias]
+        self.buffers += [bn.running_mean, bn.running_var]
+        dst = self._new((conv.out_channels, ho, wo))
+        self.instr += [self.CONV_BN, dst, a, res, layer, s, p, int(relu), 0, 0, 0, 0]
+        return dst
+
+    def add(self, a, b):
+        dst = self._new(self.shapes[a])
+        self.instr += [self.ADD, dst, a, b, 0, 0, 0, 0, 0, 0, 0, 0]
+        return dst
+
+    def relu(self, a):
+        dst = self._new(self.shapes[a])
+        self.instr += [self.RELU, dst, a, -1, 0, 0, 0, 0, 0, 0, 0, 0]
+        return dst
+
+    def upsample(self, a, size):
+        dst = self._new((self.shapes[a][0], int(size[0]), int(size[1])))
+        self.instr += [self.UPSAMPLE, dst, a, -1, 0, 0, 0, 0, int(size[0]), int(size[1]), 0, 0]
+        return dst
+
+    def chain(self, seq, a):
+        for m in seq:
+            a = m.emit(self, a)
+        return a
 
 
 class BasicBlock(nn.Module):
@@ -142,6 +197,11 @@ class BasicBlock(nn.Module):
         skip = x if self.downsample is None else self.downsample(x)
         y = conv_bn(self.conv1, self.bn1, x, None, True)
         return conv_bn(self.conv2, self.bn2, y, skip, True)
+
+    def emit(self, pb, a):
+        skip = a if self.downsample is None else self.downsample.emit(pb, a)
+        y = pb.conv_bn(self.conv1, self.bn1, a, -1, True)
+        return pb.conv_bn(self.conv2, self.bn2, y, skip, True)
 
 
 class Bottleneck(nn.Module):
@@ -163,6 +223,12 @@ class Bottleneck(nn.Module):
         y = conv_bn(self.conv1, self.bn1, x, None, True)
         y = conv_bn(self.conv2, self.bn2, y, None, True)
         return conv_bn(self.conv3, self.bn3, y, skip, True)
+
+    def emit(self, pb, a):
+        skip = a if self.downsample is None else self.downsample.emit(pb, a)
+        y = pb.conv_bn(self.conv1, self.bn1, a, -1, True)
+        y = pb.conv_bn(self.conv2, self.bn2, y, -1, True)
+        return pb.conv_bn(self.conv3, self.bn3, y, skip, True)
 
 
 def _block_chain(block, cin, planes, n):
@@ -221,6 +287,27 @@ class HighResolutionModule(nn.Module):
             outs.append(self.relu(y))
         return outs
 
+    def emit(self, pb, xs):
+        """Same dataflow as forward(), as instructions."""
+        xs = [pb.chain(br, a) for br, a in zip(self.branches, xs)]
+        if self.num_branches == 1:
+            return xs
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            y = xs[0] if i == 0 else pb.chain(row[0], xs[0])
+            for j in range(1, self.num_branches):
+                if j == i:
+                    y = pb.add(y, xs[j])
+                elif j > i:
+                    y = pb.add(y, pb.upsample(row[j].emit(pb, xs[j]), pb.shapes[xs[i]][1:]))
+                else:
+                    t = xs[j]
+                    for step in row[j][:-1]:
+                        t = step.emit(pb, t)
+                    y = row[j][-1].emit(pb, t, y)
+            outs.append(pb.relu(y))
+        return outs
+
 
 class HighResolutionNet(nn.Module):
     def __init__(self, width=18):
@@ -243,6 +330,7 @@ class HighResolutionNet(nn.Module):
         self.out_channels = prev
         self.init_weights()
         self._counters = None
+        self._programs = {}
 
     def _count_batch(self):
         if self._counters is None or self._counters[0].device != self.conv1.weight.device:
@@ -273,7 +361,59 @@ class HighResolutionNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    def program(self, in_shape):
+        """(builder, output slots) for a (C, H, W) input, compiled once."""
+        key = tuple(in_shape)
+        hit = self._programs.get(key)
+        if hit is None:
+            pb = ProgramBuilder(key)
+            a = pb.conv_bn(self.conv1, self.bn1, 0, -1, True)
+            a = pb.conv_bn(self.conv2, self.bn2, a, -1, True)
+            ys = [pb.chain(self.layer1, a)]
+            for s in (2, 3, 4):
+                trans = getattr(self, 'transition%d' % (s - 1))
+                xs = []
+                for i, t in enumerate(trans):
+                    if t is None:
+                        xs.append(ys[i])
+                    else:
+                        src = ys[-1] if (s > 2 or len(ys) == 1) else ys[i]
+                        xs.append(t.emit(pb, src) if isinstance(t, ConvBn) else pb.chain(t, src))
+                for mod in getattr(self, 'stage%d' % s):
+                    xs = mod.emit(pb, xs)
+                ys = xs
+            hit = self._programs[key] = (pb, ys)
+        return hit
+
+    def _program_args(self, x):
+        """Arguments of torch.ops.hcmoco.run_encoder, or None when this call must take the module path
+        (CPU, eval mode, switched off, a layer the kernels do not cover)."""
+        if not (ENCODER_PROGRAM and CONV_GLUE and FUSED_BN and self.training and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 4):
+            return None
+        pb, outs = self.program(x.shape[1:])
+        if not pb.ok:
+            return None
+        return (x, pb.params, pb.buffers, pb.instr, outs, len(pb.shapes), self.bn1.momentum, self.bn1.eps)
+
+    def forward_async(self, x):
+        """Start the forward on the helper thread of the CURRENT stream (C++, no GIL); returns a handle
+        for forward_wait, or None when the module path has to run (then call forward)."""
+        args = self._program_args(x)
+        if args is None:
+            return None
+        self._count_batch()
+        return _glue_op('encoder_forward_async')(*args)
+
+    @staticmethod
+    def forward_wait(handle):
+        return list(_glue_op('encoder_forward_wait')(handle))
+
     def forward(self, x):
+        args = self._program_args(x)
+        if args is not None:
+            self._count_batch()
+            return list(_glue_op('run_encoder')(*args))
         if self.training:
             self._count_batch()
         x = conv_bn(self.conv1, self.bn1, x, None, True)

@@ -195,3 +195,77 @@ def test_deferred_weight_gradients_equal_inline_ones():
             ops.set_async_wgrad(False)
         grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
     _grads_agree(grads[1], grads[0])
+
+
+def _hrnet_run(net, x, state, program, deferred=False, use_async=False):
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.networks import hrnet
+    ops = _lib.torch_glue()
+    net.load_state_dict(state)
+    net.zero_grad(set_to_none=True)
+    hrnet.ENCODER_PROGRAM = program
+    ops.set_async_wgrad(deferred)
+    try:
+        if use_async:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                h = net.forward_async(x)
+            assert h is not None
+            ys = net.forward_wait(h)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            ys = net(x)
+        sum(y.square().mean() for y in ys).backward()
+        ops.wgrad_join()
+    finally:
+        ops.set_async_wgrad(False)
+        hrnet.ENCODER_PROGRAM = True
+    torch.cuda.synchronize()
+    return ([y.detach().clone() for y in ys], {n: p.grad.clone() for n, p in net.named_parameters()},
+            {n: b.clone() for n, b in net.named_buffers()})
+
+
+def test_encoder_program_equals_module_path():
+    """run_encoder (one node, C++ forward loop, own reverse loop) against the module-by-module path:
+    the same launches in the same order, so outputs and running statistics are bit-identical; on a
+    shallow, well-conditioned HRNet the gradients agree element-wise, on the full one by direction.
+    Deferred reverse loop on the helper thread and the asynchronous forward give the same numbers."""
+    from hcmoco_amd.pycontrast.networks import hrnet
+    dev = torch.device('cuda:0')
+    saved = {k: dict(v) for k, v in hrnet.STAGES.items()}
+    try:
+        for k in ('stage2', 'stage3', 'stage4'):
+            hrnet.STAGES[k].update(modules=1, blocks=1)
+        hrnet.STAGES['stage1'].update(blocks=1)
+        torch.manual_seed(1)
+        small = hrnet.HighResolutionNet(18).to(dev).train()
+    finally:
+        hrnet.STAGES.update(saved)
+    for m in small.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+    x = torch.randn(16, 3, 128, 128, device=dev)
+    state = {k: v.clone() for k, v in small.state_dict().items()}
+    ref = _hrnet_run(small, x, state, program=False)
+    for kwargs in (dict(), dict(deferred=True), dict(deferred=True, use_async=True)):
+        got = _hrnet_run(small, x, state, program=True, **kwargs)
+        for a, b in zip(got[0], ref[0]):
+            assert torch.equal(a, b)
+        for n, b in ref[2].items():
+            assert torch.equal(got[2][n], b), n
+        for n, g in ref[1].items():
+            _close(got[1][n], g, 2e-3)
+
+    torch.manual_seed(0)
+    net = hrnet.get_hrnet_w18_backbone().to(dev).train()
+    xi = torch.randn(8, 3, 128, 128, device=dev)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    ref = _hrnet_run(net, xi, state, program=False)
+    got = _hrnet_run(net, xi, state, program=True, deferred=True, use_async=True)
+    for a, b in zip(got[0], ref[0]):
+        assert torch.equal(a, b)
+    _grads_agree(got[1], ref[1])
+    # an input size whose coarsest maps are 7x7 (H*W % 4 != 0) must take the module path, not fail
+    y = net(torch.randn(2, 3, 224, 224, device=dev))
+    assert [t.shape[-1] for t in y] == [56, 28, 14, 7]
