@@ -7,6 +7,7 @@
 // cheaper, and the step is host-paced once the kernels are fused).
 // Registers torch.ops.hcmoco.bn_act; no pybind, no Python headers.
 #include <ATen/ATen.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
@@ -511,7 +512,7 @@ Tensor upsample_bilinear(const Tensor& x, int64_t Ho, int64_t Wo) { return Upsam
 //     so the caller can issue the other encoder meanwhile.
 // ------------------------------------------------------------------------------------------------
 enum : int64_t { kOpConvBn = 0, kOpAdd = 1, kOpRelu = 2, kOpUpsample = 3 };
-constexpr int kInstrInts = 12;   // op dst a b layer stride pad relu out_h out_w 0 0
+constexpr int kInstrInts = 12;   // op dst a b layer stride pad relu out_h out_w stream 0
 
 struct Tape : torch::CustomClassHolder {
   std::vector<int64_t> prog;
@@ -532,36 +533,100 @@ Tensor upsample_forward_raw(const Tensor& x, int64_t Ho, int64_t Wo) {
   return y;
 }
 
-struct GradSlot { Tensor t; bool owned = false; };
-inline void accumulate(GradSlot& s, const Tensor& t, bool owned) {
-  if (!s.t.defined()) { s.t = t; s.owned = owned; }
-  else if (s.owned) s.t.add_(t);
-  else { s.t = s.t + t; s.owned = true; }
+// Up to four HIP streams per encoder: [0] = the stream the encoder was called on, [1..3] side streams
+// for the parallel HRNet branches (the program stamps a stream id on every instruction).  All
+// launches of one pass are issued by ONE thread in program order, so "record an event on the producer
+// stream now, make the consumer stream wait for it" is always sufficient (possibly more than needed).
+constexpr int kMaxSid = 4;
+std::mutex g_side_mutex;
+std::unordered_map<hipStream_t, std::vector<c10::hip::HIPStream>> g_side_streams;
+
+struct StreamCtx {
+  std::vector<c10::hip::HIPStream> st;
+  int cur = 0;
+  int64_t epoch[kMaxSid] = {0, 0, 0, 0};              // launches issued per stream so far
+  int64_t seen[kMaxSid][kMaxSid] = {};                // seen[from][to]: epoch of `from` that `to` has waited for
+  bool used[kMaxSid] = {true, false, false, false};
+
+  explicit StreamCtx(c10::hip::HIPStream base) {
+    st.push_back(base);
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    auto& side = g_side_streams[base.stream()];
+    while ((int)side.size() < kMaxSid - 1) side.push_back(c10::hip::getStreamFromPool(false, base.device_index()));
+    for (auto& x : side) st.push_back(x);
+  }
+  ~StreamCtx() { if (cur != 0) c10::hip::setCurrentHIPStream(st[0]); }
+  void wait(int from, int to) {
+    if (from == to || seen[from][to] >= epoch[from]) return;
+    hipEvent_t ev;
+    TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    TORCH_CHECK(hipEventRecord(ev, st[from].stream()) == hipSuccess, "hipEventRecord failed");
+    TORCH_CHECK(hipStreamWaitEvent(st[to].stream(), ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    (void)hipEventDestroy(ev);
+    seen[from][to] = epoch[from];
+  }
+  void enter(int sid) {                               // make `sid` the current stream of this thread
+    if (!used[sid]) { used[sid] = true; ++epoch[0]; wait(0, sid); }   // a side stream starts behind the base stream
+    if (sid != cur) { c10::hip::setCurrentHIPStream(st[sid]); cur = sid; }
+  }
+  // tensor t was last written on stream `from`; make it usable on the current stream
+  void acquire(const Tensor& t, int from) {
+    if (from < 0 || from == cur || !t.defined()) return;
+    wait(from, cur);
+    c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), st[cur]);
+  }
+  void issued() { ++epoch[cur]; }
+  void finish() {                                      // the base stream continues behind every side stream
+    for (int s = 1; s < kMaxSid; ++s) if (used[s]) { ++epoch[s]; wait(s, 0); }
+    enter(0);
+  }
+};
+
+Tensor& stream_workspace(hipStream_t st) {             // MIOpen workspace per (thread, stream), used in order
+  thread_local std::unordered_map<hipStream_t, Tensor> ws;
+  return ws[st];
 }
 
-// Reverse pass of a tape.  out_grads: gradients of the output slots; flat: the parameter-gradient buffer.
+struct GradSlot { Tensor t; bool owned = false; int sid = -1; };
+inline void accumulate(StreamCtx& S, GradSlot& s, const Tensor& t, bool owned) {
+  if (!s.t.defined()) { s.t = t; s.owned = owned; }
+  else {
+    S.acquire(s.t, s.sid);
+    if (s.owned) s.t.add_(t);
+    else { s.t = s.t + t; s.owned = true; }
+  }
+  s.sid = S.cur;
+}
+
+// Reverse pass of a tape.  out_grads: gradients of the output slots (on the base stream); flat: the
+// parameter-gradient buffer.  Every instruction runs on the stream its forward ran on.
 void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vector<int64_t>& out_slots,
-                          std::vector<Tensor> out_grads, Tensor flat, Tensor* ws) {
+                          std::vector<Tensor> out_grads, Tensor flat, c10::hip::HIPStream base) {
   at::NoGradGuard no_grad;
   Tape& T = *tape;
+  StreamCtx S(base);
   std::vector<GradSlot> G(T.val.size());
   for (size_t i = 0; i < out_slots.size(); ++i)
-    if (out_grads[i].defined()) accumulate(G[out_slots[i]], out_grads[i], false);
+    if (out_grads[i].defined()) accumulate(S, G[out_slots[i]], out_grads[i], false);
   out_grads.clear();
   float* fbase = flat.data_ptr<float>();
+  bool flat_on[kMaxSid] = {true, false, false, false};
   const int64_t n = (int64_t)T.prog.size() / kInstrInts;
   for (int64_t i = n - 1; i >= 0; --i) {
     const int64_t* I = &T.prog[i * kInstrInts];
     const int64_t op = I[0], dst = I[1], a = I[2], b = I[3];
     GradSlot gs = std::move(G[dst]);
     G[dst] = GradSlot();
-    if (!gs.t.defined()) continue;                       // value does not reach the outputs
+    if (!gs.t.defined()) { T.val[dst] = Tensor(); continue; }    // value does not reach the outputs
+    S.enter((int)I[10]);
+    S.acquire(gs.t, gs.sid);
     Tensor g = gs.t.contiguous();
     if (op == kOpConvBn) {
       const int64_t L = I[4];
       const bool relu = I[7] != 0, has_res = b >= 0;
       const Tensor& z = T.z[L];
       const int N = (int)z.size(0), C = (int)z.size(1), HW = (int)(z.size(2) * z.size(3));
+      if (!flat_on[S.cur]) { c10::hip::HIPCachingAllocator::recordStream(flat.storage().data_ptr(), S.st[S.cur]); flat_on[S.cur] = true; }
       Tensor dzc = at::empty_like(z);
       Tensor dz = relu ? at::empty_like(z) : Tensor();
       float* gstats = fbase + T.layer_off[L] + T.w[L].numel();
@@ -569,12 +634,12 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
                                    T.gamma[L].data_ptr<float>(), T.stats[L].data_ptr<float>(), relu ? 1 : 0, N, C, HW,
                                    fptr(dz), dzc.data_ptr<float>(), gstats, current_stream(z)),
                "hcm_bn_act_backward");
-      if (has_res) accumulate(G[b], relu ? dz : g, relu);
+      if (has_res) accumulate(S, G[b], relu ? dz : g, relu);
       const Tensor& x = T.val[a];
       const bool need_dx = a != 0 || T.need_dx0;
       ConvPlan* p = get_plan(key_of(x, T.w[L], I[5], I[6]));
+      hipStream_t st = (hipStream_t)current_stream(x);
       if (need_dx) {
-        hipStream_t st = (hipStream_t)current_stream(x);
         miopenHandle_t h = thread_handle((int)x.get_device(), st);
         Tensor dx = at::empty_like(x);
         const float one = 1.f, zero = 0.f;
@@ -593,21 +658,23 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
         if (p->bd_ws) bws = workspace(p->bd_ws, x);
         HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, dzc.data_ptr(), p->wd, T.w[L].data_ptr(), p->cd, p->bd_algo,
                                                  &zero, p->xd, dx.data_ptr(), p->bd_ws ? bws.data_ptr() : nullptr, p->bd_ws));
-        accumulate(G[a], dx, true);
+        accumulate(S, G[a], dx, true);
       }
-      run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], ws);
+      run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(st));
       T.z[L] = Tensor(); T.stats[L] = Tensor();           // release activations as the walk passes them
     } else if (op == kOpAdd) {
-      accumulate(G[a], g, false);
-      accumulate(G[b], g, false);
+      accumulate(S, G[a], g, false);
+      accumulate(S, G[b], g, false);
     } else if (op == kOpRelu) {
-      accumulate(G[a], at::threshold_backward(g, T.val[dst], 0), true);
+      accumulate(S, G[a], at::threshold_backward(g, T.val[dst], 0), true);
     } else if (op == kOpUpsample) {
       const Tensor& x = T.val[a];
-      accumulate(G[a], at::upsample_bilinear2d_backward(g, {I[8], I[9]}, x.sizes(), false, c10::nullopt, c10::nullopt), true);
+      accumulate(S, G[a], at::upsample_bilinear2d_backward(g, {I[8], I[9]}, x.sizes(), false, c10::nullopt, c10::nullopt), true);
     }
+    S.issued();
     T.val[dst] = Tensor();
   }
+  S.finish();
 }
 
 struct EncoderFn : public torch::autograd::Function<EncoderFn> {
@@ -617,6 +684,7 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
                                double momentum, double eps) {
     TORCH_CHECK(prog.size() % kInstrInts == 0 && params.size() % 3 == 0 && buffers.size() * 3 == params.size() * 2,
                 "hcmoco::run_encoder: malformed program");
+    TORCH_CHECK(x_in.is_cuda(), "hcmoco::run_encoder needs ROCm tensors (no CPU fallback exists)");
     auto tape = c10::make_intrusive<Tape>();
     Tape& T = *tape;
     const int64_t layers = (int64_t)params.size() / 3;
@@ -624,10 +692,16 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
     T.z.resize(layers); T.stats.resize(layers); T.w.resize(layers); T.gamma.resize(layers); T.layer_off.resize(layers);
     T.val[0] = x_in.contiguous();
     T.need_dx0 = x_in.requires_grad();
+    StreamCtx S(c10::hip::getCurrentHIPStream(x_in.get_device()));
+    std::vector<int8_t> vsid(n_values, 0);
     const int64_t n = (int64_t)prog.size() / kInstrInts;
     for (int64_t i = 0; i < n; ++i) {
       const int64_t* I = &prog[i * kInstrInts];
       const int64_t op = I[0], dst = I[1], a = I[2], b = I[3];
+      TORCH_CHECK(I[10] >= 0 && I[10] < kMaxSid, "hcmoco::run_encoder: stream id out of range");
+      S.enter((int)I[10]);
+      S.acquire(T.val[a], vsid[a]);
+      if (b >= 0) S.acquire(T.val[b], vsid[b]);
       if (op == kOpConvBn) {
         const int64_t L = I[4];
         const Tensor& w = params[3 * L];
@@ -646,9 +720,13 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
       } else {
         TORCH_CHECK(false, "hcmoco::run_encoder: unknown opcode ", op);
       }
+      vsid[dst] = (int8_t)S.cur;
+      S.issued();
     }
+    S.finish();
     variable_list outs;
     for (int64_t s : out_slots) {
+      if (vsid[s] != 0) c10::hip::HIPCachingAllocator::recordStream(T.val[s].storage().data_ptr(), S.st[0]);
       outs.push_back(T.val[s]);
       T.val[s] = T.val[s].detach();       // the tape keeps an alias without autograd history
     }
@@ -677,12 +755,11 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
     for (auto& g : grads) if (g.defined()) g = g.contiguous();
     auto stream = c10::hip::getCurrentHIPStream(T.val[0].get_device());
     if (g_async_wgrad.load(std::memory_order_relaxed) && !T.need_dx0) {
-      worker_for(stream).push([tape, out_slots, grads, flat](Tensor* ws) mutable {
-        run_encoder_backward(tape, out_slots, std::move(grads), flat, ws);
+      worker_for(stream).push([tape, out_slots, grads, flat, stream](Tensor*) mutable {
+        run_encoder_backward(tape, out_slots, std::move(grads), flat, stream);
       });
     } else {
-      Tensor ws;
-      run_encoder_backward(tape, out_slots, std::move(grads), flat, &ws);
+      run_encoder_backward(tape, out_slots, std::move(grads), flat, stream);
     }
     return out;
   }

