@@ -17,7 +17,9 @@ BN_MOMENTUM = 0.01                                           # official_hrnet.py
 FUSED_BN = os.environ.get('HCM_FUSED_BN', '1') != '0'        # hcm_bn_act_* on the GPU (0: stock ops)
 CONV_GLUE = os.environ.get('HCM_CONV_GLUE', '1') != '0'      # torch.ops.hcmoco.conv2d (0: ATen)
 ENCODER_PROGRAM = os.environ.get('HCM_ENCODER_PROGRAM', '1') != '0'   # whole encoder as one C++-executed program
-BRANCH_STREAMS = os.environ.get('HCM_BRANCH_STREAMS', '1') != '0'     # HRNet branch i on HIP stream i of the encoder
+# HRNet branch i on HIP stream i of the encoder.  Off: measured 530 vs 572 samples/s -- the ~300 cross-stream
+# event waits per pass cost more than the extra overlap buys (134 ms/step with GPU_MAX_HW_QUEUES=8).
+BRANCH_STREAMS = os.environ.get('HCM_BRANCH_STREAMS', '0') != '0'
 
 
 def bn_act_supported(x):

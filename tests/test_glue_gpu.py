@@ -197,13 +197,15 @@ def test_deferred_weight_gradients_equal_inline_ones():
     _grads_agree(grads[1], grads[0])
 
 
-def _hrnet_run(net, x, state, program, deferred=False, use_async=False):
+def _hrnet_run(net, x, state, program, deferred=False, use_async=False, branch_streams=False):
     from hcmoco_amd import _lib
     from hcmoco_amd.pycontrast.networks import hrnet
     ops = _lib.torch_glue()
     net.load_state_dict(state)
     net.zero_grad(set_to_none=True)
     hrnet.ENCODER_PROGRAM = program
+    hrnet.BRANCH_STREAMS = branch_streams       # branch i of every HighResolutionModule on stream i
+    net._programs.clear()
     ops.set_async_wgrad(deferred)
     try:
         if use_async:
@@ -221,6 +223,8 @@ def _hrnet_run(net, x, state, program, deferred=False, use_async=False):
     finally:
         ops.set_async_wgrad(False)
         hrnet.ENCODER_PROGRAM = True
+        hrnet.BRANCH_STREAMS = False
+        net._programs.clear()
     torch.cuda.synchronize()
     return ([y.detach().clone() for y in ys], {n: p.grad.clone() for n, p in net.named_parameters()},
             {n: b.clone() for n, b in net.named_buffers()})
@@ -250,7 +254,8 @@ def test_encoder_program_equals_module_path():
     x = torch.randn(16, 3, 128, 128, device=dev)
     state = {k: v.clone() for k, v in small.state_dict().items()}
     ref = _hrnet_run(small, x, state, program=False)
-    for kwargs in (dict(), dict(deferred=True), dict(deferred=True, use_async=True)):
+    for kwargs in (dict(), dict(deferred=True), dict(deferred=True, use_async=True),
+                   dict(deferred=True, use_async=True, branch_streams=True)):
         got = _hrnet_run(small, x, state, program=True, **kwargs)
         for a, b in zip(got[0], ref[0]):
             _close(a, b, 1e-4)
