@@ -186,26 +186,26 @@ ConvPlan* get_plan(const ConvKey& k) {
   return p;
 }
 
-// One MIOpen handle per (thread, device): forward runs on the caller's thread, backward on the
-// autograd engine's device thread.
-miopenHandle_t thread_handle(int dev, hipStream_t stream) {
-  thread_local std::unordered_map<int, miopenHandle_t> handles;
-  auto it = handles.find(dev);
+// One MIOpen handle per (thread, stream): forward runs on the caller's thread, backward on the
+// autograd engine's device thread or a helper thread, weight gradients possibly on their own stream.
+miopenHandle_t thread_handle(int /*dev*/, hipStream_t stream) {
+  // a stream belongs to one device, so (thread, stream) identifies the handle; no miopenSetStream per call
+  thread_local std::unordered_map<hipStream_t, miopenHandle_t> handles;
+  auto it = handles.find(stream);
   if (it == handles.end()) {
     miopenHandle_t h;
     HCM_MIOPEN(miopenCreateWithStream(&h, stream));
-    it = handles.emplace(dev, h).first;
+    it = handles.emplace(stream, h).first;
   }
-  HCM_MIOPEN(miopenSetStream(it->second, stream));
   return it->second;
 }
 
 // MIOpen registers the kernels of a Find with the handle that ran it, so "found" is tracked per
-// (thread-local handle, plan, direction); the algorithm choice itself is kept in the shared plan.
+// (handle, plan, direction); the algorithm choice itself is kept in the shared plan.
 enum : unsigned { kFoundFwd = 1, kFoundBwdData = 2, kFoundBwdWeights = 4 };
-bool found_here(ConvPlan* p, unsigned dir) {
-  thread_local std::unordered_map<ConvPlan*, unsigned> found;
-  unsigned& m = found[p];
+bool found_here(ConvPlan* p, unsigned dir, miopenHandle_t h) {
+  thread_local std::unordered_map<const void*, std::unordered_map<ConvPlan*, unsigned>> found;
+  unsigned& m = found[h][p];
   const bool had = (m & dir) != 0;
   m |= dir;
   return had;
@@ -230,7 +230,7 @@ Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_
   hipStream_t st = (hipStream_t)current_stream(x);
   miopenHandle_t h = thread_handle(k.dev, st);
   Tensor y = at::empty({k.N, k.K, p->Ho, p->Wo}, x.options());
-  if (!found_here(p, kFoundFwd)) {
+  if (!found_here(p, kFoundFwd, h)) {
     size_t need = 0;
     HCM_MIOPEN(miopenConvolutionForwardGetWorkSpaceSize(h, p->wd, p->xd, p->cd, p->yd, &need));
     Tensor ws = workspace(need, x);
@@ -348,6 +348,7 @@ void join_workers() {
 }
 
 std::atomic<bool> g_async_wgrad{false};
+std::atomic<bool> g_wgrad_stream{false};
 
 struct ConvGrads { Tensor dx, dw; };
 
@@ -362,7 +363,7 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   ConvGrads o;
   if (need_dx) {
     o.dx = at::empty_like(x);
-    if (!found_here(p, kFoundBwdData)) {
+    if (!found_here(p, kFoundBwdData, h)) {
       size_t need = 0;
       HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
       Tensor ws = workspace(need, x);
@@ -395,7 +396,7 @@ void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Te
   hipStream_t st = (hipStream_t)current_stream(x);
   miopenHandle_t h = thread_handle(dev, st);
   const float one = 1.f, zero = 0.f;
-  if (!found_here(p, kFoundBwdWeights)) {
+  if (!found_here(p, kFoundBwdWeights, h)) {
     size_t need = 0;
     HCM_MIOPEN(miopenConvolutionBackwardWeightsGetWorkSpaceSize(h, p->yd, p->xd, p->cd, p->wd, &need));
     Tensor ws = workspace(need, x);
@@ -418,6 +419,7 @@ void set_async_wgrad(bool on) {
   g_async_wgrad.store(on);
 }
 void wgrad_join() { join_workers(); }
+void set_wgrad_stream(bool on) { g_wgrad_stream.store(on); }
 
 struct Conv2d : public torch::autograd::Function<Conv2d> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, int64_t stride, int64_t pad) {
@@ -643,7 +645,7 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
         miopenHandle_t h = thread_handle((int)x.get_device(), st);
         Tensor dx = at::empty_like(x);
         const float one = 1.f, zero = 0.f;
-        if (!found_here(p, kFoundBwdData)) {
+        if (!found_here(p, kFoundBwdData, h)) {
           size_t need = 0;
           HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
           Tensor fws = workspace(need, x);
@@ -660,7 +662,21 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
                                                  &zero, p->xd, dx.data_ptr(), p->bd_ws ? bws.data_ptr() : nullptr, p->bd_ws));
         accumulate(S, G[a], dx, true);
       }
-      run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(st));
+      if (g_wgrad_stream.load(std::memory_order_relaxed)) {
+        // dW is off the dependency chain: its five small launches go to the encoder's stream 3, so the
+        // chain (norm backward -> data gradient -> next layer) never queues behind them
+        const int chain = S.cur;
+        S.issued();
+        S.enter(kMaxSid - 1);
+        S.acquire(dzc, chain);
+        c10::hip::HIPCachingAllocator::recordStream(x.storage().data_ptr(), S.st[S.cur]);
+        if (!flat_on[S.cur]) { c10::hip::HIPCachingAllocator::recordStream(flat.storage().data_ptr(), S.st[S.cur]); flat_on[S.cur] = true; }
+        run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(S.st[S.cur].stream()));
+        S.issued();
+        S.enter(chain);
+      } else {
+        run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(st));
+      }
       T.z[L] = Tensor(); T.stats[L] = Tensor();           // release activations as the walk passes them
     } else if (op == kOpAdd) {
       accumulate(S, G[a], g, false);
@@ -834,6 +850,7 @@ TORCH_LIBRARY(hcmoco, m) {
   m.def("encoder_forward_wait(int handle) -> Tensor[]", &encoder_forward_wait);
   m.def("set_async_wgrad(bool on) -> ()", &set_async_wgrad);
   m.def("wgrad_join() -> ()", &wgrad_join);
+  m.def("set_wgrad_stream(bool on) -> ()", &set_wgrad_stream);
   m.def("bn_act(Tensor x, Tensor? residual, Tensor weight, Tensor bias, Tensor? running_mean, "
         "Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &bn_act);
 }
