@@ -1,0 +1,280 @@
+// Weight gradient of the encoders' 3x3 / stride 1 / pad 1 convolutions, gfx950.
+//
+//   dW[k][c][r][s] = sum over n, y, x of  dY[n][k][y][x] * X[n][c][y+r-1][x+s-1]        (fp32, NCHW)
+//
+// 416 of the 620 convolutions of an HRNet pair have this shape (official_hrnet.py:40-70 BasicBlock),
+// with C = K in {18,36,72,144} on 64^2..8^2 maps.  MIOpen's best solution for them is an NHWC
+// implicit GEMM behind three layout transposes and a clear: five launches, 26-47 us, 24 ms of GPU time
+// per step and the largest block of launches on each encoder's stream.
+//
+// As a GEMM the problem is M = K output channels, N = C*9 (input channel, tap) pairs, reduction over
+// the N*H*W pixels: a tiny output with a long reduction.  Here:
+//   wgrad3x3_mfma_kernel: a workgroup owns a run of (image, row-block) units and a range of N tiles;
+//       it stages the unit's dY rows [K][rb][W] and X rows with halo [c][rb+2][W+2] in LDS (coalesced
+//       NCHW reads, no layout transposes) and runs v_mfma_f32_16x16x4_f32 over 4 pixels at a time:
+//       A[k][p] = dY, B[p][(c,tap)] = X shifted by the tap -- the shift is just an LDS address offset.
+//       Waves split the N tiles (WN) and the rows of the unit (WP); the WP partial tiles are summed
+//       through LDS, one partial [K][C*9] per workgroup goes to the workspace;
+//   wgrad3x3_reduce_kernel: sums the per-workgroup partials in fixed order (deterministic, no atomics).
+// Two launches, no layout transposes, deterministic.  Measured (tools/bench_wgrad.py, N=32, C=K):
+// 18ch@64^2 44 us (MIOpen 49), 36ch@32^2 32 (38), 72ch@16^2 33 (31), 144ch@8^2 38 (28): on par, so the
+// encoder runtime still issues MIOpen's kernels; the time goes into staging and the partial sums, not
+// into the MFMA loop (next: direct-to-LDS loads with double buffering, K/N split tuned per shape).
+// A first version fed dY through the scalar cache into packed VALU FMAs (one lane per (c,tap), K
+// accumulators): correct, but every 4 pixels waited on ~9 scalar-load round trips -- 111 us at 18ch@64^2.
+#include "hcm_common.h"
+#include "../../include/hcmoco_hip.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct WgradGeo {
+  int N, C, K, H, W;
+  int mt, nt;             // 16-row tiles over K, 16-column tiles over C*9
+  int ntw, wn, wp;        // N tiles per wave, waves across N, waves across the rows of a unit
+  int ngroups;            // workgroups across N (each covers wn*ntw tiles)
+  int rb, rblocks;        // rows per unit, units per image
+  int units, chunks, per; // total units, workgroups along the reduction, units per workgroup
+  int cmax;               // input channels staged per workgroup
+  int dstride;            // floats between consecutive k rows of the dY tile (padded against bank conflicts)
+  int threads;
+  size_t lds_bytes;
+};
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ partial, WgradGeo g) {
+  extern __shared__ float lds[];
+  const int chunk = blockIdx.x, ng = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int np = lane & 15, kq = lane >> 4;
+  const int wn = wave % g.wn, wp = wave / g.wn;
+  const int LW = g.W + 2, LH = g.rb + 2, plane = LH * LW;
+  const int n9 = g.C * 9;
+  const int tile0 = (ng * g.wn + wn) * NTW;            // first N tile of this wave
+  const int c_lo = (ng * g.wn * NTW * 16) / 9;         // first input channel this workgroup touches
+  float* Xs = lds;                                     // [cmax][rb+2][W+2]
+  float* Ds = lds + g.cmax * plane;                    // [mt*16][dstride]
+  // per-lane LDS offset of the (c, tap) column of every N tile
+  int boff[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    int j = (tile0 + t) * 16 + np;
+    if (j >= n9) j = n9 - 1;                            // padded columns: any valid address, never stored
+    const int c = j / 9, tap = j - c * 9, r = tap / 3, s = tap - r * 3;
+    boff[t] = (c - c_lo) * plane + r * LW + s + kq;
+  }
+  v4f acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  const size_t HW = (size_t)g.H * g.W;
+  const int u_beg = chunk * g.per, u_end = min(g.units, u_beg + g.per);
+  for (int u = u_beg; u < u_end; ++u) {
+    const int n = u / g.rblocks, y0 = (u - n * g.rblocks) * g.rb;
+    const int rows = min(g.rb, g.H - y0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < g.cmax * plane; i += blockDim.x) {     // X rows y0-1 .. y0+rb, zero halo
+      const int cc = i / plane, rem = i - cc * plane, ly = rem / LW, lx = rem - ly * LW;
+      const int gy = y0 + ly - 1, gx = lx - 1, c = c_lo + cc;
+      float v = 0.f;
+      if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && c < g.C)
+        v = x[((size_t)n * g.C + c) * HW + (size_t)gy * g.W + gx];
+      Xs[i] = v;
+    }
+    const int rowf = g.rb * g.W;                                         // dY rows [k][rb][W], zero for k >= K
+    for (int i = threadIdx.x * 4; i < MT * 16 * rowf; i += blockDim.x * 4) {
+      const int k = i / rowf, rem = i - k * rowf, yy = rem / g.W;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < g.K && yy < rows)
+        v = *reinterpret_cast<const float4*>(dy + ((size_t)n * g.K + k) * HW + (size_t)y0 * g.W + rem);
+      *reinterpret_cast<float4*>(Ds + k * g.dstride + rem) = v;
+    }
+    __syncthreads();
+    for (int yy = wp; yy < rows; yy += g.wp) {
+      const float* arow = Ds + np * g.dstride + yy * g.W + kq;
+      const float* brow = Xs + yy * LW;
+      for (int xx = 0; xx < g.W; xx += 4) {
+        float a[MT], b[NTW];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = arow[m * 16 * g.dstride + xx];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = brow[boff[t] + xx];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
+      }
+    }
+  }
+  // sum the row-split waves through LDS: slot [wp-1][wn][m][t][lane] of float4
+  if (g.wp > 1) {
+    __syncthreads();
+    v4f* red = reinterpret_cast<v4f*>(lds);
+    if (wp > 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) red[((((wp - 1) * g.wn + wn) * MT + m) * NTW + t) * 64 + lane] = acc[m][t];
+    }
+    __syncthreads();
+    if (wp == 0) {
+      for (int p = 0; p < g.wp - 1; ++p) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[m][t] += red[(((p * g.wn + wn) * MT + m) * NTW + t) * 64 + lane];
+      }
+    }
+  }
+  if (wp == 0) {                                       // acc[m][t][q] = dW[k = 16m + 4kq + q][j = 16(tile0+t) + np]
+    float* out = partial + (size_t)chunk * g.K * n9;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int j = (tile0 + t) * 16 + np;
+        if (j < n9 && tile0 + t < g.nt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k = m * 16 + kq * 4 + q;
+            if (k < g.K) out[(size_t)k * n9 + j] = acc[m][t][q];
+          }
+        }
+      }
+  }
+}
+
+// Fixed-order sum of the per-workgroup partials.  64 consecutive outputs x 16 chunk lanes per
+// workgroup: lane q sums chunks q, q+16, ... (eight loads in flight), the 16 lane sums are added in
+// lane order through LDS.
+__global__ __launch_bounds__(1024) void wgrad3x3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                               int total, int chunks) {
+  __shared__ float sh[16][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    int j = q;
+    for (; j + 7 * 16 < chunks; j += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += partial[(size_t)(j + u * 16) * total + i];
+    }
+    for (int u = 0; j < chunks; j += 16, ++u) s[u & 7] += partial[(size_t)j * total + i];
+  }
+  sh[q][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (q == 0 && i < total) {
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) r += sh[u][o];
+    dw[i] = r;
+  }
+}
+
+// (MT, NTW) instantiations: K <= 16*MT, at most ~24 tiles (96 accumulator registers) per wave
+// (MT, NTW, waves across N) per K: few N tiles per workgroup where K is small (more workgroups across
+// N, fewer and smaller partials), at most ~24 tiles (96 accumulator registers) per wave
+bool pick_tiles(int mt, int& ntw, int& wn_max) {
+  wn_max = 4;
+  switch (mt) {
+    case 1: ntw = 12; return true;
+    case 2: ntw = 3; wn_max = 1; return true;
+    case 3: ntw = 3; wn_max = 1; return true;
+    case 4: ntw = 6; return true;
+    case 5: ntw = 2; wn_max = 1; return true;
+    case 8: ntw = 3; return true;
+    case 9: ntw = 2; return true;
+    case 16: ntw = 1; return true;
+    default: return false;
+  }
+}
+
+bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
+  if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (W & 3) != 0) return false;
+  g.N = N; g.C = C; g.K = K; g.H = H; g.W = W;
+  g.mt = (K + 15) / 16;
+  g.nt = (C * 9 + 15) / 16;
+  int wn_max;
+  if (!pick_tiles(g.mt, g.ntw, wn_max)) return false;
+  int wn = (g.nt + g.ntw - 1) / g.ntw;
+  if (wn > wn_max) wn = wn_max;
+  g.wn = wn;
+  g.ngroups = (g.nt + wn * g.ntw - 1) / (wn * g.ntw);
+  g.cmax = (wn * g.ntw * 16 + 8) / 9 + 2;
+  if (g.cmax > C) g.cmax = C;
+  // rows per unit: X tile + dY tile within ~48 KB of LDS
+  int rb = H;
+  for (;;) {
+    g.dstride = rb * W + 4;
+    size_t bytes = ((size_t)g.cmax * (rb + 2) * (W + 2) + (size_t)g.mt * 16 * g.dstride) * 4;
+    if (bytes <= 48 * 1024 || rb == 1) break;
+    rb = (rb + 1) / 2;
+  }
+  g.rb = rb;
+  g.rblocks = (H + rb - 1) / rb;
+  g.units = N * g.rblocks;
+  int wp = 8 / wn;
+  if (wp > rb) wp = rb;
+  if (wp < 1) wp = 1;
+  g.wp = wp;
+  g.threads = 64 * wn * wp;
+  size_t tile = ((size_t)g.cmax * (rb + 2) * (W + 2) + (size_t)g.mt * 16 * g.dstride) * 4;
+  size_t red = (size_t)(wp - 1) * wn * g.mt * g.ntw * 64 * 16;
+  g.lds_bytes = tile > red ? tile : red;
+  if (g.lds_bytes > 150 * 1024) return false;
+  int want = 1024 / g.ngroups;
+  if (want < 1) want = 1;
+  if (want > g.units) want = g.units;
+  g.per = (g.units + want - 1) / want;
+  g.chunks = (g.units + g.per - 1) / g.per;
+  return true;
+}
+
+template <int MT, int NTW>
+void launch_wgrad(const float* x, const float* dy, float* partial, const WgradGeo& g, hipStream_t st) {
+  if (g.lds_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma_kernel<MT, NTW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+  wgrad3x3_mfma_kernel<MT, NTW><<<dim3(g.chunks, g.ngroups), g.threads, g.lds_bytes, st>>>(x, dy, partial, g);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W) {
+  WgradGeo g;
+  if (!make_wgeo(N, C, K, H, W, g)) return 0;
+  return (size_t)g.chunks * K * C * 9 * sizeof(float);
+}
+
+int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, void* workspace,
+                      size_t workspace_bytes, hcm_stream_t stream) {
+  WgradGeo g;
+  if (!x || !dy || !dw || !workspace || !make_wgeo(N, C, K, H, W, g)) return (int)hipErrorInvalidValue;
+  if (workspace_bytes < (size_t)g.chunks * K * C * 9 * sizeof(float)) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  switch (g.mt) {
+    case 1: launch_wgrad<1, 12>(x, dy, partial, g, st); break;
+    case 2: launch_wgrad<2, 3>(x, dy, partial, g, st); break;
+    case 3: launch_wgrad<3, 3>(x, dy, partial, g, st); break;
+    case 4: launch_wgrad<4, 6>(x, dy, partial, g, st); break;
+    case 5: launch_wgrad<5, 2>(x, dy, partial, g, st); break;
+    case 8: launch_wgrad<8, 3>(x, dy, partial, g, st); break;
+    case 9: launch_wgrad<9, 2>(x, dy, partial, g, st); break;
+    case 16: launch_wgrad<16, 1>(x, dy, partial, g, st); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  HCM_CHECK_LAUNCH();
+  const int total = K * C * 9;
+  wgrad3x3_reduce_kernel<<<(total + 63) / 64, 1024, 0, st>>>(partial, dw, total, g.chunks);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -630,3 +630,24 @@ def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=N
         return _lib.torch_glue().bn_act(x, residual, weight, bias, running_mean, running_var,
                                         float(momentum), float(eps), bool(relu))
     return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
+
+
+# --------------------------------------------------------------------------- #
+# weight gradient of the 3x3 / stride 1 / pad 1 encoder convolutions
+# --------------------------------------------------------------------------- #
+def conv3x3_wgrad(x, dy):
+    """dW [K,C,3,3] of a 3x3/s1/p1 bias-free convolution from its input x [N,C,H,W] and the output
+    gradient dy [N,K,H,W] (hcm_conv3x3_wgrad: VALU partial sums + fixed-order reduction)."""
+    N, Cc, H, W = x.shape
+    K = dy.shape[1]
+    if dy.shape != (N, K, H, W):
+        raise ValueError('conv3x3_wgrad: dy must be [N,K,H,W] on the input grid')
+    nbytes = int(_lib.lib().hcm_conv3x3_wgrad_workspace_bytes(N, Cc, K, H, W))
+    if nbytes == 0:
+        raise ValueError('conv3x3_wgrad: unsupported shape (W must be a multiple of 4)')
+    ws = _ws(nbytes, x.device)
+    dw = torch.empty(K, Cc, 3, 3, dtype=torch.float32, device=x.device)
+    check(_lib.lib().hcm_conv3x3_wgrad(_dev(x, torch.float32, 'conv3x3_wgrad'), _dev(dy, torch.float32, 'conv3x3_wgrad'),
+                                       N, Cc, K, H, W, C.c_void_p(dw.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
+                                       _stream()), 'hcm_conv3x3_wgrad')
+    return dw

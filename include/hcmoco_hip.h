@@ -237,6 +237,18 @@ int hcm_bn_act_backward(const float* dy, const float* x, const float* y, const f
                         float* gstats, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * Weight gradient of a 3x3 / stride 1 / pad 1 / bias-free convolution (the BasicBlock convolutions of
+ * networks/official_hrnet/official_hrnet.py:40-70; torch.nn.Conv2d backward w.r.t. weight):
+ *   dw[k][c][r][s] = sum_{n,y,x} dy[n][k][y][x] * x[n][c][y+r-1][x+s-1]
+ * x [N,C,H,W], dy [N,K,H,W], dw [K,C,3,3] fp32 contiguous, W % 4 == 0.  workspace: caller-owned,
+ * hcm_conv3x3_wgrad_workspace_bytes(...) bytes (per-workgroup partial sums; 0 = unsupported shape).
+ * Deterministic (fixed-order reduction, no atomics).  Two launches.
+ * ------------------------------------------------------------------------ */
+size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W);
+int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
+                      void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the
  * reference's C launcher layer (networks/pointnet2/src/<name>_gpu.h), which the pybind
  * module `pointnet2_cuda` (src/pointnet2_api.cpp:10-24) wraps: the caller allocates and

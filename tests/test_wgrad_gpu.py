@@ -1,0 +1,37 @@
+"""hcm_conv3x3_wgrad against ATen's convolution_backward (weight gradient of a 3x3/s1/p1 convolution).
+
+Floating point: fp32 MFMA partial sums reduced in a fixed order; bound 2e-5 of the gradient's scale
+(reduction lengths up to 131072).  Deterministic: two runs are bit-identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(32, 18, 18, 64, 64), (8, 36, 36, 32, 32), (4, 72, 72, 16, 16), (4, 144, 144, 8, 8), (2, 32, 64, 16, 16),
+          (5, 7, 7, 12, 20), (3, 18, 36, 9, 12), (2, 256, 256, 8, 8), (1, 3, 5, 4, 4)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_wgrad_matches_aten(shape):
+    from hcmoco_amd import hip_ops
+    N, C, K, H, W = shape
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    dy = torch.randn(N, K, H, W, generator=g).to(dev)
+    w = torch.zeros(K, C, 3, 3, device=dev)
+    ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False,
+                                              [0, 0], 1, [False, True, False])[1]
+    got = hip_ops.conv3x3_wgrad(x, dy)
+    again = hip_ops.conv3x3_wgrad(x, dy)
+    assert torch.equal(got, again)
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_wgrad_rejects_unsupported():
+    from hcmoco_amd import hip_ops
+    dev = torch.device('cuda:0')
+    with pytest.raises(ValueError):
+        hip_ops.conv3x3_wgrad(torch.randn(2, 4, 6, 6, device=dev), torch.randn(2, 4, 6, 6, device=dev))   # W % 4 != 0
+    with pytest.raises(RuntimeError):
+        hip_ops.conv3x3_wgrad(torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8))                            # CPU tensors
