@@ -158,6 +158,13 @@ struct ConvPlan {
   miopenTensorDescriptor_t xd = nullptr, wd = nullptr, yd = nullptr;
   miopenConvolutionDescriptor_t cd = nullptr;
   int Ho = 0, Wo = 0;
+};
+
+// What one MIOpen handle found for one plan.  MIOpen registers a Find's kernels with the handle that
+// ran it and two handles may rank the algorithms differently (timings are noisy when several ranks
+// share a device), so the choice is per handle, never shared between threads.
+struct HandlePlan {
+  unsigned found = 0;
   miopenConvFwdAlgorithm_t fwd_algo{};
   miopenConvBwdDataAlgorithm_t bd_algo{};
   miopenConvBwdWeightsAlgorithm_t bw_algo{};
@@ -200,15 +207,11 @@ miopenHandle_t thread_handle(int /*dev*/, hipStream_t stream) {
   return it->second;
 }
 
-// MIOpen registers the kernels of a Find with the handle that ran it, so "found" is tracked per
-// (handle, plan, direction); the algorithm choice itself is kept in the shared plan.
+// Find results live with the (thread-local) handle that produced them; see HandlePlan.
 enum : unsigned { kFoundFwd = 1, kFoundBwdData = 2, kFoundBwdWeights = 4 };
-bool found_here(ConvPlan* p, unsigned dir, miopenHandle_t h) {
-  thread_local std::unordered_map<const void*, std::unordered_map<ConvPlan*, unsigned>> found;
-  unsigned& m = found[h][p];
-  const bool had = (m & dir) != 0;
-  m |= dir;
-  return had;
+HandlePlan& handle_plan(miopenHandle_t h, ConvPlan* p) {
+  thread_local std::unordered_map<const void*, std::unordered_map<ConvPlan*, HandlePlan>> found;
+  return found[h][p];
 }
 
 inline Tensor workspace(size_t bytes, const Tensor& like) {
@@ -230,7 +233,8 @@ Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_
   hipStream_t st = (hipStream_t)current_stream(x);
   miopenHandle_t h = thread_handle(k.dev, st);
   Tensor y = at::empty({k.N, k.K, p->Ho, p->Wo}, x.options());
-  if (!found_here(p, kFoundFwd, h)) {
+  HandlePlan& hp = handle_plan(h, p);
+  if (!(hp.found & kFoundFwd)) {
     size_t need = 0;
     HCM_MIOPEN(miopenConvolutionForwardGetWorkSpaceSize(h, p->wd, p->xd, p->cd, p->yd, &need));
     Tensor ws = workspace(need, x);
@@ -238,14 +242,13 @@ Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_
     HCM_MIOPEN(miopenFindConvolutionForwardAlgorithm(h, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->yd,
                                                      y.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
     TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no forward algorithm");
-    std::lock_guard<std::mutex> lock(g_plan_mutex);
-    p->fwd_algo = perf.fwd_algo; p->fwd_ws = perf.memory;
+    hp.fwd_algo = perf.fwd_algo; hp.fwd_ws = perf.memory; hp.found |= kFoundFwd;
   }
   Tensor ws;                                   // the Winograd kernels HRNet mostly gets need none
-  if (p->fwd_ws) ws = workspace(p->fwd_ws, x);
+  if (hp.fwd_ws) ws = workspace(hp.fwd_ws, x);
   const float one = 1.f, zero = 0.f;
-  HCM_MIOPEN(miopenConvolutionForward(h, &one, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, p->fwd_algo, &zero,
-                                      p->yd, y.data_ptr(), p->fwd_ws ? ws.data_ptr() : nullptr, p->fwd_ws));
+  HCM_MIOPEN(miopenConvolutionForward(h, &one, p->xd, x.data_ptr(), p->wd, w.data_ptr(), p->cd, hp.fwd_algo, &zero,
+                                      p->yd, y.data_ptr(), hp.fwd_ws ? ws.data_ptr() : nullptr, hp.fwd_ws));
   return y;
 }
 
@@ -363,7 +366,8 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   ConvGrads o;
   if (need_dx) {
     o.dx = at::empty_like(x);
-    if (!found_here(p, kFoundBwdData, h)) {
+    HandlePlan& hp = handle_plan(h, p);
+    if (!(hp.found & kFoundBwdData)) {
       size_t need = 0;
       HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
       Tensor ws = workspace(need, x);
@@ -371,13 +375,12 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
       HCM_MIOPEN(miopenFindConvolutionBackwardDataAlgorithm(h, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->xd,
                                                             o.dx.data_ptr(), 1, &got, &perf, ws.data_ptr(), need, false));
       TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no backward-data algorithm");
-      std::lock_guard<std::mutex> lock(g_plan_mutex);
-      p->bd_algo = perf.bwd_data_algo; p->bd_ws = perf.memory;
+      hp.bd_algo = perf.bwd_data_algo; hp.bd_ws = perf.memory; hp.found |= kFoundBwdData;
     }
     Tensor ws;
-    if (p->bd_ws) ws = workspace(p->bd_ws, x);
-    HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, p->bd_algo, &zero,
-                                             p->xd, o.dx.data_ptr(), p->bd_ws ? ws.data_ptr() : nullptr, p->bd_ws));
+    if (hp.bd_ws) ws = workspace(hp.bd_ws, x);
+    HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, g.data_ptr(), p->wd, w.data_ptr(), p->cd, hp.bd_algo, &zero,
+                                             p->xd, o.dx.data_ptr(), hp.bd_ws ? ws.data_ptr() : nullptr, hp.bd_ws));
   }
   if (need_dw) {
     o.dw = at::empty_like(w);
@@ -396,7 +399,8 @@ void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Te
   hipStream_t st = (hipStream_t)current_stream(x);
   miopenHandle_t h = thread_handle(dev, st);
   const float one = 1.f, zero = 0.f;
-  if (!found_here(p, kFoundBwdWeights, h)) {
+  HandlePlan& hp = handle_plan(h, p);
+  if (!(hp.found & kFoundBwdWeights)) {
     size_t need = 0;
     HCM_MIOPEN(miopenConvolutionBackwardWeightsGetWorkSpaceSize(h, p->yd, p->xd, p->cd, p->wd, &need));
     Tensor ws = workspace(need, x);
@@ -404,14 +408,13 @@ void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Te
     HCM_MIOPEN(miopenFindConvolutionBackwardWeightsAlgorithm(h, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, p->wd, dw,
                                                              1, &got, &perf, ws.data_ptr(), need, false));
     TORCH_CHECK(got >= 1, "hcmoco::conv2d: MIOpen found no backward-weights algorithm");
-    std::lock_guard<std::mutex> lock(g_plan_mutex);
-    p->bw_algo = perf.bwd_weights_algo; p->bw_ws = perf.memory;
+    hp.bw_algo = perf.bwd_weights_algo; hp.bw_ws = perf.memory; hp.found |= kFoundBwdWeights;
   }
   Tensor local;
   Tensor* ws = cached_ws ? cached_ws : &local;
-  if (!ws->defined() || (size_t)ws->numel() < p->bw_ws) *ws = workspace(p->bw_ws, x);
-  HCM_MIOPEN(miopenConvolutionBackwardWeights(h, &one, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, p->bw_algo, &zero,
-                                              p->wd, dw, ws->data_ptr(), p->bw_ws));
+  if (!ws->defined() || (size_t)ws->numel() < hp.bw_ws) *ws = workspace(hp.bw_ws, x);
+  HCM_MIOPEN(miopenConvolutionBackwardWeights(h, &one, p->yd, g.data_ptr(), p->xd, x.data_ptr(), p->cd, hp.bw_algo, &zero,
+                                              p->wd, dw, ws->data_ptr(), hp.bw_ws));
 }
 
 void set_async_wgrad(bool on) {
@@ -645,7 +648,8 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
         miopenHandle_t h = thread_handle((int)x.get_device(), st);
         Tensor dx = at::empty_like(x);
         const float one = 1.f, zero = 0.f;
-        if (!found_here(p, kFoundBwdData, h)) {
+        HandlePlan& hp = handle_plan(h, p);
+    if (!(hp.found & kFoundBwdData)) {
           size_t need = 0;
           HCM_MIOPEN(miopenConvolutionBackwardDataGetWorkSpaceSize(h, p->yd, p->wd, p->cd, p->xd, &need));
           Tensor fws = workspace(need, x);
@@ -653,13 +657,12 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
           HCM_MIOPEN(miopenFindConvolutionBackwardDataAlgorithm(h, p->yd, dzc.data_ptr(), p->wd, T.w[L].data_ptr(), p->cd, p->xd,
                                                                 dx.data_ptr(), 1, &got, &perf, fws.data_ptr(), need, false));
           TORCH_CHECK(got >= 1, "hcmoco: MIOpen found no backward-data algorithm");
-          std::lock_guard<std::mutex> lock(g_plan_mutex);
-          p->bd_algo = perf.bwd_data_algo; p->bd_ws = perf.memory;
+          hp.bd_algo = perf.bwd_data_algo; hp.bd_ws = perf.memory; hp.found |= kFoundBwdData;
         }
         Tensor bws;
-        if (p->bd_ws) bws = workspace(p->bd_ws, x);
-        HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, dzc.data_ptr(), p->wd, T.w[L].data_ptr(), p->cd, p->bd_algo,
-                                                 &zero, p->xd, dx.data_ptr(), p->bd_ws ? bws.data_ptr() : nullptr, p->bd_ws));
+        if (hp.bd_ws) bws = workspace(hp.bd_ws, x);
+        HCM_MIOPEN(miopenConvolutionBackwardData(h, &one, p->yd, dzc.data_ptr(), p->wd, T.w[L].data_ptr(), p->cd, hp.bd_algo,
+                                                 &zero, p->xd, dx.data_ptr(), hp.bd_ws ? bws.data_ptr() : nullptr, hp.bd_ws));
         accumulate(S, G[a], dx, true);
       }
       if (g_wgrad_stream.load(std::memory_order_relaxed)) {

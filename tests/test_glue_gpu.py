@@ -234,8 +234,9 @@ def test_encoder_program_equals_module_path():
     """run_encoder (one node, C++ forward loop, own reverse loop) against the module-by-module path:
     the same launches in the same order.  (Not bit-identical: MIOpen's forward convolutions are not
     run-to-run deterministic on this part -- the module path differs from ITSELF by ~1.5e-5 of the
-    output scale.)  On a shallow, well-conditioned HRNet outputs, running statistics and gradients
-    agree element-wise, on the full one outputs element-wise and gradients by direction.  The deferred
+    output scale.)  On a shallow, well-conditioned HRNet outputs and running statistics agree element-wise
+    and every gradient tensor has cosine >= 0.999 with its reference; on the full one outputs element-wise and
+    gradients by direction (>= 0.995).  The deferred
     reverse loop on the helper thread and the asynchronous forward give the same numbers."""
     from hcmoco_amd.pycontrast.networks import hrnet
     dev = torch.device('cuda:0')
@@ -261,8 +262,7 @@ def test_encoder_program_equals_module_path():
             _close(a, b, 1e-4)
         for n, b in ref[2].items():
             assert torch.allclose(got[2][n].float(), b.float(), rtol=1e-4, atol=1e-6), n
-        for n, g in ref[1].items():
-            _close(got[1][n], g, 2e-2)
+        _grads_agree(got[1], ref[1], min_cos=0.999)
 
     torch.manual_seed(0)
     net = hrnet.get_hrnet_w18_backbone().to(dev).train()
