@@ -32,6 +32,7 @@ class ContrastTrainer(BaseTrainer):
         self.graphed = None          # GraphedEncoder once enable_graphs() ran
         self.manual_allreduce = False
         self.async_wgrad = None      # torch.ops.hcmoco namespace once deferred weight gradients are on
+        self._find_done = False      # the first training step runs single-stream (quiet MIOpen Find)
 
     def enable_graphs(self, model, sample_batch, stage2=True):
         """Capture the encoder forward/backward as hipGraphs (learning/graphed.py).  Call BEFORE
@@ -190,6 +191,25 @@ class ContrastTrainer(BaseTrainer):
     def train_step(self, data, model, contrast, optimizer, stage2):
         """Forward, losses, backward, SGD step, bank update for one batch tuple.
         Returns a dict of DEVICE scalars (no host sync)."""
+        if self.async_wgrad is not None and not self._find_done:
+            # First step: MIOpen's Find benchmarks every convolution shape once.  Run it on a quiet
+            # GPU -- one stream, nothing deferred -- so the timings it ranks algorithms by are not
+            # disturbed by the other encoder; the records land in MIOpen's find-db, which the helper
+            # threads' handles then hit instead of benchmarking under load.
+            self._find_done = True
+            net = self.unwrap(model)
+            streams = getattr(net, 'two_streams', None)
+            self.async_wgrad.set_async_wgrad(False)
+            if streams is not None:
+                net.two_streams = 0
+            try:
+                out = self.train_step(data, model, contrast, optimizer, stage2)
+                torch.cuda.synchronize(self.device)
+            finally:
+                if streams is not None:
+                    net.two_streams = streams
+                self.async_wgrad.set_async_wgrad(True)
+            return out
         args = self.args
         inputs = self._to_dev(data[0]).float()
         index = self._to_dev(data[1])
