@@ -99,3 +99,36 @@ def scatter_add_lds(grad_out, idx, coef, m, div=1):
                                          idx2.shape[1], m, div, _f(out, 'scatter_add_lds'), _stream()),
           'hcm_scatter_add_lds')
     return out
+
+
+class _BallMax(torch.autograd.Function):
+    """max over the last axis with ATen max_pool2d's tie rule (first index); hcm_rowmax_*."""
+
+    @staticmethod
+    def forward(ctx, x):
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError('hcmoco_amd.ball_max needs fp32 ROCm tensors (no CPU fallback exists)')
+        x = x.contiguous()
+        ns = x.shape[-1]
+        rows = x.numel() // ns
+        y = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        arg = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+        check(_lib.lib().hcm_rowmax_forward(_f(x, 'ball_max'), rows, ns, _f(y, 'ball_max'), _i(arg, 'ball_max'), _stream()),
+              'hcm_rowmax_forward')
+        ctx.save_for_backward(arg)
+        ctx.ns = ns
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty(*arg.shape, ctx.ns, dtype=torch.float32, device=g.device)
+        check(_lib.lib().hcm_rowmax_backward(_f(g, 'ball_max'), _i(arg, 'ball_max'), arg.numel(), ctx.ns,
+                                             _f(dx, 'ball_max'), _stream()), 'hcm_rowmax_backward')
+        return dx
+
+
+def ball_max(x):
+    """x [..., nsample] -> max over the last axis (the reference's F.max_pool2d(x, [1, nsample]).squeeze(-1))."""
+    return _BallMax.apply(x)

@@ -32,6 +32,10 @@ class PointnetSAModuleMSG(nn.Module):
         for grouper, mlp in zip(self.groupers, self.mlps):
             y = mlp(grouper(xyz, new_xyz, features))                       # (B, C, npoint, nsample)
             if self.pool_method == 'max_pool':
+                if y.is_cuda and y.dtype == torch.float32:   # hcm_rowmax_*: same values, same (first-index) tie rule
+                    from .... import pointnet2_hip
+                    outs.append(pointnet2_hip.ball_max(y))
+                    continue
                 y = F.max_pool2d(y, kernel_size=[1, y.size(3)])
             elif self.pool_method == 'avg_pool':
                 y = F.avg_pool2d(y, kernel_size=[1, y.size(3)])

@@ -1,7 +1,11 @@
 """Conv/BN building blocks with the reference's module names, so ``state_dict`` keys match
 (/root/reference/pycontrast/networks/pointnet2/pytorch_utils.py:5-200):
 ``...layer{i}.conv.weight``, ``...layer{i}.bn.bn.weight`` etc."""
+import os
+
 import torch.nn as nn
+
+FUSED = os.environ.get('HCM_FUSED_BN', '1') != '0' and os.environ.get('HCM_CONV_GLUE', '1') != '0'
 
 
 class _BN(nn.Sequential):
@@ -26,6 +30,21 @@ class _ConvBNAct(nn.Sequential):
             self.add_module('bn', _BN(norm, cout))
         if activation is not None:
             self.add_module('activation', activation)
+        self._fusable = (conv is nn.Conv2d and bn and norm is nn.BatchNorm2d
+                         and (activation is None or isinstance(activation, nn.ReLU)))
+
+    def forward(self, x):
+        """1x1 conv -> BatchNorm2d -> ReLU of the shared MLPs.  A training step on the MI355X runs the
+        three as ONE autograd node (torch.ops.hcmoco.conv_bn_act: MIOpen convolution + hcm_bn_act_*;
+        MIOpen's own batch-norm takes 0.5 ms per layer on the [32,64,1024,32] ball tensors)."""
+        if (self._fusable and FUSED and self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and (x.shape[2] * x.shape[3]) % 4 == 0):
+            from .... import _lib
+            bn = self.bn.bn
+            bn.num_batches_tracked.add_(1)          # nn.BatchNorm2d.forward's bookkeeping
+            return _lib.torch_glue().conv_bn_act(x, self.conv.weight, 1, 0, None, bn.weight, bn.bias, bn.running_mean,
+                                                 bn.running_var, bn.momentum, bn.eps, hasattr(self, 'activation'))
+        return super().forward(x)
 
 
 class Conv1d(_ConvBNAct):

@@ -294,6 +294,13 @@ int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
 int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx, int B, int C,
                         int Qsrc, int Q, int m, int div, float* grad_points, hcm_stream_t stream);
 
+/* Max over the ball (F.max_pool2d(y, [1, nsample]) in PointnetSAModuleMSG.forward,
+ * networks/pointnet2/pointnet2_modules.py:60-63): x [rows, ns] fp32 contiguous (rows = B*C*npoint) ->
+ * y [rows], arg [rows] (first index of the maximum, ATen's tie rule); backward writes
+ * dx[r][j] = dy[r] if j == arg[r] else 0 for every element (no zero-fill needed). */
+int hcm_rowmax_forward(const float* x, long long rows, int ns, float* y, int* arg, hcm_stream_t stream);
+int hcm_rowmax_backward(const float* dy, const int* arg, long long rows, int ns, float* dx, hcm_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Measurement helper: launches `reps` back-to-back hcm_bank_nce_fused passes bracketed by
  * hipEvents on `stream` and returns the mean milliseconds per pass (host float).

@@ -147,3 +147,52 @@ def test_lds_scatter_refuses_targets_that_do_not_fit_lds():
     with pytest.raises(_lib.HipError):
         mod().scatter_add_lds(torch.zeros(1, 2, 8, device=d()), torch.zeros(1, 8, dtype=torch.int32, device=d()),
                               None, 100000, 1)
+
+
+def test_ball_max_matches_max_pool2d_including_ties():
+    """hcm_rowmax_* = F.max_pool2d(x, [1, nsample]).squeeze(-1): values, and the gradient goes to the
+    FIRST maximum of a row (ATen's rule) -- exercised with heavily tied (post-ReLU, quantised) inputs."""
+    import torch.nn.functional as F
+    from hcmoco_amd import pointnet2_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    for shape in [(4, 16, 64, 16), (2, 8, 128, 32), (3, 5, 7, 64), (2, 3, 9, 128), (2, 4, 6, 5), (1, 2, 3, 1)]:
+        x = torch.relu(torch.randn(shape, generator=g)).mul(4).round().div(4).to(dev)     # many exact ties
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ya = pointnet2_hip.ball_max(xa)
+        yb = F.max_pool2d(xb, kernel_size=[1, shape[-1]]).squeeze(-1)
+        gy = torch.randn(yb.shape, generator=g).to(dev)
+        ya.backward(gy)
+        yb.backward(gy)
+        assert torch.equal(ya, yb)
+        assert torch.equal(xa.grad, xb.grad)
+
+
+def test_shared_mlp_fused_layer_matches_stock_ops():
+    from hcmoco_amd.pycontrast.networks.pointnet2 import pytorch_utils as pt_utils
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    mlp = pt_utils.SharedMLP([6, 32, 64], bn=True).to(dev).train()
+    x = torch.randn(8, 6, 128, 16, device=dev)
+    state = {k: v.clone() for k, v in mlp.state_dict().items()}
+    res = {}
+    for fused in (True, False):
+        mlp.load_state_dict(state)
+        mlp.zero_grad(set_to_none=True)
+        pt_utils.FUSED = fused
+        try:
+            xs = x.clone().requires_grad_()
+            y = mlp(xs)
+            y.square().mean().backward()
+        finally:
+            pt_utils.FUSED = True
+        res[fused] = (y.detach(), xs.grad, {n: p.grad.clone() for n, p in mlp.named_parameters()},
+                      {n: b.clone() for n, b in mlp.named_buffers()})
+    def close(a, b, tol):
+        assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-12)
+    close(res[True][0], res[False][0], 1e-4)
+    close(res[True][1], res[False][1], 1e-3)
+    for n, gb in res[False][2].items():
+        close(res[True][2][n], gb, 1e-3)
+    for n, bb in res[False][3].items():
+        assert torch.allclose(res[True][3][n].float(), bb.float(), rtol=1e-4, atol=1e-6), n
