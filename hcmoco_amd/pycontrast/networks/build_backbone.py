@@ -179,6 +179,8 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         sgcn_dim = 128
         self.encoder3 = create_sgcn(opt.skeleton_meta_name, sgcn_dim, 4)
         self.head1 = nn.Sequential(nn.Linear(dim_in, feat_dim), Normalize(2))
+        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '3'))
+        self._side_streams = {}
         self.head2 = nn.Sequential(nn.Linear(self.pn_dim, feat_dim), Normalize(2))
         self.head3 = nn.Sequential(nn.Linear(sgcn_dim, feat_dim), Normalize(2))
         if self.linear_feat_map:
@@ -187,6 +189,7 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
 
     merge_all_res = staticmethod(CMC3HRNetSGCNSingleHead.merge_all_res)
     _pool = CMC3HRNetSGCNSingleHead._pool
+    _side = CMC3HRNetSGCNSingleHead._side
 
     def depth2pts(self, depth, depth_mask, grid_xy, ori_h, ori_w, mean):
         """Back-project every pixel (X=(gx-H0/2) z k, Y=(W0/2-gy) z k, Z=z, k=0.0035; z = depth+mean,
@@ -218,11 +221,32 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
 
     def forward(self, x, s, depth_mask, grid_xy, original_h, original_w, mean, mode=0, return_fm=False):
         x1, x2 = torch.split(x, self.in_channel_list, dim=1)
-        _feat1 = self.encoder1(x1)
         h, w = x1.shape[-2:]
-        sample_pn, full_pn, _ = self.depth2pts(x2, depth_mask, grid_xy, original_h, original_w, mean)
-        _feat2 = self.encoder2(sample_pn.transpose(1, 2))                      # [B, 128, 4096]
-        _feat3 = self.encoder3(s)
+
+        def cloud_branch():
+            sample, full, _ = self.depth2pts(x2, depth_mask, grid_xy, original_h, original_w, mean)
+            return sample, full, self.encoder2(sample.transpose(1, 2))           # [B, 128, 4096]
+
+        if x.is_cuda and self.two_streams:
+            # the point-cloud branch (back-projection, PointNet++) and the SemGCN on side HIP streams,
+            # the HRNet on the caller's: same placement rule as CMC3HRNetSGCNSingleHead._encode
+            main = torch.cuda.current_stream(x.device)
+            side_pn, side_g = self._side(1, x.device), self._side(0, x.device)
+            side_pn.wait_stream(main)
+            side_g.wait_stream(main)
+            with torch.cuda.stream(side_g):
+                _feat3 = self.encoder3(s)
+            with torch.cuda.stream(side_pn):
+                sample_pn, full_pn, _feat2 = cloud_branch()
+            _feat1 = self.encoder1(x1)
+            main.wait_stream(side_pn)
+            main.wait_stream(side_g)
+            for t in (sample_pn, full_pn, _feat2, _feat3):
+                t.record_stream(main)
+        else:
+            _feat1 = self.encoder1(x1)
+            sample_pn, full_pn, _feat2 = cloud_branch()
+            _feat3 = self.encoder3(s)
         avg1, avg2, avg3 = self._pool(_feat1), _feat2.mean(-1), _feat3.mean(1)
         if mode in (0, 1):
             feat1, feat2, feat3 = self.head1(avg1), self.head2(avg2), self.head3(avg3)

@@ -3,6 +3,7 @@
 ``...layer{i}.conv.weight``, ``...layer{i}.bn.bn.weight`` etc."""
 import os
 
+import torch
 import torch.nn as nn
 
 FUSED = os.environ.get('HCM_FUSED_BN', '1') != '0' and os.environ.get('HCM_CONV_GLUE', '1') != '0'
