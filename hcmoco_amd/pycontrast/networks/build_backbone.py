@@ -51,12 +51,13 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # The three encoders are independent until the heads.  HCM_TWO_STREAMS is a bit mask:
         #   1            SemGCN on a side HIP stream, issued first: its single-workgroup kernels
         #                (3.5 ms per step, one CU) run underneath the HRNets instead of in line;
-        #   2            encoder2 on a second side stream (small HRNet kernels overlap); default 3 = 1|2
-        #   4            with 2: encoder2 is also issued from a helper thread.
+        #   2            encoder2 on a second side stream (small HRNet kernels overlap; when it runs as a
+        #                compiled program its forward is issued by that stream's C++ helper thread);
+        #                default 3 = 1|2.  (Issuing encoder2 from a PYTHON helper thread was measured
+        #                slower -- the GIL -- and is gone.)
         # Backward follows automatically: autograd replays every node on its forward stream.
         self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '3'))
         self._side_streams = {}
-        self._helper = None
 
     def _side(self, idx, device):
         st = self._side_streams.get((idx, device))
@@ -91,18 +92,10 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
                 handle.append(h)
                 return [] if h is not None else self.encoder2(x2)
 
-            if mode & 4 and torch.is_grad_enabled():
-                if self._helper is None:
-                    from concurrent.futures import ThreadPoolExecutor
-                    self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix='hcm-enc2')
-                pending = self._helper.submit(on_side, 1, lambda: self.encoder2(x2))
-                feat1 = self.encoder1(x1)
-                feat2 = pending.result()
-            else:
-                feat2 = on_side(1, start)
-                feat1 = self.encoder1(x1)
-                if handle[0] is not None:
-                    feat2.extend(self.encoder2.forward_wait(handle[0]))
+            feat2 = on_side(1, start)
+            feat1 = self.encoder1(x1)
+            if handle[0] is not None:
+                feat2.extend(self.encoder2.forward_wait(handle[0]))
         else:
             feat1, feat2 = self.encoder1(x1), self.encoder2(x2)
         if feat3 is None:
