@@ -69,7 +69,7 @@ SIGNATURES = {
     'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 6),
     'hcm_bn_act_stats_floats': (C.c_size_t, [_i, _i, _i]),
     'hcm_bn_act_forward': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3),
-    'hcm_bn_act_backward': (_i, [_p] * 5 + [_i] * 4 + [_p] * 4),
+    'hcm_bn_act_backward': (_i, [_p] * 6 + [_i] * 4 + [_p] * 4),
     'hcm_conv3x3_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
     'hcm_conv3x3_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_rowmax_forward': (_i, [_p, C.c_longlong, _i, _p, _p, _p]),

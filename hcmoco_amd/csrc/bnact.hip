@@ -13,7 +13,7 @@
 //   forward : stats  (per-slice shifted sums  S1 = sum(x-k), S2 = sum((x-k)^2), k = x[0,c,0,0])
 //             apply  (merge slices in fixed order -> mean, invstd, running stats;
 //                     y = relu(x*sc + sh + residual))
-//   backward: reduce (dz = dy * [y > 0]; per-slice sum(dz), sum(dz*(x-mean)); dz doubles as d residual)
+//   backward: reduce (dz = (dy + dy2?) * [y > 0]; per-slice sum(dz), sum(dz*(x-mean)); dz doubles as d residual)
 //             apply  (dgamma, dbeta; dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)))
 // Sums are plain additions of per-slice partials in slice order: deterministic, no atomics.
 // HBM-bound: forward moves 3 (4 with residual) tensor passes, backward 7; see DESIGN.md 4.7.
@@ -134,10 +134,13 @@ __global__ __launch_bounds__(kBT) void bn_apply_kernel(
   }
 }
 
-template <bool RELU>
+// dy2 (optional): a second gradient of the same tensor -- the sum a residual block's input receives
+// (skip path + convolution path) is formed here instead of in a separate add kernel.
+template <bool RELU, bool TWO>
 __global__ __launch_bounds__(kBT) void bn_bwd_reduce_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-    const float* __restrict__ stats, Geo g, float* __restrict__ dz, float* __restrict__ part) {
+    const float* __restrict__ dy, const float* __restrict__ dy2, const float* __restrict__ x,
+    const float* __restrict__ y, const float* __restrict__ stats, Geo g, float* __restrict__ dz,
+    float* __restrict__ part) {
   const int c = blockIdx.x, s = blockIdx.y;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
   const float mean = stats[c];
@@ -147,12 +150,16 @@ __global__ __launch_bounds__(kBT) void bn_bwd_reduce_kernel(
     const size_t o = elem_offset(g, c, f);
     float4 d = *reinterpret_cast<const float4*>(dy + o);
     const float4 v = *reinterpret_cast<const float4*>(x + o);
+    if (TWO) {
+      const float4 e = *reinterpret_cast<const float4*>(dy2 + o);
+      d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+    }
     if (RELU) {
       const float4 out = *reinterpret_cast<const float4*>(y + o);
       d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
       d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
-      *reinterpret_cast<float4*>(dz + o) = d;
     }
+    if (RELU || TWO) *reinterpret_cast<float4*>(dz + o) = d;
     s1 += (d.x + d.y) + (d.z + d.w);
     s2 = fmaf(d.x, v.x - mean, s2); s2 = fmaf(d.y, v.y - mean, s2);
     s2 = fmaf(d.z, v.z - mean, s2); s2 = fmaf(d.w, v.w - mean, s2);
@@ -232,19 +239,25 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
   return 0;
 }
 
-int hcm_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma,
+int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
                         const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
                         float* gstats, hcm_stream_t stream) {
-  if (bad_shape(N, C, HW) || !dy || !x || !gamma || !stats || !gstats || (relu && (!y || !dz)))
+  const bool needs_dz = relu || dy2 != nullptr;
+  if (bad_shape(N, C, HW) || !dy || !x || !gamma || !stats || !gstats || (relu && !y) || (needs_dz && !dz))
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(N, C, HW);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(C, g.split);
   float* part = gstats + 2 * (size_t)C;
-  if (relu) bn_bwd_reduce_kernel<true><<<grid, kBT, 0, st>>>(dy, x, y, stats, g, dz, part);
-  else      bn_bwd_reduce_kernel<false><<<grid, kBT, 0, st>>>(dy, x, nullptr, stats, g, nullptr, part);
+  if (relu) {
+    if (dy2) bn_bwd_reduce_kernel<true, true><<<grid, kBT, 0, st>>>(dy, dy2, x, y, stats, g, dz, part);
+    else     bn_bwd_reduce_kernel<true, false><<<grid, kBT, 0, st>>>(dy, nullptr, x, y, stats, g, dz, part);
+  } else {
+    if (dy2) bn_bwd_reduce_kernel<false, true><<<grid, kBT, 0, st>>>(dy, dy2, x, nullptr, stats, g, dz, part);
+    else     bn_bwd_reduce_kernel<false, false><<<grid, kBT, 0, st>>>(dy, nullptr, x, nullptr, stats, g, nullptr, part);
+  }
   HCM_CHECK_LAUNCH();
-  bn_bwd_apply_kernel<<<grid, kBT, 0, st>>>(relu ? dz : dy, x, gamma, stats, part, g, gstats, dx);
+  bn_bwd_apply_kernel<<<grid, kBT, 0, st>>>(needs_dz ? dz : dy, x, gamma, stats, part, g, gstats, dx);
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -82,7 +82,7 @@ BnGrads bn_backward_raw(const Tensor& g, const Tensor& x, const Tensor& y, const
   if (need_dx) o.dx = at::empty_like(x);
   Tensor dz = relu ? at::empty_like(x) : Tensor();
   Tensor gstats = at::empty_like(stats);
-  check_rc(hcm_bn_act_backward(g.data_ptr<float>(), x.data_ptr<float>(), fptr(y), weight.data_ptr<float>(),
+  check_rc(hcm_bn_act_backward(g.data_ptr<float>(), nullptr, x.data_ptr<float>(), fptr(y), weight.data_ptr<float>(),
                                stats.data_ptr<float>(), relu ? 1 : 0, N, C, HW, fptr(dz), fptr(o.dx),
                                gstats.data_ptr<float>(), current_stream(x)),
            "hcm_bn_act_backward");
@@ -592,15 +592,24 @@ Tensor& stream_workspace(hipStream_t st) {             // MIOpen workspace per (
   return ws[st];
 }
 
-struct GradSlot { Tensor t; bool owned = false; int sid = -1; };
-inline void accumulate(StreamCtx& S, GradSlot& s, const Tensor& t, bool owned) {
-  if (!s.t.defined()) { s.t = t; s.owned = owned; }
-  else {
-    S.acquire(s.t, s.sid);
-    if (s.owned) s.t.add_(t);
-    else { s.t = s.t + t; s.owned = true; }
-  }
+// A gradient slot holds up to two tensors whose sum is the gradient: where the consumer is a conv+bn
+// instruction the sum is formed inside hcm_bn_act_backward (no add kernel); anything else resolves it.
+struct GradSlot { Tensor t, t2; bool owned = false; int sid = -1, sid2 = -1; };
+inline void resolve(StreamCtx& S, GradSlot& s) {            // t <- t + t2 on the current stream
+  if (!s.t2.defined()) return;
+  S.acquire(s.t, s.sid);
+  S.acquire(s.t2, s.sid2);
+  if (s.owned) s.t.add_(s.t2);
+  else { s.t = s.t + s.t2; s.owned = true; }
+  s.t2 = Tensor(); s.sid2 = -1;
   s.sid = S.cur;
+}
+
+inline void accumulate(StreamCtx& S, GradSlot& s, const Tensor& t, bool owned) {
+  if (!s.t.defined()) { s.t = t; s.owned = owned; s.sid = S.cur; return; }
+  if (!s.t2.defined()) { s.t2 = t; s.sid2 = S.cur; return; }     // keep the pair lazy
+  resolve(S, s);
+  s.t2 = t; s.sid2 = S.cur;
 }
 
 // Reverse pass of a tape.  out_grads: gradients of the output slots (on the base stream); flat: the
@@ -624,8 +633,11 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
     G[dst] = GradSlot();
     if (!gs.t.defined()) { T.val[dst] = Tensor(); continue; }    // value does not reach the outputs
     S.enter((int)I[10]);
+    if (op != kOpConvBn) resolve(S, gs);
     S.acquire(gs.t, gs.sid);
+    S.acquire(gs.t2, gs.sid2);
     Tensor g = gs.t.contiguous();
+    Tensor g2 = gs.t2.defined() ? gs.t2.contiguous() : Tensor();
     if (op == kOpConvBn) {
       const int64_t L = I[4];
       const bool relu = I[7] != 0, has_res = b >= 0;
@@ -633,13 +645,15 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
       const int N = (int)z.size(0), C = (int)z.size(1), HW = (int)(z.size(2) * z.size(3));
       if (!flat_on[S.cur]) { c10::hip::HIPCachingAllocator::recordStream(flat.storage().data_ptr(), S.st[S.cur]); flat_on[S.cur] = true; }
       Tensor dzc = at::empty_like(z);
-      Tensor dz = relu ? at::empty_like(z) : Tensor();
+      const bool has_dz = relu || g2.defined();
+      Tensor dz = has_dz ? at::empty_like(z) : Tensor();
       float* gstats = fbase + T.layer_off[L] + T.w[L].numel();
-      check_rc(hcm_bn_act_backward(g.data_ptr<float>(), z.data_ptr<float>(), relu ? T.val[dst].data_ptr<float>() : nullptr,
-                                   T.gamma[L].data_ptr<float>(), T.stats[L].data_ptr<float>(), relu ? 1 : 0, N, C, HW,
-                                   fptr(dz), dzc.data_ptr<float>(), gstats, current_stream(z)),
+      check_rc(hcm_bn_act_backward(g.data_ptr<float>(), fptr(g2), z.data_ptr<float>(),
+                                   relu ? T.val[dst].data_ptr<float>() : nullptr, T.gamma[L].data_ptr<float>(),
+                                   T.stats[L].data_ptr<float>(), relu ? 1 : 0, N, C, HW, fptr(dz), dzc.data_ptr<float>(),
+                                   gstats, current_stream(z)),
                "hcm_bn_act_backward");
-      if (has_res) accumulate(S, G[b], relu ? dz : g, relu);
+      if (has_res) accumulate(S, G[b], has_dz ? dz : g, has_dz);
       const Tensor& x = T.val[a];
       const bool need_dx = a != 0 || T.need_dx0;
       ConvPlan* p = get_plan(key_of(x, T.w[L], I[5], I[6]));

@@ -612,7 +612,7 @@ class _BnAct(torch.autograd.Function):
         dz = torch.empty_like(x) if ctx.relu else None
         gstats = torch.empty(stats.numel(), dtype=torch.float32, device=x.device)
         check(_lib.lib().hcm_bn_act_backward(
-            g.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), weight.data_ptr(), stats.data_ptr(),
+            g.data_ptr(), None, x.data_ptr(), None if y is None else y.data_ptr(), weight.data_ptr(), stats.data_ptr(),
             int(ctx.relu), N, Cc, H * W, None if dz is None else dz.data_ptr(),
             None if dx is None else dx.data_ptr(), gstats.data_ptr(), _stream()), 'hcm_bn_act_backward')
         dres = (dz if ctx.relu else g) if ctx.has_res else None

@@ -224,15 +224,17 @@ int hcm_sgc_backward(const float* dOut, const float* out, const float* xhat, con
  *   gstats = [dgamma C][dbeta C][scratch]  (written by backward)
  * forward : y = relu?(gamma * (x - mean) * invstd + beta + residual?), biased batch variance;
  *           running_mean/var (nullable pair) <- (1 - momentum) * running + momentum * {mean, unbiased var}.
- * backward: dz = dy * [y > 0] when relu (dz is also the gradient of `residual`; without relu that
- *           gradient is dy itself and y, dz may be NULL); dx (NULL to skip), dgamma, dbeta.
+ * backward: dz = (dy + dy2) * [y > 0]; dy2 is an optional second gradient of the same tensor (NULL: none;
+ *           saves the add kernel where a residual block's input collects its two gradients).  dz is
+ *           also the gradient of `residual`; with neither relu nor dy2 that gradient is dy itself and
+ *           y, dz may be NULL.  dx (NULL to skip), dgamma, dbeta.
  * Deterministic (fixed-order partial sums, no atomics).
  * ------------------------------------------------------------------------ */
 size_t hcm_bn_act_stats_floats(int N, int C, int HW);
 int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, int relu,
                        int N, int C, int HW, float* y, float* stats, hcm_stream_t stream);
-int hcm_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma,
+int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
                         const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
                         float* gstats, hcm_stream_t stream);
 

@@ -124,3 +124,32 @@ def test_hrnet_fused_bn_matches_stock_ops():
     _grads_agree(res[True][1], res[False][1])
     for n, bb in res[False][2].items():
         assert torch.allclose(res[True][2][n].float(), bb.float(), rtol=1e-3, atol=1e-5), n
+
+
+@pytest.mark.parametrize('relu', [False, True])
+def test_backward_second_gradient_equals_presummed(relu):
+    """hcm_bn_act_backward(dy, dy2) == hcm_bn_act_backward(dy + dy2, NULL), bit for bit."""
+    from hcmoco_amd import _lib
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    N, C, H, W = 8, 36, 32, 32
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    w, b = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    a, c = torch.randn(N, C, H, W, generator=g).to(dev), torch.randn(N, C, H, W, generator=g).to(dev)
+    nf = int(L.hcm_bn_act_stats_floats(N, C, H * W))
+    y, stats = torch.empty_like(x), torch.empty(nf, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.hcm_bn_act_forward(x.data_ptr(), None, w.data_ptr(), b.data_ptr(), None, None, 0.1, 1e-5, int(relu),
+                                    N, C, H * W, y.data_ptr(), stats.data_ptr(), st), 'fwd')
+    outs = []
+    for dy, dy2 in ((a, c), (a + c, None)):
+        dz, dx, gs = torch.zeros_like(x), torch.empty_like(x), torch.empty(nf, device=dev)
+        need_dz = relu or dy2 is not None
+        _lib.check(L.hcm_bn_act_backward(dy.data_ptr(), None if dy2 is None else dy2.data_ptr(), x.data_ptr(),
+                                         y.data_ptr() if relu else None, w.data_ptr(), stats.data_ptr(), int(relu),
+                                         N, C, H * W, dz.data_ptr() if need_dz else None, dx.data_ptr(), gs.data_ptr(), st),
+                   'bwd')
+        outs.append((dx, gs[:2 * C].clone(), dz if need_dz else dy))
+    for p, q in zip(*outs):
+        assert torch.equal(p, q)
