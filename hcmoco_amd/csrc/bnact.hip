@@ -15,6 +15,7 @@
 //                     y = relu(x*sc + sh + residual))
 //   backward: reduce (dz = (dy + dy2?) * [y > 0]; per-slice sum(dz), sum(dz*(x-mean)); dz doubles as d residual)
 //             apply  (dgamma, dbeta; dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)))
+// Maps of <= 8192 values per channel take the one-kernel-per-direction path further down.
 // Sums are plain additions of per-slice partials in slice order: deterministic, no atomics.
 // HBM-bound: forward moves 3 (4 with residual) tensor passes, backward 7; see DESIGN.md 4.7.
 #include "hcm_common.h"
@@ -203,6 +204,144 @@ __global__ __launch_bounds__(kBT) void bn_bwd_apply_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small maps (N*H*W <= 8192 per channel: the two coarse HRNet branches, ~40 % of the layers): one
+// workgroup owns a whole channel, its slice lives in registers (<= 2 float4 per thread), so each
+// direction is ONE kernel that reads every tensor once.  For these maps a launch is ~4.5 us of
+// latency whatever it does, so halving the launch count is the whole gain.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmallM = 8192;
+
+__device__ __forceinline__ void block_sum2_n(float& a, float& b) {   // up to 16 waves
+  __shared__ float sh[2][16];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; }
+  __syncthreads();
+  float ra = 0.f, rb = 0.f;
+  for (int i = 0; i < nw; ++i) { ra += sh[0][i]; rb += sh[1][i]; }
+  a = ra; b = rb;
+  __syncthreads();
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(1024) void bn_small_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, Geo g, float eps, float momentum, float* __restrict__ rmean,
+    float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
+  const int c = blockIdx.x;
+  const float k = x[(size_t)c * g.HW];
+  float4 v[2];
+  size_t o[2];
+  bool ok[2];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = (threadIdx.x + i * blockDim.x) * 4;
+    ok[i] = f < g.M;
+    if (ok[i]) {
+      o[i] = elem_offset(g, c, f);
+      v[i] = *reinterpret_cast<const float4*>(x + o[i]);
+      const float a = v[i].x - k, b = v[i].y - k, cc = v[i].z - k, d = v[i].w - k;
+      s1 += (a + b) + (cc + d);
+      s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(cc, cc, s2); s2 = fmaf(d, d, s2);
+    }
+  }
+  block_sum2_n(s1, s2);
+  const float invM = 1.f / (float)g.M;
+  const float m1 = s1 * invM;
+  const float var = fmaxf(fmaf(-m1, m1, s2 * invM), 0.f);
+  const float mean = k + m1;
+  const float invstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    stats[c] = mean;
+    stats[g.C + c] = invstd;
+    if (rmean != nullptr) {
+      const float unbiased = g.M > 1 ? var * ((float)g.M / (float)(g.M - 1)) : var;
+      rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+      rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+    }
+  }
+  const float sc = gamma[c] * invstd;
+  const float sh = fmaf(-mean, sc, beta[c]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!ok[i]) continue;
+    float4 r = make_float4(fmaf(v[i].x, sc, sh), fmaf(v[i].y, sc, sh), fmaf(v[i].z, sc, sh), fmaf(v[i].w, sc, sh));
+    if (RES) {
+      const float4 q = *reinterpret_cast<const float4*>(res + o[i]);
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *reinterpret_cast<float4*>(y + o[i]) = r;
+  }
+}
+
+template <bool RELU, bool TWO>
+__global__ __launch_bounds__(1024) void bn_small_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ dy2, const float* __restrict__ x,
+    const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ stats, Geo g,
+    float* __restrict__ dz, float* __restrict__ dx, float* __restrict__ gstats) {
+  const int c = blockIdx.x;
+  const float mean = stats[c], invstd = stats[g.C + c];
+  float4 d[2], v[2];
+  size_t o[2];
+  bool ok[2];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = (threadIdx.x + i * blockDim.x) * 4;
+    ok[i] = f < g.M;
+    if (ok[i]) {
+      o[i] = elem_offset(g, c, f);
+      d[i] = *reinterpret_cast<const float4*>(dy + o[i]);
+      v[i] = *reinterpret_cast<const float4*>(x + o[i]);
+      if (TWO) {
+        const float4 e = *reinterpret_cast<const float4*>(dy2 + o[i]);
+        d[i].x += e.x; d[i].y += e.y; d[i].z += e.z; d[i].w += e.w;
+      }
+      if (RELU) {
+        const float4 out = *reinterpret_cast<const float4*>(y + o[i]);
+        d[i].x = out.x > 0.f ? d[i].x : 0.f; d[i].y = out.y > 0.f ? d[i].y : 0.f;
+        d[i].z = out.z > 0.f ? d[i].z : 0.f; d[i].w = out.w > 0.f ? d[i].w : 0.f;
+      }
+      if (RELU || TWO) *reinterpret_cast<float4*>(dz + o[i]) = d[i];
+      s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+      s2 = fmaf(d[i].x, v[i].x - mean, s2); s2 = fmaf(d[i].y, v[i].y - mean, s2);
+      s2 = fmaf(d[i].z, v[i].z - mean, s2); s2 = fmaf(d[i].w, v[i].w - mean, s2);
+    }
+  }
+  block_sum2_n(s1, s2);
+  if (threadIdx.x == 0) {
+    gstats[c] = s2 * invstd;     // d gamma
+    gstats[g.C + c] = s1;        // d beta
+  }
+  if (dx == nullptr) return;
+  const float invM = 1.f / (float)g.M;
+  const float a = gamma[c] * invstd;
+  const float b = s1 * invM;
+  const float q = s2 * invstd * invstd * invM;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!ok[i]) continue;
+    float4 r;
+    r.x = a * (d[i].x - b - (v[i].x - mean) * q);
+    r.y = a * (d[i].y - b - (v[i].y - mean) * q);
+    r.z = a * (d[i].z - b - (v[i].z - mean) * q);
+    r.w = a * (d[i].w - b - (v[i].w - mean) * q);
+    *reinterpret_cast<float4*>(dx + o[i]) = r;
+  }
+}
+
+inline bool small_map(const Geo& g) { return g.M <= kSmallM; }
+inline int small_threads(const Geo& g) {           // each thread holds up to two float4 of the channel
+  int t = ((g.M / 4 + 1) / 2 + 63) / 64 * 64;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  return t;
+}
+
 bool bad_shape(int N, int C, int HW) {
   return N <= 0 || C <= 0 || HW <= 0 || (HW & 3) != 0 || (long long)N * HW > 0x7fffffffLL - kVec ||
          C > 65535;
@@ -225,6 +364,17 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(N, C, HW);
   hipStream_t st = (hipStream_t)stream;
+  if (small_map(g)) {
+    const int th = small_threads(g);
+#define HCM_BN_SMALL(R, S)                                                                                \
+  bn_small_fwd_kernel<R, S><<<C, th, 0, st>>>(x, residual, gamma, beta, g, eps, momentum, running_mean,   \
+                                              running_var, stats, y)
+    if (relu) { if (residual) HCM_BN_SMALL(true, true); else HCM_BN_SMALL(true, false); }
+    else      { if (residual) HCM_BN_SMALL(false, true); else HCM_BN_SMALL(false, false); }
+#undef HCM_BN_SMALL
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(C, g.split);
   float* part = stats + 2 * (size_t)C;
   bn_stats_kernel<<<grid, kBT, 0, st>>>(x, g, part);
@@ -247,6 +397,18 @@ int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(N, C, HW);
   hipStream_t st = (hipStream_t)stream;
+  if (small_map(g)) {
+    const int th = small_threads(g);
+    if (relu) {
+      if (dy2) bn_small_bwd_kernel<true, true><<<C, th, 0, st>>>(dy, dy2, x, y, gamma, stats, g, dz, dx, gstats);
+      else     bn_small_bwd_kernel<true, false><<<C, th, 0, st>>>(dy, nullptr, x, y, gamma, stats, g, dz, dx, gstats);
+    } else {
+      if (dy2) bn_small_bwd_kernel<false, true><<<C, th, 0, st>>>(dy, dy2, x, nullptr, gamma, stats, g, dz, dx, gstats);
+      else     bn_small_bwd_kernel<false, false><<<C, th, 0, st>>>(dy, nullptr, x, nullptr, gamma, stats, g, nullptr, dx, gstats);
+    }
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(C, g.split);
   float* part = gstats + 2 * (size_t)C;
   if (relu) {
