@@ -8,8 +8,7 @@
 // branch) that is 18 workgroups on a 256-CU part (r01 profile: 19-21 us per launch for a 9.4 MB map).
 //
 // Here a layer is two kernels per direction, both on a (channel, slice) grid so that even C = 18 is
-// several hundred workgroups, and the second kernel of a pair re-reads exactly the slice its
-// twin just streamed (same blockIdx -> same XCD -> L2 hit):
+// several hundred workgroups (PMC: HBM traffic = the algorithmic passes below, profiles/r01_bnact_pmc.json):
 //   forward : stats  (per-slice shifted sums  S1 = sum(x-k), S2 = sum((x-k)^2), k = x[0,c,0,0])
 //             apply  (merge slices in fixed order -> mean, invstd, running stats;
 //                     y = relu(x*sc + sh + residual))
