@@ -352,6 +352,7 @@ void join_workers() {
 
 std::atomic<bool> g_async_wgrad{false};
 std::atomic<bool> g_wgrad_stream{false};
+std::atomic<int> g_wgrad_batch{16};
 
 struct ConvGrads { Tensor dx, dw; };
 
@@ -422,7 +423,7 @@ void set_async_wgrad(bool on) {
   g_async_wgrad.store(on);
 }
 void wgrad_join() { join_workers(); }
-void set_wgrad_stream(bool on) { g_wgrad_stream.store(on); }
+void set_wgrad_stream(bool on, int64_t batch) { g_wgrad_stream.store(on); g_wgrad_batch.store(batch > 0 ? (int)batch : 16); }
 
 struct Conv2d : public torch::autograd::Function<Conv2d> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, int64_t stride, int64_t pad) {
@@ -625,6 +626,24 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
   out_grads.clear();
   float* fbase = flat.data_ptr<float>();
   bool flat_on[kMaxSid] = {true, false, false, false};
+  struct PendingWgrad { ConvPlan* p; Tensor g, x; float* dw; Tensor w; int sid; };
+  std::vector<PendingWgrad> pending;
+  const int wgrad_batch = g_wgrad_stream.load(std::memory_order_relaxed) ? g_wgrad_batch.load(std::memory_order_relaxed) : 0;
+  auto flush_wgrads = [&]() {
+    if (pending.empty()) return;
+    const int back = S.cur;
+    S.issued();
+    S.enter(kMaxSid - 1);
+    if (!flat_on[S.cur]) { c10::hip::HIPCachingAllocator::recordStream(flat.storage().data_ptr(), S.st[S.cur]); flat_on[S.cur] = true; }
+    for (auto& j : pending) {
+      S.acquire(j.g, j.sid);                              // one event per producing stream and batch
+      c10::hip::HIPCachingAllocator::recordStream(j.x.storage().data_ptr(), S.st[S.cur]);
+      run_wgrad(j.p, j.g, j.x, j.dw, j.w, &stream_workspace(S.st[S.cur].stream()));
+    }
+    pending.clear();
+    S.issued();
+    S.enter(back);
+  };
   const int64_t n = (int64_t)T.prog.size() / kInstrInts;
   for (int64_t i = n - 1; i >= 0; --i) {
     const int64_t* I = &T.prog[i * kInstrInts];
@@ -679,18 +698,12 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
                                                  &zero, p->xd, dx.data_ptr(), hp.bd_ws ? bws.data_ptr() : nullptr, hp.bd_ws));
         accumulate(S, G[a], dx, true);
       }
-      if (g_wgrad_stream.load(std::memory_order_relaxed)) {
-        // dW is off the dependency chain: its five small launches go to the encoder's stream 3, so the
-        // chain (norm backward -> data gradient -> next layer) never queues behind them
-        const int chain = S.cur;
-        S.issued();
-        S.enter(kMaxSid - 1);
-        S.acquire(dzc, chain);
-        c10::hip::HIPCachingAllocator::recordStream(x.storage().data_ptr(), S.st[S.cur]);
-        if (!flat_on[S.cur]) { c10::hip::HIPCachingAllocator::recordStream(flat.storage().data_ptr(), S.st[S.cur]); flat_on[S.cur] = true; }
-        run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(S.st[S.cur].stream()));
-        S.issued();
-        S.enter(chain);
+      if (wgrad_batch > 0) {
+        // dW is off the dependency chain: the calls are collected and issued in batches on the encoder's
+        // stream 3 behind ONE event per batch, so the chain (norm backward -> data gradient -> next
+        // layer) never queues behind their five small launches each
+        pending.push_back(PendingWgrad{p, dzc, x, fbase + T.layer_off[L], T.w[L], S.cur});
+        if ((int)pending.size() >= wgrad_batch) flush_wgrads();
       } else {
         run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(st));
       }
@@ -707,6 +720,7 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
     S.issued();
     T.val[dst] = Tensor();
   }
+  flush_wgrads();
   S.finish();
 }
 
@@ -867,7 +881,7 @@ TORCH_LIBRARY(hcmoco, m) {
   m.def("encoder_forward_wait(int handle) -> Tensor[]", &encoder_forward_wait);
   m.def("set_async_wgrad(bool on) -> ()", &set_async_wgrad);
   m.def("wgrad_join() -> ()", &wgrad_join);
-  m.def("set_wgrad_stream(bool on) -> ()", &set_wgrad_stream);
+  m.def("set_wgrad_stream(bool on, int batch) -> ()", &set_wgrad_stream);
   m.def("bn_act(Tensor x, Tensor? residual, Tensor weight, Tensor bias, Tensor? running_mean, "
         "Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &bn_act);
 }

@@ -86,7 +86,8 @@ class ContrastTrainer(BaseTrainer):
             from ... import _lib
             self.async_wgrad = _lib.torch_glue()
             self.async_wgrad.set_async_wgrad(True)
-            self.async_wgrad.set_wgrad_stream(os.environ.get('HCM_WGRAD_STREAM', '0') != '0')
+            self.async_wgrad.set_wgrad_stream(os.environ.get('HCM_WGRAD_STREAM', '0') != '0',
+                                              int(os.environ.get('HCM_WGRAD_BATCH', '16')))
         if multi and self.graphed is None and (deferred or sync == 'flat'):
             from .graphed import broadcast_model
             broadcast_model(model)
