@@ -16,6 +16,8 @@
 
 #include <miopen/miopen.h>
 
+#include <stdlib.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -395,9 +397,31 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   return o;
 }
 
+// hcm_conv3x3_wgrad (csrc/wgrad.hip) serves the 3x3/s1/p1 layers of at most 48 channels (the 18- and
+// 36-channel HRNet branches): 31 / 23 us against 49 / 38 us for MIOpen's five-launch path, two
+// launches, deterministic.  Wider layers stay on MIOpen.  HCM_WGRAD_KERNEL=0 keeps every layer there.
+bool own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {
+  static const bool on = [] { const char* e = getenv("HCM_WGRAD_KERNEL"); return !(e && e[0] == '0'); }();
+  return on && w.size(2) == 3 && w.size(3) == 3 && g.size(2) == x.size(2) && g.size(3) == x.size(3) &&
+         w.size(0) <= 48 && w.size(1) <= 48 && (x.size(3) & 3) == 0;
+}
+
 void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Tensor& w, Tensor* cached_ws) {
   const int dev = (int)x.get_device();
   hipStream_t st = (hipStream_t)current_stream(x);
+  if (own_wgrad(x, w, g)) {
+    const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)x.size(2), W = (int)x.size(3);
+    const size_t need = hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W);
+    if (need > 0) {
+      Tensor local;
+      Tensor* ws = cached_ws ? cached_ws : &local;
+      if (!ws->defined() || (size_t)ws->numel() < need) *ws = workspace(need, x);
+      check_rc(hcm_conv3x3_wgrad(x.data_ptr<float>(), g.data_ptr<float>(), N, C, K, H, W, static_cast<float*>(dw),
+                                 ws->data_ptr(), need, st),
+               "hcm_conv3x3_wgrad");
+      return;
+    }
+  }
   miopenHandle_t h = thread_handle(dev, st);
   const float one = 1.f, zero = 0.f;
   HandlePlan& hp = handle_plan(h, p);

@@ -17,10 +17,12 @@
 //       through LDS, one partial [K][C*9] per workgroup goes to the workspace;
 //   wgrad3x3_reduce_kernel: sums the per-workgroup partials in fixed order (deterministic, no atomics).
 // Two launches, no layout transposes, deterministic.  Measured (tools/bench_wgrad.py, N=32, C=K):
-// 18ch@64^2 44 us (MIOpen 49), 36ch@32^2 32 (38), 72ch@16^2 33 (31), 144ch@8^2 38 (28): on par, so the
-// encoder runtime still issues MIOpen's kernels; the time goes into staging and the partial sums, not
-// into the MFMA loop (next: direct-to-LDS loads with double buffering, K/N split tuned per shape).
-// A first version fed dY through the scalar cache into packed VALU FMAs (one lane per (c,tap), K
+// 18ch@64^2 31 us (MIOpen 49), 36ch@32^2 23 (38), 32ch@64^2 39 (58), 72ch@16^2 30 (31), 144ch@8^2 42 (28):
+// the encoder runtime uses it for layers of at most 48 channels (+3.7 % on the step), MIOpen for the rest.
+// What it took (PMC, 18ch@64^2, per launch): 0.79 M MFMA instructions against 12.7 M VALU in the first
+// version -- integer divisions by run-time map sizes in the staging loops.  Map width and rows per unit
+// as template constants and float4 staging of an aligned X tile brought VALU to 3.8 M.
+// A first attempt fed dY through the scalar cache into packed VALU FMAs (one lane per (c,tap), K
 // accumulators): correct, but every 4 pixels waited on ~9 scalar-load round trips -- 111 us at 18ch@64^2.
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
@@ -42,15 +44,22 @@ struct WgradGeo {
   size_t lds_bytes;
 };
 
-template <int MT, int NTW>
+// WT, RBT: map width and rows per unit as compile-time constants (0 = take them from g).  With them
+// every index computation of the staging loops is a division by a constant (multiply-shift); with
+// runtime values the integer divisions were two thirds of the kernel's VALU instructions (PMC:
+// 12.7 M VALU vs 0.79 M MFMA per launch at 18ch@64x64).
+template <int MT, int NTW, int WT, int RBT>
 __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ partial, WgradGeo g) {
+                                                            float* __restrict__ partial, WgradGeo gin) {
+  WgradGeo g = gin;
+  if (WT) { g.W = WT; g.rb = RBT; g.dstride = RBT * WT + 4; }
   extern __shared__ float lds[];
   const int chunk = blockIdx.x, ng = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int np = lane & 15, kq = lane >> 4;
   const int wn = wave % g.wn, wp = wave / g.wn;
-  const int LW = g.W + 2, LH = g.rb + 2, plane = LH * LW;
+  // X tile row: [3 unused][left halo][W interior][right halo][3 unused] -> the interior is float4-aligned
+  const int LW = g.W + 8, LH = g.rb + 2, plane = LH * LW;
   const int n9 = g.C * 9;
   const int tile0 = (ng * g.wn + wn) * NTW;            // first N tile of this wave
   const int c_lo = (ng * g.wn * NTW * 16) / 9;         // first input channel this workgroup touches
@@ -63,7 +72,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
     int j = (tile0 + t) * 16 + np;
     if (j >= n9) j = n9 - 1;                            // padded columns: any valid address, never stored
     const int c = j / 9, tap = j - c * 9, r = tap / 3, s = tap - r * 3;
-    boff[t] = (c - c_lo) * plane + r * LW + s + kq;
+    boff[t] = (c - c_lo) * plane + r * LW + s + 3 + kq;
   }
   v4f acc[MT][NTW];
 #pragma unroll
@@ -73,17 +82,22 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
 
   const size_t HW = (size_t)g.H * g.W;
   const int u_beg = chunk * g.per, u_end = min(g.units, u_beg + g.per);
+  for (int i = threadIdx.x; i < g.cmax * LH * 2; i += blockDim.x)      // the halo columns stay zero for every unit
+    Xs[(i >> 1) * LW + ((i & 1) ? g.W + 4 : 3)] = 0.f;
   for (int u = u_beg; u < u_end; ++u) {
     const int n = u / g.rblocks, y0 = (u - n * g.rblocks) * g.rb;
     const int rows = min(g.rb, g.H - y0);
     __syncthreads();
-    for (int i = threadIdx.x; i < g.cmax * plane; i += blockDim.x) {     // X rows y0-1 .. y0+rb, zero halo
-      const int cc = i / plane, rem = i - cc * plane, ly = rem / LW, lx = rem - ly * LW;
-      const int gy = y0 + ly - 1, gx = lx - 1, c = c_lo + cc;
-      float v = 0.f;
-      if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && c < g.C)
-        v = x[((size_t)n * g.C + c) * HW + (size_t)gy * g.W + gx];
-      Xs[i] = v;
+    {                                                                    // X rows y0-1 .. y0+rb, float4 per thread
+      const int w4 = g.W >> 2, per_c = LH * w4;
+      for (int i = threadIdx.x; i < g.cmax * per_c; i += blockDim.x) {
+        const int cc = i / per_c, rem = i - cc * per_c, ly = rem / w4, q4 = rem - ly * w4;
+        const int gy = y0 + ly - 1, c = c_lo + cc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < g.H && c < g.C)
+          v = *reinterpret_cast<const float4*>(x + ((size_t)n * g.C + c) * HW + (size_t)gy * g.W + q4 * 4);
+        *reinterpret_cast<float4*>(Xs + cc * plane + ly * LW + 4 + q4 * 4) = v;
+      }
     }
     const int rowf = g.rb * g.W;                                         // dY rows [k][rb][W], zero for k >= K
     for (int i = threadIdx.x * 4; i < MT * 16 * rowf; i += blockDim.x * 4) {
@@ -210,7 +224,7 @@ bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
   int rb = H;
   for (;;) {
     g.dstride = rb * W + 4;
-    size_t bytes = ((size_t)g.cmax * (rb + 2) * (W + 2) + (size_t)g.mt * 16 * g.dstride) * 4;
+    size_t bytes = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)g.mt * 16 * g.dstride) * 4;
     if (bytes <= 48 * 1024 || rb == 1) break;
     rb = (rb + 1) / 2;
   }
@@ -222,7 +236,7 @@ bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
   if (wp < 1) wp = 1;
   g.wp = wp;
   g.threads = 64 * wn * wp;
-  size_t tile = ((size_t)g.cmax * (rb + 2) * (W + 2) + (size_t)g.mt * 16 * g.dstride) * 4;
+  size_t tile = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)g.mt * 16 * g.dstride) * 4;
   size_t red = (size_t)(wp - 1) * wn * g.mt * g.ntw * 64 * 16;
   g.lds_bytes = tile > red ? tile : red;
   if (g.lds_bytes > 150 * 1024) return false;
@@ -234,12 +248,24 @@ bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
   return true;
 }
 
+template <int MT, int NTW, int WT, int RBT>
+void launch_wgrad_t(const float* x, const float* dy, float* partial, const WgradGeo& g, hipStream_t st) {
+  if (g.lds_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma_kernel<MT, NTW, WT, RBT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+  wgrad3x3_mfma_kernel<MT, NTW, WT, RBT><<<dim3(g.chunks, g.ngroups), g.threads, g.lds_bytes, st>>>(x, dy, partial, g);
+}
+
 template <int MT, int NTW>
 void launch_wgrad(const float* x, const float* dy, float* partial, const WgradGeo& g, hipStream_t st) {
-  if (g.lds_bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma_kernel<MT, NTW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
-  wgrad3x3_mfma_kernel<MT, NTW><<<dim3(g.chunks, g.ngroups), g.threads, g.lds_bytes, st>>>(x, dy, partial, g);
+  // the (W, rows-per-unit) pairs the HRNet branches produce get constant-folded instantiations
+  if (g.W == 64 && g.rb == 4)      launch_wgrad_t<MT, NTW, 64, 4>(x, dy, partial, g, st);
+  else if (g.W == 32 && g.rb == 4) launch_wgrad_t<MT, NTW, 32, 4>(x, dy, partial, g, st);
+  else if (g.W == 32 && g.rb == 8) launch_wgrad_t<MT, NTW, 32, 8>(x, dy, partial, g, st);
+  else if (g.W == 16 && g.rb == 8) launch_wgrad_t<MT, NTW, 16, 8>(x, dy, partial, g, st);
+  else if (g.W == 16 && g.rb == 16) launch_wgrad_t<MT, NTW, 16, 16>(x, dy, partial, g, st);
+  else if (g.W == 8 && g.rb == 8)  launch_wgrad_t<MT, NTW, 8, 8>(x, dy, partial, g, st);
+  else                             launch_wgrad_t<MT, NTW, 0, 0>(x, dy, partial, g, st);
 }
 
 }  // namespace
