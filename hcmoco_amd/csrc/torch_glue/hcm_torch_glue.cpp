@@ -402,8 +402,9 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
 // launches, deterministic.  Wider layers stay on MIOpen.  HCM_WGRAD_KERNEL=0 keeps every layer there.
 bool own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {
   static const bool on = [] { const char* e = getenv("HCM_WGRAD_KERNEL"); return !(e && e[0] == '0'); }();
+  static const int64_t maxc = [] { const char* e = getenv("HCM_WGRAD_MAXC"); return e ? (int64_t)atoi(e) : (int64_t)48; }();
   return on && w.size(2) == 3 && w.size(3) == 3 && g.size(2) == x.size(2) && g.size(3) == x.size(3) &&
-         w.size(0) <= 48 && w.size(1) <= 48 && (x.size(3) & 3) == 0;
+         w.size(0) <= maxc && w.size(1) <= maxc && (x.size(3) & 3) == 0;
 }
 
 void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Tensor& w, Tensor* cached_ws) {

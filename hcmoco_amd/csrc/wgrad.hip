@@ -17,11 +17,12 @@
 //       through LDS, one partial [K][C*9] per workgroup goes to the workspace;
 //   wgrad3x3_reduce_kernel: sums the per-workgroup partials in fixed order (deterministic, no atomics).
 // Two launches, no layout transposes, deterministic.  Measured (tools/bench_wgrad.py, N=32, C=K):
-// 18ch@64^2 31 us (MIOpen 49), 36ch@32^2 23 (38), 32ch@64^2 39 (58), 72ch@16^2 30 (31), 144ch@8^2 42 (28):
+// 18ch@64^2 25 us (MIOpen 49), 36ch@32^2 22 (38), 32ch@64^2 39 (58), 72ch@16^2 28 (31), 144ch@8^2 42 (28):
 // the encoder runtime uses it for layers of at most 48 channels (+3.7 % on the step), MIOpen for the rest.
 // What it took (PMC, 18ch@64^2, per launch): 0.79 M MFMA instructions against 12.7 M VALU in the first
 // version -- integer divisions by run-time map sizes in the staging loops.  Map width and rows per unit
-// as template constants and float4 staging of an aligned X tile brought VALU to 3.8 M.
+// as template constants and float4 staging of an aligned X tile brought VALU to 3.8 M; keeping only the
+// K real dY rows (+ one shared zero row for the padded channels) in LDS lets four workgroups share a CU.
 // A first attempt fed dY through the scalar cache into packed VALU FMAs (one lane per (c,tap), K
 // accumulators): correct, but every 4 pixels waited on ~9 scalar-load round trips -- 111 us at 18ch@64^2.
 #include "hcm_common.h"
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
   const int tile0 = (ng * g.wn + wn) * NTW;            // first N tile of this wave
   const int c_lo = (ng * g.wn * NTW * 16) / 9;         // first input channel this workgroup touches
   float* Xs = lds;                                     // [cmax][rb+2][W+2]
-  float* Ds = lds + g.cmax * plane;                    // [mt*16][dstride]
+  float* Ds = lds + g.cmax * plane;                    // [K + 1][dstride]
   // per-lane LDS offset of the (c, tap) column of every N tile
   int boff[NTW];
 #pragma unroll
@@ -74,6 +75,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
     const int c = j / 9, tap = j - c * 9, r = tap / 3, s = tap - r * 3;
     boff[t] = (c - c_lo) * plane + r * LW + s + 3 + kq;
   }
+  int aoff[MT];                                        // dY tile row of output channel 16m+np; padded channels read the zero row K
+#pragma unroll
+  for (int m = 0; m < MT; ++m) aoff[m] = min(m * 16 + np, g.K) * g.dstride;
   v4f acc[MT][NTW];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
   const int u_beg = chunk * g.per, u_end = min(g.units, u_beg + g.per);
   for (int i = threadIdx.x; i < g.cmax * LH * 2; i += blockDim.x)      // the halo columns stay zero for every unit
     Xs[(i >> 1) * LW + ((i & 1) ? g.W + 4 : 3)] = 0.f;
+  for (int i = threadIdx.x; i < g.dstride; i += blockDim.x) Ds[g.K * g.dstride + i] = 0.f;   // and so does dY row K
   for (int u = u_beg; u < u_end; ++u) {
     const int n = u / g.rblocks, y0 = (u - n * g.rblocks) * g.rb;
     const int rows = min(g.rb, g.H - y0);
@@ -99,22 +104,22 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
         *reinterpret_cast<float4*>(Xs + cc * plane + ly * LW + 4 + q4 * 4) = v;
       }
     }
-    const int rowf = g.rb * g.W;                                         // dY rows [k][rb][W], zero for k >= K
-    for (int i = threadIdx.x * 4; i < MT * 16 * rowf; i += blockDim.x * 4) {
+    const int rowf = g.rb * g.W;                                         // dY rows [k < K][rb][W]; row K stays zero
+    for (int i = threadIdx.x * 4; i < g.K * rowf; i += blockDim.x * 4) {
       const int k = i / rowf, rem = i - k * rowf, yy = rem / g.W;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < g.K && yy < rows)
+      if (yy < rows)
         v = *reinterpret_cast<const float4*>(dy + ((size_t)n * g.K + k) * HW + (size_t)y0 * g.W + rem);
       *reinterpret_cast<float4*>(Ds + k * g.dstride + rem) = v;
     }
     __syncthreads();
     for (int yy = wp; yy < rows; yy += g.wp) {
-      const float* arow = Ds + np * g.dstride + yy * g.W + kq;
+      const float* arow = Ds + yy * g.W + kq;
       const float* brow = Xs + yy * LW;
       for (int xx = 0; xx < g.W; xx += 4) {
         float a[MT], b[NTW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = arow[m * 16 * g.dstride + xx];
+        for (int m = 0; m < MT; ++m) a[m] = arow[aoff[m] + xx];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) b[t] = brow[boff[t] + xx];
 #pragma unroll
@@ -224,7 +229,7 @@ bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
   int rb = H;
   for (;;) {
     g.dstride = rb * W + 4;
-    size_t bytes = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)g.mt * 16 * g.dstride) * 4;
+    size_t bytes = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)(K + 1) * g.dstride) * 4;
     if (bytes <= 48 * 1024 || rb == 1) break;
     rb = (rb + 1) / 2;
   }
@@ -236,7 +241,7 @@ bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
   if (wp < 1) wp = 1;
   g.wp = wp;
   g.threads = 64 * wn * wp;
-  size_t tile = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)g.mt * 16 * g.dstride) * 4;
+  size_t tile = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)(K + 1) * g.dstride) * 4;
   size_t red = (size_t)(wp - 1) * wn * g.mt * g.ntw * 64 * 16;
   g.lds_bytes = tile > red ? tile : red;
   if (g.lds_bytes > 150 * 1024) return false;
