@@ -397,29 +397,33 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   return o;
 }
 
-// hcm_conv3x3_wgrad (csrc/wgrad.hip) serves the 3x3/s1/p1 layers of at most 48 channels (the 18- and
-// 36-channel HRNet branches): 31 / 23 us against 49 / 38 us for MIOpen's five-launch path, two
-// launches, deterministic.  Wider layers stay on MIOpen.  HCM_WGRAD_KERNEL=0 keeps every layer there.
-bool own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {
+// hcm_conv3x3_wgrad / hcm_conv1x1_wgrad (csrc/wgrad.hip) serve the stride-1 layers where they beat
+// MIOpen's five-launch path: 3x3 with at most 48 channels (25 / 22 us against 49 / 38 us) and the 1x1
+// convolutions of the fuse layers (9-11 us against 25-47 us); two launches, deterministic.  Everything
+// else stays on MIOpen.  HCM_WGRAD_KERNEL=0 keeps every layer there.
+int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no, else the kernel size
   static const bool on = [] { const char* e = getenv("HCM_WGRAD_KERNEL"); return !(e && e[0] == '0'); }();
   static const int64_t maxc = [] { const char* e = getenv("HCM_WGRAD_MAXC"); return e ? (int64_t)atoi(e) : (int64_t)48; }();
-  return on && w.size(2) == 3 && w.size(3) == 3 && g.size(2) == x.size(2) && g.size(3) == x.size(3) &&
-         w.size(0) <= maxc && w.size(1) <= maxc && (x.size(3) & 3) == 0;
+  static const int64_t max1 = [] { const char* e = getenv("HCM_WGRAD_MAX1X1"); return e ? (int64_t)atoi(e) : (int64_t)160; }();
+  if (!on || g.size(2) != x.size(2) || g.size(3) != x.size(3) || (x.size(3) & 3) != 0) return 0;
+  if (w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= maxc && w.size(1) <= maxc) return 3;
+  if (w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= max1 && w.size(1) <= max1) return 1;
+  return 0;
 }
 
 void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Tensor& w, Tensor* cached_ws) {
   const int dev = (int)x.get_device();
   hipStream_t st = (hipStream_t)current_stream(x);
-  if (own_wgrad(x, w, g)) {
+  if (const int ks = own_wgrad(x, w, g)) {
     const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)x.size(2), W = (int)x.size(3);
-    const size_t need = hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W);
+    const size_t need = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W) : hcm_conv1x1_wgrad_workspace_bytes(N, C, K, H, W);
     if (need > 0) {
       Tensor local;
       Tensor* ws = cached_ws ? cached_ws : &local;
       if (!ws->defined() || (size_t)ws->numel() < need) *ws = workspace(need, x);
-      check_rc(hcm_conv3x3_wgrad(x.data_ptr<float>(), g.data_ptr<float>(), N, C, K, H, W, static_cast<float*>(dw),
-                                 ws->data_ptr(), need, st),
-               "hcm_conv3x3_wgrad");
+      check_rc((ks == 3 ? hcm_conv3x3_wgrad : hcm_conv1x1_wgrad)(x.data_ptr<float>(), g.data_ptr<float>(), N, C, K, H, W,
+                                                                 static_cast<float*>(dw), ws->data_ptr(), need, st),
+               "hcm_conv_wgrad");
       return;
     }
   }

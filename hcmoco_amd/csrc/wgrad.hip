@@ -42,6 +42,7 @@ struct WgradGeo {
   int cmax;               // input channels staged per workgroup
   int dstride;            // floats between consecutive k rows of the dY tile (padded against bank conflicts)
   int threads;
+  int taps;               // 9 (3x3, pad 1) or 1 (1x1, pad 0: only the centre tap of the same tile layout)
   size_t lds_bytes;
 };
 
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
   const int wn = wave % g.wn, wp = wave / g.wn;
   // X tile row: [3 unused][left halo][W interior][right halo][3 unused] -> the interior is float4-aligned
   const int LW = g.W + 8, LH = g.rb + 2, plane = LH * LW;
-  const int n9 = g.C * 9;
+  const int n9 = g.C * g.taps;
   const int tile0 = (ng * g.wn + wn) * NTW;            // first N tile of this wave
-  const int c_lo = (ng * g.wn * NTW * 16) / 9;         // first input channel this workgroup touches
+  const int c_lo = (ng * g.wn * NTW * 16) / g.taps;    // first input channel this workgroup touches
   float* Xs = lds;                                     // [cmax][rb+2][W+2]
   float* Ds = lds + g.cmax * plane;                    // [K + 1][dstride]
   // per-lane LDS offset of the (c, tap) column of every N tile
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
   for (int t = 0; t < NTW; ++t) {
     int j = (tile0 + t) * 16 + np;
     if (j >= n9) j = n9 - 1;                            // padded columns: any valid address, never stored
-    const int c = j / 9, tap = j - c * 9, r = tap / 3, s = tap - r * 3;
+    const int c = j / g.taps, tap = g.taps == 9 ? j - c * 9 : 4, r = tap / 3, s = tap - r * 3;
     boff[t] = (c - c_lo) * plane + r * LW + s + 3 + kq;
   }
   int aoff[MT];                                        // dY tile row of output channel 16m+np; padded channels read the zero row K
@@ -212,18 +213,19 @@ bool pick_tiles(int mt, int& ntw, int& wn_max) {
   }
 }
 
-bool make_wgeo(int N, int C, int K, int H, int W, WgradGeo& g) {
+bool make_wgeo(int N, int C, int K, int H, int W, int taps, WgradGeo& g) {
+  g.taps = taps;
   if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (W & 3) != 0) return false;
   g.N = N; g.C = C; g.K = K; g.H = H; g.W = W;
   g.mt = (K + 15) / 16;
-  g.nt = (C * 9 + 15) / 16;
+  g.nt = (C * taps + 15) / 16;
   int wn_max;
   if (!pick_tiles(g.mt, g.ntw, wn_max)) return false;
   int wn = (g.nt + g.ntw - 1) / g.ntw;
   if (wn > wn_max) wn = wn_max;
   g.wn = wn;
   g.ngroups = (g.nt + wn * g.ntw - 1) / (wn * g.ntw);
-  g.cmax = (wn * g.ntw * 16 + 8) / 9 + 2;
+  g.cmax = (wn * g.ntw * 16 + taps - 1) / taps + 2;
   if (g.cmax > C) g.cmax = C;
   // rows per unit: X tile + dY tile within ~48 KB of LDS
   int rb = H;
@@ -277,17 +279,17 @@ void launch_wgrad(const float* x, const float* dy, float* partial, const WgradGe
 
 extern "C" {
 
-size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W) {
+static size_t wgrad_ws_bytes(int N, int C, int K, int H, int W, int taps) {
   WgradGeo g;
-  if (!make_wgeo(N, C, K, H, W, g)) return 0;
-  return (size_t)g.chunks * K * C * 9 * sizeof(float);
+  if (!make_wgeo(N, C, K, H, W, taps, g)) return 0;
+  return (size_t)g.chunks * K * C * taps * sizeof(float);
 }
 
-int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, void* workspace,
-                      size_t workspace_bytes, hcm_stream_t stream) {
+static int wgrad_run(const float* x, const float* dy, int N, int C, int K, int H, int W, int taps, float* dw,
+                     void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
   WgradGeo g;
-  if (!x || !dy || !dw || !workspace || !make_wgeo(N, C, K, H, W, g)) return (int)hipErrorInvalidValue;
-  if (workspace_bytes < (size_t)g.chunks * K * C * 9 * sizeof(float)) return (int)hipErrorInvalidValue;
+  if (!x || !dy || !dw || !workspace || !make_wgeo(N, C, K, H, W, taps, g)) return (int)hipErrorInvalidValue;
+  if (workspace_bytes < (size_t)g.chunks * K * C * taps * sizeof(float)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   switch (g.mt) {
@@ -302,10 +304,22 @@ int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int 
     default: return (int)hipErrorInvalidValue;
   }
   HCM_CHECK_LAUNCH();
-  const int total = K * C * 9;
+  const int total = K * C * taps;
   wgrad3x3_reduce_kernel<<<(total + 63) / 64, 1024, 0, st>>>(partial, dw, total, g.chunks);
   HCM_CHECK_LAUNCH();
   return 0;
+}
+
+size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W) { return wgrad_ws_bytes(N, C, K, H, W, 9); }
+int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, void* workspace,
+                      size_t workspace_bytes, hcm_stream_t stream) {
+  return wgrad_run(x, dy, N, C, K, H, W, 9, dw, workspace, workspace_bytes, stream);
+}
+
+size_t hcm_conv1x1_wgrad_workspace_bytes(int N, int C, int K, int H, int W) { return wgrad_ws_bytes(N, C, K, H, W, 1); }
+int hcm_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, void* workspace,
+                      size_t workspace_bytes, hcm_stream_t stream) {
+  return wgrad_run(x, dy, N, C, K, H, W, 1, dw, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

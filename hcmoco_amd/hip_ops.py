@@ -635,19 +635,23 @@ def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=N
 # --------------------------------------------------------------------------- #
 # weight gradient of the 3x3 / stride 1 / pad 1 encoder convolutions
 # --------------------------------------------------------------------------- #
-def conv3x3_wgrad(x, dy):
-    """dW [K,C,3,3] of a 3x3/s1/p1 bias-free convolution from its input x [N,C,H,W] and the output
-    gradient dy [N,K,H,W] (hcm_conv3x3_wgrad: VALU partial sums + fixed-order reduction)."""
+def conv3x3_wgrad(x, dy, ksize=3):
+    """dW [K,C,k,k] of a bias-free stride-1 convolution (k = 3 with pad 1, or k = 1 with pad 0) from its
+    input x [N,C,H,W] and the output gradient dy [N,K,H,W] (hcm_conv3x3_wgrad / hcm_conv1x1_wgrad:
+    fp32 MFMA partial sums + fixed-order reduction)."""
     N, Cc, H, W = x.shape
     K = dy.shape[1]
     if dy.shape != (N, K, H, W):
         raise ValueError('conv3x3_wgrad: dy must be [N,K,H,W] on the input grid')
-    nbytes = int(_lib.lib().hcm_conv3x3_wgrad_workspace_bytes(N, Cc, K, H, W))
+    if ksize not in (1, 3):
+        raise ValueError('conv3x3_wgrad: kernel size must be 1 or 3')
+    name = 'hcm_conv3x3_wgrad' if ksize == 3 else 'hcm_conv1x1_wgrad'
+    nbytes = int(getattr(_lib.lib(), name + '_workspace_bytes')(N, Cc, K, H, W))
     if nbytes == 0:
         raise ValueError('conv3x3_wgrad: unsupported shape (W must be a multiple of 4)')
     ws = _ws(nbytes, x.device)
-    dw = torch.empty(K, Cc, 3, 3, dtype=torch.float32, device=x.device)
-    check(_lib.lib().hcm_conv3x3_wgrad(_dev(x, torch.float32, 'conv3x3_wgrad'), _dev(dy, torch.float32, 'conv3x3_wgrad'),
-                                       N, Cc, K, H, W, C.c_void_p(dw.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
-                                       _stream()), 'hcm_conv3x3_wgrad')
+    dw = torch.empty(K, Cc, ksize, ksize, dtype=torch.float32, device=x.device)
+    check(getattr(_lib.lib(), name)(_dev(x, torch.float32, 'conv3x3_wgrad'), _dev(dy, torch.float32, 'conv3x3_wgrad'),
+                                    N, Cc, K, H, W, C.c_void_p(dw.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
+                                    _stream()), name)
     return dw

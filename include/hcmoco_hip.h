@@ -249,6 +249,10 @@ int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const
 size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W);
 int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
                       void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+/* The same for a 1x1 / stride 1 / pad 0 convolution (fuse-layer and bottleneck 1x1s): dw [K,C,1,1]. */
+size_t hcm_conv1x1_wgrad_workspace_bytes(int N, int C, int K, int H, int W);
+int hcm_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
+                      void* workspace, size_t workspace_bytes, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the

@@ -35,3 +35,23 @@ def test_wgrad_rejects_unsupported():
         hip_ops.conv3x3_wgrad(torch.randn(2, 4, 6, 6, device=dev), torch.randn(2, 4, 6, 6, device=dev))   # W % 4 != 0
     with pytest.raises(RuntimeError):
         hip_ops.conv3x3_wgrad(torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8))                            # CPU tensors
+
+
+SHAPES_1X1 = [(32, 36, 18, 32, 32), (8, 72, 18, 16, 16), (4, 144, 36, 8, 8), (8, 64, 256, 16, 16), (3, 5, 7, 12, 20),
+              (2, 18, 144, 8, 8)]
+
+
+@pytest.mark.parametrize('shape', SHAPES_1X1)
+def test_wgrad_1x1_matches_aten(shape):
+    from hcmoco_amd import hip_ops
+    N, C, K, H, W = shape
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    dy = torch.randn(N, K, H, W, generator=g).to(dev)
+    w = torch.zeros(K, C, 1, 1, device=dev)
+    ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [0, 0], [1, 1], False,
+                                              [0, 0], 1, [False, True, False])[1]
+    got = hip_ops.conv3x3_wgrad(x, dy, ksize=1)
+    assert torch.equal(got, hip_ops.conv3x3_wgrad(x, dy, ksize=1))
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
