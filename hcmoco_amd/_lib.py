@@ -74,6 +74,8 @@ SIGNATURES = {
     'hcm_conv3x3_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_conv1x1_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
     'hcm_conv1x1_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
+    'hcm_conv3x3s2_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
+    'hcm_conv3x3s2_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_rowmax_forward': (_i, [_p, C.c_longlong, _i, _p, _p, _p]),
     'hcm_rowmax_backward': (_i, [_p, _p, C.c_longlong, _i, _p, _p]),
     'hcm_prof_enable': (_i, [_i]),

@@ -399,15 +399,19 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
 
 // hcm_conv3x3_wgrad / hcm_conv1x1_wgrad (csrc/wgrad.hip) serve the stride-1 layers where they beat
 // MIOpen's five-launch path: 3x3 with at most 48 channels (25 / 22 us against 49 / 38 us) and the 1x1
-// convolutions of the fuse layers (9-11 us against 25-47 us); two launches, deterministic.  Everything
+// convolutions of the fuse layers (9-11 us against 25-47 us) and their 3x3 stride-2 convolutions (14-23 us
+// against 27-37 us); two launches, deterministic.  Everything
 // else stays on MIOpen.  HCM_WGRAD_KERNEL=0 keeps every layer there.
-int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no, else the kernel size
+int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no; 3 / 1: kernel size at stride 1; 2: 3x3 at stride 2
   static const bool on = [] { const char* e = getenv("HCM_WGRAD_KERNEL"); return !(e && e[0] == '0'); }();
   static const int64_t maxc = [] { const char* e = getenv("HCM_WGRAD_MAXC"); return e ? (int64_t)atoi(e) : (int64_t)48; }();
   static const int64_t max1 = [] { const char* e = getenv("HCM_WGRAD_MAX1X1"); return e ? (int64_t)atoi(e) : (int64_t)160; }();
-  if (!on || g.size(2) != x.size(2) || g.size(3) != x.size(3) || (x.size(3) & 3) != 0) return 0;
-  if (w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= maxc && w.size(1) <= maxc) return 3;
-  if (w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= max1 && w.size(1) <= max1) return 1;
+  if (!on || (g.size(3) & 3) != 0) return 0;
+  const bool same = g.size(2) == x.size(2) && g.size(3) == x.size(3);
+  const bool half = 2 * g.size(2) == x.size(2) && 2 * g.size(3) == x.size(3);
+  if (same && w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= maxc && w.size(1) <= maxc) return 3;
+  if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= max1 && w.size(1) <= max1) return 1;
+  if (half && w.size(2) == 3 && w.size(3) == 3 && w.size(1) <= maxc && w.size(0) <= 2 * maxc) return 2;   // stride 2
   return 0;
 }
 
@@ -415,14 +419,17 @@ void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Te
   const int dev = (int)x.get_device();
   hipStream_t st = (hipStream_t)current_stream(x);
   if (const int ks = own_wgrad(x, w, g)) {
-    const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)x.size(2), W = (int)x.size(3);
-    const size_t need = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W) : hcm_conv1x1_wgrad_workspace_bytes(N, C, K, H, W);
+    // H, W: the OUTPUT map (= the input map at stride 1)
+    const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)g.size(2), W = (int)g.size(3);
+    const auto bytes = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes : ks == 1 ? hcm_conv1x1_wgrad_workspace_bytes
+                                                                             : hcm_conv3x3s2_wgrad_workspace_bytes;
+    const auto run = ks == 3 ? hcm_conv3x3_wgrad : ks == 1 ? hcm_conv1x1_wgrad : hcm_conv3x3s2_wgrad;
+    const size_t need = bytes(N, C, K, H, W);
     if (need > 0) {
       Tensor local;
       Tensor* ws = cached_ws ? cached_ws : &local;
       if (!ws->defined() || (size_t)ws->numel() < need) *ws = workspace(need, x);
-      check_rc((ks == 3 ? hcm_conv3x3_wgrad : hcm_conv1x1_wgrad)(x.data_ptr<float>(), g.data_ptr<float>(), N, C, K, H, W,
-                                                                 static_cast<float*>(dw), ws->data_ptr(), need, st),
+      check_rc(run(x.data_ptr<float>(), g.data_ptr<float>(), N, C, K, H, W, static_cast<float*>(dw), ws->data_ptr(), need, st),
                "hcm_conv_wgrad");
       return;
     }

@@ -1,4 +1,4 @@
-// Weight gradient of the encoders' 3x3 / stride 1 / pad 1 convolutions, gfx950.
+// Weight gradients of the encoders' convolutions (3x3 at stride 1 or 2 with pad 1, and 1x1), gfx950.
 //
 //   dW[k][c][r][s] = sum over n, y, x of  dY[n][k][y][x] * X[n][c][y+r-1][x+s-1]        (fp32, NCHW)
 //
@@ -43,6 +43,7 @@ struct WgradGeo {
   int dstride;            // floats between consecutive k rows of the dY tile (padded against bank conflicts)
   int threads;
   int taps;               // 9 (3x3, pad 1) or 1 (1x1, pad 0: only the centre tap of the same tile layout)
+  int st;                 // convolution stride (1 or 2): x is [N,C,st*H,st*W], dy [N,K,H,W]
   size_t lds_bytes;
 };
 
@@ -50,18 +51,19 @@ struct WgradGeo {
 // every index computation of the staging loops is a division by a constant (multiply-shift); with
 // runtime values the integer divisions were two thirds of the kernel's VALU instructions (PMC:
 // 12.7 M VALU vs 0.79 M MFMA per launch at 18ch@64x64).
-template <int MT, int NTW, int WT, int RBT>
+template <int MT, int NTW, int WT, int RBT, int ST>
 __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ partial, WgradGeo gin) {
   WgradGeo g = gin;
-  if (WT) { g.W = WT; g.rb = RBT; g.dstride = RBT * WT + 4; }
+  if (WT) { g.W = WT; g.rb = RBT; g.dstride = RBT * WT + 4; g.st = ST; }
+  const int Wx = g.st * g.W, Hx = g.st * g.H;          // input map
   extern __shared__ float lds[];
   const int chunk = blockIdx.x, ng = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int np = lane & 15, kq = lane >> 4;
   const int wn = wave % g.wn, wp = wave / g.wn;
   // X tile row: [3 unused][left halo][W interior][right halo][3 unused] -> the interior is float4-aligned
-  const int LW = g.W + 8, LH = g.rb + 2, plane = LH * LW;
+  const int LW = Wx + 8, LH = g.st * g.rb + 2, plane = LH * LW;
   const int n9 = g.C * g.taps;
   const int tile0 = (ng * g.wn + wn) * NTW;            // first N tile of this wave
   const int c_lo = (ng * g.wn * NTW * 16) / g.taps;    // first input channel this workgroup touches
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
     int j = (tile0 + t) * 16 + np;
     if (j >= n9) j = n9 - 1;                            // padded columns: any valid address, never stored
     const int c = j / g.taps, tap = g.taps == 9 ? j - c * 9 : 4, r = tap / 3, s = tap - r * 3;
-    boff[t] = (c - c_lo) * plane + r * LW + s + 3 + kq;
+    boff[t] = (c - c_lo) * plane + r * LW + s + 3 + g.st * kq;
   }
   int aoff[MT];                                        // dY tile row of output channel 16m+np; padded channels read the zero row K
 #pragma unroll
@@ -85,23 +87,23 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  const size_t HW = (size_t)g.H * g.W;
+  const size_t HW = (size_t)g.H * g.W, HWx = (size_t)Hx * Wx;
   const int u_beg = chunk * g.per, u_end = min(g.units, u_beg + g.per);
   for (int i = threadIdx.x; i < g.cmax * LH * 2; i += blockDim.x)      // the halo columns stay zero for every unit
-    Xs[(i >> 1) * LW + ((i & 1) ? g.W + 4 : 3)] = 0.f;
+    Xs[(i >> 1) * LW + ((i & 1) ? Wx + 4 : 3)] = 0.f;
   for (int i = threadIdx.x; i < g.dstride; i += blockDim.x) Ds[g.K * g.dstride + i] = 0.f;   // and so does dY row K
   for (int u = u_beg; u < u_end; ++u) {
     const int n = u / g.rblocks, y0 = (u - n * g.rblocks) * g.rb;
     const int rows = min(g.rb, g.H - y0);
     __syncthreads();
     {                                                                    // X rows y0-1 .. y0+rb, float4 per thread
-      const int w4 = g.W >> 2, per_c = LH * w4;
+      const int w4 = Wx >> 2, per_c = LH * w4;
       for (int i = threadIdx.x; i < g.cmax * per_c; i += blockDim.x) {
         const int cc = i / per_c, rem = i - cc * per_c, ly = rem / w4, q4 = rem - ly * w4;
-        const int gy = y0 + ly - 1, c = c_lo + cc;
+        const int gy = g.st * y0 + ly - 1, c = c_lo + cc;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < g.H && c < g.C)
-          v = *reinterpret_cast<const float4*>(x + ((size_t)n * g.C + c) * HW + (size_t)gy * g.W + q4 * 4);
+        if (gy >= 0 && gy < Hx && c < g.C)
+          v = *reinterpret_cast<const float4*>(x + ((size_t)n * g.C + c) * HWx + (size_t)gy * Wx + q4 * 4);
         *reinterpret_cast<float4*>(Xs + cc * plane + ly * LW + 4 + q4 * 4) = v;
       }
     }
@@ -116,13 +118,13 @@ __global__ __launch_bounds__(512) void wgrad3x3_mfma_kernel(const float* __restr
     __syncthreads();
     for (int yy = wp; yy < rows; yy += g.wp) {
       const float* arow = Ds + yy * g.W + kq;
-      const float* brow = Xs + yy * LW;
+      const float* brow = Xs + g.st * yy * LW;
       for (int xx = 0; xx < g.W; xx += 4) {
         float a[MT], b[NTW];
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[m] = arow[aoff[m] + xx];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t] = brow[boff[t] + xx];
+        for (int t = 0; t < NTW; ++t) b[t] = brow[boff[t] + g.st * xx];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -213,8 +215,9 @@ bool pick_tiles(int mt, int& ntw, int& wn_max) {
   }
 }
 
-bool make_wgeo(int N, int C, int K, int H, int W, int taps, WgradGeo& g) {
-  g.taps = taps;
+bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g) {
+  g.taps = taps; g.st = st;
+  if (st != 1 && st != 2) return false;
   if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || (W & 3) != 0) return false;
   g.N = N; g.C = C; g.K = K; g.H = H; g.W = W;
   g.mt = (K + 15) / 16;
@@ -231,7 +234,7 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, WgradGeo& g) {
   int rb = H;
   for (;;) {
     g.dstride = rb * W + 4;
-    size_t bytes = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)(K + 1) * g.dstride) * 4;
+    size_t bytes = ((size_t)g.cmax * (st * rb + 2) * (st * W + 8) + (size_t)(K + 1) * g.dstride) * 4;
     if (bytes <= 48 * 1024 || rb == 1) break;
     rb = (rb + 1) / 2;
   }
@@ -243,7 +246,7 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, WgradGeo& g) {
   if (wp < 1) wp = 1;
   g.wp = wp;
   g.threads = 64 * wn * wp;
-  size_t tile = ((size_t)g.cmax * (rb + 2) * (W + 8) + (size_t)(K + 1) * g.dstride) * 4;
+  size_t tile = ((size_t)g.cmax * (st * rb + 2) * (st * W + 8) + (size_t)(K + 1) * g.dstride) * 4;
   size_t red = (size_t)(wp - 1) * wn * g.mt * g.ntw * 64 * 16;
   g.lds_bytes = tile > red ? tile : red;
   if (g.lds_bytes > 150 * 1024) return false;
@@ -255,40 +258,49 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, WgradGeo& g) {
   return true;
 }
 
-template <int MT, int NTW, int WT, int RBT>
+template <int MT, int NTW, int WT, int RBT, int ST>
 void launch_wgrad_t(const float* x, const float* dy, float* partial, const WgradGeo& g, hipStream_t st) {
   if (g.lds_bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma_kernel<MT, NTW, WT, RBT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_mfma_kernel<MT, NTW, WT, RBT, ST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
-  wgrad3x3_mfma_kernel<MT, NTW, WT, RBT><<<dim3(g.chunks, g.ngroups), g.threads, g.lds_bytes, st>>>(x, dy, partial, g);
+  wgrad3x3_mfma_kernel<MT, NTW, WT, RBT, ST><<<dim3(g.chunks, g.ngroups), g.threads, g.lds_bytes, st>>>(x, dy, partial, g);
 }
 
 template <int MT, int NTW>
 void launch_wgrad(const float* x, const float* dy, float* partial, const WgradGeo& g, hipStream_t st) {
   // the (W, rows-per-unit) pairs the HRNet branches produce get constant-folded instantiations
-  if (g.W == 64 && g.rb == 4)      launch_wgrad_t<MT, NTW, 64, 4>(x, dy, partial, g, st);
-  else if (g.W == 32 && g.rb == 4) launch_wgrad_t<MT, NTW, 32, 4>(x, dy, partial, g, st);
-  else if (g.W == 32 && g.rb == 8) launch_wgrad_t<MT, NTW, 32, 8>(x, dy, partial, g, st);
-  else if (g.W == 16 && g.rb == 8) launch_wgrad_t<MT, NTW, 16, 8>(x, dy, partial, g, st);
-  else if (g.W == 16 && g.rb == 16) launch_wgrad_t<MT, NTW, 16, 16>(x, dy, partial, g, st);
-  else if (g.W == 8 && g.rb == 8)  launch_wgrad_t<MT, NTW, 8, 8>(x, dy, partial, g, st);
-  else                             launch_wgrad_t<MT, NTW, 0, 0>(x, dy, partial, g, st);
+  if (g.st == 1) {
+    if (g.W == 64 && g.rb == 4)      launch_wgrad_t<MT, NTW, 64, 4, 1>(x, dy, partial, g, st);
+    else if (g.W == 32 && g.rb == 4) launch_wgrad_t<MT, NTW, 32, 4, 1>(x, dy, partial, g, st);
+    else if (g.W == 32 && g.rb == 8) launch_wgrad_t<MT, NTW, 32, 8, 1>(x, dy, partial, g, st);
+    else if (g.W == 16 && g.rb == 8) launch_wgrad_t<MT, NTW, 16, 8, 1>(x, dy, partial, g, st);
+    else if (g.W == 16 && g.rb == 16) launch_wgrad_t<MT, NTW, 16, 16, 1>(x, dy, partial, g, st);
+    else if (g.W == 8 && g.rb == 8)  launch_wgrad_t<MT, NTW, 8, 8, 1>(x, dy, partial, g, st);
+    else                             launch_wgrad_t<MT, NTW, 0, 0, 0>(x, dy, partial, g, st);
+  } else {
+    if (g.W == 32 && g.rb == 2)      launch_wgrad_t<MT, NTW, 32, 2, 2>(x, dy, partial, g, st);
+    else if (g.W == 32 && g.rb == 4) launch_wgrad_t<MT, NTW, 32, 4, 2>(x, dy, partial, g, st);
+    else if (g.W == 16 && g.rb == 4) launch_wgrad_t<MT, NTW, 16, 4, 2>(x, dy, partial, g, st);
+    else if (g.W == 16 && g.rb == 8) launch_wgrad_t<MT, NTW, 16, 8, 2>(x, dy, partial, g, st);
+    else if (g.W == 8 && g.rb == 8)  launch_wgrad_t<MT, NTW, 8, 8, 2>(x, dy, partial, g, st);
+    else                             launch_wgrad_t<MT, NTW, 0, 0, 0>(x, dy, partial, g, st);
+  }
 }
 
 }  // namespace
 
 extern "C" {
 
-static size_t wgrad_ws_bytes(int N, int C, int K, int H, int W, int taps) {
+static size_t wgrad_ws_bytes(int N, int C, int K, int H, int W, int taps, int st) {
   WgradGeo g;
-  if (!make_wgeo(N, C, K, H, W, taps, g)) return 0;
+  if (!make_wgeo(N, C, K, H, W, taps, st, g)) return 0;
   return (size_t)g.chunks * K * C * taps * sizeof(float);
 }
 
-static int wgrad_run(const float* x, const float* dy, int N, int C, int K, int H, int W, int taps, float* dw,
+static int wgrad_run(const float* x, const float* dy, int N, int C, int K, int H, int W, int taps, int cst, float* dw,
                      void* workspace, size_t workspace_bytes, hcm_stream_t stream) {
   WgradGeo g;
-  if (!x || !dy || !dw || !workspace || !make_wgeo(N, C, K, H, W, taps, g)) return (int)hipErrorInvalidValue;
+  if (!x || !dy || !dw || !workspace || !make_wgeo(N, C, K, H, W, taps, cst, g)) return (int)hipErrorInvalidValue;
   if (workspace_bytes < (size_t)g.chunks * K * C * taps * sizeof(float)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
@@ -310,16 +322,23 @@ static int wgrad_run(const float* x, const float* dy, int N, int C, int K, int H
   return 0;
 }
 
-size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W) { return wgrad_ws_bytes(N, C, K, H, W, 9); }
+size_t hcm_conv3x3_wgrad_workspace_bytes(int N, int C, int K, int H, int W) { return wgrad_ws_bytes(N, C, K, H, W, 9, 1); }
 int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, void* workspace,
                       size_t workspace_bytes, hcm_stream_t stream) {
-  return wgrad_run(x, dy, N, C, K, H, W, 9, dw, workspace, workspace_bytes, stream);
+  return wgrad_run(x, dy, N, C, K, H, W, 9, 1, dw, workspace, workspace_bytes, stream);
 }
 
-size_t hcm_conv1x1_wgrad_workspace_bytes(int N, int C, int K, int H, int W) { return wgrad_ws_bytes(N, C, K, H, W, 1); }
+size_t hcm_conv1x1_wgrad_workspace_bytes(int N, int C, int K, int H, int W) { return wgrad_ws_bytes(N, C, K, H, W, 1, 1); }
 int hcm_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, void* workspace,
                       size_t workspace_bytes, hcm_stream_t stream) {
-  return wgrad_run(x, dy, N, C, K, H, W, 1, dw, workspace, workspace_bytes, stream);
+  return wgrad_run(x, dy, N, C, K, H, W, 1, 1, dw, workspace, workspace_bytes, stream);
+}
+
+// 3x3 / stride 2 / pad 1: x [N,C,2Ho,2Wo], dy [N,K,Ho,Wo] (Ho, Wo are the arguments)
+size_t hcm_conv3x3s2_wgrad_workspace_bytes(int N, int C, int K, int Ho, int Wo) { return wgrad_ws_bytes(N, C, K, Ho, Wo, 9, 2); }
+int hcm_conv3x3s2_wgrad(const float* x, const float* dy, int N, int C, int K, int Ho, int Wo, float* dw, void* workspace,
+                        size_t workspace_bytes, hcm_stream_t stream) {
+  return wgrad_run(x, dy, N, C, K, Ho, Wo, 9, 2, dw, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -635,17 +635,19 @@ def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=N
 # --------------------------------------------------------------------------- #
 # weight gradient of the 3x3 / stride 1 / pad 1 encoder convolutions
 # --------------------------------------------------------------------------- #
-def conv3x3_wgrad(x, dy, ksize=3):
-    """dW [K,C,k,k] of a bias-free stride-1 convolution (k = 3 with pad 1, or k = 1 with pad 0) from its
-    input x [N,C,H,W] and the output gradient dy [N,K,H,W] (hcm_conv3x3_wgrad / hcm_conv1x1_wgrad:
-    fp32 MFMA partial sums + fixed-order reduction)."""
-    N, Cc, H, W = x.shape
+def conv3x3_wgrad(x, dy, ksize=3, stride=1):
+    """dW [K,C,k,k] of a bias-free convolution (k = 3 / pad 1 at stride 1 or 2, or k = 1 / pad 0 at stride 1)
+    from its input x [N,C,H,W] and the output gradient dy [N,K,H/stride,W/stride]
+    (hcm_conv3x3_wgrad / hcm_conv3x3s2_wgrad / hcm_conv1x1_wgrad: fp32 MFMA partial sums + fixed-order
+    reduction)."""
+    N, Cc, Hx, Wx = x.shape
     K = dy.shape[1]
-    if dy.shape != (N, K, H, W):
-        raise ValueError('conv3x3_wgrad: dy must be [N,K,H,W] on the input grid')
-    if ksize not in (1, 3):
-        raise ValueError('conv3x3_wgrad: kernel size must be 1 or 3')
-    name = 'hcm_conv3x3_wgrad' if ksize == 3 else 'hcm_conv1x1_wgrad'
+    if (ksize, stride) not in ((3, 1), (3, 2), (1, 1)):
+        raise ValueError('conv3x3_wgrad: kernel size / stride must be (3,1), (3,2) or (1,1)')
+    if Hx % stride or Wx % stride or dy.shape != (N, K, Hx // stride, Wx // stride):
+        raise ValueError('conv3x3_wgrad: dy must be [N,K,H/stride,W/stride]')
+    H, W = Hx // stride, Wx // stride
+    name = {(3, 1): 'hcm_conv3x3_wgrad', (3, 2): 'hcm_conv3x3s2_wgrad', (1, 1): 'hcm_conv1x1_wgrad'}[(ksize, stride)]
     nbytes = int(getattr(_lib.lib(), name + '_workspace_bytes')(N, Cc, K, H, W))
     if nbytes == 0:
         raise ValueError('conv3x3_wgrad: unsupported shape (W must be a multiple of 4)')

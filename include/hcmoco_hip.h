@@ -253,6 +253,11 @@ int hcm_conv3x3_wgrad(const float* x, const float* dy, int N, int C, int K, int 
 size_t hcm_conv1x1_wgrad_workspace_bytes(int N, int C, int K, int H, int W);
 int hcm_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
                       void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+/* 3x3 / stride 2 / pad 1 (the down-sampling convolutions of the fuse layers and transitions):
+ * x [N,C,2Ho,2Wo], dy [N,K,Ho,Wo], dw [K,C,3,3]; Ho, Wo are the arguments. */
+size_t hcm_conv3x3s2_wgrad_workspace_bytes(int N, int C, int K, int Ho, int Wo);
+int hcm_conv3x3s2_wgrad(const float* x, const float* dy, int N, int C, int K, int Ho, int Wo, float* dw,
+                        void* workspace, size_t workspace_bytes, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the

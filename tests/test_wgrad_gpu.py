@@ -55,3 +55,23 @@ def test_wgrad_1x1_matches_aten(shape):
     got = hip_ops.conv3x3_wgrad(x, dy, ksize=1)
     assert torch.equal(got, hip_ops.conv3x3_wgrad(x, dy, ksize=1))
     assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+SHAPES_S2 = [(32, 18, 18, 64, 64), (8, 18, 36, 64, 64), (4, 36, 72, 32, 32), (4, 72, 144, 16, 16), (2, 5, 7, 12, 24),
+             (8, 36, 36, 32, 32)]
+
+
+@pytest.mark.parametrize('shape', SHAPES_S2)
+def test_wgrad_3x3_stride2_matches_aten(shape):
+    from hcmoco_amd import hip_ops
+    N, C, K, H, W = shape                    # input map H x W, output map H/2 x W/2
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(sum(shape) + 2)
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    dy = torch.randn(N, K, H // 2, W // 2, generator=g).to(dev)
+    w = torch.zeros(K, C, 3, 3, device=dev)
+    ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [2, 2], [1, 1], [1, 1], False,
+                                              [0, 0], 1, [False, True, False])[1]
+    got = hip_ops.conv3x3_wgrad(x, dy, ksize=3, stride=2)
+    assert torch.equal(got, hip_ops.conv3x3_wgrad(x, dy, ksize=3, stride=2))
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
