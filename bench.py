@@ -53,7 +53,7 @@ def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, 
         return TrainOptions().parse(argv)
 
 
-def build(args, trainer, engine_device, graphs=False):
+def build(args, trainer, engine_device):
     from hcmoco_amd.pycontrast.networks.build_backbone import build_model
     from hcmoco_amd.pycontrast.memory.build_memory import build_mem
     from hcmoco_amd.pycontrast.datasets.synthetic import build_synthetic_contrast_loader
@@ -67,8 +67,6 @@ def build(args, trainer, engine_device, graphs=False):
     # tensors in a handful of multi-tensor launches (6.9 -> ~1 ms of host time per step)
     opt = torch.optim.SGD(model.parameters(), lr=args.learning_rate, momentum=args.momentum,
                           weight_decay=args.weight_decay, fused=torch.device(engine_device).type == 'cuda')
-    if graphs:
-        trainer.enable_graphs(model, data.pool[0], stage2=True)
     model, _, opt = trainer.wrap_up(model, None, opt)
     trainer.broadcast_memory(contrast)
     model.train()
@@ -148,8 +146,6 @@ def main():
     ap.add_argument('--backend', type=str, default='nccl',
                     help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '
                          'multi-rank control flow be exercised on a single-GPU box')
-    ap.add_argument('--graphs', type=int, default=int(os.environ.get('HCMOCO_GRAPHS', '0')),
-                    help='capture the encoder forward/backward as hipGraphs')
     a = ap.parse_args()
     if a.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker(a.nce_k, a.n_data, a.size, a.skeleton, a.batch_per_gpu, a.cpu_budget_s)))
@@ -182,7 +178,7 @@ def main():
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     trainer = ContrastTrainer(args)                                          # HIP loss engine
     trainer.device = dev
-    model, contrast, opt, data = build(args, trainer, dev, graphs=bool(a.graphs))
+    model, contrast, opt, data = build(args, trainer, dev)
     torch.cuda.manual_seed(1234 + rank)          # per-replica pixel sampling; weights were built from seed 0
 
     it = iter(data)
@@ -243,7 +239,7 @@ def main():
                        'bank_dtype': a.bank_dtype,
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
-                       'channels_last': bool(a.channels_last), 'hip_graphs': bool(a.graphs), 'sampled_projection': bool(a.sampled_projection),
+                       'channels_last': bool(a.channels_last), 'sampled_projection': bool(a.sampled_projection),
                        'final_loss': round(loss, 4)},
             'roofline': {'kernel': 'bank_pass_kernel<2,fused> (gather + 6 logit sets + online softmax + d/dx)',
                          'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),

@@ -393,8 +393,15 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
 int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
                         const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
                         float* gstats, hcm_stream_t stream) {
+  return hcm_bn_act_backward_ws(dy, dy2, x, y, gamma, stats, relu, N, C, HW, dz, dx, gstats,
+                                gstats ? gstats + 2 * (size_t)(C > 0 ? C : 0) : nullptr, stream);
+}
+
+int hcm_bn_act_backward_ws(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
+                           const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
+                           float* gstats, float* scratch, hcm_stream_t stream) {
   const bool needs_dz = relu || dy2 != nullptr;
-  if (bad_shape(N, C, HW) || !dy || !x || !gamma || !stats || !gstats || (relu && !y) || (needs_dz && !dz))
+  if (bad_shape(N, C, HW) || !dy || !x || !gamma || !stats || !gstats || !scratch || (relu && !y) || (needs_dz && !dz))
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(N, C, HW);
   hipStream_t st = (hipStream_t)stream;
@@ -411,7 +418,7 @@ int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const
     return 0;
   }
   const dim3 grid(C, g.split);
-  float* part = gstats + 2 * (size_t)C;
+  float* part = scratch;
   if (relu) {
     if (dy2) bn_bwd_reduce_kernel<true, true><<<grid, kBT, 0, st>>>(dy, dy2, x, y, stats, g, dz, part);
     else     bn_bwd_reduce_kernel<true, false><<<grid, kBT, 0, st>>>(dy, nullptr, x, y, stats, g, dz, part);

@@ -561,10 +561,91 @@ struct Tape : torch::CustomClassHolder {
   std::vector<Tensor> val;            // value slots (outputs held as detached aliases: no cycle with the node)
   std::vector<Tensor> z, stats;       // per conv+bn layer
   std::vector<Tensor> w, gamma;       // parameters the backward reads
-  std::vector<int64_t> layer_off;     // offset of layer L's [dw | dgamma dbeta scratch] block in the flat gradient buffer
-  int64_t flat_numel = 0;
+  std::vector<int64_t> layer_off;     // offset of layer L's [dw | dgamma | dbeta] block in the flat gradient buffer
+  std::vector<int64_t> scratch_off;   // offset of layer L's partial-sum scratch (hcm_bn_act_backward_ws) in its own buffer
+  int64_t flat_numel = 0, scratch_numel = 0;
+  int64_t tag = 0;                    // encoder id given by the caller (grad_chunk_wait looks the gradients up by it)
   bool need_dx0 = false;
 };
+
+// ------------------------------------------------------------------------------------------------
+// Gradient chunks.  The flat parameter-gradient buffer of an encoder is dense ([dw | dgamma | dbeta]
+// per layer, layers in program order) and the reverse loop fills it from the back, so it is handed to
+// the collective library piecewise WHILE the loop is still running: with set_grad_chunks(n) the loop
+// records a HIP event on its stream each time another n-th of the buffer is complete (chunk 0 = the
+// LAST layers, finished first) and grad_chunk_wait(tag, k) -- called by the trainer thread after
+// backward() returned -- blocks until chunk k's launches are in the stream, orders the CALLER's
+// current stream behind that event and returns the chunk as a 1-D view of the flat buffer, ready for
+// an in-place RCCL all-reduce (learning/grad_sync.py).  That is DistributedDataParallel's bucket
+// overlap (reference: learning/contrast_trainer.py:74) for gradients that are written off the
+// autograd thread, where DDP's own hooks cannot see them.
+// ------------------------------------------------------------------------------------------------
+struct GradChunks {
+  Tensor flat;
+  std::vector<int64_t> off;           // chunk k = flat[off[k+1], off[k]) -- descending, off[0] = numel, off.back() = 0
+  std::vector<int64_t> first_layer;   // chunk k is complete once layer first_layer[k] has been issued
+  std::vector<hipEvent_t> ev;
+  std::mutex m;
+  std::condition_variable cv;
+  int ready = 0;                      // chunks [0, ready) have been issued
+  std::string error;
+  ~GradChunks() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+std::atomic<int> g_grad_chunks{0};
+std::mutex g_chunks_mutex;
+std::unordered_map<int64_t, std::shared_ptr<GradChunks>> g_chunks;
+
+std::shared_ptr<GradChunks> make_chunks(const Tape& T, const Tensor& flat) {
+  const int want = g_grad_chunks.load(std::memory_order_relaxed);
+  if (want <= 0 || T.tag == 0) return nullptr;
+  auto gc = std::make_shared<GradChunks>();
+  gc->flat = flat;
+  const int64_t layers = (int64_t)T.layer_off.size();
+  const int64_t per = (T.flat_numel + want - 1) / want;
+  gc->off.push_back(T.flat_numel);
+  // walk the layers from the back; cut when the open chunk reached its share
+  for (int64_t L = layers - 1; L >= 0; --L) {
+    const bool last = L == 0;
+    if (last || gc->off.back() - T.layer_off[L] >= per) {
+      gc->off.push_back(T.layer_off[L]);
+      gc->first_layer.push_back(L);
+    }
+  }
+  gc->ev.resize(gc->first_layer.size());
+  for (auto& e : gc->ev) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+  std::lock_guard<std::mutex> lk(g_chunks_mutex);
+  g_chunks[T.tag] = gc;
+  return gc;
+}
+
+void set_grad_chunks(int64_t n) { g_grad_chunks.store((int)n); }
+
+int64_t grad_chunk_count(int64_t tag) {
+  std::lock_guard<std::mutex> lk(g_chunks_mutex);
+  auto it = g_chunks.find(tag);
+  return it == g_chunks.end() ? 0 : (int64_t)it->second->ev.size();
+}
+
+Tensor grad_chunk_wait(int64_t tag, int64_t k) {
+  std::shared_ptr<GradChunks> gc;
+  {
+    std::lock_guard<std::mutex> lk(g_chunks_mutex);
+    auto it = g_chunks.find(tag);
+    TORCH_CHECK(it != g_chunks.end(), "hcmoco::grad_chunk_wait: encoder ", tag, " has no backward pass in flight");
+    gc = it->second;
+    if (k + 1 == (int64_t)gc->ev.size()) g_chunks.erase(it);      // last chunk handed out: entry is spent
+  }
+  TORCH_CHECK(k >= 0 && k < (int64_t)gc->ev.size(), "hcmoco::grad_chunk_wait: chunk index out of range");
+  {
+    std::unique_lock<std::mutex> lk(gc->m);
+    gc->cv.wait(lk, [&] { return gc->ready > k || !gc->error.empty(); });
+    TORCH_CHECK(gc->error.empty(), "hcmoco: encoder backward failed: ", gc->error);
+  }
+  const auto cur = c10::hip::getCurrentHIPStream(gc->flat.get_device());
+  TORCH_CHECK(hipStreamWaitEvent(cur.stream(), gc->ev[k], 0) == hipSuccess, "hipStreamWaitEvent failed");
+  c10::hip::HIPCachingAllocator::recordStream(gc->flat.storage().data_ptr(), cur);
+  return gc->flat.narrow(0, gc->off[k + 1], gc->off[k] - gc->off[k + 1]);
+}
 
 Tensor upsample_forward_raw(const Tensor& x, int64_t Ho, int64_t Wo) {
   const int64_t N = x.size(0), C = x.size(1), Hi = x.size(2), Wi = x.size(3);
@@ -651,11 +732,31 @@ inline void accumulate(StreamCtx& S, GradSlot& s, const Tensor& t, bool owned) {
 
 // Reverse pass of a tape.  out_grads: gradients of the output slots (on the base stream); flat: the
 // parameter-gradient buffer.  Every instruction runs on the stream its forward ran on.
+void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::vector<int64_t>& out_slots,
+                               std::vector<Tensor> out_grads, Tensor flat, Tensor scratch, c10::hip::HIPStream base,
+                               GradChunks* gc);
+
 void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vector<int64_t>& out_slots,
-                          std::vector<Tensor> out_grads, Tensor flat, c10::hip::HIPStream base) {
+                          std::vector<Tensor> out_grads, Tensor flat, Tensor scratch, c10::hip::HIPStream base,
+                          std::shared_ptr<GradChunks> gc) {
+  try {
+    run_encoder_backward_impl(tape, out_slots, std::move(out_grads), flat, scratch, base, gc.get());
+  } catch (const std::exception& e) {
+    if (gc) {                                   // wake grad_chunk_wait instead of leaving it blocked
+      { std::lock_guard<std::mutex> lk(gc->m); gc->error = e.what(); }
+      gc->cv.notify_all();
+    }
+    throw;
+  }
+}
+
+void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::vector<int64_t>& out_slots,
+                               std::vector<Tensor> out_grads, Tensor flat, Tensor scratch, c10::hip::HIPStream base,
+                               GradChunks* gc) {
   at::NoGradGuard no_grad;
   Tape& T = *tape;
   StreamCtx S(base);
+  float* sbase = scratch.data_ptr<float>();
   std::vector<GradSlot> G(T.val.size());
   for (size_t i = 0; i < out_slots.size(); ++i)
     if (out_grads[i].defined()) accumulate(S, G[out_slots[i]], out_grads[i], false);
@@ -680,13 +781,31 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
     S.issued();
     S.enter(back);
   };
+  // chunk k of the flat buffer is complete once layer gc->first_layer[k] has been walked (issued or skipped)
+  auto signal_chunks = [&](int64_t layer_done) {
+    if (!gc) return;
+    while (gc->ready < (int)gc->first_layer.size() && gc->first_layer[gc->ready] >= layer_done) {
+      flush_wgrads();
+      const int back = S.cur;
+      S.issued();
+      for (int s2 = 1; s2 < kMaxSid; ++s2) if (S.used[s2]) { ++S.epoch[s2]; S.wait(s2, 0); }
+      TORCH_CHECK(hipEventRecord(gc->ev[gc->ready], S.st[0].stream()) == hipSuccess, "hipEventRecord failed");
+      S.enter(back);
+      { std::lock_guard<std::mutex> lk(gc->m); ++gc->ready; }
+      gc->cv.notify_all();
+    }
+  };
   const int64_t n = (int64_t)T.prog.size() / kInstrInts;
   for (int64_t i = n - 1; i >= 0; --i) {
     const int64_t* I = &T.prog[i * kInstrInts];
     const int64_t op = I[0], dst = I[1], a = I[2], b = I[3];
     GradSlot gs = std::move(G[dst]);
     G[dst] = GradSlot();
-    if (!gs.t.defined()) { T.val[dst] = Tensor(); continue; }    // value does not reach the outputs
+    if (!gs.t.defined()) {                                       // value does not reach the outputs: its
+      T.val[dst] = Tensor();                                     // parameters keep the zeros `flat` starts with
+      if (op == kOpConvBn) signal_chunks(I[4]);
+      continue;
+    }
     S.enter((int)I[10]);
     if (op != kOpConvBn) resolve(S, gs);
     S.acquire(gs.t, gs.sid);
@@ -703,11 +822,11 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
       const bool has_dz = relu || g2.defined();
       Tensor dz = has_dz ? at::empty_like(z) : Tensor();
       float* gstats = fbase + T.layer_off[L] + T.w[L].numel();
-      check_rc(hcm_bn_act_backward(g.data_ptr<float>(), fptr(g2), z.data_ptr<float>(),
-                                   relu ? T.val[dst].data_ptr<float>() : nullptr, T.gamma[L].data_ptr<float>(),
-                                   T.stats[L].data_ptr<float>(), relu ? 1 : 0, N, C, HW, fptr(dz), dzc.data_ptr<float>(),
-                                   gstats, current_stream(z)),
-               "hcm_bn_act_backward");
+      check_rc(hcm_bn_act_backward_ws(g.data_ptr<float>(), fptr(g2), z.data_ptr<float>(),
+                                      relu ? T.val[dst].data_ptr<float>() : nullptr, T.gamma[L].data_ptr<float>(),
+                                      T.stats[L].data_ptr<float>(), relu ? 1 : 0, N, C, HW, fptr(dz), dzc.data_ptr<float>(),
+                                      gstats, sbase + T.scratch_off[L], current_stream(z)),
+               "hcm_bn_act_backward_ws");
       if (has_res) accumulate(S, G[b], has_dz ? dz : g, has_dz);
       const Tensor& x = T.val[a];
       const bool need_dx = a != 0 || T.need_dx0;
@@ -744,6 +863,10 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
         run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(st));
       }
       T.z[L] = Tensor(); T.stats[L] = Tensor();           // release activations as the walk passes them
+      S.issued();
+      T.val[dst] = Tensor();
+      signal_chunks(L);
+      continue;
     } else if (op == kOpAdd) {
       accumulate(S, G[a], g, false);
       accumulate(S, G[b], g, false);
@@ -757,6 +880,7 @@ void run_encoder_backward(const c10::intrusive_ptr<Tape>& tape, const std::vecto
     T.val[dst] = Tensor();
   }
   flush_wgrads();
+  signal_chunks(0);
   S.finish();
 }
 
@@ -764,7 +888,7 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
   // params: 3 per layer (w, gamma, beta); buffers: 2 per layer (running_mean, running_var)
   static variable_list forward(AutogradContext* ctx, const Tensor& x_in, at::TensorList params, at::TensorList buffers,
                                std::vector<int64_t> prog, std::vector<int64_t> out_slots, int64_t n_values,
-                               double momentum, double eps) {
+                               double momentum, double eps, int64_t tag) {
     TORCH_CHECK(prog.size() % kInstrInts == 0 && params.size() % 3 == 0 && buffers.size() * 3 == params.size() * 2,
                 "hcmoco::run_encoder: malformed program");
     TORCH_CHECK(x_in.is_cuda(), "hcmoco::run_encoder needs ROCm tensors (no CPU fallback exists)");
@@ -773,6 +897,8 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
     const int64_t layers = (int64_t)params.size() / 3;
     T.val.resize(n_values);
     T.z.resize(layers); T.stats.resize(layers); T.w.resize(layers); T.gamma.resize(layers); T.layer_off.resize(layers);
+    T.scratch_off.resize(layers);
+    T.tag = tag;
     T.val[0] = x_in.contiguous();
     T.need_dx0 = x_in.requires_grad();
     StreamCtx S(c10::hip::getCurrentHIPStream(x_in.get_device()));
@@ -792,8 +918,11 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
         BnOut o = bn_forward_raw(z, b >= 0 ? T.val[b] : Tensor(), params[3 * L + 1], params[3 * L + 2], buffers[2 * L],
                                  buffers[2 * L + 1], momentum, eps, I[7] != 0);
         T.val[dst] = o.y; T.z[L] = z; T.stats[L] = o.stats; T.w[L] = w; T.gamma[L] = params[3 * L + 1];
+        const int64_t C2 = 2 * params[3 * L + 1].numel();
         T.layer_off[L] = T.flat_numel;
-        T.flat_numel += w.numel() + o.stats.numel();
+        T.flat_numel += w.numel() + C2;
+        T.scratch_off[L] = T.scratch_numel;
+        T.scratch_numel += std::max<int64_t>(o.stats.numel() - C2, 0);
       } else if (op == kOpAdd) {
         T.val[dst] = at::add(T.val[a], T.val[b]);
       } else if (op == kOpRelu) {
@@ -822,13 +951,20 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    TORCH_CHECK(ctx->saved_data.count("tape"),
+                "hcmoco::run_encoder: the activations were released by the first backward pass "
+                "(retain_graph / a second backward through the same forward is not supported)");
     auto tape = c10::static_intrusive_pointer_cast<Tape>(ctx->saved_data["tape"].toCapsule());
     std::vector<int64_t> out_slots = ctx->saved_data["outs"].toIntVector();
     const int64_t layers = ctx->saved_data["layers"].toInt();
     ctx->saved_data.erase("tape");
     Tape& T = *tape;
-    Tensor flat = at::empty({T.flat_numel}, T.w[0].options());
-    variable_list out(1 + 5 * layers + 5);           // x, params, buffers, then the five non-tensor arguments
+    // zeros, not empty: a layer whose value reaches no used output is skipped by the reverse loop and its
+    // slice must still be a valid (zero) gradient for the optimizer
+    Tensor flat = at::zeros({T.flat_numel}, T.w[0].options());
+    Tensor scratch = at::empty({std::max<int64_t>(T.scratch_numel, 1)}, T.w[0].options());
+    std::shared_ptr<GradChunks> gc = make_chunks(T, flat);
+    variable_list out(1 + 5 * layers + 6);           // x, params, buffers, then the six non-tensor arguments
     for (int64_t L = 0; L < layers; ++L) {
       const int64_t C = T.gamma[L].numel(), off = T.layer_off[L], wn = T.w[L].numel();
       out[1 + 3 * L] = flat.narrow(0, off, wn).view(T.w[L].sizes());
@@ -838,19 +974,19 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
     for (auto& g : grads) if (g.defined()) g = g.contiguous();
     auto stream = c10::hip::getCurrentHIPStream(T.val[0].get_device());
     if (g_async_wgrad.load(std::memory_order_relaxed) && !T.need_dx0) {
-      worker_for(stream).push([tape, out_slots, grads, flat, stream](Tensor*) mutable {
-        run_encoder_backward(tape, out_slots, std::move(grads), flat, stream);
+      worker_for(stream).push([tape, out_slots, grads, flat, scratch, stream, gc](Tensor*) mutable {
+        run_encoder_backward(tape, out_slots, std::move(grads), flat, scratch, stream, gc);
       });
     } else {
-      run_encoder_backward(tape, out_slots, std::move(grads), flat, stream);
+      run_encoder_backward(tape, out_slots, std::move(grads), flat, scratch, stream, gc);
     }
     return out;
   }
 };
 
 std::vector<Tensor> run_encoder(const Tensor& x, at::TensorList params, at::TensorList buffers, std::vector<int64_t> prog,
-                                std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps) {
-  return EncoderFn::apply(x, params, buffers, std::move(prog), std::move(out_slots), n_values, momentum, eps);
+                                std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps, int64_t tag) {
+  return EncoderFn::apply(x, params, buffers, std::move(prog), std::move(out_slots), n_values, momentum, eps, tag);
 }
 
 // Forward on the helper thread of the current stream; the caller collects the outputs with _wait.
@@ -860,7 +996,7 @@ std::unordered_map<int64_t, std::shared_ptr<PendingForward>> g_pending;
 int64_t g_pending_next = 1;
 
 int64_t encoder_forward_async(const Tensor& x, at::TensorList params, at::TensorList buffers, std::vector<int64_t> prog,
-                              std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps) {
+                              std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps, int64_t tag) {
   auto pend = std::make_shared<PendingForward>();
   int64_t id;
   {
@@ -871,13 +1007,13 @@ int64_t encoder_forward_async(const Tensor& x, at::TensorList params, at::Tensor
   std::vector<Tensor> pv(params.begin(), params.end()), bv(buffers.begin(), buffers.end());
   const bool grad = at::GradMode::is_enabled();
   worker_for(c10::hip::getCurrentHIPStream(x.get_device())).push(
-      [pend, x, pv, bv, prog, out_slots, n_values, momentum, eps, grad](Tensor*) mutable {
+      [pend, x, pv, bv, prog, out_slots, n_values, momentum, eps, grad, tag](Tensor*) mutable {
         std::vector<Tensor> outs;
         std::string err;
         try {
           at::AutoGradMode mode(grad);
           outs = EncoderFn::apply(x, at::TensorList(pv), at::TensorList(bv), std::move(prog), std::move(out_slots), n_values,
-                                  momentum, eps);
+                                  momentum, eps, tag);
         } catch (const std::exception& e) { err = e.what(); }
         {
           std::lock_guard<std::mutex> lk(pend->m);
@@ -911,9 +1047,12 @@ TORCH_LIBRARY(hcmoco, m) {
         "Tensor? running_mean, Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &conv_bn_act);
   m.def("upsample_bilinear(Tensor x, int out_h, int out_w) -> Tensor", &upsample_bilinear);
   m.def("run_encoder(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
-        "float momentum, float eps) -> Tensor[]", &run_encoder);
+        "float momentum, float eps, int tag=0) -> Tensor[]", &run_encoder);
   m.def("encoder_forward_async(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
-        "float momentum, float eps) -> int", &encoder_forward_async);
+        "float momentum, float eps, int tag=0) -> int", &encoder_forward_async);
+  m.def("set_grad_chunks(int n) -> ()", &set_grad_chunks);
+  m.def("grad_chunk_count(int tag) -> int", &grad_chunk_count);
+  m.def("grad_chunk_wait(int tag, int k) -> Tensor", &grad_chunk_wait);
   m.def("encoder_forward_wait(int handle) -> Tensor[]", &encoder_forward_wait);
   m.def("set_async_wgrad(bool on) -> ()", &set_async_wgrad);
   m.def("wgrad_join() -> ()", &wgrad_join);

@@ -26,26 +26,18 @@ from .util import AverageMeter
 
 
 class ContrastTrainer(BaseTrainer):
-    def __init__(self, args, engine=None):
+    def __init__(self, args, engine=None, force_collectives=None):
         super().__init__(args)
         self.engine = engine if engine is not None else HipLossEngine()
-        self.graphed = None          # GraphedEncoder once enable_graphs() ran
-        self.manual_allreduce = False
+        self.grad_sync = None        # learning/grad_sync.py:GradSync when this class averages the gradients itself
         self.async_wgrad = None      # torch.ops.hcmoco namespace once deferred weight gradients are on
         self._find_done = False      # the first training step runs single-stream (quiet MIOpen Find)
+        # run every collective of the N>1 path even in a 1-rank group (GPU tests drive RCCL on a 1-GPU box)
+        self.force_collectives = (os.environ.get('HCM_FORCE_COLLECTIVES', '0') != '0'
+                                  if force_collectives is None else bool(force_collectives))
 
-    def enable_graphs(self, model, sample_batch, stage2=True):
-        """Capture the encoder forward/backward as hipGraphs (learning/graphed.py).  Call BEFORE
-        wrap_up: in graph mode the model is not wrapped in DistributedDataParallel; gradients are
-        averaged by one explicit all-reduce per step instead."""
-        from .graphed import GraphedEncoder, broadcast_model
-        model.to(self.device)
-        broadcast_model(model)
-        model.train()
-        x = self._to_dev(sample_batch[0]).float()
-        self.graphed = GraphedEncoder(model, x, self._to_dev(sample_batch[2]), stage2=stage2)
-        self.manual_allreduce = dist.is_initialized() and dist.get_world_size() > 1
-        return model
+    def _multi(self):
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collectives)
 
     # ------------------------------------------------------------------ set-up / bookkeeping
     def logging(self, epoch, logs, lr):
@@ -64,7 +56,7 @@ class ContrastTrainer(BaseTrainer):
         args = self.args
         model.to(self.device)
         # engines that can project at the sampled pixels get the raw branch maps from the model
-        if (hasattr(self.engine, 'fmap_sampled') and hasattr(model, 'defer_projection') and self.graphed is None
+        if (hasattr(self.engine, 'fmap_sampled') and hasattr(model, 'defer_projection')
                 and getattr(args, 'sampled_projection', 1)):
             model.defer_projection = True
         if getattr(args, 'channels_last', False):
@@ -73,26 +65,33 @@ class ContrastTrainer(BaseTrainer):
             model_ema.to(self.device)
         if args.amp:
             raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
-        multi = dist.is_initialized() and dist.get_world_size() > 1
+        multi = self._multi()
         sync = getattr(args, 'grad_sync', 'auto')
-        deferred = (self.device.type == 'cuda' and self.graphed is None and sync != 'ddp'
+        if sync == 'auto':           # ROCm: own bucketed reduction (see below); CPU: DistributedDataParallel
+            sync = 'overlap' if self.device.type == 'cuda' else 'ddp'
+        deferred = (self.device.type == 'cuda' and sync != 'ddp'
                     and os.environ.get('HCM_ASYNC_WGRAD', '1') != '0')
         if deferred:
-            # Deferred weight gradients (csrc/torch_glue): a helper thread issues the 620 MIOpen
-            # backward-weights calls while the autograd thread walks on.  Its contract -- gradients reset
-            # with set_to_none, nothing reads .grad before wgrad_join() -- rules out
-            # DistributedDataParallel's in-backward bucket copies, so N > 1 uses the single flat RCCL
-            # all-reduce after the join (78 MB over xGMI: well under a millisecond of a ~60 ms step).
+            # Deferred weight gradients (csrc/torch_glue): helper threads issue the encoders' reverse loops
+            # and the MIOpen backward-weights calls while the autograd thread walks on.  The contract --
+            # gradients reset with set_to_none, nothing reads .grad before wgrad_join() -- rules out
+            # DistributedDataParallel's hooks (they fire when .grad is assigned, not when it is written),
+            # so N > 1 uses learning/grad_sync.py: in-place RCCL all-reduces of the encoders' flat gradient
+            # buffers, launched chunk by chunk while the reverse loops are still running.
             from ... import _lib
             self.async_wgrad = _lib.torch_glue()
-            self.async_wgrad.set_async_wgrad(True)
             self.async_wgrad.set_wgrad_stream(os.environ.get('HCM_WGRAD_STREAM', '0') != '0',
                                               int(os.environ.get('HCM_WGRAD_BATCH', '16')))
-        if multi and self.graphed is None and (deferred or sync == 'flat'):
-            from .graphed import broadcast_model
+        if multi and sync in ('flat', 'overlap'):
+            from .grad_sync import GradSync, broadcast_model
             broadcast_model(model)
-            self.manual_allreduce = True
-        if multi and self.graphed is None and not self.manual_allreduce:
+            glue = None
+            if self.device.type == 'cuda':
+                from ... import _lib
+                glue = _lib.torch_glue()
+            self.grad_sync = GradSync(model, [p for g in optimizer.param_groups for p in g['params']], mode=sync,
+                                      chunks=int(os.environ.get('HCM_GRAD_CHUNKS', '4')), glue=glue)
+        if multi and self.grad_sync is None:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # stage 1 never touches the 1x1 feature-map projections when --linear_feat_map 1 is set
             unused = args.mem == 'bank' and bool(getattr(args, 'linear_feat_map', 0))
@@ -107,7 +106,7 @@ class ContrastTrainer(BaseTrainer):
 
     def broadcast_memory(self, contrast):
         """rank 0's banks everywhere -- all of them (contrast_trainer.py:81-91 skips memory_3)."""
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not self._multi():
             return
         for name, buf in contrast.named_buffers():
             dist.broadcast(buf, 0)
@@ -135,6 +134,9 @@ class ContrastTrainer(BaseTrainer):
                 optimizer.load_state_dict(ckpt['optimizer'])
                 if isinstance(model_ema, torch.nn.Module):
                     model_ema.load_state_dict(ckpt['model_ema'])
+                sampler = getattr(contrast, 'multinomial', None)
+                if sampler is not None and 'sampler' in ckpt:      # continue the negative stream, do not replay it
+                    sampler.seed, sampler.offset = int(ckpt['sampler']['seed']), int(ckpt['sampler']['offset'])
                 print("=> resume successfully '{}' (epoch {})".format(args.resume, ckpt['epoch']))
                 del ckpt
             else:
@@ -150,6 +152,11 @@ class ContrastTrainer(BaseTrainer):
                  'optimizer': optimizer.state_dict(), 'epoch': epoch}
         if isinstance(model_ema, torch.nn.Module):
             state['model_ema'] = model_ema.state_dict()
+        sampler = getattr(contrast, 'multinomial', None)
+        if sampler is not None and hasattr(sampler, 'offset'):
+            # build-side key (the reference's sampler lives on torch's global generator, which it does not
+            # checkpoint either): Philox (seed, offset) of the negative draws; loaders that index by key ignore it
+            state['sampler'] = {'seed': sampler.seed, 'offset': sampler.offset}
         torch.save(state, os.path.join(args.model_folder, 'current.pth'))
         if epoch % args.save_freq == 0:
             torch.save(state, os.path.join(args.model_folder, 'ckpt_epoch_{}.pth'.format(epoch)))
@@ -178,7 +185,7 @@ class ContrastTrainer(BaseTrainer):
 
     def _packed_gather(self, f, index):
         """One collective per step; rank-major row order (it defines the duplicate-update winner)."""
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not self._multi():
             return f.detach(), index
         mine = self.pack_features(f, index)
         out = torch.empty(dist.get_world_size() * mine.shape[0], mine.shape[1], dtype=mine.dtype, device=mine.device)
@@ -200,17 +207,26 @@ class ContrastTrainer(BaseTrainer):
             self._find_done = True
             net = self.unwrap(model)
             streams = getattr(net, 'two_streams', None)
-            self.async_wgrad.set_async_wgrad(False)
             if streams is not None:
                 net.two_streams = 0
             try:
-                out = self.train_step(data, model, contrast, optimizer, stage2)
+                out = self._train_step(data, model, contrast, optimizer, stage2)
                 torch.cuda.synchronize(self.device)
             finally:
                 if streams is not None:
                     net.two_streams = streams
-                self.async_wgrad.set_async_wgrad(True)
             return out
+        if self.async_wgrad is None:
+            return self._train_step(data, model, contrast, optimizer, stage2)
+        # Deferred mode is process-global state of the encoder runtime: it is on only inside this step,
+        # so any other backward in the process (linear probe, tests) sees complete .grad tensors.
+        self.async_wgrad.set_async_wgrad(True)
+        try:
+            return self._train_step(data, model, contrast, optimizer, stage2)
+        finally:
+            self.async_wgrad.set_async_wgrad(False)         # joins the helper threads
+
+    def _train_step(self, data, model, contrast, optimizer, stage2):
         args = self.args
         inputs = self._to_dev(data[0]).float()
         index = self._to_dev(data[1])
@@ -227,12 +243,6 @@ class ContrastTrainer(BaseTrainer):
                 _feat1, _feat2, _feat3, f, aux = model(inputs, skeleton, *extra, return_fm=True)
             else:
                 f = model(inputs, skeleton, *extra)
-        elif self.graphed is not None:
-            outs = self.graphed(inputs, skeleton)
-            f = outs[0]
-            if stage2:
-                aux = {'linear_merge1': outs[1], 'linear_merge2': outs[2]}
-                _feat3 = outs[3]
         elif stage2:
             _feat1, _feat2, _feat3, f, aux = model(inputs, skeleton, return_fm=True)
         else:
@@ -261,11 +271,11 @@ class ContrastTrainer(BaseTrainer):
             loss = total
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if self.async_wgrad is not None:
-            self.async_wgrad.wgrad_join()
-        if self.manual_allreduce:
-            from .graphed import allreduce_grads
-            allreduce_grads([p for g in optimizer.param_groups for p in g['params']], dist.get_world_size())
+        join = self.async_wgrad.wgrad_join if self.async_wgrad is not None else None
+        if self.grad_sync is not None:
+            self.grad_sync.reduce(join)      # chunked RCCL all-reduces, launched while the helper threads still issue
+        elif join is not None:
+            join()
         optimizer.step()
         out.update(loss=loss.detach(), bank_losses=losses, bank_accs=accs)
         return out

@@ -1,0 +1,145 @@
+"""Gradient averaging across replicas, overlapped with the backward pass.
+
+The reference wraps the model in ``DistributedDataParallel`` (learning/contrast_trainer.py:74):
+gradients are all-reduced bucket by bucket while autograd is still walking backwards.  DDP's hooks
+fire on the autograd thread when a parameter's ``.grad`` is *assigned*; in this build the HRNet
+encoders' gradients are *written* later, by the encoder runtime's helper threads (csrc/torch_glue:
+one C++ reverse loop per encoder, on that encoder's HIP stream), so DDP would reduce buffers that are
+not filled yet.  ``GradSync`` keeps the overlap and drops the hooks:
+
+* **Encoder buckets** -- every HRNet that ran as an encoder program owns ONE dense flat gradient
+  buffer (``[dw | dgamma | dbeta]`` per layer, program order).  Its reverse loop fills that buffer
+  from the back and records a HIP event each time another n-th is complete
+  (``torch.ops.hcmoco.set_grad_chunks``).  After ``loss.backward()`` returned -- the helper threads
+  are typically still issuing -- this class walks the chunks in completion order:
+  ``grad_chunk_wait`` blocks until chunk k is *issued*, makes a dedicated comm-launch stream wait for
+  its event, and the chunk is all-reduced **in place** (RCCL, ``async_op=True``: the process group's
+  own communication stream runs it as soon as the event fires).  Encoder1's last layers are on the
+  wire while both encoders' earlier layers are still being differentiated; no concatenation, no copy
+  back -- the parameters' ``.grad`` are views of the buffer that was reduced.
+* **Rest bucket** -- SemGCN, heads, 1x1 projections (and anything that did not run as a program,
+  which is everything on CPU): copied into one persistent flat buffer with one multi-tensor launch,
+  reduced, and ``.grad`` re-bound to views of it.  Built over a FIXED parameter list; a parameter
+  without a gradient contributes zeros and receives the average, so every replica applies the same
+  update whatever its local graph looked like.
+* ``optimizer.step()`` is ordered behind all of it by ``work.wait()`` on the caller's stream.
+
+``mode='flat'`` keeps the single-bucket behaviour (one all-reduce after the join) for comparison;
+both modes produce bit-identical parameters (tests/test_plumbing_cpu.py, world_size 2 over gloo).
+
+Not synchronised, unlike DDP's default ``broadcast_buffers=True``: BatchNorm running statistics stay
+per-replica.  They never enter a training-mode forward, and rank 0 writes the checkpoint from its
+own buffers in both implementations, so checkpoints agree with the reference's.
+"""
+import torch
+import torch.distributed as dist
+
+
+def broadcast_model(model, src=0):
+    """Replica consistency at start-up when DistributedDataParallel is not wrapping the model."""
+    if not dist.is_initialized():
+        return
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t, src)
+
+
+class GradSync(object):
+    def __init__(self, model, params, mode='overlap', chunks=4, glue=None):
+        """model: the (unwrapped) network; params: the optimizer's parameters, in its order;
+        glue: ``torch.ops.hcmoco`` on ROCm (None on CPU)."""
+        assert mode in ('overlap', 'flat')
+        self.world = dist.get_world_size()
+        self.mode = mode
+        self.params = [p for p in params if p.requires_grad]
+        self.glue = glue
+        self.chunks = int(chunks)
+        self.avg = dist.get_backend() == 'nccl'          # RCCL averages in the collective; gloo sums
+        self.encoders = []
+        if glue is not None and mode == 'overlap' and self.chunks > 0:
+            from ..networks.hrnet import HighResolutionNet
+            self.encoders = [m for m in model.modules() if isinstance(m, HighResolutionNet)]
+            glue.set_grad_chunks(self.chunks)
+        # CPU / module-path buckets of the overlapped schedule: one per top-level child of the model
+        # (encoder1, encoder2, ...), launched in reverse registration order like DDP's buckets
+        self.groups = None
+        if mode == 'overlap':
+            seen, groups = set(), []
+            for child in reversed(list(model.children())):
+                g = [p for p in child.parameters() if p.requires_grad and id(p) not in seen]
+                seen.update(id(p) for p in g)
+                if g:
+                    groups.append(g)
+            known = set(id(p) for p in self.params)
+            stray = [p for p in self.params if id(p) not in seen]
+            groups = [[p for p in g if id(p) in known] for g in groups]
+            if stray:
+                groups.append(stray)
+            self.groups = [g for g in groups if g]
+        self._flat = {}
+        self._comm = None
+        self.launched = 0            # collectives launched by the last reduce() (tests / bench read it)
+
+    # ------------------------------------------------------------------ helpers
+    def _launch(self, t):
+        self.launched += 1
+        if self.avg:
+            return t, dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
+        return t, dist.all_reduce(t, async_op=True)
+
+    def _bucket(self, key, group):
+        """Copy the group's gradients into its persistent flat buffer (zeros where a parameter got no
+        gradient) and re-bind ``.grad`` to views of it; returns the buffer."""
+        n = sum(p.numel() for p in group)
+        flat = self._flat.get(key)
+        if flat is None or flat.numel() != n or flat.device != group[0].device:
+            flat = self._flat[key] = torch.zeros(n, dtype=group[0].dtype, device=group[0].device)
+        views = [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in group]), group)]
+        have = [(v, p.grad) for v, p in zip(views, group) if p.grad is not None]
+        if len(have) != len(group):
+            flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for p, v in zip(group, views):
+            p.grad = v
+        return flat
+
+    # ------------------------------------------------------------------ the step
+    def reduce(self, join=None):
+        """Call right after ``loss.backward()``.  ``join``: callable that blocks until every deferred
+        gradient is in its stream and orders the current stream behind them (``wgrad_join``)."""
+        self.launched = 0
+        works, handled = [], set()
+        if self.encoders:
+            dev = self.params[0].device
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=dev)
+            live = []
+            for enc in self.encoders:
+                n = int(self.glue.grad_chunk_count(enc.grad_tag)) if enc.last_program is not None else 0
+                if n:
+                    live.append((enc, n))
+            # chunk-major: chunk k of every encoder before chunk k+1 of any (= completion order)
+            for k in range(max([n for _, n in live] or [0])):
+                for enc, n in live:
+                    if k >= n:
+                        continue
+                    with torch.cuda.stream(self._comm):
+                        piece = self.glue.grad_chunk_wait(enc.grad_tag, k)
+                        works.append(self._launch(piece))
+            for enc, _ in live:
+                handled.update(id(p) for p in enc.last_program.params)
+        if join is not None:
+            join()
+        if self.mode == 'flat':
+            groups = [self.params]
+        else:
+            groups = [[p for p in g if id(p) not in handled] for g in self.groups]
+        for i, g in enumerate(groups):
+            if g:
+                works.append(self._launch(self._bucket(i, g)))
+        for t, w in works:
+            w.wait()                 # RCCL: orders the current stream behind the collective, no host block
+            if not self.avg:
+                t.div_(self.world)
+        return self.launched

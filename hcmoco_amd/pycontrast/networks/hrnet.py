@@ -324,6 +324,8 @@ class HighResolutionModule(nn.Module):
 
 
 class HighResolutionNet(nn.Module):
+    _next_tag = 0
+
     def __init__(self, width=18):
         super().__init__()
         self.width = width
@@ -345,6 +347,11 @@ class HighResolutionNet(nn.Module):
         self.init_weights()
         self._counters = None
         self._programs = {}
+        # id under which the encoder runtime publishes this network's flat gradient buffer
+        # (torch.ops.hcmoco.grad_chunk_wait, learning/grad_sync.py); 0 = not published
+        HighResolutionNet._next_tag += 1
+        self.grad_tag = HighResolutionNet._next_tag
+        self.last_program = None        # ProgramBuilder of the most recent forward that ran as a program
 
     def _count_batch(self):
         if self._counters is None or self._counters[0].device != self.conv1.weight.device:
@@ -408,8 +415,11 @@ class HighResolutionNet(nn.Module):
             return None
         pb, outs = self.program(x.shape[1:])
         if not pb.ok:
+            self.last_program = None
             return None
-        return (x, pb.params, pb.buffers, pb.instr, outs, len(pb.shapes), self.bn1.momentum, self.bn1.eps)
+        self.last_program = pb
+        return (x, pb.params, pb.buffers, pb.instr, outs, len(pb.shapes), self.bn1.momentum, self.bn1.eps,
+                self.grad_tag)
 
     def forward_async(self, x):
         """Start the forward on the helper thread of the CURRENT stream (C++, no GIL); returns a handle
@@ -429,6 +439,7 @@ class HighResolutionNet(nn.Module):
         if args is not None:
             self._count_batch()
             return list(_glue_op('run_encoder')(*args))
+        self.last_program = None
         if self.training:
             self._count_batch()
         x = conv_bn(self.conv1, self.bn1, x, None, True)

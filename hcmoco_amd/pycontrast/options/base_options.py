@@ -100,9 +100,11 @@ BASE_FLAGS = [
     (('--sampled_projection',), dict(type=_I, default=1,
                                      help='1: apply merge_all_res + the 1x1 feature-map projection only at the '
                                           'pixels the losses sample (same math, SURVEY 8f-1); 0: full maps')),
-    (('--grad_sync',), dict(type=_S, default='auto', choices=['auto', 'ddp', 'flat'],
-                            help='N>1 gradient averaging: DistributedDataParallel buckets, or ONE flat all-reduce '
-                                 'after backward (required by the deferred weight gradients); auto = flat on ROCm')),
+    (('--grad_sync',), dict(type=_S, default='auto', choices=['auto', 'ddp', 'flat', 'overlap'],
+                            help='N>1 gradient averaging: ddp = DistributedDataParallel; overlap = in-place RCCL '
+                                 'all-reduces of the encoders\' flat gradient buffers, launched chunk by chunk while '
+                                 'backward is still running (learning/grad_sync.py); flat = ONE all-reduce after '
+                                 'backward; auto = overlap on ROCm, ddp on CPU')),
     (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
                              help='storage type of the memory banks (bf16: BASELINE config 5)')),
 ]

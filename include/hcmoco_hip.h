@@ -237,6 +237,12 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
 int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
                         const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
                         float* gstats, hcm_stream_t stream);
+/* Same, with the partial-sum scratch in its own buffer (hcm_bn_act_stats_floats - 2C floats): `gstats`
+ * is then exactly [dgamma C][dbeta C], so a caller can lay every parameter gradient of a network out in
+ * one dense buffer (what the encoder runtime hands to RCCL in place, csrc/torch_glue). */
+int hcm_bn_act_backward_ws(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
+                           const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
+                           float* gstats, float* scratch, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Weight gradient of a 3x3 / stride 1 / pad 1 / bias-free convolution (the BasicBlock convolutions of

@@ -276,3 +276,102 @@ def test_encoder_program_equals_module_path():
     # an input size whose coarsest maps are 7x7 (H*W % 4 != 0) must take the module path, not fail
     y = net(torch.randn(2, 3, 224, 224, device=dev))
     assert [t.shape[-1] for t in y] == [56, 28, 14, 7]
+
+
+def test_encoder_program_partial_outputs_and_second_backward():
+    """A caller that consumes only ONE of the four maps: layers whose value reaches no used output are
+    skipped by the reverse loop, and their gradients must be ZERO (not uninitialised memory) and equal
+    the module path's.  A second backward through the same forward raises a clear error."""
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.networks import hrnet
+    ops = _lib.torch_glue()
+    dev = torch.device('cuda:0')
+    saved = {k: dict(v) for k, v in hrnet.STAGES.items()}
+    try:
+        for k in ('stage2', 'stage3', 'stage4'):
+            hrnet.STAGES[k].update(modules=1, blocks=1)
+        hrnet.STAGES['stage1'].update(blocks=1)
+        torch.manual_seed(2)
+        net = hrnet.HighResolutionNet(18).to(dev).train()
+    finally:
+        hrnet.STAGES.update(saved)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+    x = torch.randn(8, 3, 64, 64, device=dev)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    # poison the caching allocator's free blocks so that "uninitialised" would not happen to be zero
+    junk = torch.full((64 << 20,), float('nan'), device=dev)
+    del junk
+    grads = []
+    for program in (False, True):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        hrnet.ENCODER_PROGRAM = program
+        net._programs.clear()
+        try:
+            ys = net(x)
+            loss = ys[0].square().mean()
+            loss.backward()
+            ops.wgrad_join()
+            if program:
+                with pytest.raises(RuntimeError, match='second backward'):
+                    ys[0].square().mean().backward()
+        finally:
+            hrnet.ENCODER_PROGRAM = True
+            net._programs.clear()
+        torch.cuda.synchronize()
+        grads.append({n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()})
+    ref, got = grads
+    unused = [n for n, g in ref.items() if g is None or float(g.abs().max()) == 0.0]
+    assert unused, 'the test needs parameters that do not reach maps[0]'
+    for n in unused:
+        assert got[n] is not None and bool(torch.isfinite(got[n]).all()) and float(got[n].abs().max()) == 0.0, n
+    used = {n: g for n, g in ref.items() if n not in unused}
+    _grads_agree({n: got[n] for n in used}, used, min_cos=0.999)
+
+
+def test_gradient_chunks_cover_the_flat_buffer_in_completion_order():
+    """set_grad_chunks(n): the reverse loop publishes the encoder's dense flat gradient buffer in n pieces,
+    last layers first; grad_chunk_wait hands each out as a view once it is issued.  The pieces tile the
+    buffer exactly, and they are the SAME memory the parameters' .grad live in."""
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.networks import hrnet
+    ops = _lib.torch_glue()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    net = hrnet.get_hrnet_w18_backbone().to(dev).train()
+    x = torch.randn(4, 3, 128, 128, device=dev)
+    total = sum(p.numel() for p in net.parameters())
+    for deferred in (False, True):
+        net.zero_grad(set_to_none=True)
+        ops.set_grad_chunks(4)
+        ops.set_async_wgrad(deferred)
+        try:
+            ys = net(x)
+            sum(y.square().mean() for y in ys).backward()
+            n = int(ops.grad_chunk_count(net.grad_tag))
+            assert n == 4
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                pieces = [ops.grad_chunk_wait(net.grad_tag, k) for k in range(n)]
+            assert int(ops.grad_chunk_count(net.grad_tag)) == 0            # entry spent
+            ops.wgrad_join()
+        finally:
+            ops.set_async_wgrad(False)
+            ops.set_grad_chunks(0)
+        torch.cuda.synchronize()
+        assert sum(p.numel() for p in pieces) == total
+        base = pieces[-1].data_ptr()
+        ends = [p.data_ptr() + 4 * p.numel() for p in pieces]
+        assert ends[0] == base + 4 * total
+        for k in range(1, n):
+            assert ends[k] == pieces[k - 1].data_ptr()                    # contiguous, descending
+        pb = net.last_program
+        off = base
+        for p in pb.params:                                               # program order = buffer order
+            assert p.grad.data_ptr() == off, 'gradient is not a view of the flat buffer'
+            off += 4 * p.numel()
+        flat = torch.cat([p.reshape(-1) for p in reversed(pieces)])
+        want = torch.cat([p.grad.reshape(-1) for p in pb.params])
+        assert torch.equal(flat, want) and bool(torch.isfinite(flat).all()) and float(flat.abs().max()) > 0

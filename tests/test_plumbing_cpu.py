@@ -41,7 +41,7 @@ def test_config1_stage1_runs_on_cpu_with_oracle_engine():
     outs, trainer, model, contrast = main_contrast.main(base_args(tmp, 'CMCRGBD2S'), engine=OracleLossEngine())
     assert len(outs) == 6 and all(torch.isfinite(torch.tensor(outs)))
     ck = torch.load(os.path.join(trainer.args.model_folder, 'current.pth'), map_location='cpu')
-    assert set(ck) == {'model', 'contrast', 'optimizer', 'epoch'}
+    assert set(ck) >= {'model', 'contrast', 'optimizer', 'epoch'} and set(ck) <= {'model', 'contrast', 'optimizer', 'epoch', 'sampler'}
     assert all(k.startswith('module.') for k in ck['model'])                  # reference checkpoint layout
     assert set(ck['contrast']) == {'memory_1', 'memory_2', 'memory_3'}
     assert os.path.exists(os.path.join(trainer.args.model_folder, 'ckpt_epoch_1.pth'))
@@ -133,7 +133,8 @@ argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNe
 outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
 # parameters only: BatchNorm running statistics are per-replica by design (local batches)
 w = torch.cat([p.detach().flatten().double() for p in trainer.unwrap(model).parameters()])
-torch.save({'bank': [b.clone() for b in contrast.banks()], 'wsum': w.sum(), 'wabs': w.abs().sum()},
+torch.save({'bank': [b.clone() for b in contrast.banks()], 'wsum': w.sum(), 'wabs': w.abs().sum(), 'w': w.float(),
+            'launched': None if trainer.grad_sync is None else trainer.grad_sync.launched},
            os.path.join(%r, 'rank%%d.pt' %% rank))
 '''
 
@@ -153,6 +154,7 @@ def _run_two_ranks(grad_sync):
     for b0, b1 in zip(r0['bank'], r1['bank']):
         assert torch.equal(b0, b1)                                     # replicated banks stay bit-identical
     assert float(r0['wsum']) == float(r1['wsum']) and float(r0['wabs']) == float(r1['wabs'])
+    assert torch.equal(r0['w'], r1['w'])
     return r0
 
 
@@ -167,6 +169,13 @@ def test_world_size_2_gloo_replicas_stay_identical():
         assert torch.allclose(b0, b1, rtol=1e-5, atol=1e-6)
     assert abs(float(ddp['wsum']) - float(flat['wsum'])) <= 1e-6 * float(ddp['wabs'])
     assert abs(float(ddp['wabs']) - float(flat['wabs'])) <= 1e-6 * float(ddp['wabs'])
+    # the overlapped schedule (learning/grad_sync.py: one async all-reduce per bucket, launched in
+    # completion order, re-bound .grad views) must give BIT-identical weights and banks to the flat one
+    over = _run_two_ranks('overlap')
+    assert flat['launched'] == 1 and over['launched'] > 1
+    assert torch.equal(over['w'], flat['w'])
+    for b0, b1 in zip(over['bank'], flat['bank']):
+        assert torch.equal(b0, b1)
 
 
 def test_pretrain_handoff_stage1_to_stage2(capsys):

@@ -1,0 +1,106 @@
+"""The N>1 path executed on RCCL on the GPU box: a 1-rank ``nccl`` group on
+cuda:0 with every collective forced on -- packed feature/index ``all_gather_into_tensor``, the three
+bank ``broadcast``s, the model broadcast, and the chunked in-place ``all_reduce``s of the encoders'
+flat gradient buffers that learning/grad_sync.py launches while the reverse loops are still being
+issued.  With one rank every collective is the identity, so two training steps must reproduce the
+run that has no process group at all.  (Reference: learning/contrast_trainer.py:74, 81-91, 160-165.)
+"""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHUNKS = 4
+
+
+def _run(grad_sync, steps=2, stage2=True):
+    """grad_sync None: no process group (collectives skipped); 'overlap' / 'flat': 1-rank nccl group."""
+    import bench
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    dev = torch.device('cuda:0')
+    args = bench.make_args(8, 1024, 4096, 128, 'coco17', 'nccl', tempfile.mkdtemp(), steps + 1)
+    args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
+    info = {}
+    if grad_sync is not None:
+        args.grad_sync = grad_sync
+        os.environ['HCM_GRAD_CHUNKS'] = str(CHUNKS)
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % (23000 + os.getpid() % 4000),
+                                rank=0, world_size=1, device_id=dev)
+    try:
+        tr = ContrastTrainer(args, force_collectives=grad_sync is not None)
+        tr.device = dev
+        model, contrast, opt, data = bench.build(args, tr, dev)
+        net = tr.unwrap(model)
+        it = iter(data)
+        losses = []
+        for _ in range(steps):
+            out = tr.train_step(next(it), model, contrast, opt, stage2)
+            losses.append(float(out['loss']))
+            if tr.grad_sync is not None:
+                info.setdefault('launched', []).append(tr.grad_sync.launched)
+        torch.cuda.synchronize()
+        if tr.grad_sync is not None and grad_sync == 'overlap':
+            # the encoders' gradients were reduced in place: every .grad is a view of ONE buffer per encoder
+            for enc in (net.encoder1, net.encoder2):
+                ptrs = {p.grad.untyped_storage().data_ptr() for p in enc.parameters()}
+                info.setdefault('storages', []).append(len(ptrs))
+                info.setdefault('numel', []).append(sum(p.numel() for p in enc.parameters()))
+                info.setdefault('storage_numel', []).append(
+                    next(enc.parameters()).grad.untyped_storage().nbytes() // 4)
+            info['groups'] = len(tr.grad_sync.groups)
+        params = {n: p.detach().clone() for n, p in net.named_parameters()}
+        banks = [b.clone() for b in contrast.banks()]
+    finally:
+        _lib.torch_glue().set_async_wgrad(False)
+        _lib.torch_glue().set_grad_chunks(0)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    return losses, params, banks, info
+
+
+def _same(a, b):
+    la, pa, ba, _ = a
+    lb, pb, bb, _ = b
+    # step 1 is bit-reproducible up to MIOpen's atomic weight-gradient kernels; two steps at lr 0.03 keep
+    # run-to-run differences many orders below these bounds, a missing / doubled / mis-scaled reduction does not
+    assert abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0]), (la, lb)
+    assert abs(la[1] - lb[1]) <= 1e-3 * abs(lb[1]), (la, lb)
+    worst = 0.0
+    for n in pb:
+        scale = pb[n].abs().max().item() + 1e-12
+        worst = max(worst, (pa[n] - pb[n]).abs().max().item() / scale)
+    assert worst <= 2e-3, worst
+    for x, y in zip(ba, bb):
+        assert (x.float() - y.float()).abs().max().item() <= 1e-4
+
+
+@pytest.fixture(scope='module')
+def baseline():
+    return _run(None)
+
+
+def test_overlapped_rccl_allreduce_one_rank_group(baseline):
+    got = _run('overlap')
+    info = got[3]
+    # per step: CHUNKS in-place all-reduces per HRNet + one per remaining top-level module group; the
+    # first step (quiet Find, everything inline) takes the same route
+    assert info['storages'] == [1, 1], info                    # one flat buffer per encoder ...
+    assert info['storage_numel'] == info['numel'], info        # ... and it is dense (nothing but gradients)
+    for n in info['launched']:
+        assert 2 * CHUNKS < n <= 2 * CHUNKS + info['groups'], info
+    _same(got, baseline)
+
+
+def test_flat_rccl_allreduce_one_rank_group(baseline):
+    got = _run('flat')
+    assert got[3]['launched'] == [1, 1]
+    _same(got, baseline)
