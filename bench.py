@@ -163,8 +163,9 @@ def main():
     os.environ.setdefault('MASTER_PORT', '29511')
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.device('cuda', torch.cuda.current_device())
-    if world > 1:
-        dist.init_process_group(a.backend, rank=rank, world_size=world)      # nccl = RCCL over xGMI
+    forced = world == 1 and os.environ.get('HCM_FORCE_COLLECTIVES', '0') != '0'
+    if world > 1 or forced:      # forced: a 1-rank group that still runs every collective (cost of the N>1 path)
+        dist.init_process_group(a.backend, rank=rank, world_size=world, device_id=dev)   # nccl = RCCL over xGMI
 
     import tempfile
     from hcmoco_amd import hip_ops
@@ -253,7 +254,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -24,7 +24,13 @@ def _dev(t, dtype, name):
         raise TypeError('%s: expected %s, got %s' % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise ValueError('%s: tensor must be contiguous' % name)
-    return C.c_void_p(t.data_ptr())
+    p = C.c_void_p(t.data_ptr())
+    # The pointer object owns a reference to the tensor until the foreign call has been issued: a temporary
+    # (``x.contiguous()``, ``mask.to(int32)``) written inline in an argument list would otherwise be freed
+    # before the NEXT argument is evaluated, and the caching allocator hands the same block to the next
+    # temporary -- three chunk views of one [B, 384] feature matrix then arrive as three aliases of the last one.
+    p._keepalive = t
+    return p
 
 
 def _opt(t, dtype, name):

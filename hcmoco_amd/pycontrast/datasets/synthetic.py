@@ -16,9 +16,10 @@ import torch
 
 class SyntheticContrastData(object):
     def __init__(self, n_data, batch_size, size=256, joints=16, steps=50, device='cpu', rank=0, world=1,
-                 seed=0, pool=4, p_depth=0.75, ntu=False):
+                 seed=0, pool=4, p_depth=0.75, ntu=False, p_rgb=1.0):
         self.n_data, self.batch_size, self.size, self.joints = n_data, batch_size, size, joints
         self.ntu = ntu               # append the NTU-only items 9-15 (needed by the HRNetPN arch)
+        self.p_rgb = p_rgb           # P(use_rgb = 1) in NTU mode
         self.steps, self.device, self.rank, self.world = steps, torch.device(device), rank, world
         self.pool = [self._make(seed * 1000003 + i, p_depth) for i in range(pool)]
 
@@ -53,7 +54,10 @@ class SyntheticContrastData(object):
             gy, gx = torch.meshgrid(ys, xs, indexing='ij')
             grid_xy = torch.stack([gy, gx], -1).unsqueeze(0).expand(B, H, H, 2).contiguous()
             mean = torch.rand(B, generator=gl) * 2 + 2
-            batch += [torch.zeros(B, H, H, dtype=torch.long), torch.zeros(B, dtype=torch.long), torch.ones(B, dtype=torch.long),
+            # item 11 = true_rgb -> use_rgb (datasets/dataset.py:1083-1103): NTU frames can lack the RGB modality
+            use_rgb = (torch.rand(B, generator=gl) < self.p_rgb).long()
+            use_rgb[0] = 1                               # sample 0 keeps both modalities (use_depth[0] = 1 too)
+            batch += [torch.zeros(B, H, H, dtype=torch.long), torch.zeros(B, dtype=torch.long), use_rgb,
                       grid_xy, torch.full((B,), 1080), torch.full((B,), 1920), mean]
         return [t.to(self.device) for t in batch]
 
@@ -85,5 +89,6 @@ def build_synthetic_contrast_loader(opt, device, rank=0, world=1):
     per_rank = max(1, opt.batch_size // max(1, world))
     data = SyntheticContrastData(opt.synthetic_n_data, per_rank, opt.synthetic_size, num_joints(opt.skeleton_meta_name),
                                  opt.synthetic_steps, device, rank, world, seed=opt.seed or 0,
-                                 ntu=(opt.arch == 'HRNetPN'))
+                                 ntu=(opt.arch == 'HRNetPN' or bool(getattr(opt, 'synthetic_ntu', 0))),
+                                 p_rgb=float(getattr(opt, 'synthetic_p_rgb', 1.0)))
     return data, _Loader(data), _Sampler()

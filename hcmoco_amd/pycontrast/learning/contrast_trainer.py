@@ -321,6 +321,9 @@ class ContrastTrainer(BaseTrainer):
                     fmap_m[k].update(out['fmap'][k], bsz)
             bt.update(time.time() - end)
             end = time.time()
+            if (idx + 1) % args.print_freq == 0 or idx + 1 == nb:
+                if hasattr(contrast, 'check_indices'):
+                    contrast.check_indices()                    # a sync point anyway (meters are printed here)
             if args.local_rank == 0 and (idx + 1) % args.print_freq == 0:
                 msg = ('Train: [{0}][{1}/{2}]\tBT {3:.3f} ({4:.3f})\tDT {5:.3f} ({6:.3f})\tL {7:.3f} ({8:.3f})\t'
                        'a_I {9:.3f} {10:.3f} {11:.3f}').format(epoch, idx + 1, nb, bt.val, bt.avg, dt.val, dt.avg,

@@ -37,6 +37,7 @@ class CMCMem3(BaseMem):
         self.multinomial = AliasMethod(torch.ones(n_data), seed=seed)
         for name in ('memory_1', 'memory_2', 'memory_3'):
             self.register_buffer(name, F.normalize(torch.randn(n_data, n_dim)).to(bank_dtype))
+        self._oob = None             # device flag: some index had to be clamped (see _in_range)
 
     # nn.Module.cuda()/.to() move the buffers; the sampler tables follow
     def _apply(self, fn):
@@ -47,10 +48,30 @@ class CMCMem3(BaseMem):
     def banks(self):
         return [self.memory_1, self.memory_2, self.memory_3]
 
+    # The reference's index_select / index_copy_ device-assert on a row index outside [0, n_data); the
+    # kernels here take raw pointers, so the module range-checks what it hands them: indices are clamped
+    # (nothing outside the banks is ever read or written) and a sticky device flag records that a clamp
+    # changed something.  ``check_indices()`` reads the flag (one host sync: the trainer calls it where
+    # it syncs anyway) and raises like the reference would have.
+    def _in_range(self, t):
+        if t is None:
+            return None
+        safe = t.clamp(0, self.n_data - 1)
+        bad = (safe != t).any()
+        self._oob = bad if self._oob is None else (self._oob | bad)
+        return safe
+
+    def check_indices(self):
+        if self._oob is not None:
+            bad, self._oob = bool(self._oob), None
+            if bad:
+                raise IndexError('CMCMem3: a bank row index was outside [0, %d) (dataset index / injected idx)'
+                                 % self.n_data)
+
     def _indices(self, y, idx):
         if idx is not None:
             assert idx.shape == (y.shape[0], self.K + 1)
-            return idx.contiguous()
+            return self._in_range(idx).contiguous()
         return self.multinomial.draw_with_positive(y, self.K + 1)
 
     def _update(self, x1, x2, x3, y, all_x1, all_x2, all_x3, all_y):
@@ -60,6 +81,9 @@ class CMCMem3(BaseMem):
             hip_ops.bank_update(self.banks(), [x1, x2, x3], y, self.m)
 
     def forward(self, x1, x2, x3, y, all_x1=None, all_x2=None, all_x3=None, all_y=None, idx=None):
+        same = all_y is y
+        y = self._in_range(y)
+        all_y = y if same else self._in_range(all_y)
         idx = self._indices(y, idx)
         logits = hip_ops.bank_logits([x1, x2, x3], self.banks(), idx, self.T)
         labels = torch.zeros(x1.shape[0], dtype=torch.long, device=x1.device)
@@ -69,6 +93,9 @@ class CMCMem3(BaseMem):
     def forward_loss(self, x1, x2, x3, y, all_x1=None, all_x2=None, all_x3=None, all_y=None,
                      use_depth=None, use_rgb=None, idx=None):
         """-> (total, losses[6], accs[6]); total = sum(losses) is differentiable in x1..x3."""
+        same = all_y is y
+        y = self._in_range(y)
+        all_y = y if same else self._in_range(all_y)
         idx = self._indices(y, idx)
         total, losses, accs = hip_ops.bank_nce_fused([x1, x2, x3], self.banks(), idx, self.T, use_depth, use_rgb)
         self._update(x1, x2, x3, y, all_x1, all_x2, all_x3, all_y)

@@ -431,12 +431,109 @@ def gen_options():
     print('wrote options_cases.json')
 
 
+# --------------------------------------------------------------------------- #
+# 9. 2-step traces of the reference's OWN training loops (SURVEY 8c "harness rows")
+#    learning/contrast_trainer.py:532-640 (_train_mem_skeleton3d, stage 1, use_rgb + use_depth)
+#    learning/contrast_trainer.py:894-1039 (_train_bank_joints_pri3d_cmc3, stage 2)
+#    driven with the reference CMCMem3, torch.optim.SGD and a stand-in encoder (tests/golden/standin.py).
+# --------------------------------------------------------------------------- #
+def gen_trace():
+    import importlib.util
+    import torch.distributed as dist
+    import torch.nn as nn
+    from memory.mem_bank import CMCMem3
+    from learning.contrast_trainer import ContrastTrainer
+    spec = importlib.util.spec_from_file_location('standin', os.path.join(OUT, 'standin.py'))
+    standin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(standin)
+    if not dist.is_initialized():                  # the loops call dist.all_gather (world size 1 here)
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29871', rank=0, world_size=1)
+
+    B, n, K, H, J, S, steps = 6, 48, 20, 32, 16, 12, 2
+    T, mom, lr = 0.07, 0.5, 0.05
+    for stage in (1, 2):
+        torch.manual_seed(900 + stage)
+        model = standin.StandInEncoder()
+        mem = CMCMem3(128, n, K, T, mom)
+        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+        batches = standin.make_batches(steps, B, n, H, J, seed=40 + stage)
+        tr = ContrastTrainer.__new__(ContrastTrainer)
+        tr.args = argparse.Namespace(gpu=None, arch='HRNet', modality_missing=1, amp=False, local_rank=0,
+                                     print_freq=10 ** 6, warm=False, jigsaw=False, temperature=T,
+                                     pri3d_num_samples_per_image=S)
+        arrays = dict(B=B, n=n, K=K, H=H, J=J, S=S, T=T, m=mom, lr=lr, momentum=0.9, weight_decay=1e-4, steps=steps,
+                      bank0_1=mem.memory_1.clone(), bank0_2=mem.memory_2.clone(), bank0_3=mem.memory_3.clone())
+        for k, v in model.state_dict().items():
+            arrays['w0_' + k] = v.clone()
+        for t, b in enumerate(batches):
+            for i, item in enumerate(b):
+                arrays['s%d_data%d' % (t, i)] = item
+        rec = {'idx': [], 'ind': [], 'bank': [], 'dense': [], 'joint': [], 'scl': [], 'after': []}
+
+        orig_draw = mem.multinomial.draw
+        mem.multinomial.draw = lambda N: rec['idx'].append(orig_draw(N).clone()) or rec['idx'][-1].clone()
+        orig_mn = torch.Tensor.multinomial
+
+        def mn(self, *a, **k):
+            out = orig_mn(self, *a, **k)
+            rec['ind'].append(out.clone())
+            return out
+
+        def wrap(name, key):
+            fn = getattr(tr, name)
+
+            def inner(*a, **k):
+                out = fn(*a, **k)
+                rec[key].append([[f32(v) for v in part] for part in out])
+                return out
+            setattr(tr, name, inner)
+        wrap('_compute_loss_accuracy', 'bank')
+        wrap('_compute_soft_pri3d_loss_accuracy', 'dense')
+        wrap('_compute_joints_pri3d_loss_accuracy', 'joint')
+        wrap('_compute_cross_subject_joints_pri3d_loss', 'scl')
+        orig_step = opt.step
+
+        def step(*a, **k):
+            out = orig_step(*a, **k)
+            rec['after'].append(([mem.memory_1.clone(), mem.memory_2.clone(), mem.memory_3.clone()],
+                                 {k2: v.clone() for k2, v in model.state_dict().items()}))
+            return out
+        opt.step = step
+        torch.Tensor.multinomial = mn
+        try:
+            if stage == 1:
+                outs = tr._train_mem_skeleton3d(1, batches, model, mem, nn.CrossEntropyLoss(), opt)
+            else:
+                outs = tr._train_bank_joints_pri3d_cmc3(1, batches, model, mem, nn.CrossEntropyLoss(),
+                                                        [nn.CrossEntropyLoss(), nn.CrossEntropyLoss()], opt)
+        finally:
+            torch.Tensor.multinomial = orig_mn
+        assert len(rec['after']) == steps and len(rec['idx']) == steps
+        arrays['epoch_outs'] = np.array([float(o) for o in outs], np.float64)
+        for t in range(steps):
+            arrays['s%d_idx' % t] = rec['idx'][t].view(B, K + 1)
+            arrays['s%d_bank_losses' % t] = np.array(rec['bank'][t][0], np.float32)
+            arrays['s%d_bank_accs' % t] = np.array(rec['bank'][t][1], np.float32)
+            if stage == 2:
+                arrays['s%d_sample_ind' % t] = rec['ind'][t]
+                arrays['s%d_dense' % t] = np.array(rec['dense'][t][0] + rec['dense'][t][1], np.float32)
+                arrays['s%d_joint' % t] = np.array(rec['joint'][t][0] + rec['joint'][t][1], np.float32)
+                arrays['s%d_scl' % t] = np.array(rec['scl'][t][0], np.float32)
+            banks, sd = rec['after'][t]
+            for i, bk in enumerate(banks):
+                arrays['s%d_bank_%d' % (t, i + 1)] = bk
+                arrays['s%d_bank_%d_checksum' % (t, i + 1)] = np.float64(bk.double().sum().item())
+            for k, v in sd.items():
+                arrays['s%d_w_%s' % (t, k)] = v
+        npz('trace_stage%d' % stage, **arrays)
+
+
 if __name__ == '__main__':
     install_shims()
     only = set(sys.argv[1:])
     sys.argv = sys.argv[:1]
     gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
-                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options)
+                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options, trace=gen_trace)
     for name, fn in gens.items():
         if not only or name in only:
             fn()

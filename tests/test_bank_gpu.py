@@ -282,3 +282,91 @@ def test_config3_size_k65536_properties():
         lse_neg = torch.logsumexp(lg[p][:, 1:].double(), 1)
         want = (torch.logaddexp(lse1, lse_neg) - lg[p][:, 0].double()).mean()
         assert abs(float(l2[p]) - float(want)) < 2e-5 * float(want)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE sizes against the ORACLE (not against another HIP path): the oracle is evaluated one sample at a
+# time (each call gathers (K+1) x 128 x 3 rows, trivial on the host) and the per-sample terms are composed
+# into the masked means of _compute_loss_accuracy (contrast_trainer.py:212-253) exactly as O.bank_nce does.
+# ----------------------------------------------------------------------------------------------
+def _oracle_per_sample(banks, idx, xs, T, use_depth=None, use_rgb=None):
+    B = idx.shape[0]
+    per_l = torch.zeros(B, 6, dtype=torch.float64)
+    per_ok = torch.zeros(B, 6, dtype=torch.float64)
+    per_g = [torch.zeros(B, 6, xs[0].shape[1], dtype=torch.float64) for _ in range(3)]
+    for b in range(B):
+        logits = O.bank_logits(banks, idx[b:b + 1], [x[b:b + 1] for x in xs], T)
+        rows = [bk.index_select(0, idx[b]).double() for bk in banks]
+        for p, (a, c) in enumerate(O.PAIRS):
+            l = logits[p][0].double()
+            per_l[b, p] = torch.logsumexp(l, 0) - l[0]
+            per_ok[b, p] = float(l[0] >= l.max())
+            per_g[a][b, p] = (torch.softmax(l, 0) @ rows[c] - rows[c][0]) / T
+    sel, deg = O.bank_row_sets(B, use_depth, use_rgb)
+    losses, accs = torch.zeros(6, dtype=torch.float64), torch.zeros(6, dtype=torch.float64)
+    grads = [torch.zeros(B, xs[0].shape[1], dtype=torch.float64) for _ in range(3)]
+    for p, (a, c) in enumerate(O.PAIRS):
+        if deg[p]:
+            continue
+        R = sel[p]
+        cnt = int(R.sum())
+        losses[p] = per_l[R, p].sum() / cnt
+        accs[p] = 100.0 * per_ok[R, p].sum() / cnt
+        grads[a] += per_g[a][:, p] * R.double().unsqueeze(1) / cnt
+    return losses, accs, grads
+
+
+@pytest.mark.parametrize('K,dtype,masked', [(16384, torch.float32, True), (16384, torch.float32, False),
+                                            (65536, torch.float32, True), (131072, torch.bfloat16, True)])
+def test_baseline_sizes_against_the_oracle(K, dtype, masked):
+    """B=32, n=131072, D=128 at K=16384 (config 2), K=65536 (config 3) and bf16 banks at K=131072 (config 5):
+    all six losses, accuracies and all 32 gradient rows per modality against the oracle, plus the momentum
+    update of the touched rows.  bf16: the oracle reads the same bf16-rounded rows in fp32."""
+    torch.manual_seed(K)
+    d = dev()
+    B, n, D, T, mom = 32, 131072, 128, 0.07, 0.5
+    nrm = torch.nn.functional.normalize
+    banks_s = [nrm(torch.randn(n, D)).to(dtype) for _ in range(3)]
+    banks_o = [b.float() for b in banks_s]
+    xs = [nrm(torch.randn(B, D)) for _ in range(3)]
+    y = torch.randperm(n)[:B]
+    idx = torch.randint(0, n, (B, K + 1))
+    idx[:, 0] = y
+    # make a few positives genuinely the arg-max so that the accuracies are not all zero
+    for b in range(0, B, 5):
+        for m in range(3):
+            banks_o[m][y[b]] = nrm(xs[(m + 1) % 3][b] + 0.05 * torch.randn(D), dim=0)
+            banks_s[m][y[b]] = banks_o[m][y[b]].to(dtype)
+            banks_o[m][y[b]] = banks_s[m][y[b]].float()
+    ud = None
+    if masked:
+        ud = (torch.rand(B) < 0.75).long()
+        ud[0] = 1
+    lo, ao, go = _oracle_per_sample(banks_o, idx, xs, T, use_depth=ud)
+    gb = [b.to(d) for b in banks_s]
+    l, a, gx = ops().bank_nce_fused_raw(gb, idx.to(d), [x.to(d) for x in xs], T, None if ud is None else ud.to(d))
+    torch.cuda.synchronize()
+    assert torch.allclose(l.cpu().double(), lo, rtol=LOSS_RTOL, atol=1e-6), (l, lo)
+    assert torch.allclose(a.cpu().double(), ao, atol=1e-3), (a, ao)
+    assert float(ao.max()) > 0
+    for i in range(3):
+        assert rel_l2(gx[i], go[i]) < GRAD_REL_L2, (i, rel_l2(gx[i], go[i]))
+    # momentum update after the reads (rank-major, last duplicate wins), oracle on the touched rows only
+    all_y = torch.cat([y, y[:3], torch.randint(0, n, (B - 3,))])
+    all_x = [nrm(torch.randn(2 * B, D)) for _ in range(3)]
+    before = [b.clone() for b in gb]
+    ops().bank_update(gb, [x.to(d) for x in all_x], all_y.to(d), mom)
+    torch.cuda.synchronize()
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[all_y] = True
+    rows = touched.nonzero().flatten()
+    for i in range(3):
+        new = gb[i].cpu()
+        assert torch.equal(new[~touched].view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                           before[i].cpu()[~touched].view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+        ref = O.bank_update(banks_o[i], all_x[i], all_y, mom)[rows]
+        err = (new[rows].float() - ref).abs()
+        if dtype == torch.bfloat16:
+            assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all())
+        else:
+            assert float(err.max()) <= 1e-6

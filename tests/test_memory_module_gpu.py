@@ -105,3 +105,53 @@ def test_build_mem_and_moco_module(golden):
         gq, = torch.autograd.grad(l1, q1, gl)
         ref = (gl[:, :1].cpu() * g['s%d_k2' % s] + gl[:, 1:].cpu() @ (g['queue0_2'] if s == 0 else g['s%d_queue_2' % (s - 1)])) / g['T']
         assert float((gq.cpu() - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_update_reads_chunk_views_of_one_feature_matrix(golden):
+    """The trainer hands the module three column chunks of ONE [B, 384] matrix (torch.chunk views, stride
+    384).  Each bank must be updated from ITS chunk: the contiguous copies made for the C ABI are distinct
+    buffers that stay alive until the launch (a freed temporary is re-used by the next one otherwise, and all
+    three banks would silently receive the last chunk)."""
+    g = golden('bank_nce')
+    d = dev()
+    f = torch.cat([g['all_x1'], g['all_x2'], g['all_x3']], dim=1).to(d)
+    y = g['all_y'].to(d)
+    B = g['B']
+    ref = make_mem(g, d)
+    ref.forward_loss(g['all_x1'][:B].to(d), g['all_x2'][:B].to(d), g['all_x3'][:B].to(d), y[:B],
+                     g['all_x1'].to(d), g['all_x2'].to(d), g['all_x3'].to(d), y, idx=g['idx'].to(d))
+    mem = make_mem(g, d)
+    c1, c2, c3 = torch.chunk(f, 3, dim=1)
+    assert not c1.is_contiguous()
+    mem.forward_loss(c1[:B], c2[:B], c3[:B], y[:B], c1, c2, c3, y, idx=g['idx'].to(d))
+    torch.cuda.synchronize()
+    for i in (1, 2, 3):
+        assert torch.equal(getattr(mem, 'memory_%d' % i), getattr(ref, 'memory_%d' % i))
+        assert torch.allclose(getattr(mem, 'memory_%d' % i).cpu(), g['bank1_%d' % i], rtol=1e-6, atol=1e-7)
+
+
+def test_out_of_range_indices_are_contained_and_reported(golden):
+    """A dataset index outside [0, n_data) (the reference would device-assert in index_select/index_copy_):
+    nothing outside the banks is touched, the step still runs, and check_indices() raises."""
+    g = golden('bank_nce')
+    d = dev()
+    mem = make_mem(g, d)
+    B, n = g['B'], g['n']
+    xs = [g['x%d' % i].to(d) for i in (1, 2, 3)]
+    y = g['y'].to(d).clone()
+    mem.forward_loss(xs[0], xs[1], xs[2], y)
+    mem.check_indices()                                   # in range: silent
+    guard = torch.full((1 << 20,), 7.0, device=d)         # memory next to whatever the allocator hands out
+    y[1] = n + 12345
+    y[2] = -3
+    total, losses, accs = mem.forward_loss(xs[0], xs[1], xs[2], y)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(losses).all()) and bool((guard == 7.0).all())
+    with pytest.raises(IndexError, match='outside'):
+        mem.check_indices()
+    mem.check_indices()                                   # flag is consumed
+    bad = g['idx'].to(d).clone()
+    bad[0, 5] = n
+    mem(xs[0], xs[1], xs[2], g['y'].to(d), idx=bad)
+    with pytest.raises(IndexError):
+        mem.check_indices()

@@ -21,8 +21,10 @@ sys.path.insert(0, ROOT)
 CHUNKS = 4
 
 
-def _run(grad_sync, steps=2, stage2=True):
-    """grad_sync None: no process group (collectives skipped); 'overlap' / 'flat': 1-rank nccl group."""
+def _run(grad_sync, steps=2, stage2=True, check_identity=False):
+    """grad_sync None: no process group (collectives skipped); 'overlap' / 'flat': 1-rank nccl group.
+    check_identity: join the helper threads and snapshot every gradient BEFORE GradSync.reduce, compare
+    bit for bit after it (one rank: every all-reduce must be the identity, whatever buffer it ran on)."""
     import bench
     from hcmoco_amd import _lib
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
@@ -40,6 +42,25 @@ def _run(grad_sync, steps=2, stage2=True):
         tr.device = dev
         model, contrast, opt, data = bench.build(args, tr, dev)
         net = tr.unwrap(model)
+        before = {n: p.detach().clone() for n, p in net.named_parameters()}
+        if check_identity:
+            sync = tr.grad_sync
+            real = sync.reduce
+
+            def checked(join=None):
+                if join is not None:
+                    join()
+                torch.cuda.synchronize()
+                snap = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+                n = real(None)
+                torch.cuda.synchronize()
+                bad = [k for k, p in net.named_parameters()
+                       if (snap[k] is None and float(p.grad.abs().max()) != 0.0)
+                       or (snap[k] is not None and not torch.equal(p.grad, snap[k]))]
+                info.setdefault('not_identity', []).extend(bad)
+                info.setdefault('none_grads', []).append(sum(v is None for v in snap.values()))
+                return n
+            sync.reduce = checked
         it = iter(data)
         losses = []
         for _ in range(steps):
@@ -57,30 +78,30 @@ def _run(grad_sync, steps=2, stage2=True):
                 info.setdefault('storage_numel', []).append(
                     next(enc.parameters()).grad.untyped_storage().nbytes() // 4)
             info['groups'] = len(tr.grad_sync.groups)
-        params = {n: p.detach().clone() for n, p in net.named_parameters()}
+        update = torch.cat([(p.detach() - before[n]).flatten() for n, p in net.named_parameters()]).double()
         banks = [b.clone() for b in contrast.banks()]
     finally:
         _lib.torch_glue().set_async_wgrad(False)
         _lib.torch_glue().set_grad_chunks(0)
         if dist.is_initialized():
             dist.destroy_process_group()
-    return losses, params, banks, info
+    return losses, update, banks, info
 
 
 def _same(a, b):
-    la, pa, ba, _ = a
-    lb, pb, bb, _ = b
-    # step 1 is bit-reproducible up to MIOpen's atomic weight-gradient kernels; two steps at lr 0.03 keep
-    # run-to-run differences many orders below these bounds, a missing / doubled / mis-scaled reduction does not
+    """Statistical agreement with the run that has no process group.  Individual parameters are NOT
+    comparable between two runs of even the same configuration (MIOpen's kernels are not run-to-run
+    deterministic and ~150 stacked batch-norm layers amplify it: batch-norm biases differ by tens of percent,
+    the second loss by ~1e-3); a missing, doubled or mis-scaled reduction moves these numbers by far more."""
+    la, ua, ba, _ = a
+    lb, ub, bb, _ = b
     assert abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0]), (la, lb)
-    assert abs(la[1] - lb[1]) <= 1e-3 * abs(lb[1]), (la, lb)
-    worst = 0.0
-    for n in pb:
-        scale = pb[n].abs().max().item() + 1e-12
-        worst = max(worst, (pa[n] - pb[n]).abs().max().item() / scale)
-    assert worst <= 2e-3, worst
+    assert abs(la[1] - lb[1]) <= 5e-3 * abs(lb[1]), (la, lb)
+    cos = float(torch.dot(ua, ub) / (ua.norm() * ub.norm()))
+    ratio = float(ua.norm() / ub.norm())
+    assert cos >= 0.98 and 0.9 <= ratio <= 1.1, (cos, ratio)
     for x, y in zip(ba, bb):
-        assert (x.float() - y.float()).abs().max().item() <= 1e-4
+        assert (x.float() - y.float()).abs().max().item() <= 1e-3
 
 
 @pytest.fixture(scope='module')
@@ -88,7 +109,20 @@ def baseline():
     return _run(None)
 
 
+def test_every_collective_is_the_identity_in_a_one_rank_group():
+    """Exactness: with the helper threads joined first, the gradients before and after GradSync.reduce are
+    bit-identical -- chunk views alias the encoders' buffers, the rest buckets are copied in, reduced and
+    re-bound without loss, parameters without a gradient receive zeros."""
+    got = _run('overlap', check_identity=True)
+    info = got[3]
+    assert info['not_identity'] == [], info['not_identity'][:10]
+    assert info['storages'] == [1, 1] and info['storage_numel'] == info['numel'], info
+    for n in info['launched']:
+        assert 2 * CHUNKS < n <= 2 * CHUNKS + info['groups'], info
+
+
 def test_overlapped_rccl_allreduce_one_rank_group(baseline):
+    """The real schedule: all-reduces launched while the reverse loops are still being issued."""
     got = _run('overlap')
     info = got[3]
     # per step: CHUNKS in-place all-reduces per HRNet + one per remaining top-level module group; the

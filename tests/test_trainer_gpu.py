@@ -61,3 +61,114 @@ def test_default_runtime_matches_plain_autograd():
     _grads_agree(p_fast, p_ref, min_cos=0.99)
     for a, b in zip(b_fast, b_ref):
         assert (a.float() - b.float()).abs().max().item() <= 1e-3
+
+
+class CheckingEngine(object):
+    """HipLossEngine that re-evaluates every call with the oracle on CPU copies of the SAME tensors (same
+    negative indices, same sampled pixels): the training loop under test is the product's, the numbers it
+    produces are checked where they are produced, so encoder noise cannot blur the comparison."""
+
+    def __init__(self):
+        from hcmoco_amd.pycontrast.learning.engine import HipLossEngine
+        from oracle.oracle_engine import OracleLossEngine
+        self.hip, self.oracle = HipLossEngine(), OracleLossEngine()
+        self.calls = {'bank': 0, 'fmap': 0, 'grad': 0, 'regimes': set()}
+
+    @staticmethod
+    def _cpu(t):
+        return None if t is None else t.detach().cpu()
+
+    def bank(self, contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index, use_depth=None, use_rgb=None,
+             idx=None):
+        from oracle import hcmoco_oracle as O
+        c = self._cpu
+        idx = contrast.multinomial.draw_with_positive(index, contrast.K + 1)
+        banks0 = [c(b).float() for b in contrast.banks()]
+        total, losses, accs = self.hip.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+                                            use_depth=use_depth, use_rgb=use_rgb, idx=idx)
+        lo, ao, go, _ = O.bank_nce(banks0, c(idx), [c(f1), c(f2), c(f3)], contrast.T, c(use_depth), c(use_rgb))
+        assert torch.allclose(c(losses), lo, rtol=1e-5, atol=1e-6), (losses, lo)
+        assert torch.allclose(c(accs), ao, atol=1e-3), (accs, ao)
+        for i, (bank, ax) in enumerate(zip(contrast.banks(), (all_f1, all_f2, all_f3))):
+            ref = O.bank_update(banks0[i], c(ax), c(all_index), contrast.m)
+            assert (c(bank).float() - ref).abs().max().item() <= 1e-6
+        for i, f in enumerate((f1, f2, f3)):
+            def hook(g, i=i):
+                ref = go[i]
+                if float(ref.norm()) == 0:
+                    assert float(g.abs().max()) == 0
+                else:
+                    assert float((c(g) - ref).norm() / ref.norm()) < 1e-4
+                self.calls['grad'] += 1
+            f.register_hook(hook)
+        self.calls['bank'] += 1
+        self.calls['regimes'].add((use_depth is not None, use_rgb is not None))
+        return total, losses, accs
+
+    def fmap_sampled(self, branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
+                     use_depth, use_rgb, num_samples, temperature, sample_ind=None, keep=None):
+        c = self._cpu
+        h, w = branches1[0].shape[-2:]
+        sample_ind, keep = self.hip.dense_samples(depth_mask, h, w, num_samples, use_depth)
+        total, meters = self.hip.fmap_sampled(branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
+                                              use_depth, use_rgb, num_samples, temperature, sample_ind=sample_ind, keep=keep)
+        import copy
+        p1, p2 = copy.deepcopy(proj1).cpu(), copy.deepcopy(proj2).cpu()
+        with torch.no_grad():       # reference data flow: merge_all_res + full 1x1 projection + oracle losses
+            _, want = self.oracle.fmap_sampled([c(m) for m in branches1], [c(m) for m in branches2], p1, p2, c(feat3),
+                                               c(depth_mask), c(joints2d), c(joints_vis), c(use_depth), c(use_rgb),
+                                               num_samples, temperature, sample_ind=c(sample_ind), keep=c(keep))
+        assert torch.allclose(c(meters), want, rtol=2e-4, atol=2e-5), (meters, want)
+        self.calls['fmap'] += 1
+        return total, meters
+
+
+def _main_args(method, extra):
+    tmp = tempfile.mkdtemp()
+    return ['--method', method, '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list', '3,3',
+            '--batch_size', '8', '--nce_k', '1024', '--world-size', '1', '--dist-backend', 'nccl', '--synthetic',
+            '--synthetic_n_data', '4096', '--synthetic_size', '128', '--synthetic_steps', '2', '--epochs', '1',
+            '--print_freq', '1', '--save_freq', '1', '--model_path', tmp, '--tb_path', tmp, '--seed', '3',
+            '--learning_rate', '0.01', '--modality_missing', '1', '--synthetic_ntu', '1',
+            '--synthetic_p_rgb', '0.7'] + list(extra)
+
+
+@pytest.fixture
+def _pg_env(monkeypatch):
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(24000 + os.getpid() % 3000))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
+        monkeypatch.delenv(k, raising=False)
+    yield
+    from hcmoco_amd import _lib
+    _lib.torch_glue().set_async_wgrad(False)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def test_stage1_loop_on_the_hip_engine_through_main(_pg_env):
+    """BASELINE config 1's method (CMCRGBD2S, learning/contrast_trainer.py:532-640) on the MI355X through the
+    real entry point: two steps with use_depth AND use_rgb masks (the `both_*` row-selection regime), the fused
+    bank kernel's losses / accuracies / d/dx / momentum update checked against the oracle at every step."""
+    from hcmoco_amd.pycontrast import main_contrast
+    eng = CheckingEngine()
+    outs, trainer, model, contrast = main_contrast.main(_main_args('CMCRGBD2S', []), engine=eng)
+    torch.cuda.synchronize()
+    assert trainer.device.type == 'cuda' and trainer.args.mem == 'bank'
+    assert len(outs) == 6 and all(v == v for v in outs)
+    assert eng.calls['bank'] == 2 and eng.calls['grad'] == 6 and eng.calls['regimes'] == {(True, True)}
+    ck = torch.load(os.path.join(trainer.args.model_folder, 'current.pth'), map_location='cpu')
+    assert ck['sampler']['offset'] == 2 and set(ck['contrast']) == {'memory_1', 'memory_2', 'memory_3'}
+
+
+def test_stage2_loop_on_the_hip_engine_through_main(_pg_env):
+    """Stage 2 (:894-1039) through the entry point with the default runtime (sampled projection, encoder
+    programs, deferred backward): bank terms against the oracle, and the nine feature-map meters against the
+    reference data flow (merge_all_res + full 1x1 projection + oracle losses) on the same branch maps."""
+    from hcmoco_amd.pycontrast import main_contrast
+    eng = CheckingEngine()
+    argv = _main_args('CMCJointsPri3DRGBD2S', ['--linear_feat_map', '1', '--pri3d_num_samples_per_image', '64'])
+    outs, trainer, model, contrast = main_contrast.main(argv, engine=eng)
+    torch.cuda.synchronize()
+    assert len(outs) == 4 and outs[0] == outs[0]
+    assert eng.calls['bank'] == 2 and eng.calls['fmap'] == 2 and eng.calls['regimes'] == {(True, False)}
