@@ -64,6 +64,10 @@ SIGNATURES = {
     'hcm_three_nn': (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_three_interpolate': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'hcm_three_interpolate_grad': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'hcm_furthest_point_sampling_contract': (_i, [_i, _i, _i, _p, _p, _p, _i, _p]),
+    'hcm_ball_query_contract': (_i, [_i, _i, _i, _f, _i, _p, _p, _p, _i, _p]),
+    'hcm_three_nn_contract': (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _p]),
+    'hcm_three_interpolate_contract': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 5),
     'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 6),

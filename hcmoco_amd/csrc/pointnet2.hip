@@ -4,9 +4,20 @@
 // fp32 data, int32 indices, caller-allocated and caller-initialised outputs, asynchronous on the
 // given stream.  Launch failures are returned instead of exit(-1).
 //
-// This translation unit is compiled with -ffp-contract=off: squared distances are evaluated as
-// ((dx*dx + dy*dy) + dz*dz) in un-fused IEEE fp32, the arithmetic the index-producing kernels
-// (FPS, ball query, three-NN) are bit-exact against (oracle/pointnet2_oracle.c).
+// Arithmetic contract of the four kernels that do fp32 arithmetic (FPS, ball query, three-NN,
+// three_interpolate).  The reference writes  a*a + b*b + c*c  (sampling_gpu.cu:131, ball_query_gpu.cu:33,
+// interpolate_gpu.cu:39, :96) and is built with `nvcc -O2` (networks/pointnet2/setup.py:20), whose
+// default is --fmad=true: the compiler contracts the expression.  Every LLVM-family and GNU compiler
+// available here contracts that source form the same way (checked on the ISA: amdgcn, x86 clang, x86
+// gcc): the MIDDLE product is rounded on its own, then two fused multiply-adds,
+//     fma(c, c, fma(a, a, b*b)).
+// NVVM is the same LLVM DAG combiner, so that is taken as the reference's real arithmetic
+// (kContractFma, the default).  kContractIeee is the un-fused evaluation ((a*a + b*b) + c*c) -- what the
+// same source gives with --fmad=false, and what a CPU port of the reference would compute.
+// Near-ties are routine (clouds are sampled WITH replacement, build_backbone.py:427), so the two
+// contracts can pick different FPS points / ball members / third neighbours; both are bit-exact against
+// oracle/pointnet2_oracle.c in the same mode.  This translation unit is compiled with
+// -ffp-contract=off so that only the fmaf() calls written below fuse.
 //
 // MI355X notes: the three search kernels stage the scanned cloud through LDS in coalesced tiles
 // and read it back as wave-wide broadcasts; gather/scatter kernels load each index once and walk
@@ -21,9 +32,16 @@ namespace {
 
 constexpr int kT = 256;
 
+template <bool FMA>
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
   const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  if (FMA) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
   return (dx * dx + dy * dy) + dz * dz;
+}
+template <bool FMA>
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  if (FMA) return fmaf(a2, b2, fmaf(a0, b0, a1 * b1));
+  return (a0 * b0 + a1 * b1) + a2 * b2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -64,6 +82,7 @@ __global__ __launch_bounds__(kT) void scatter_rows_kernel(int c, int n, int q,
 // three_interpolate: out[b,c,n] = sum_j w[b,n,j] * points[b,c,idx[b,n,j]]
 // interpolate_gpu.cu:77-97 / :120-142
 // ------------------------------------------------------------------------------------------
+template <bool FMA>
 __global__ __launch_bounds__(kT) void three_interp_kernel(int c, int m, int n,
                                                           const float* __restrict__ points,
                                                           const int* __restrict__ idx,
@@ -77,7 +96,7 @@ __global__ __launch_bounds__(kT) void three_interp_kernel(int c, int m, int n,
   const int c0 = blockIdx.y * kCB, c1 = min(c, c0 + kCB);
   const float* p = points + ((int64_t)b * c + c0) * m;
   float* o = out + ((int64_t)b * c + c0) * n + pos;
-  for (int ch = c0; ch < c1; ++ch, p += m, o += n) *o = (w0 * p[i0] + w1 * p[i1]) + w2 * p[i2];
+  for (int ch = c0; ch < c1; ++ch, p += m, o += n) *o = dot3<FMA>(w0, p[i0], w1, p[i1], w2, p[i2]);
 }
 
 __global__ __launch_bounds__(kT) void three_interp_grad_kernel(int c, int n, int m,
@@ -145,6 +164,7 @@ constexpr int kTile = 1024;
 // Hits are collected in LDS ([slot][thread], conflict-free) and written out once at the end: a global
 // store inside the scan loop is issued by ~half of all iterations (any of the 64 lanes hitting) and
 // paces the kernel otherwise.
+template <bool FMA>
 __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radius2, int nsample,
                                                         const float* __restrict__ new_xyz,
                                                         const float* __restrict__ xyz,
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float4 p = tile[min(k0 + j, len - 1)];
-          d2[j] = (k0 + j < len) ? sqdist(cx, cy, cz, p.x, p.y, p.z) : __builtin_inff();
+          d2[j] = (k0 + j < len) ? sqdist<FMA>(cx, cy, cz, p.x, p.y, p.z) : __builtin_inff();
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -229,6 +249,7 @@ struct Top3 {
   }
 };
 
+template <bool FMA>
 __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
                                                       const float* __restrict__ unknown,
                                                       const float* __restrict__ known,
@@ -260,8 +281,8 @@ __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
     __syncthreads();
     for (int k = 0; k < len; ++k) {
       const float4 p = tile[k];
-      t0.push(sqdist(ux0, uy0, uz0, p.x, p.y, p.z), base + k);
-      t1.push(sqdist(ux1, uy1, uz1, p.x, p.y, p.z), base + k);
+      t0.push(sqdist<FMA>(ux0, uy0, uz0, p.x, p.y, p.z), base + k);
+      t1.push(sqdist<FMA>(ux1, uy1, uz1, p.x, p.y, p.z), base + k);
     }
   }
   if (pt0 < n) {
@@ -319,7 +340,7 @@ __device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, i
 // Every point k has the unique key (distance, ~(bitrev(k % bs) << 21 | k / bs)); the global maximum
 // of that key IS the reference winner whatever physical thread evaluated the point, so the physical
 // workgroup size P is a pure performance choice (fewer waves = cheaper barrier, more points each).
-template <int PER>
+template <int PER, bool FMA>
 __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log2bs,
                                                    const float* __restrict__ dataset,
                                                    float* __restrict__ temp,
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
         if (tid + j * P < n) {
-          const float d = sqdist(px[j], py[j], pz[j], ox, oy, oz);
+          const float d = sqdist<FMA>(px[j], py[j], pz[j], ox, oy, oz);
           const float d2 = fminf(d, pt[j]);
           pt[j] = d2;
           c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | pk[j]);
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
       }
     } else {
       for (int k = tid; k < n; k += P) {
-        const float d = sqdist(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
+        const float d = sqdist<FMA>(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
         const float d2 = fminf(d, tmp[k]);
         tmp[k] = d2;
         c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | point_key(k));
@@ -489,8 +510,16 @@ int hcm_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
 }
 int hcm_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
                           const float* weight, float* out, hcm_stream_t stream) {
+  return hcm_three_interpolate_contract(b, c, m, n, points, idx, weight, out, HCM_CONTRACT_FMA, stream);
+}
+int hcm_three_interpolate_contract(int b, int c, int m, int n, const float* points, const int* idx,
+                                   const float* weight, float* out, int contract, hcm_stream_t stream) {
+  if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || c <= 0 || n <= 0) return b < 0 || c < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
-  three_interp_kernel<<<grid3(n, c, b), kT, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+  if (contract == HCM_CONTRACT_FMA)
+    three_interp_kernel<true><<<grid3(n, c, b), kT, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+  else
+    three_interp_kernel<false><<<grid3(n, c, b), kT, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
   HCM_CHECK_LAUNCH();
   return 0;
 }
@@ -503,6 +532,11 @@ int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out
 }
 int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
                    const float* xyz, int* idx, hcm_stream_t stream) {
+  return hcm_ball_query_contract(b, n, m, radius, nsample, new_xyz, xyz, idx, HCM_CONTRACT_FMA, stream);
+}
+int hcm_ball_query_contract(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                            const float* xyz, int* idx, int contract, hcm_stream_t stream) {
+  if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || m <= 0 || nsample <= 0) return b < 0 || m < 0 || nsample < 0 ? (int)hipErrorInvalidValue : 0;
   // one thread per centre: shrink the workgroup when there are too few centres to fill 256 CUs
   int threads = kT;
@@ -510,19 +544,31 @@ int hcm_ball_query(int b, int n, int m, float radius, int nsample, const float* 
   while (threads > 64 && (size_t)threads * nsample * sizeof(int) > 96 * 1024) threads >>= 1;
   const size_t lds = (size_t)threads * nsample * sizeof(int);
   if (lds > 128 * 1024) return (int)hipErrorInvalidValue;   // nsample > 512
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const void* fn = contract == HCM_CONTRACT_FMA ? reinterpret_cast<const void*>(ball_query_kernel<true>)
+                                                : reinterpret_cast<const void*>(ball_query_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((m + threads - 1) / threads, b);
-  ball_query_kernel<<<grid, threads, lds, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
+  if (contract == HCM_CONTRACT_FMA)
+    ball_query_kernel<true><<<grid, threads, lds, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
+  else
+    ball_query_kernel<false><<<grid, threads, lds, (hipStream_t)stream>>>(n, m, radius * radius, nsample, new_xyz, xyz, idx);
   HCM_CHECK_LAUNCH();
   return 0;
 }
 int hcm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
                  int* idx, hcm_stream_t stream) {
+  return hcm_three_nn_contract(b, n, m, unknown, known, dist2, idx, HCM_CONTRACT_FMA, stream);
+}
+int hcm_three_nn_contract(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                          int* idx, int contract, hcm_stream_t stream) {
+  if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || n <= 0) return b < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
   dim3 grid((n + 2 * kT - 1) / (2 * kT), b);
-  three_nn_kernel<<<grid, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+  if (contract == HCM_CONTRACT_FMA)
+    three_nn_kernel<true><<<grid, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+  else
+    three_nn_kernel<false><<<grid, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
   HCM_CHECK_LAUNCH();
   return 0;
 }
@@ -549,6 +595,11 @@ int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx
 
 int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
                                 hcm_stream_t stream) {
+  return hcm_furthest_point_sampling_contract(b, n, m, dataset, temp, idxs, HCM_CONTRACT_FMA, stream);
+}
+int hcm_furthest_point_sampling_contract(int b, int n, int m, const float* dataset, float* temp, int* idxs,
+                                         int contract, hcm_stream_t stream) {
+  if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || n <= 0 || m <= 0) return b < 0 || n < 0 || m < 0 ? (int)hipErrorInvalidValue : 0;
   const int bs = opt_n_threads(n);   // the reference's block size: defines the tie-break order only
   static const int pt_env = getenv("HCM_FPS_THREADS") ? atoi(getenv("HCM_FPS_THREADS")) : 512;
@@ -559,19 +610,23 @@ int hcm_furthest_point_sampling(int b, int n, int m, const float* dataset, float
   while ((1 << log2bs) < bs) ++log2bs;
   const size_t lds = (size_t)n * 3 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define HCM_FPS(P)                                                                          \
+  const bool fma = contract == HCM_CONTRACT_FMA;
+#define HCM_FPS1(P, F)                                                                      \
   do {                                                                                      \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P>),                        \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P, F>),                     \
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-    fps_kernel<P><<<b, threads, lds, st>>>(n, m, bs, log2bs, dataset, temp, idxs);           \
+    fps_kernel<P, F><<<b, threads, lds, st>>>(n, m, bs, log2bs, dataset, temp, idxs);        \
   } while (0)
+#define HCM_FPS(P) do { if (fma) HCM_FPS1(P, true); else HCM_FPS1(P, false); } while (0)
   if (per <= 1 && lds <= 150 * 1024) HCM_FPS(1);
   else if (per <= 2 && lds <= 150 * 1024) HCM_FPS(2);
   else if (per <= 4 && lds <= 150 * 1024) HCM_FPS(4);
   else if (per <= 8 && lds <= 150 * 1024) HCM_FPS(8);
   else if (per <= 16 && lds <= 150 * 1024) HCM_FPS(16);
-  else fps_kernel<0><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
+  else if (fma) fps_kernel<0, true><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
+  else fps_kernel<0, false><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
 #undef HCM_FPS
+#undef HCM_FPS1
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -17,6 +17,19 @@ from ._lib import check
 from .hip_ops import _dev, _stream
 
 
+# Arithmetic contract of FPS / ball query / three_nn / three_interpolate (include/hcmoco_hip.h):
+# 'fma' = what the reference's `nvcc -O2` build computes (fused multiply-adds, the default),
+# 'ieee' = un-fused fp32 (an --fmad=false or CPU build).  HCM_PN2_CONTRACT=ieee selects the latter.
+import os as _os
+
+CONTRACTS = {'ieee': 0, 'fma': 1}
+CONTRACT = _os.environ.get('HCM_PN2_CONTRACT', 'fma')
+
+
+def _contract():
+    return CONTRACTS[CONTRACT]
+
+
 def _f(t, name):
     return _dev(t, torch.float32, name)
 
@@ -26,8 +39,9 @@ def _i(t, name):
 
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
-    check(_lib.lib().hcm_ball_query(b, n, m, float(radius), nsample, _f(new_xyz, 'ball_query'),
-                                    _f(xyz, 'ball_query'), _i(idx, 'ball_query'), _stream()), 'hcm_ball_query')
+    check(_lib.lib().hcm_ball_query_contract(b, n, m, float(radius), nsample, _f(new_xyz, 'ball_query'),
+                                             _f(xyz, 'ball_query'), _i(idx, 'ball_query'), _contract(), _stream()),
+          'hcm_ball_query')
     return 1
 
 
@@ -59,19 +73,20 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
-    check(_lib.lib().hcm_furthest_point_sampling(b, n, m, _f(points, 'fps'), _f(temp, 'fps'), _i(idx, 'fps'),
-                                                 _stream()), 'hcm_furthest_point_sampling')
+    check(_lib.lib().hcm_furthest_point_sampling_contract(b, n, m, _f(points, 'fps'), _f(temp, 'fps'), _i(idx, 'fps'),
+                                                          _contract(), _stream()), 'hcm_furthest_point_sampling')
     return 1
 
 
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
-    check(_lib.lib().hcm_three_nn(b, n, m, _f(unknown, 'three_nn'), _f(known, 'three_nn'), _f(dist2, 'three_nn'),
-                                  _i(idx, 'three_nn'), _stream()), 'hcm_three_nn')
+    check(_lib.lib().hcm_three_nn_contract(b, n, m, _f(unknown, 'three_nn'), _f(known, 'three_nn'), _f(dist2, 'three_nn'),
+                                           _i(idx, 'three_nn'), _contract(), _stream()), 'hcm_three_nn')
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
-    check(_lib.lib().hcm_three_interpolate(b, c, m, n, _f(points, 'three_interpolate'), _i(idx, 'three_interpolate'),
-                                           _f(weight, 'three_interpolate'), _f(out, 'three_interpolate'), _stream()),
+    check(_lib.lib().hcm_three_interpolate_contract(b, c, m, n, _f(points, 'three_interpolate'),
+                                                    _i(idx, 'three_interpolate'), _f(weight, 'three_interpolate'),
+                                                    _f(out, 'three_interpolate'), _contract(), _stream()),
           'hcm_three_interpolate')
 
 

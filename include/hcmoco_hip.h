@@ -298,6 +298,26 @@ int hcm_three_interpolate(int b, int c, int m, int n, const float* points, const
 int hcm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
                                const float* weight, float* grad_points, hcm_stream_t stream);
 
+/* Arithmetic contract of the four ops above that do fp32 arithmetic.  The reference evaluates
+ *   d = a*a + b*b + c*c   (src/sampling_gpu.cu:131, src/ball_query_gpu.cu:33, src/interpolate_gpu.cu:39)
+ *   o = w0*p0 + w1*p1 + w2*p2   (src/interpolate_gpu.cu:96)
+ * and is built by `nvcc -O2` (networks/pointnet2/setup.py:20; --fmad=true is nvcc's default), which
+ * contracts the source form to  fma(c, c, fma(a, a, b*b)):  HCM_CONTRACT_FMA, what the plain entry
+ * points above compute.  HCM_CONTRACT_IEEE is the un-fused ((a*a + b*b) + c*c) of an --fmad=false /
+ * CPU build.  Indices can differ between the two on near-ties (duplicate points are routine:
+ * networks/build_backbone.py:427 samples with replacement); each is bit-exact against the oracle
+ * in the same mode. */
+#define HCM_CONTRACT_IEEE 0
+#define HCM_CONTRACT_FMA 1
+int hcm_furthest_point_sampling_contract(int b, int n, int m, const float* dataset, float* temp, int* idxs,
+                                         int contract, hcm_stream_t stream);
+int hcm_ball_query_contract(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                            const float* xyz, int* idx, int contract, hcm_stream_t stream);
+int hcm_three_nn_contract(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                          int* idx, int contract, hcm_stream_t stream);
+int hcm_three_interpolate_contract(int b, int c, int m, int n, const float* points, const int* idx,
+                                   const float* weight, float* out, int contract, hcm_stream_t stream);
+
 /* LDS-resident backward of the three scatter-add ops above (they share one algebraic form):
  *   grad_points[b, c, j] = sum_{q : idx[b, q] == j} coef[b, q] * grad_out[b, c, q / div]
  * group_points_grad : idx [B, npoints*nsample], coef NULL, div 1, Qsrc = npoints*nsample

@@ -8,19 +8,36 @@
  * the reference ships no tests or fixtures for them: PARITY UNPINNED by the reference.  It is
  * pinned instead by hand-checkable known-answer tests (tests/test_pointnet2_oracle.py).
  *
- * Arithmetic contract: un-fused IEEE fp32, squared distance = ((dx*dx + dy*dy) + dz*dz)
- * (compile with -ffp-contract=off; the HIP translation unit is built the same way).
+ * Arithmetic contract (oracle_set_contract): the reference source evaluates  a*a + b*b + c*c  and is
+ * built with `nvcc -O2` (networks/pointnet2/setup.py:20, --fmad=true by default).  Mode 1 (default)
+ * restates the contracted form every LLVM / GNU compiler here produces for that source,
+ * fma(c, c, fma(a, a, b*b)) -- taken as the reference's real arithmetic; mode 0 is the un-fused
+ * ((a*a + b*b) + c*c) of an --fmad=false / CPU build.  Compiled with -ffp-contract=off: only the
+ * fmaf() calls below fuse.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-static float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
-  volatile float dx = ax - bx, dy = ay - by, dz = az - bz;
-  volatile float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+static int g_contract = 1;   /* 0 = IEEE un-fused, 1 = FMA (nvcc -O2 default) */
+void oracle_set_contract(int c) { g_contract = c ? 1 : 0; }
+int oracle_get_contract(void) { return g_contract; }
+
+/* a0*b0 + a1*b1 + a2*b2 in source order under the selected contract */
+static float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  if (g_contract) {
+    volatile float mid = a1 * b1;
+    return fmaf(a2, b2, fmaf(a0, b0, mid));
+  }
+  volatile float xx = a0 * b0, yy = a1 * b1, zz = a2 * b2;
   volatile float s = xx + yy;
   return s + zz;
+}
+
+static float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+  volatile float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return dot3(dx, dx, dy, dy, dz, dz);
 }
 
 /* cuda_utils.h:10-14 */
@@ -164,9 +181,7 @@ void oracle_three_interpolate(int b, int c, int m, int n, const float* points, c
         const float* w = weight + ((size_t)bi * n + pt) * 3;
         const int* id = idx + ((size_t)bi * n + pt) * 3;
         const float* p = points + ((size_t)bi * c + ci) * m;
-        volatile float a = w[0] * p[id[0]], bb = w[1] * p[id[1]], cc = w[2] * p[id[2]];
-        volatile float s = a + bb;
-        out[((size_t)bi * c + ci) * n + pt] = s + cc;
+        out[((size_t)bi * c + ci) * n + pt] = dot3(w[0], p[id[0]], w[1], p[id[1]], w[2], p[id[2]]);
       }
 }
 

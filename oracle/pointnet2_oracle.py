@@ -34,6 +34,15 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def set_contract(mode):
+    """'fma' (the reference's nvcc -O2 build, default) or 'ieee' (un-fused fp32)."""
+    lib().oracle_set_contract({'ieee': 0, 'fma': 1}[mode])
+
+
+def get_contract():
+    return 'fma' if lib().oracle_get_contract() else 'ieee'
+
+
 def furthest_point_sampling(xyz, npoint):
     B, N, _ = xyz.shape
     xyz = xyz.contiguous().float()
@@ -95,6 +104,12 @@ def three_nn(unknown, known):
     u, k = unknown.contiguous().float(), known.contiguous().float()
     lib().oracle_three_nn(B, N, m, _p(u), _p(k), _p(dist2), _p(idx))
     return dist2, idx
+
+
+def three_nn_rows(unknown, known, rows):
+    """three_nn for the unknown points ``rows`` (1-D index tensor) of every batch element only -- the same
+    per-point scan, used where the full problem (32 x 65536 x 4096) would take minutes on the host."""
+    return three_nn(unknown[:, rows].contiguous(), known)
 
 
 def three_interpolate(points, idx, weight):

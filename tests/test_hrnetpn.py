@@ -109,3 +109,42 @@ def test_hrnetpn_stage2_step_runs_on_gpu():
     changed = (mem.memory_2 != before).any(1).nonzero().flatten().tolist()
     assert sorted(changed) == sorted(data.pool[0][1].tolist())
     assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in model.encoder2.parameters())
+
+
+@pytest.mark.gpu
+def test_hrnetpn_w32_stage2_steps_at_256(tmp_path):
+    """BASELINE config 4's model at its own width and resolution (HRNet-w32 RGB encoder + PointNet++ MSG on
+    4096-point clouds + SemGCN, 256x256, K=16384; batch 8 to keep the test short): two stage-2 steps through
+    bench.build / ContrastTrainer with the default runtime.  Losses finite and moving, banks change only at
+    the batch's rows, every encoder receives gradients, the w32 HRNet ran as an encoder program."""
+    import bench
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    dev = torch.device('cuda:0')
+    args = bench.make_args(8, 16384, 131072, 256, 'coco17', 'nccl', str(tmp_path), 3, arch='HRNetPN', width=32)
+    args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
+    try:
+        tr = ContrastTrainer(args)
+        tr.device = dev
+        model, contrast, opt, data = bench.build(args, tr, dev)
+        assert model.encoder1.width == 32 and sum(p.numel() for p in model.encoder1.parameters()) > 29e6
+        before = [b.clone() for b in contrast.banks()]
+        it = iter(data)
+        rows, losses = [], []
+        for _ in range(2):
+            batch = next(it)
+            rows += batch[1].tolist()
+            out = tr.train_step(batch, model, contrast, opt, True)
+            losses.append(float(out['loss']))
+            assert bool(torch.isfinite(out['fmap']).all()) and bool(torch.isfinite(out['bank_losses']).all())
+        torch.cuda.synchronize()
+        contrast.check_indices()
+        assert all(v == v for v in losses) and losses[0] != losses[1]
+        assert model.encoder1.last_program is not None
+        for bank, b0 in zip(contrast.banks(), before):
+            changed = (bank != b0).any(1).nonzero().flatten().tolist()
+            assert sorted(changed) == sorted(set(rows))
+        for enc in (model.encoder1, model.encoder2, model.encoder3, model.encoder1_linear, model.encoder2_linear):
+            assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in enc.parameters())
+    finally:
+        _lib.torch_glue().set_async_wgrad(False)

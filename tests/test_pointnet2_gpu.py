@@ -19,6 +19,19 @@ def d():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(params=['fma', 'ieee'])
+def contract(request):
+    """Both arithmetic contracts (include/hcmoco_hip.h): 'fma' = the reference's nvcc -O2 build (default),
+    'ieee' = un-fused.  The oracle and the HIP ops are switched together."""
+    m = mod()
+    old = m.CONTRACT
+    m.CONTRACT = request.param
+    P.set_contract(request.param)
+    yield request.param
+    m.CONTRACT = old
+    P.set_contract('fma')
+
+
 def cloud(B, N, seed, dup=True):
     g = torch.Generator().manual_seed(seed)
     xyz = torch.rand(B, N, 3, generator=g)
@@ -32,7 +45,7 @@ def cloud(B, N, seed, dup=True):
 
 @pytest.mark.parametrize('N,M', [(5, 5), (37, 20), (64, 64), (100, 33), (1024, 256), (1500, 700), (4096, 1024),
                                  (9000, 50)])
-def test_fps_bit_exact(N, M):
+def test_fps_bit_exact(N, M, contract):
     xyz = cloud(2, N, N * 7 + M)
     ref, ref_temp = P.furthest_point_sampling(xyz, M)
     out = torch.zeros(2, M, dtype=torch.int32, device=d())
@@ -52,7 +65,7 @@ def test_fps_known_answer_tie_break():
 
 @pytest.mark.parametrize('N,M,r,ns', [(10, 4, 0.3, 3), (300, 300, 0.2, 16), (4096, 1024, 0.125, 32),
                                       (2500, 777, 0.05, 16), (1024, 256, 1.0, 32)])
-def test_ball_query_bit_exact(N, M, r, ns):
+def test_ball_query_bit_exact(N, M, r, ns, contract):
     xyz = cloud(2, N, N + M)
     new_xyz = xyz[:, torch.randperm(N)[:M]].contiguous()
     new_xyz[:, 0] = 50.0   # a centre with an empty ball
@@ -64,7 +77,7 @@ def test_ball_query_bit_exact(N, M, r, ns):
 
 
 @pytest.mark.parametrize('n,m', [(7, 2), (256, 64), (4096, 1024), (3000, 4096)])
-def test_three_nn_bit_exact(n, m):
+def test_three_nn_bit_exact(n, m, contract):
     unknown, known = cloud(2, n, n), cloud(2, m, m + 1)
     rd, ri = P.three_nn(unknown, known)
     dist2 = torch.zeros(2, n, 3, device=d())
@@ -74,7 +87,7 @@ def test_three_nn_bit_exact(n, m):
     assert torch.equal(dist2.cpu(), rd)
 
 
-def test_group_gather_interpolate_and_grads():
+def test_group_gather_interpolate_and_grads(contract):
     torch.manual_seed(1)
     B, C, N, npts, ns = 2, 37, 500, 128, 16
     pts = torch.randn(B, C, N)
@@ -108,6 +121,78 @@ def test_group_gather_interpolate_and_grads():
     g = torch.zeros(B, C, m, device=d())
     mod().three_interpolate_grad_wrapper(B, C, n, m, go.to(d()), ii.to(d()), w.to(d()), g)
     assert torch.allclose(g.cpu(), P.three_interpolate_grad(go, ii, w, m), rtol=1e-4, atol=1e-5)
+
+
+def test_contracts_differ_on_near_ties_and_default_is_fma():
+    """The two contracts are not interchangeable: on a cloud with many near-equal distances at least one
+    three-NN distance differs in its last bit, and each mode reproduces ITS oracle bit for bit.  The plain
+    reference-ABI entry points (hcm_three_nn, ...) compute the FMA contract."""
+    import ctypes as C
+    from hcmoco_amd import _lib
+    assert mod().CONTRACT == 'fma'
+    n, m = 2048, 512
+    unknown, known = cloud(1, n, 11), cloud(1, m, 12)
+    res = {}
+    for mode in ('fma', 'ieee'):
+        P.set_contract(mode)
+        mod().CONTRACT = mode
+        try:
+            rd, ri = P.three_nn(unknown, known)
+            dist2 = torch.zeros(1, n, 3, device=d())
+            idx = torch.zeros(1, n, 3, dtype=torch.int32, device=d())
+            mod().three_nn_wrapper(1, n, m, unknown.to(d()), known.to(d()), dist2, idx)
+            assert torch.equal(dist2.cpu(), rd) and torch.equal(idx.cpu(), ri)
+            res[mode] = dist2.cpu()
+        finally:
+            P.set_contract('fma')
+            mod().CONTRACT = 'fma'
+    assert not torch.equal(res['fma'], res['ieee'])
+    assert (res['fma'] - res['ieee']).abs().max().item() < 1e-6
+    # plain C entry point == FMA contract
+    dist2 = torch.zeros(1, n, 3, device=d())
+    idx = torch.zeros(1, n, 3, dtype=torch.int32, device=d())
+    u, k = unknown.to(d()), known.to(d())
+    rc = _lib.lib().hcm_three_nn(1, n, m, C.c_void_p(u.data_ptr()), C.c_void_p(k.data_ptr()),
+                                 C.c_void_p(dist2.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dist2.cpu(), res['fma'])
+    assert _lib.lib().hcm_three_nn_contract(1, n, m, C.c_void_p(u.data_ptr()), C.c_void_p(k.data_ptr()),
+                                            C.c_void_p(dist2.data_ptr()), C.c_void_p(idx.data_ptr()), 7,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+
+
+def test_pts2depth_scale_three_nn_and_interpolate_against_the_oracle(contract):
+    """BASELINE config 4's heaviest point op at its own size (networks/build_backbone.py:447-455: every pixel
+    of a 256x256 depth map looks up its 3 nearest of the 4096 sampled points, B=32): n=65536, m=4096.  The HIP
+    ops run the full problem; the oracle scans a strided subset of the unknown points (each point's scan is
+    independent, so a subset is a complete check of those rows): indices and squared distances bit-exact,
+    interpolated features bit-exact on the same subset."""
+    B, n, m, Cc = 32, 65536, 4096, 16
+    g = torch.Generator().manual_seed(2026)
+    # back-projected pixel grid + depth noise; the 4096 known points are drawn from it WITH replacement
+    ys, xs = torch.meshgrid(torch.arange(256.), torch.arange(256.), indexing='ij')
+    z = 3.0 + 0.1 * torch.randn(B, 256, 256, generator=g)
+    full = torch.stack([(xs - 128) * z * 0.0035, (128 - ys) * z * 0.0035, z - 3.0], -1).reshape(B, n, 3).contiguous()
+    pick = torch.randint(0, n, (B, m), generator=g)
+    known = torch.gather(full, 1, pick.unsqueeze(-1).expand(B, m, 3)).contiguous()
+    dist2 = torch.zeros(B, n, 3, device=d())
+    idx = torch.zeros(B, n, 3, dtype=torch.int32, device=d())
+    mod().three_nn_wrapper(B, n, m, full.to(d()), known.to(d()), dist2, idx)
+    rows = torch.arange(7, n, 257)                      # 255 unknown points per cloud, all image regions
+    rd, ri = P.three_nn_rows(full, known, rows)
+    assert torch.equal(idx.cpu()[:, rows], ri)
+    assert torch.equal(dist2.cpu()[:, rows], rd)
+    assert int((rd[..., 0] == 0).sum()) > 0             # exact hits exist (sampled pixels are among the unknowns)
+    feats = torch.randn(B, Cc, m, generator=g)
+    dist = torch.sqrt(dist2)
+    w = 1.0 / (dist + 1e-8)
+    w = (w / w.sum(2, keepdim=True)).contiguous()
+    out = torch.empty(B, Cc, n, device=d())
+    mod().three_interpolate_wrapper(B, Cc, m, n, feats.to(d()), idx, w, out)
+    ref = P.three_interpolate(feats, idx.cpu()[:, rows].contiguous(), w.cpu()[:, rows].contiguous())
+    assert torch.equal(out.cpu()[:, :, rows], ref)
 
 
 def test_bad_arguments_raise_instead_of_exit():

@@ -75,3 +75,47 @@ def test_three_nn_and_interpolate():
     assert out[0, 0].tolist() == [0.5 * 2 + 0.25 * 4 + 0.25 * 1, 8.0]
     g = P.three_interpolate_grad(torch.tensor([[[2., 3]]]), ii, w, 4)
     assert g[0, 0].tolist() == [0.5, 1.0, 0.5, 3.0]
+
+
+def test_arithmetic_contracts_are_distinguishable():
+    """The two contracts of oracle/pointnet2_oracle.c on inputs where they differ by construction.
+    fma mode: fma(dz, dz, fma(dx, dx, dy*dy)) -- only dy*dy is rounded; ieee mode rounds every product."""
+    import numpy as np
+    f = np.float32
+    dx, dy, dz = f(1.0) + f(2.0 ** -12), f(0.0), f(0.0)        # dx*dx = 1 + 2^-11 + 2^-24: inexact in fp32
+    ieee = f(dx * dx)                                          # rounds to 1 + 2^-11
+    known = torch.tensor([[[0.0, 0, 0]]])
+    unknown = torch.tensor([[[float(dx), 0, 0]]])
+    try:
+        P.set_contract('ieee')
+        assert P.get_contract() == 'ieee'
+        d_ieee, _ = P.three_nn(unknown, known)
+        P.set_contract('fma')
+        d_fma, _ = P.three_nn(unknown, known)
+        # with dy = dz = 0 both give round(dx*dx): the contracts agree when only one term is non-zero
+        assert float(d_ieee[0, 0, 0]) == float(ieee) == float(d_fma[0, 0, 0])
+        # two non-zero terms: fma keeps dx*dx exact inside the fused add, ieee rounds it first
+        a = f(1.0) + f(2.0 ** -12)
+        b = f(2.0 ** -12)                                      # dy*dy = 2^-24 exactly
+        unknown = torch.tensor([[[float(a), float(b), 0]]])
+        P.set_contract('ieee')
+        d_ieee, _ = P.three_nn(unknown, known)
+        P.set_contract('fma')
+        d_fma, _ = P.three_nn(unknown, known)
+        exact = float(np.float64(a) * np.float64(a) + np.float64(b) * np.float64(b))   # 1 + 2^-11 + 2^-23
+        want_ieee = f(f(a * a) + f(b * b))                     # (1 + 2^-11) + 2^-24 -> ties-to-even -> 1 + 2^-11
+        want_fma = f(exact)                                    # one rounding of the exact sum -> 1 + 2^-11 + 2^-23
+        assert float(d_ieee[0, 0, 0]) == float(want_ieee)
+        assert float(d_fma[0, 0, 0]) == float(want_fma)
+        assert float(want_fma) != float(want_ieee)
+        # three_interpolate: w0*p0 + w1*p1 + w2*p2, same contraction shape
+        feats = torch.tensor([[[float(a), float(b), 0.0]]])
+        w = torch.tensor([[[float(a), float(b), 0.0]]])
+        ii = torch.tensor([[[0, 1, 2]]], dtype=torch.int32)
+        P.set_contract('ieee')
+        o_ieee = float(P.three_interpolate(feats, ii, w)[0, 0, 0])
+        P.set_contract('fma')
+        o_fma = float(P.three_interpolate(feats, ii, w)[0, 0, 0])
+        assert o_ieee == float(want_ieee) and o_fma == float(want_fma)
+    finally:
+        P.set_contract('fma')

@@ -36,9 +36,10 @@ def _run(plain, steps=2):
         losses = [float(tr.train_step(next(it), model, contrast, opt, True)['loss'])]
         torch.cuda.synchronize()
         params = {n: p.detach() - before[n] for n, p in tr.unwrap(model).named_parameters()}    # first update
+        banks = [[b.clone() for b in contrast.banks()]]
         losses += [float(tr.train_step(next(it), model, contrast, opt, True)['loss']) for _ in range(steps - 1)]
         torch.cuda.synchronize()
-        banks = [b.clone() for b in contrast.banks()]
+        banks.append([b.clone() for b in contrast.banks()])
     finally:
         hrnet.ENCODER_PROGRAM = True
         _lib.torch_glue().set_async_wgrad(False)
@@ -59,8 +60,16 @@ def test_default_runtime_matches_plain_autograd():
     # is not available through ~150 batch-norm layers (see tests/test_glue_gpu.py::_grads_agree)
     from test_glue_gpu import _grads_agree
     _grads_agree(p_fast, p_ref, min_cos=0.99)
-    for a, b in zip(b_fast, b_ref):
+    # banks after step 1: written from features of IDENTICAL weights -> tight; after step 2 the features sit
+    # behind one SGD step at random-init scale (chaotic, like the second loss): rows must still point the same way
+    for a, b in zip(b_fast[0], b_ref[0]):
         assert (a.float() - b.float()).abs().max().item() <= 1e-3
+    for a, b, b1 in zip(b_fast[1], b_ref[1], b_ref[0]):
+        rows = (b != b1).any(1)
+        assert bool(rows.any())
+        assert torch.equal(a[~rows], b[~rows])
+        cos = torch.nn.functional.cosine_similarity(a[rows].float(), b[rows].float(), dim=1)
+        assert float(cos.min()) >= 0.9, float(cos.min())
 
 
 class CheckingEngine(object):
