@@ -69,8 +69,9 @@ SIGNATURES = {
     'hcm_three_nn_contract': (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_three_interpolate_contract': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 5),
-    'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 6),
+    'hcm_sgc_workspace_floats': (C.c_size_t, [_i] * 4),
+    'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 6),
+    'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 7),
     'hcm_bn_act_stats_floats': (C.c_size_t, [_i, _i, _i]),
     'hcm_bn_act_forward': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3),
     'hcm_bn_act_backward': (_i, [_p] * 6 + [_i] * 4 + [_p] * 4),

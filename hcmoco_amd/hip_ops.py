@@ -492,6 +492,20 @@ def upsample_bilinear(x, size):
 # --------------------------------------------------------------------------- #
 # SemGCN layer: library GEMM + one fused kernel per direction
 # --------------------------------------------------------------------------- #
+_SGC_WS = {}
+
+
+def _sgc_ws(B, J, Cc, E):
+    key = (B, J, Cc, E)
+    n = _SGC_WS.get(key)
+    if n is None:
+        n = int(_lib.lib().hcm_sgc_workspace_floats(B, J, Cc, E))
+        if n == 0:
+            raise ValueError('sgc_layer: unsupported shape B=%d J=%d C=%d E=%d (J <= 32, C in {64, 128}, E <= 256)' % key)
+        _SGC_WS[key] = n
+    return n
+
+
 class _SgcLayer(torch.autograd.Function):
     """SemGraphConv [+ BatchNorm1d + ReLU] (networks/SGCN/sem_graph_conv.py:34-48, sem_gcn.py:8-28).
     forward: H = X [W0|W1] (rocBLAS) -> hcm_sgc_forward ; backward: hcm_sgc_backward -> two GEMMs."""
@@ -513,10 +527,12 @@ class _SgcLayer(torch.autograd.Function):
         nul = C.c_void_p(0)
         p = lambda t: nul if t is None else C.c_void_p(t.data_ptr())
         ec = e.reshape(-1).contiguous()
+        ws = torch.empty(_sgc_ws(B, J, cout, E), dtype=torch.float32, device=dev)
         check(_lib.lib().hcm_sgc_forward(
             p(H), _dev(ec, torch.float32, 'sgc'), p(graph[0]), p(graph[1]), p(graph[2]), p(graph[3]), p(graph[4]),
             p(bias), p(gamma), p(beta), p(running_mean), p(running_var), B, J, cout, E, int(has_bn), int(relu),
-            int(training), float(momentum), float(eps), p(out), p(xhat), p(invstd), p(A), _stream()), 'hcm_sgc_forward')
+            int(training), float(momentum), float(eps), p(out), p(xhat), p(invstd), p(A), p(ws), _stream()),
+            'hcm_sgc_forward')
         ctx.save_for_backward(x2, wcat, H, out, xhat, invstd, A, gamma if gamma is not None else invstd)
         ctx.graph, ctx.dims = graph, (B, J, cin, cout, E, int(has_bn), int(relu), int(training), bias is not None)
         return out.view(B, J, cout)
@@ -532,10 +548,11 @@ class _SgcLayer(torch.autograd.Function):
         small = torch.empty(3 * cout + E, dtype=torch.float32, device=dev)
         dgamma, dbeta, dbias, de = small[:cout], small[cout:2 * cout], small[2 * cout:3 * cout], small[3 * cout:]
         p = lambda t: C.c_void_p(t.data_ptr())
+        ws = torch.empty(_sgc_ws(B, J, cout, E), dtype=torch.float32, device=dev)
         check(_lib.lib().hcm_sgc_backward(
             p(g), p(out), p(xhat), p(invstd), p(gamma), p(A), p(graph[0]), p(graph[1]), p(graph[2]), p(graph[3]),
             p(graph[4]), p(H), B, J, cout, E, has_bn, relu, training, p(dH), p(dgamma), p(dbeta), p(dbias), p(de),
-            _stream()), 'hcm_sgc_backward')
+            p(ws), _stream()), 'hcm_sgc_backward')
         dx = torch.mm(dH, wcat.t()).view(B, J, cin)
         dW = torch.mm(x2.t(), dH).view(cin, 2, cout).permute(1, 0, 2)
         return (dx, dW, de.view(1, E), dbias if has_bias else None, dgamma if has_bn else None,

@@ -200,20 +200,24 @@ int hcm_sampling_matrix(const int64_t* pix, int nrows, int hi, int wi, int h0, i
  *           statistics when training, running statistics updated in place with `momentum`);
  *           saves xhat [B*J, C], invstd [C], A_out [E] for the backward.
  * backward: dH [B*J, 2C] (for dX = dH Wcat^T and dWcat = X^T dH), dgamma/dbeta/dbias [C], de [E].
- * J <= 32, C in {64, 128}, E <= 256.  One 1024-thread workgroup per call: the layer is launch- and
- * latency-bound, not throughput-bound (B*J*C ~ 70k outputs).
+ * J <= 32, C in {64, 128}, E <= 256.  One workgroup per batch element; the BatchNorm1d statistics split a
+ * direction into two (forward) / three (backward) launches whose per-sample partial sums live in
+ * `workspace` (caller-owned, hcm_sgc_workspace_floats(B, J, C, E) floats, contents undefined on entry;
+ * the backward call may use a different buffer than the forward call).  Deterministic: partials are
+ * merged in sample order, no atomics.
  * ------------------------------------------------------------------------ */
+size_t hcm_sgc_workspace_floats(int B, int J, int C, int E);
 int hcm_sgc_forward(const float* H, const float* e, const int* row_ptr, const int* col_idx,
                     const int* csc_ptr, const int* csc_edge, const int* edge_row, const float* bias,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                     int B, int J, int C, int E, int has_bn, int relu, int training, float momentum,
-                    float eps, float* out, float* xhat, float* invstd, float* A_out,
+                    float eps, float* out, float* xhat, float* invstd, float* A_out, float* workspace,
                     hcm_stream_t stream);
 int hcm_sgc_backward(const float* dOut, const float* out, const float* xhat, const float* invstd,
                      const float* gamma, const float* A, const int* row_ptr, const int* col_idx,
                      const int* csc_ptr, const int* csc_edge, const int* edge_row, const float* H, int B,
                      int J, int C, int E, int has_bn, int relu, int training, float* dH, float* dgamma,
-                     float* dbeta, float* dbias, float* de, hcm_stream_t stream);
+                     float* dbeta, float* dbias, float* de, float* workspace, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Encoder normalisation: training-mode BatchNorm2d [+ residual add] [+ ReLU] on fp32 NCHW maps

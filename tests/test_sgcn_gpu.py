@@ -71,5 +71,57 @@ def test_fused_path_is_taken_and_launch_count_drops():
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
     n = sum(e.count for e in prof.key_averages())
-    assert any('sgc_fwd_kernel' in k for k in names) and any('sgc_bwd_kernel' in k for k in names)
+    assert any('sgc_mix_kernel' in k for k in names) and any('sgc_bwd_kernel' in k for k in names)
     assert n < 500, n          # ~1500 launches in eager mode
+
+
+def test_layer_is_deterministic_and_spread_over_the_batch():
+    """One workgroup per batch element, partial sums merged in sample order: bit-identical run to run
+    (forward, every gradient, running statistics), at the bench shape B=32, J=17, C=128."""
+    d = dev()
+    torch.manual_seed(4)
+    net = sgcn.create_sgcn('coco17', 128, 4).to(d).train()
+    x = torch.rand(32, 17, 2, device=d) * 2 - 1
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        y = net(xr)
+        (y * torch.linspace(-1, 1, y.numel(), device=d).view_as(y)).sum().backward()
+        torch.cuda.synchronize()
+        runs.append([y.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+                    + [b.clone() for b in net.buffers()])
+    for other in runs[1:]:
+        for a, b in zip(other, runs[0]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,skel,C', [(1, 'mpii', 128), (3, 'coco_reduce', 64), (70, 'coco17', 128)])
+def test_single_layer_shapes(B, skel, C, monkeypatch):
+    """Odd batch sizes (1 sample, more samples than joint slices) and the 64-channel variant."""
+    d = dev()
+    torch.manual_seed(B)
+    adj = sgcn.adjacency(skel)
+    J = adj.shape[0]
+    ref = sgcn._GraphConv(adj, 128, C).to(d).train()
+    with torch.no_grad():
+        ref.bn.weight.uniform_(0.5, 1.5); ref.bn.bias.normal_(0, 0.1); ref.gconv.e.uniform_(0.2, 1.8)
+    fused = copy.deepcopy(ref)
+    x = torch.randn(B, J, 128, device=d)
+    xr, xf = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    monkeypatch.setattr(sgcn, '_fusable', lambda t, c: False)
+    yr = ref(xr)
+    monkeypatch.undo()
+    yf = fused(xf)
+    if B * J > 1:
+        assert torch.allclose(yf, yr, rtol=2e-4, atol=2e-4), float((yf - yr).abs().max())
+    g = torch.randn_like(yr)
+    yr.backward(g); yf.backward(g)
+    scale = max(float(p.grad.norm()) for p in ref.parameters())
+    assert float((xf.grad - xr.grad).norm()) < 2e-3 * float(xr.grad.norm()) + 1e-5 * scale
+    for (n, pr), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
+        err = float((pf.grad - pr.grad).norm())
+        assert err < 2e-3 * float(pr.grad.norm()) + 1e-5 * scale, (n, err, float(pr.grad.norm()))
+    assert torch.allclose(fused.bn.running_var, ref.bn.running_var, rtol=1e-4, atol=1e-5)

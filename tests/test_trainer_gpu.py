@@ -67,7 +67,7 @@ def test_default_runtime_matches_plain_autograd():
     for a, b, b1 in zip(b_fast[1], b_ref[1], b_ref[0]):
         rows = (b != b1).any(1)
         assert bool(rows.any())
-        assert torch.equal(a[~rows], b[~rows])
+        assert (a[~rows].float() - b[~rows].float()).abs().max().item() <= 1e-3
         cos = torch.nn.functional.cosine_similarity(a[rows].float(), b[rows].float(), dim=1)
         assert float(cos.min()) >= 0.9, float(cos.min())
 
