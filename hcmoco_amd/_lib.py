@@ -86,6 +86,7 @@ SIGNATURES = {
     'hcm_rowmax_backward': (_i, [_p, _p, C.c_longlong, _i, _p, _p]),
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
+    'hcm_prof_read_tag': (_i, [_i, _p, _p]),
 }
 
 for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits_fwd', 'hcm_bank_logits_bwd',

@@ -19,6 +19,9 @@
 #include <utility>
 #include <vector>
 
+#include <mutex>
+#include <vector>
+
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
 
@@ -641,35 +644,42 @@ inline FusedWs carve(void* ws, int B, int K1, int D) {
   return o;
 }
 
-// ---- optional in-library timing of the dominant kernel (bench.py roofline) -------------------
-// The only process-global state of the library; off by default.
+// ---- optional in-library timing of selected kernels (bench.py roofline objects) ----------------
+// The only process-global state of the library; off by default; mutex-protected.
+constexpr int kProfTags = 8;
 struct ProfState {
+  std::mutex mu;
   bool on = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[kProfTags];
 };
 ProfState& prof() {
   static ProfState p;
   return p;
 }
-struct ProfSpan {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  hipStream_t st;
-  explicit ProfSpan(hipStream_t s) : st(s) {
-    if (prof().on && prof().spans.size() < 65536 && hipEventCreate(&e0) == hipSuccess &&
-        hipEventCreate(&e1) == hipSuccess)
-      hipEventRecord(e0, st);
-    else
-      e0 = nullptr;
-  }
-  void stop() {
-    if (e0 != nullptr) {
-      hipEventRecord(e1, st);
-      prof().spans.emplace_back(e0, e1);
-    }
-  }
-};
 
 }  // namespace
+
+namespace hcm {
+ProfSpan::ProfSpan(int tag_, hipStream_t s) : st(s), tag(tag_) {
+  bool on;
+  {
+    std::lock_guard<std::mutex> lk(prof().mu);
+    on = prof().on && tag >= 0 && tag < kProfTags && prof().spans[tag].size() < 65536;
+  }
+  if (on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+    hipEventRecord(e0, st);
+  else
+    e0 = nullptr;
+}
+void ProfSpan::stop() {
+  if (e0 != nullptr) {
+    hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(prof().mu);
+    prof().spans[tag].emplace_back(e0, e1);
+    e0 = nullptr;
+  }
+}
+}  // namespace hcm
 
 // ---- host launch logic, shared by the fp32 and bf16 entry points -----------------------------
 namespace {
@@ -691,7 +701,7 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
   const float invT = (float)(1.0 / (double)T_);
   const float scale2 = (float)((double)HCM_LOG2E / (double)T_);
   dim3 grid(nch, B);
-  ProfSpan span(st);  // brackets the dominant kernel only
+  hcm::ProfSpan span(HCM_PROF_BANK_PASS, st);  // brackets the dominant kernel only
   if (D == 128) {
     static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
 #define HCM_LAUNCH_PASS(NPF, MINW)                                                                   \
@@ -847,19 +857,28 @@ int fused_timed_impl(const T* bank1, const T* bank2, const T* bank3, const int64
 extern "C" {
 
 int hcm_prof_enable(int enable) {
-  for (auto& sp : prof().spans) {
-    hipEventDestroy(sp.first);
-    hipEventDestroy(sp.second);
+  std::lock_guard<std::mutex> lk(prof().mu);
+  for (auto& v : prof().spans) {
+    for (auto& sp : v) {
+      hipEventDestroy(sp.first);
+      hipEventDestroy(sp.second);
+    }
+    v.clear();
   }
-  prof().spans.clear();
   prof().on = enable != 0;
   return 0;
 }
 
-int hcm_prof_read(double* total_ms_host, int64_t* launches_host) {
+int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host) {
+  if (tag < 0 || tag >= kProfTags) return (int)hipErrorInvalidValue;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+  {
+    std::lock_guard<std::mutex> lk(prof().mu);
+    spans = prof().spans[tag];
+  }
   double total = 0.0;
   int64_t n = 0;
-  for (auto& sp : prof().spans) {
+  for (auto& sp : spans) {
     hipError_t e = hipEventSynchronize(sp.second);
     if (e != hipSuccess) return (int)e;
     float ms = 0.f;
@@ -871,6 +890,10 @@ int hcm_prof_read(double* total_ms_host, int64_t* launches_host) {
   if (total_ms_host) *total_ms_host = total;
   if (launches_host) *launches_host = n;
   return 0;
+}
+
+int hcm_prof_read(double* total_ms_host, int64_t* launches_host) {
+  return hcm_prof_read_tag(HCM_PROF_BANK_PASS, total_ms_host, launches_host);
 }
 
 int hcm_abi_version(void) { return HCM_ABI_VERSION; }

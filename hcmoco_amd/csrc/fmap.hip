@@ -116,6 +116,13 @@ struct StripArgs {
   float* rowloss;       // [norient][rows]
   float* rowcorrect;    // [norient][rows]
   float* dX;            // [2][nbatch*S][128]  gradient wrt the gathered (un-normalised) rows
+  // Key-axis split (symmetric problems only; blockIdx.y = key chunk).  The SCL problem is ONE 1088 x 1088
+  // similarity: 17 row blocks cannot fill 256 CUs, so the key tiles are dealt to nkc chunks and every
+  // (row block, chunk) workgroup leaves a partial -- online-softmax state per row (stats pass) or an
+  // un-normalised d/dq-hat row (grad pass) -- that strip_merge_* combine in chunk order (deterministic).
+  int nkc;              // 1: no split, results are final
+  float* pstat;         // [nkc][N][8] = running max, sum, target dot, target mass, best logit, its column
+  float* pdq;           // [nkc][N][128]
 };
 
 constexpr int kKS = 144;  // LDS row stride of the key tile (16 mod 32 -> conflict-free b32 reads)
@@ -130,7 +137,8 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int np = lane & 15, g = lane >> 4;
   const int o = blockIdx.z;  // orientation (dense): 0 -> Q = depth rows, K = rgb rows; 1 -> swapped
-  const int b = blockIdx.y;
+  const int b = a.symmetric ? 0 : blockIdx.y;
+  const int kc = a.symmetric ? blockIdx.y : 0;   // key chunk (StripArgs::nkc)
   const int rows_total = a.nbatch * a.S;           // rows per modality
   const int S = a.symmetric ? 2 * rows_total : a.S;  // problem size
   if (!a.symmetric && a.keep != nullptr && a.keep[b] == 0) return;
@@ -181,7 +189,9 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   for (int nt = 0; nt < 8; ++nt) dq[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (S + 15) / 16;
-  for (int tile = 0; tile < ntiles; ++tile) {
+  const int tiles_per = (ntiles + a.nkc - 1) / a.nkc;
+  const int tile_lo = kc * tiles_per, tile_hi = min(ntiles, tile_lo + tiles_per);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int c0 = tile * 16;
     __syncthreads();  // previous tile fully consumed
     {
@@ -277,6 +287,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
       const float cand = (best[q] == bAll) ? (float)bestc[q] : 3.0e38f;
       const float cmin = -row16_max(-cand);
       const int r = row0 + 4 * g + q;
+      if (a.nkc > 1) {
+        if (np == 0 && r < S) {
+          float* ps = a.pstat + ((int64_t)kc * S + r) * 8;
+          ps[0] = M; ps[1] = sAll; ps[2] = tdAll; ps[3] = zAll; ps[4] = bAll; ps[5] = cmin;
+        }
+        continue;
+      }
       if (np == 0 && r < S) {
         const float lse = M + __logf(sAll);
         float loss, alpha, beta;
@@ -291,6 +308,18 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   } else {
     // dq[nt][q] = d loss / d qhat[row0+4g+q][16nt+np]; push it through F.normalize
     const int64_t qrow_base = (int64_t)qmod * rows_total + base;
+    if (a.nkc > 1) {       // partial over this chunk's keys: strip_merge_grad_kernel sums and normalises
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = row0 + 4 * g + q;
+        if (r < S) {
+          float* dst = a.pdq + ((int64_t)kc * S + r) * kC;
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) dst[16 * nt + np] = dq[nt][q];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = row0 + 4 * g + q;
@@ -312,6 +341,50 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
       }
     }
   }
+}
+
+// Chunk merges of a key-split symmetric problem (N rows, chunks in ascending key order).
+template <class Policy>
+__global__ __launch_bounds__(kWG) void strip_merge_stats_kernel(StripArgs a, Policy pol, int N) {
+  const int r = blockIdx.x * kWG + threadIdx.x;
+  if (r >= N) return;
+  float M = -1.0e30f, sum = 0.f, td = 0.f, z = 0.f, best = -3.0e38f, col = 3.0e38f;
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    const float* ps = a.pstat + ((int64_t)kc * N + r) * 8;
+    const float Mn = fmaxf(M, ps[0]);
+    sum = sum * __expf(M - Mn) + ps[1] * __expf(ps[0] - Mn);
+    M = Mn;
+    td += ps[2];
+    z += ps[3];
+    if (ps[4] > best) { best = ps[4]; col = ps[5]; }   // strict: the first chunk keeps a tie (lowest column)
+  }
+  const float lse = M + __logf(sum);
+  float loss, alpha, beta;
+  pol.finish(lse, td, z, loss, alpha, beta);
+  a.stat[(int64_t)r * 4 + 0] = lse;
+  a.stat[(int64_t)r * 4 + 1] = alpha;
+  a.stat[(int64_t)r * 4 + 2] = beta;
+  a.rowloss[r] = loss;
+  a.rowcorrect[r] = ((int)col == r) ? 1.f : 0.f;
+}
+
+// one wave per row: sum the chunk partials in order, then F.normalize's backward (as in strip_kernel)
+__global__ __launch_bounds__(kWG) void strip_merge_grad_kernel(StripArgs a, int N) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= N) return;
+  float d0 = 0.f, d1 = 0.f;
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    const float* src = a.pdq + ((int64_t)kc * N + r) * kC;
+    d0 += src[lane];
+    d1 += src[lane + 64];
+  }
+  const float f0 = a.F[(int64_t)r * kC + lane], f1 = a.F[(int64_t)r * kC + lane + 64];
+  const float dot = wave_sum(fmaf(d0, f0, d1 * f1));
+  const float inv = a.invn[r];
+  float* dst = a.dX + (int64_t)r * kC;
+  dst[lane] = (inv < 0.f) ? d0 * (-inv) : (d0 - dot * f0) * inv;
+  dst[lane + 64] = (inv < 0.f) ? d1 * (-inv) : (d1 - dot * f1) * inv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -801,14 +874,28 @@ DenseWs carve_dense(void* ws, int B, int S) {
   return o;
 }
 struct SclWs {
-  float *F, *invn, *stat, *rowloss, *rowcorrect, *dX, *gscale;
+  float *F, *invn, *stat, *rowloss, *rowcorrect, *dX, *gscale, *pstat, *pdq;
   int* meta;
+  int nkc;
   size_t bytes;
 };
+// key chunks of the SCL problem: enough (row block, chunk) workgroups for ~3/4 of the 256 CUs, at most 16
+inline int scl_key_chunks(int N) {
+  const int row_blocks = (N + 63) / 64, ntiles = (N + 15) / 16;
+  int nkc = (192 + row_blocks - 1) / row_blocks;
+  if (nkc > 16) nkc = 16;
+  if (nkc > ntiles) nkc = ntiles;
+  if (nkc < 1) nkc = 1;
+  const int tiles_per = (ntiles + nkc - 1) / nkc;
+  return (ntiles + tiles_per - 1) / tiles_per;      // drop chunks that would be empty
+}
 SclWs carve_scl(void* ws, int B, int J) {
   Carver c(ws);
   SclWs o;
   const size_t rows = (size_t)B * J;
+  o.nkc = scl_key_chunks((int)(2 * rows));
+  o.pstat = c.take<float>(o.nkc > 1 ? (size_t)o.nkc * 2 * rows * 8 : 4);
+  o.pdq = c.take<float>(o.nkc > 1 ? (size_t)o.nkc * 2 * rows * kC : 4);
   o.F = c.take<float>(2 * rows * kC);
   o.dX = c.take<float>(2 * rows * kC);
   o.invn = c.take<float>(2 * rows);
@@ -875,12 +962,21 @@ int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4
   a.F = ws.F; a.invn = ws.invn; a.meta = ws.meta; a.keep = keep; a.S = S; a.nbatch = B;
   a.symmetric = 0; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
+  a.nkc = 1; a.pstat = nullptr; a.pdq = nullptr;
   const dim3 grid((S + 63) / 64, B, 2);
   DensePolicy pol{coord_w};
-  strip_kernel<DensePolicy, false><<<grid, kWG, 0, s>>>(a, pol);
-  HCM_CHECK_LAUNCH();
-  strip_kernel<DensePolicy, true><<<grid, kWG, 0, s>>>(a, pol);
-  HCM_CHECK_LAUNCH();
+  {
+    ProfSpan span(HCM_PROF_DENSE_STATS, s);
+    strip_kernel<DensePolicy, false><<<grid, kWG, 0, s>>>(a, pol);
+    HCM_CHECK_LAUNCH();
+    span.stop();
+  }
+  {
+    ProfSpan span(HCM_PROF_DENSE_GRAD, s);
+    strip_kernel<DensePolicy, true><<<grid, kWG, 0, s>>>(a, pol);
+    HCM_CHECK_LAUNCH();
+    span.stop();
+  }
   dense_finish_kernel<<<1, 1024, 0, s>>>(ws.rowloss, ws.rowcorrect, keep, B, S, ws.gscale, out4);
   HCM_CHECK_LAUNCH();
   scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, sample_ind, S, rows, keep, mv,
@@ -915,12 +1011,29 @@ int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
   a.F = ws.F; a.invn = ws.invn; a.meta = ws.meta; a.keep = nullptr; a.S = J; a.nbatch = B;
   a.symmetric = 1; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
-  const dim3 grid((N + 63) / 64, 1, 1);
+  a.nkc = ws.nkc; a.pstat = ws.pstat; a.pdq = ws.pdq;
+  const dim3 grid((N + 63) / 64, ws.nkc, 1);
   SclPolicy pol;
-  strip_kernel<SclPolicy, false><<<grid, kWG, 0, s>>>(a, pol);
-  HCM_CHECK_LAUNCH();
-  strip_kernel<SclPolicy, true><<<grid, kWG, 0, s>>>(a, pol);
-  HCM_CHECK_LAUNCH();
+  {
+    ProfSpan span(HCM_PROF_SCL_STATS, s);
+    strip_kernel<SclPolicy, false><<<grid, kWG, 0, s>>>(a, pol);
+    HCM_CHECK_LAUNCH();
+    if (ws.nkc > 1) {
+      strip_merge_stats_kernel<SclPolicy><<<(N + kWG - 1) / kWG, kWG, 0, s>>>(a, pol, N);
+      HCM_CHECK_LAUNCH();
+    }
+    span.stop();
+  }
+  {
+    ProfSpan span(HCM_PROF_SCL_GRAD, s);
+    strip_kernel<SclPolicy, true><<<grid, kWG, 0, s>>>(a, pol);
+    HCM_CHECK_LAUNCH();
+    if (ws.nkc > 1) {
+      strip_merge_grad_kernel<<<(N + 3) / 4, kWG, 0, s>>>(a, N);
+      HCM_CHECK_LAUNCH();
+    }
+    span.stop();
+  }
   scl_finish_kernel<<<1, kWG, 0, s>>>(ws.rowloss, N, ws.gscale, out1);
   HCM_CHECK_LAUNCH();
   scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, pix, J, rows, nullptr, mv,

@@ -15,6 +15,17 @@
 
 namespace hcm {
 
+// Opt-in hipEvent timing of individual kernels (bench.py's roofline objects): tags are the HCM_PROF_* values of
+// include/hcmoco_hip.h.  Defined in bank.hip; the library's only process-global state, mutex-protected
+// (kernels are launched from the trainer thread, autograd's device thread and the encoder runtime's helpers).
+struct ProfSpan {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st;
+  int tag;
+  ProfSpan(int tag, hipStream_t s);
+  void stop();
+};
+
 // One DPP-modified move: lane <- lane' of the same 16-lane row.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {

@@ -329,6 +329,7 @@ int hcm_sgc_forward(const float* H, const float* e, const int* row_ptr, const in
   Graph g{row_ptr, col_idx, csc_ptr, csc_edge, edge_row};
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)J * 2 * C * sizeof(float);
+  ProfSpan span(HCM_PROF_SGC_FWD, st);
   sgc_mix_kernel<<<B, kThreads, lds, st>>>(H, e, g, bias, gamma, beta, running_mean, running_var, J, C, E, has_bn,
                                            relu, training, eps, out, xhat, invstd, A_out, workspace);
   HCM_CHECK_LAUNCH();
@@ -337,6 +338,7 @@ int hcm_sgc_forward(const float* H, const float* e, const int* row_ptr, const in
                                             momentum, eps, out, xhat, invstd);
     HCM_CHECK_LAUNCH();
   }
+  span.stop();
   return 0;
 }
 
@@ -353,6 +355,7 @@ int hcm_sgc_backward(const float* dOut, const float* out, const float* xhat, con
   float* part = workspace;
   float* pdb = part + (size_t)B * 2 * C;
   float* pda = pdb + (size_t)B * C;
+  ProfSpan span(HCM_PROF_SGC_BWD, st);
   if (has_bn) {
     sgc_bwd_stats_kernel<<<B, kThreads, 0, st>>>(dOut, out, xhat, J, C, relu, part);
     HCM_CHECK_LAUNCH();
@@ -363,6 +366,7 @@ int hcm_sgc_backward(const float* dOut, const float* out, const float* xhat, con
   HCM_CHECK_LAUNCH();
   sgc_bwd_finish_kernel<<<1, kThreads, 0, st>>>(part, pdb, pda, A, g, B, J, C, E, has_bn, dgamma, dbeta, dbias, de);
   HCM_CHECK_LAUNCH();
+  span.stop();
   return 0;
 }
 

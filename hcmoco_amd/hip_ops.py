@@ -168,10 +168,14 @@ def prof_enable(on):
     check(_lib.lib().hcm_prof_enable(1 if on else 0), 'hcm_prof_enable')
 
 
-def prof_read():
-    """(total ms, launches) of the gather-pass kernel since prof_enable(True); synchronises."""
+PROF_TAGS = {'bank_pass': 0, 'dense_stats': 1, 'dense_grad': 2, 'scl_stats': 3, 'scl_grad': 4, 'sgc_fwd': 5,
+             'sgc_bwd': 6}
+
+
+def prof_read(tag='bank_pass'):
+    """(total ms, launches) of the tagged kernel(s) since prof_enable(True); synchronises."""
     total, n = C.c_double(0.0), C.c_int64(0)
-    check(_lib.lib().hcm_prof_read(C.byref(total), C.byref(n)), 'hcm_prof_read')
+    check(_lib.lib().hcm_prof_read_tag(PROF_TAGS[tag], C.byref(total), C.byref(n)), 'hcm_prof_read_tag')
     return float(total.value), int(n.value)
 
 

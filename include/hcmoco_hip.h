@@ -361,12 +361,21 @@ int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2, 
                                   void* workspace, size_t workspace_bytes, hcm_stream_t stream,
                                   int reps, float* ms_per_pass_host);
 
-/* In-library timing of the dominant kernel (the gather pass of hcm_bank_nce_fused): while enabled,
- * every launch is bracketed by hipEvents on its own stream.  hcm_prof_read synchronises those
- * events and returns their summed duration and count (host pointers).  hcm_prof_enable(x) also
- * clears what was recorded.  This is the library's only process-global state; not thread safe. */
+/* In-library timing of selected kernels (bench.py's `roofline` objects): while enabled, every launch of
+ * a tagged kernel is bracketed by hipEvents on its own stream.  hcm_prof_read_tag synchronises those
+ * events and returns their summed duration and count (host pointers); hcm_prof_read = tag
+ * HCM_PROF_BANK_PASS.  hcm_prof_enable(x) also clears what was recorded.  BENCH-ONLY: this is the
+ * library's only process-global state (mutex-protected); leave it off in production. */
+#define HCM_PROF_BANK_PASS 0    /* bank_pass_kernel of hcm_bank_nce_fused                    */
+#define HCM_PROF_DENSE_STATS 1  /* strip_kernel<Dense, stats> of hcm_dense_soft_nce           */
+#define HCM_PROF_DENSE_GRAD 2   /* strip_kernel<Dense, grad>                                  */
+#define HCM_PROF_SCL_STATS 3    /* strip_kernel<Scl, stats> (+ its chunk merge) of hcm_scl    */
+#define HCM_PROF_SCL_GRAD 4     /* strip_kernel<Scl, grad> (+ its chunk merge)                */
+#define HCM_PROF_SGC_FWD 5      /* the kernels of hcm_sgc_forward                             */
+#define HCM_PROF_SGC_BWD 6      /* the kernels of hcm_sgc_backward                            */
 int hcm_prof_enable(int enable);
 int hcm_prof_read(double* total_ms_host, int64_t* launches_host);
+int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host);
 
 #ifdef __cplusplus
 }
