@@ -54,6 +54,7 @@ SIGNATURES = {
     'hcm_scl': (_i, [_p, _p, Strides4, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _p, _p, _sz, _p]),
     'hcm_joint_pixels': (_i, [_p, _i, _i, _p, _p]),
     'hcm_upsample_bilinear2d': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    'hcm_upsample_bilinear2d_backward': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     'hcm_upsample_bilinear2d_nhwc': (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     'hcm_furthest_point_sampling': (_i, [_i, _i, _i, _p, _p, _p, _p]),
     'hcm_ball_query': (_i, [_i, _i, _i, _f, _i, _p, _p, _p, _p]),

@@ -723,6 +723,68 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_kernel(const float* __r
   }
 }
 
+// Backward of the same op in GATHER form: one thread per INPUT pixel sums, in a fixed order (output rows
+// ascending, columns ascending), the contributions of every output pixel whose 2x2 stencil touches it.
+// ATen's backward scatters with float atomics (upsample_bilinear2d_backward_out_frame: 62 launches x 30 us
+// per step and the last run-to-run non-deterministic kernel of the loss section); this one is
+// deterministic and reads grad_out ~(2 + 1/s)^2 / 4 times through L2.  The stencil of an output pixel is
+// re-derived with exactly the forward's float expressions, so forward and backward agree on every tap.
+constexpr int kBwdWin = 12;   // x-window whose weights are kept in registers (covers scale factors <= 4)
+__global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float* __restrict__ g,
+                                                                    float* __restrict__ dx, int planes,
+                                                                    int Hi, int Wi, int Ho, int Wo,
+                                                                    float sy, float sx) {
+  const int64_t total = (int64_t)planes * Hi * Wi;
+  const float isy = 1.f / sy, isx = 1.f / sx;
+  for (int64_t e = (int64_t)blockIdx.x * kWG + threadIdx.x; e < total; e += (int64_t)gridDim.x * kWG) {
+    const int xi = (int)(e % Wi);
+    const int yi = (int)((e / Wi) % Hi);
+    const int64_t pl = e / ((int64_t)Wi * Hi);
+    // outputs whose source row floor is yi-1 or yi (one row of slack for float rounding; rows outside
+    // get weight 0 from the exact test below)
+    const int ylo = max(0, (int)floorf(((float)yi - 0.5f) * isy - 0.5f) - 1);
+    const int yhi = min(Ho - 1, (int)ceilf(((float)yi + 1.5f) * isy - 0.5f) + 1);
+    const int xlo = max(0, (int)floorf(((float)xi - 0.5f) * isx - 0.5f) - 1);
+    const int xhi = min(Wo - 1, (int)ceilf(((float)xi + 1.5f) * isx - 0.5f) + 1);
+    auto wx_of = [&](int ox) -> float {
+      const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
+      const int x0 = min((int)fx, Wi - 1);
+      const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+      const float lx = fx - (float)x0;
+      return (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+    };
+    const int nwin = xhi - xlo + 1;
+    float wxv[kBwdWin];
+    if (nwin <= kBwdWin) {
+#pragma unroll
+      for (int k = 0; k < kBwdWin; ++k) wxv[k] = k < nwin ? wx_of(xlo + k) : 0.f;
+    }
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
+      const int y0 = (int)fy;
+      const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+      const float ly = fy - (float)y0;
+      const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const float* grow = g + (pl * Ho + oy) * Wo;
+      float racc = 0.f;
+      if (nwin <= kBwdWin) {
+#pragma unroll
+        for (int k = 0; k < kBwdWin; ++k)
+          if (k < nwin) racc = fmaf(wxv[k], grow[xlo + k], racc);
+      } else {
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = wx_of(ox);
+          if (wx != 0.f) racc = fmaf(wx, grow[ox], racc);
+        }
+      }
+      acc = fmaf(wy, racc, acc);
+    }
+    dx[e] = acc;
+  }
+}
+
 // channels-last variant: memory is [N][H][W][C]; one thread per (pixel, channel), channel fastest.
 __global__ __launch_bounds__(kWG) void upsample_bilinear_nhwc_kernel(const float* __restrict__ in,
                                                                      float* __restrict__ out, int N,
@@ -796,7 +858,42 @@ __global__ __launch_bounds__(kWG) void sample_rows_kernel(const float* __restric
   }
 }
 
-// backward: gx[b, c, tap] += weight * g[r, col0 + c]   (atomic, like ATen's own bilinear backward)
+// Backward when the branch IS the sampling grid (hi == h0, wi == w0: every row is a plain gather of pixel
+// pix[r] -- the finest HRNet branch, the only one the trainer routes here): owner-computes scatter-add like
+// scatter_rows_kernel.  A row owns its pixel when no EARLIER row of the same image has it; the owner adds
+// its own and all later duplicates' rows in index order and STORES the sum (gx arrives zero-filled):
+// deterministic, no atomics.
+__global__ __launch_bounds__(kWG) void scatter_sample_rows_same_grid_kernel(
+    const float* __restrict__ g, int ldo, int col0, hcm_strides4 st, int C, int w0,
+    const int64_t* __restrict__ pix, int R, int nrows, float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nrows) return;
+  const int b = r / R, s = r - b * R;
+  const int64_t p = pix[r];
+  const int64_t* pb = pix + (int64_t)b * R;
+  bool earlier = false;
+  for (int i = lane; i < s; i += 64) earlier |= (pb[i] == p);
+  if (__any(earlier)) return;
+  const float* src = g + (int64_t)b * R * ldo + col0;
+  const int64_t dst0 = b * st.sN + (p / w0) * st.sH + (p % w0) * st.sW;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    float a = c < C ? src[(int64_t)s * ldo + c] : 0.f;
+    for (int i0 = s + 1; i0 < R; i0 += 64) {
+      const int i = i0 + lane;
+      unsigned long long mm = __ballot(i < R && pb[i] == p);
+      while (mm) {
+        const int bit = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        if (c < C) a += src[(int64_t)(i0 + bit) * ldo + c];
+      }
+    }
+    if (c < C) gx[dst0 + c * st.sC] = a;
+  }
+}
+
+// general backward: gx[b, c, tap] += weight * g[r, col0 + c]   (atomic, like ATen's own bilinear backward)
 __global__ __launch_bounds__(kWG) void scatter_sample_rows_kernel(const float* __restrict__ g, int ldo,
                                                                   int col0, hcm_strides4 st, int C,
                                                                   int hi, int wi, int h0, int w0,
@@ -1086,6 +1183,18 @@ int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho,
   return 0;
 }
 
+int hcm_upsample_bilinear2d_backward(const float* grad_out, int planes, int Hi, int Wi, int Ho, int Wo,
+                                     float* grad_in, hcm_stream_t stream) {
+  if (planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || !grad_out || !grad_in) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)planes * Hi * Wi;
+  int64_t blocks = (total + kWG - 1) / kWG;
+  if (blocks > 32768) blocks = 32768;
+  upsample_bilinear_bwd_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
+      grad_out, grad_in, planes, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
 int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, int Ho, int Wo,
                                  float* out, hcm_stream_t stream) {
   if (N <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
@@ -1115,8 +1224,12 @@ int hcm_sample_rows_grad(const float* grad_rows, int ldo, int col0, hcm_strides4
   if (B <= 0 || C <= 0 || hi <= 0 || wi <= 0 || h0 <= 0 || w0 <= 0 || R <= 0 || ldo < col0 + C)
     return (int)hipErrorInvalidValue;
   const int nrows = B * R;
-  scatter_sample_rows_kernel<<<(nrows + 3) / 4, kWG, 0, (hipStream_t)stream>>>(
-      grad_rows, ldo, col0, st, C, hi, wi, h0, w0, pix, R, nrows, gx);
+  if (hi == h0 && wi == w0)      // plain gather: deterministic owner-computes scatter
+    scatter_sample_rows_same_grid_kernel<<<(nrows + 3) / 4, kWG, 0, (hipStream_t)stream>>>(
+        grad_rows, ldo, col0, st, C, w0, pix, R, nrows, gx);
+  else
+    scatter_sample_rows_kernel<<<(nrows + 3) / 4, kWG, 0, (hipStream_t)stream>>>(
+        grad_rows, ldo, col0, st, C, hi, wi, h0, w0, pix, R, nrows, gx);
   HCM_CHECK_LAUNCH();
   return 0;
 }

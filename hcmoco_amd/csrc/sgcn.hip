@@ -275,23 +275,32 @@ __global__ __launch_bounds__(kThreads) void sgc_bwd_finish_kernel(
     const float* __restrict__ A, Graph g, int B, int J, int C, int E, int has_bn, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ de) {
   __shared__ float sA[kMaxE], sDA[kMaxE];
+  __shared__ float sRed[kThreads];
   const int tid = threadIdx.x;
-  if (tid < C) {
-    float db = 0.f, a = 0.f, q = 0.f;
-    for (int b = 0; b < B; ++b) {
-      db += pdb[(int64_t)b * C + tid];
-      if (has_bn) {
-        a += part[((int64_t)b * 2) * C + tid];
-        q += part[((int64_t)b * 2 + 1) * C + tid];
-      }
-    }
-    if (dbias) dbias[tid] = db;
-    if (has_bn) { dbeta[tid] = a; dgamma[tid] = q; }
+  const int c = tid % C, r = tid / C, RS = kThreads / C;
+  // channel sums: threads (c, r) take samples r, r+RS, ...; the slices are then added in slice order
+  float db = 0.f;
+  for (int b = r; b < B; b += RS) db += pdb[(int64_t)b * C + c];
+  db = slice_sum(sRed, db, C, RS);
+  if (tid < C && dbias) dbias[tid] = db;
+  if (has_bn) {
+    float a, q;
+    merge_pairs(part, sRed, B, C, RS, a, q);
+    if (tid < C) { dbeta[tid] = a; dgamma[tid] = q; }
   }
+  // edge sums: threads (k, r2) with r2 < RE = kThreads / E sample slices
+  const int RE = kThreads / E;
+  const int k = tid % E, r2 = tid / E;
+  float v = 0.f;
+  if (r2 < RE)
+    for (int b = r2; b < B; b += RE) v += pda[(int64_t)b * E + k];
+  __syncthreads();
+  sRed[tid] = v;
+  __syncthreads();
   if (tid < E) {
-    float v = 0.f;
-    for (int b = 0; b < B; ++b) v += pda[(int64_t)b * E + tid];
-    sDA[tid] = v;
+    float t = 0.f;
+    for (int q = 0; q < RE; ++q) t += sRed[q * E + tid];
+    sDA[tid] = t;
     sA[tid] = A[tid];
   }
   __syncthreads();
@@ -299,8 +308,8 @@ __global__ __launch_bounds__(kThreads) void sgc_bwd_finish_kernel(
   if (tid < J) {
     const int lo = g.row_ptr[tid], hi = g.row_ptr[tid + 1];
     float dot = 0.f;
-    for (int k = lo; k < hi; ++k) dot = fmaf(sA[k], sDA[k], dot);
-    for (int k = lo; k < hi; ++k) de[k] = sA[k] * (sDA[k] - dot);
+    for (int q = lo; q < hi; ++q) dot = fmaf(sA[q], sDA[q], dot);
+    for (int q = lo; q < hi; ++q) de[q] = sA[q] * (sDA[q] - dot);
   }
 }
 

@@ -514,8 +514,17 @@ Tensor conv_bn_act(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad
   return ConvBnAct::apply(x, w, stride, pad, residual, gamma, beta, running_mean, running_var, momentum, eps, relu);
 }
 
+// g [N, C, Ho, Wo] contiguous -> gradient of the [N, C, Hi, Wi] input (gather form, deterministic)
+Tensor upsample_backward_raw(const Tensor& g, int64_t N, int64_t C, int64_t Hi, int64_t Wi) {
+  Tensor gi = at::empty({N, C, Hi, Wi}, g.options());
+  check_rc(hcm_upsample_bilinear2d_backward(g.data_ptr<float>(), (int)(N * C), (int)Hi, (int)Wi, (int)g.size(2),
+                                            (int)g.size(3), gi.data_ptr<float>(), current_stream(g)),
+           "hcm_upsample_bilinear2d_backward");
+  return gi;
+}
+
 // F.interpolate(mode='bilinear', align_corners=False) on NCHW maps: forward hcm_upsample_bilinear2d,
-// backward ATen's kernel (official_hrnet.py:231-236, build_backbone.py:247-254).
+// backward hcm_upsample_bilinear2d_backward (official_hrnet.py:231-236, build_backbone.py:247-254).
 struct Upsample : public torch::autograd::Function<Upsample> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x_in, int64_t Ho, int64_t Wo) {
     TORCH_CHECK(x_in.is_cuda() && x_in.scalar_type() == at::kFloat && x_in.dim() == 4,
@@ -533,7 +542,7 @@ struct Upsample : public torch::autograd::Function<Upsample> {
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto in = ctx->saved_data["in"].toIntVector();
     const auto out = ctx->saved_data["out"].toIntVector();
-    Tensor gi = at::upsample_bilinear2d_backward(grads[0].contiguous(), out, in, false, c10::nullopt, c10::nullopt);
+    Tensor gi = upsample_backward_raw(grads[0].contiguous(), in[0], in[1], in[2], in[3]);
     return {gi, Tensor(), Tensor()};
   }
 };
@@ -874,7 +883,7 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
       accumulate(S, G[a], at::threshold_backward(g, T.val[dst], 0), true);
     } else if (op == kOpUpsample) {
       const Tensor& x = T.val[a];
-      accumulate(S, G[a], at::upsample_bilinear2d_backward(g, {I[8], I[9]}, x.sizes(), false, c10::nullopt, c10::nullopt), true);
+      accumulate(S, G[a], upsample_backward_raw(g, x.size(0), x.size(1), x.size(2), x.size(3)), true);
     }
     S.issued();
     T.val[dst] = Tensor();

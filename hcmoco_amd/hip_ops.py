@@ -381,8 +381,9 @@ def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth,
 # --------------------------------------------------------------------------- #
 class _SampleRows(torch.autograd.Function):
     """x[b, :, pix[b, r]] sampled bilinearly on the finest grid -> [B, R, C] (hcm_sample_rows);
-    backward scatter-adds with atomics (hcm_sample_rows_grad).  Used for the finest branch, whose
-    sampling matrix would be too large to materialise."""
+    backward = hcm_sample_rows_grad (owner-computes scatter, deterministic, when the branch has the
+    sampling grid's resolution -- the finest branch, the only use in the trainer; atomics otherwise).
+    Used for the finest branch, whose sampling matrix would be too large to materialise."""
 
     @staticmethod
     def forward(ctx, x, pix, h0, w0):
@@ -459,7 +460,7 @@ def fmap_losses_rows(rows1, rows2, feat3, S, coord_ind, coord_w, keep, joints_vi
 # --------------------------------------------------------------------------- #
 class _UpsampleBilinear(torch.autograd.Function):
     """Forward: hcm_upsample_bilinear2d (coalesced, ~10x faster than ATen's NCHW forward on MI355X).
-    Backward: ATen's upsample_bilinear2d_backward (already fast: 29 us/launch in the r01 profile)."""
+    Backward: hcm_upsample_bilinear2d_backward (gather form: deterministic, no atomics)."""
 
     @staticmethod
     def forward(ctx, x, size):
@@ -484,7 +485,14 @@ class _UpsampleBilinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        gi = torch.ops.aten.upsample_bilinear2d_backward(g, list(ctx.size), list(ctx.in_shape), False, None, None)
+        # gather-form kernel (deterministic); a channels-last gradient is brought to NCHW first
+        N, Cc, Hi, Wi = ctx.in_shape
+        Ho, Wo = ctx.size
+        g = g.contiguous()
+        gi = torch.empty(N, Cc, Hi, Wi, dtype=torch.float32, device=g.device)
+        check(_lib.lib().hcm_upsample_bilinear2d_backward(_dev(g, torch.float32, 'upsample_bilinear'), N * Cc, Hi, Wi,
+                                                          Ho, Wo, C.c_void_p(gi.data_ptr()), _stream()),
+              'hcm_upsample_bilinear2d_backward')
         return gi, None
 
 

@@ -174,6 +174,11 @@ int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho,
 /* Same op on channels-last memory: in [N,Hi,Wi,C] -> out [N,Ho,Wo,C]. */
 int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, int Ho, int Wo,
                                  float* out, hcm_stream_t stream);
+/* Backward of hcm_upsample_bilinear2d in gather form: grad_in [planes, Hi, Wi] = sum over the output pixels
+ * whose stencil touches each input pixel, in a fixed order.  Deterministic, no atomics (ATen's
+ * upsample_bilinear2d_backward scatters with float atomicAdd); overwrites grad_in. */
+int hcm_upsample_bilinear2d_backward(const float* grad_out, int planes, int Hi, int Wi, int Ho, int Wo,
+                                     float* grad_in, hcm_stream_t stream);
 
 /* Row 8, sampled form: bilinear(x)[b, :, pix[b,r]] for one HRNet branch
  * x [B, C, hi, wi] (strides st), evaluated on the finest grid (h0 x w0, align_corners=False), written

@@ -254,3 +254,58 @@ def test_losses_on_sampled_rows_equal_losses_on_full_maps():
     assert torch.allclose(m1, m2, rtol=2e-5, atol=1e-6), (m1, m2)
     for a, b in zip(g2, g1):
         assert rel_l2(a, b) < 2e-4
+
+
+@pytest.mark.parametrize('shape,size', [((32, 18, 8, 8), (64, 64)), ((32, 18, 16, 16), (64, 64)), ((32, 36, 8, 8), (32, 32)),
+                                        ((4, 18, 32, 32), (64, 64)), ((2, 3, 7, 5), (21, 20)), ((2, 3, 6, 6), (6, 6)),
+                                        ((1, 2, 1, 1), (4, 4)), ((2, 2, 12, 10), (5, 3))])
+def test_upsample_backward_gather_form(shape, size):
+    """hcm_upsample_bilinear2d_backward (row 8's backward, HRNet fuse layers): equals the float64 backward of
+    F.interpolate to fp32 round-off -- up-sampling by 2/4/8, non-integer factors, identity and down-sampling --
+    and is bit-identical run to run (ATen's kernel scatters with float atomics)."""
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=d(), requires_grad=True)
+    g = torch.randn(shape[0], shape[1], *size, device=d())
+    y = ops().upsample_bilinear(x, size)
+    gx1, = torch.autograd.grad(y, x, g, retain_graph=True)
+    gx2, = torch.autograd.grad(y, x, g)
+    assert torch.equal(gx1, gx2)
+    x64 = x.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(x64, size=size, mode='bilinear', align_corners=False)
+    gr, = torch.autograd.grad(ref, x64, g.double())
+    scale = float(gr.abs().max()) + 1e-12
+    assert float((gx1.double() - gr).abs().max()) <= 2e-6 * scale, float((gx1.double() - gr).abs().max()) / scale
+    # sum-preserving: every output pixel's weights add up to 1
+    assert abs(float(gx1.double().sum()) - float(g.double().sum())) <= 1e-5 * float(g.abs().double().sum())
+
+
+def test_sampled_loss_section_is_bitwise_deterministic():
+    """Rows 5-8 as the trainer runs them (engine.fmap_sampled: finest branch through hcm_sample_rows with its
+    owner-computes backward, coarse branches through sampling matrices + library GEMMs, 1x1 projection, the
+    three loss kernels with key-split SCL): two passes from the same inputs give bit-identical losses and
+    gradients for all eight branch maps, both projections and the graph features."""
+    from hcmoco_amd.pycontrast.learning.engine import HipLossEngine
+    torch.manual_seed(12)
+    dev = d()
+    B, h, S, J = 8, 32, 100, 17
+    chans = [18, 36, 72, 144]
+    convs = [torch.nn.Conv2d(sum(chans), 128, 1).to(dev) for _ in range(2)]
+    br = [[torch.randn(B, c, h >> i, h >> i, device=dev, requires_grad=True) for i, c in enumerate(chans)]
+          for _ in range(2)]
+    feat3 = torch.randn(B, J, 128, device=dev, requires_grad=True)
+    mask = torch.zeros(B, 4 * h, 4 * h, device=dev)
+    mask[:, 8:24, 8:24] = 1                                     # 16 mask pixels on the map: many duplicate samples
+    j2d = torch.rand(B, J, 2, device=dev) * 4 * h
+    j2d[:, 1] = j2d[:, 0]                                       # two joints on one pixel
+    vis = (torch.rand(B, J, device=dev) < 0.85).int()
+    ud = torch.ones(B, dtype=torch.long, device=dev)
+    eng = HipLossEngine()
+    ind, keep = eng.dense_samples(mask, h, h, S, ud)
+    leaves = br[0] + br[1] + [feat3] + [p for c in convs for p in c.parameters()]
+    runs = []
+    for _ in range(2):
+        t, m = eng.fmap_sampled(br[0], br[1], convs[0], convs[1], feat3, mask, j2d, vis, ud, None, S, 0.07,
+                                sample_ind=ind, keep=keep)
+        runs.append([t.detach().clone(), m.clone()] + [g_.clone() for g_ in torch.autograd.grad(t, leaves)])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
