@@ -90,6 +90,9 @@ SIGNATURES = {
     'hcm_prof_read_tag': (_i, [_i, _p, _p]),
 }
 
+SIGNATURES['hcm_dense_soft_nce_coords_bf16'] = SIGNATURES['hcm_dense_soft_nce_coords']
+SIGNATURES['hcm_scl_bf16'] = SIGNATURES['hcm_scl']
+
 for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits_fwd', 'hcm_bank_logits_bwd',
               'hcm_bank_update'):
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]

@@ -25,6 +25,10 @@ using namespace hcm;
 constexpr int kC = 128;  // linear_merge channels (build_backbone.py:243-245)
 constexpr int kWG = 256;
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
 
 struct MapView {
   int64_t sN, sC, sH, sW;
@@ -127,7 +131,13 @@ struct StripArgs {
 
 constexpr int kKS = 144;  // LDS row stride of the key tile (16 mod 32 -> conflict-free b32 reads)
 
-template <class Policy, bool GRAD>
+// BF16 (BASELINE config 5, "bf16 feature-map GEMMs"): both contractions run on the bf16 matrix cores with
+// fp32 accumulation -- the similarity P = Q K^T as 4 x v_mfma_f32_16x16x32_bf16 per tile (32 fp32 MFMAs
+// otherwise) and the gradient contraction G K as 8 x v_mfma_f32_16x16x16_bf16 (32 otherwise).  Operands
+// are rounded to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) in registers on their way from the
+// fp32 unit rows / the fp32 LDS tile into the MFMA; everything else (softmax statistics, targets,
+// normalisation backward) stays fp32.  Parity is stated against the fp32 oracle at 1e-2.
+template <class Policy, bool GRAD, bool BF16>
 __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   __shared__ __attribute__((aligned(16))) float sK[16 * kKS];
   __shared__ float sG[4][16][17];
@@ -155,13 +165,28 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
 
   const int row0 = blockIdx.x * 64 + wave * 16;  // first row of this wave's strip
   // A operand: lane (m = np, kslot = g) holds Q[row0+np][16j + 4g + e], j<8, e<4
-  float4 qf[8];
+  // (BF16: Q[row0+np][32j + 8g + e], j<4, e<8, rounded to bf16)
+  float4 qf[BF16 ? 1 : 8];
+  v8bf qh[BF16 ? 4 : 1];
   {
     const int r = row0 + np;
+    if constexpr (BF16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      qf[j] = (r < S) ? *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 16 * j + 4 * g)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 4; ++j) {
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (r < S) {
+          lo = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g);
+          hi = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g + 4);
+        }
+        const v8f v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        qh[j] = __builtin_convertvector(v, v8bf);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        qf[j] = (r < S) ? *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 16 * j + 4 * g)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   // rows owned in the C layout: row0 + 4g + reg
   int mrow[4];
@@ -218,13 +243,23 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
 
     // GEMM 1: P[16 x 16] = Qstrip . Ktile^T   (32 x v_mfma_f32_16x16x4_f32)
     v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float4 kb = *reinterpret_cast<const float4*>(&sK[np * kKS + 16 * j + 4 * g]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const float4 lo = *reinterpret_cast<const float4*>(&sK[np * kKS + 32 * j + 8 * g]);
+        const float4 hi = *reinterpret_cast<const float4*>(&sK[np * kKS + 32 * j + 8 * g + 4]);
+        const v8f kv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], __builtin_convertvector(kv, v8bf), acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 kb = *reinterpret_cast<const float4*>(&sK[np * kKS + 16 * j + 4 * g]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, acc, 0, 0, 0);
+      }
     }
     // C layout: acc[q] = P[row0 + 4g + q][c0 + np]
     const int c = c0 + np;
@@ -262,13 +297,26 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
       }
       __syncthreads();  // sG visible (also orders the LDS traffic of the four waves)
       // GEMM 2: dQ[16 x 128] += G[16 x 16] . Ktile[16 x 128]   (4 k-steps x 8 channel tiles)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const float av = sG[wave][np][4 * ks + g];
+      if constexpr (BF16) {
+        // A = G[np][4g + i], B = Ktile[4g + i][16nt + np], i < 4: one 16-key contraction per channel tile
+        const v4f gv = {sG[wave][np][4 * g], sG[wave][np][4 * g + 1], sG[wave][np][4 * g + 2], sG[wave][np][4 * g + 3]};
+        const v4s ga = __builtin_bit_cast(v4s, __builtin_convertvector(gv, v4bf));
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
-          const float bv = sK[(4 * ks + g) * kKS + 16 * nt + np];
-          dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dq[nt], 0, 0, 0);
+          const v4f kv = {sK[(4 * g) * kKS + 16 * nt + np], sK[(4 * g + 1) * kKS + 16 * nt + np],
+                          sK[(4 * g + 2) * kKS + 16 * nt + np], sK[(4 * g + 3) * kKS + 16 * nt + np]};
+          dq[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga, __builtin_bit_cast(v4s, __builtin_convertvector(kv, v4bf)),
+                                                             dq[nt], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const float av = sG[wave][np][4 * ks + g];
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) {
+            const float bv = sK[(4 * ks + g) * kKS + 16 * nt + np];
+            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dq[nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -729,7 +777,24 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_kernel(const float* __r
 // per step and the last run-to-run non-deterministic kernel of the loss section); this one is
 // deterministic and reads grad_out ~(2 + 1/s)^2 / 4 times through L2.  The stencil of an output pixel is
 // re-derived with exactly the forward's float expressions, so forward and backward agree on every tap.
-constexpr int kBwdWin = 12;   // x-window whose weights are kept in registers (covers scale factors <= 4)
+constexpr int kBwdWin = 8;    // x-window whose weights are kept in registers (covers scale factors <= 4)
+
+// source index of output position o along one axis, exactly as the forward computes it
+__device__ __forceinline__ int src_floor(int o, float scale, int n_in) {
+  const float f = fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+  return min((int)f, n_in - 1);
+}
+// [lo, hi] = the outputs whose source floor is i-1 or i (the only ones that can touch input i); the floor is
+// monotone in the output position, so the estimate from the inverse map is corrected by a few exact probes
+__device__ __forceinline__ void touch_range(int i, float scale, float inv_scale, int n_in, int n_out, int& lo, int& hi) {
+  lo = min(max((int)floorf(((float)i - 0.5f) * inv_scale - 0.5f), 0), n_out - 1);
+  while (lo > 0 && src_floor(lo - 1, scale, n_in) >= i - 1) --lo;
+  while (lo < n_out - 1 && src_floor(lo, scale, n_in) < i - 1) ++lo;
+  hi = min(max((int)floorf(((float)i + 1.5f) * inv_scale - 0.5f), lo), n_out - 1);
+  while (hi < n_out - 1 && src_floor(hi + 1, scale, n_in) <= i) ++hi;
+  while (hi > lo && src_floor(hi, scale, n_in) > i) --hi;
+}
+
 __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float* __restrict__ g,
                                                                     float* __restrict__ dx, int planes,
                                                                     int Hi, int Wi, int Ho, int Wo,
@@ -740,12 +805,9 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float*
     const int xi = (int)(e % Wi);
     const int yi = (int)((e / Wi) % Hi);
     const int64_t pl = e / ((int64_t)Wi * Hi);
-    // outputs whose source row floor is yi-1 or yi (one row of slack for float rounding; rows outside
-    // get weight 0 from the exact test below)
-    const int ylo = max(0, (int)floorf(((float)yi - 0.5f) * isy - 0.5f) - 1);
-    const int yhi = min(Ho - 1, (int)ceilf(((float)yi + 1.5f) * isy - 0.5f) + 1);
-    const int xlo = max(0, (int)floorf(((float)xi - 0.5f) * isx - 0.5f) - 1);
-    const int xhi = min(Wo - 1, (int)ceilf(((float)xi + 1.5f) * isx - 0.5f) + 1);
+    int ylo, yhi, xlo, xhi;
+    touch_range(yi, sy, isy, Hi, Ho, ylo, yhi);
+    touch_range(xi, sx, isx, Wi, Wo, xlo, xhi);
     auto wx_of = [&](int ox) -> float {
       const float fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.f);
       const int x0 = min((int)fx, Wi - 1);
@@ -762,11 +824,10 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float*
     float acc = 0.f;
     for (int oy = ylo; oy <= yhi; ++oy) {
       const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.f);
-      const int y0 = (int)fy;
+      const int y0 = min((int)fy, Hi - 1);
       const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
       const float ly = fy - (float)y0;
       const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
-      if (wy == 0.f) continue;
       const float* grow = g + (pl * Ho + oy) * Wo;
       float racc = 0.f;
       if (nwin <= kBwdWin) {
@@ -774,10 +835,7 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float*
         for (int k = 0; k < kBwdWin; ++k)
           if (k < nwin) racc = fmaf(wxv[k], grow[xlo + k], racc);
       } else {
-        for (int ox = xlo; ox <= xhi; ++ox) {
-          const float wx = wx_of(ox);
-          if (wx != 0.f) racc = fmaf(wx, grow[ox], racc);
-        }
+        for (int ox = xlo; ox <= xhi; ++ox) racc = fmaf(wx_of(ox), grow[ox], racc);
       }
       acc = fmaf(wy, racc, acc);
     }
@@ -1036,11 +1094,34 @@ int hcm_dense_soft_nce(const float* map1, const float* map2, hcm_strides4 st, in
                                    temperature, out4, gmap1, gmap2, workspace, workspace_bytes, stream);
 }
 
+static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                      int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                      int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                      float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                      hcm_stream_t stream, bool bf16);
+
 int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
                               int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
                               int coord_w, const int32_t* keep, int S, float temperature, float* out4,
                               float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
                               hcm_stream_t stream) {
+  return dense_impl(map1, map2, st, B, C, h, w, sample_ind, coord_ind, coord_w, keep, S, temperature, out4, gmap1, gmap2,
+                    workspace, workspace_bytes, stream, false);
+}
+int hcm_dense_soft_nce_coords_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                                   int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                                   int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                                   float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                                   hcm_stream_t stream) {
+  return dense_impl(map1, map2, st, B, C, h, w, sample_ind, coord_ind, coord_w, keep, S, temperature, out4, gmap1, gmap2,
+                    workspace, workspace_bytes, stream, true);
+}
+
+static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                      int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                      int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                      float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                      hcm_stream_t stream, bool bf16) {
   if (coord_ind == nullptr) { coord_ind = sample_ind; coord_w = w; }
   if (coord_w <= 0) return (int)hipErrorInvalidValue;
   if (C != kC || B <= 0 || S <= 0 || h <= 0 || w <= 0 || !(temperature > 0.f) || keep == nullptr)
@@ -1064,13 +1145,15 @@ int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4
   DensePolicy pol{coord_w};
   {
     ProfSpan span(HCM_PROF_DENSE_STATS, s);
-    strip_kernel<DensePolicy, false><<<grid, kWG, 0, s>>>(a, pol);
+    if (bf16) strip_kernel<DensePolicy, false, true><<<grid, kWG, 0, s>>>(a, pol);
+    else strip_kernel<DensePolicy, false, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     span.stop();
   }
   {
     ProfSpan span(HCM_PROF_DENSE_GRAD, s);
-    strip_kernel<DensePolicy, true><<<grid, kWG, 0, s>>>(a, pol);
+    if (bf16) strip_kernel<DensePolicy, true, true><<<grid, kWG, 0, s>>>(a, pol);
+    else strip_kernel<DensePolicy, true, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     span.stop();
   }
@@ -1087,10 +1170,30 @@ size_t hcm_scl_workspace_bytes(int B, int J, int C) {
   return carve_scl(nullptr, B, J).bytes;
 }
 
+static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                    const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+                    float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+                    size_t workspace_bytes, hcm_stream_t stream, bool bf16);
+
 int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
             const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
             float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
             size_t workspace_bytes, hcm_stream_t stream) {
+  return scl_impl(map1, map2, st, B, C, h, w, pix, use_depth, use_rgb, J, temperature, out1, gmap1, gmap2, workspace,
+                  workspace_bytes, stream, false);
+}
+int hcm_scl_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                 const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+                 float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+                 size_t workspace_bytes, hcm_stream_t stream) {
+  return scl_impl(map1, map2, st, B, C, h, w, pix, use_depth, use_rgb, J, temperature, out1, gmap1, gmap2, workspace,
+                  workspace_bytes, stream, true);
+}
+
+static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                    const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+                    float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+                    size_t workspace_bytes, hcm_stream_t stream, bool bf16) {
   if (C != kC || B <= 0 || J <= 0 || J > 0xffff || h <= 0 || w <= 0 || !(temperature > 0.f) ||
       use_depth == nullptr)
     return (int)hipErrorInvalidValue;
@@ -1113,7 +1216,8 @@ int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
   SclPolicy pol;
   {
     ProfSpan span(HCM_PROF_SCL_STATS, s);
-    strip_kernel<SclPolicy, false><<<grid, kWG, 0, s>>>(a, pol);
+    if (bf16) strip_kernel<SclPolicy, false, true><<<grid, kWG, 0, s>>>(a, pol);
+    else strip_kernel<SclPolicy, false, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     if (ws.nkc > 1) {
       strip_merge_stats_kernel<SclPolicy><<<(N + kWG - 1) / kWG, kWG, 0, s>>>(a, pol, N);
@@ -1123,7 +1227,8 @@ int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
   }
   {
     ProfSpan span(HCM_PROF_SCL_GRAD, s);
-    strip_kernel<SclPolicy, true><<<grid, kWG, 0, s>>>(a, pol);
+    if (bf16) strip_kernel<SclPolicy, true, true><<<grid, kWG, 0, s>>>(a, pol);
+    else strip_kernel<SclPolicy, true, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     if (ws.nkc > 1) {
       strip_merge_grad_kernel<<<(N + 3) / 4, kWG, 0, s>>>(a, N);

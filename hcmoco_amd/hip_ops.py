@@ -311,7 +311,7 @@ class _FmapLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
-                temperature, do_dense, do_joint, do_scl, coord_ind=None, coord_w=0):
+                temperature, do_dense, do_joint, do_scl, coord_ind=None, coord_w=0, gemm_dtype='fp32'):
         map1, map2 = _dense_map(map1), _dense_map(map2)
         _check_maps(map1, map2, 'fmap_losses')
         B, Cc, h, w = map1.shape
@@ -331,7 +331,8 @@ class _FmapLosses(torch.autograd.Function):
             S = sample_ind.shape[1]
             nb = L.hcm_dense_soft_nce_workspace_bytes(B, S, Cc)
             ws = _ws(nb, dev)
-            check(L.hcm_dense_soft_nce_coords(p1, p2, st, B, Cc, h, w,
+            dense = L.hcm_dense_soft_nce_coords_bf16 if gemm_dtype == 'bf16' else L.hcm_dense_soft_nce_coords
+            check(dense(p1, p2, st, B, Cc, h, w,
                                               _dev(sample_ind, torch.int64, 'dense'),
                                               _opt(coord_ind, torch.int64, 'dense'), int(coord_w),
                                               _dev(_i32(keep), torch.int32, 'dense'),
@@ -351,7 +352,8 @@ class _FmapLosses(torch.autograd.Function):
         if do_scl:
             nb = L.hcm_scl_workspace_bytes(B, J, Cc)
             ws = _ws(nb, dev)
-            check(L.hcm_scl(p1, p2, st, B, Cc, h, w, _dev(pix, torch.int64, 'scl'),
+            scl = L.hcm_scl_bf16 if gemm_dtype == 'bf16' else L.hcm_scl
+            check(scl(p1, p2, st, B, Cc, h, w, _dev(pix, torch.int64, 'scl'),
                             _dev(ud, torch.int32, 'scl'), _opt(ur, torch.int32, 'scl'), J, float(temperature),
                             C.c_void_p(out.data_ptr() + 32), pg1, pg2,
                             C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_scl')
@@ -363,17 +365,20 @@ class _FmapLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, g_out):
         g1, g2, g3 = ctx.saved_tensors
-        return (g1 * g_total, g2 * g_total, (g3 * g_total) if ctx.has_g3 else None) + (None,) * 12
+        return (g1 * g_total, g2 * g_total, (g3 * g_total) if ctx.has_g3 else None) + (None,) * 13
 
 
 def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb, temperature,
-                do_dense=True, do_joint=True, do_scl=True, coord_ind=None, coord_w=0):
+                do_dense=True, do_joint=True, do_scl=True, coord_ind=None, coord_w=0, gemm_dtype='fp32'):
     """total (differentiable in map1, map2, feat3) and the 9 detached meters
     [loss_r2d, loss_d2r, acc_r2d, acc_d2r, loss_rgb2j, loss_d2j, acc_rgb2j, acc_d2j, loss_scl].
     ``coord_ind``/``coord_w``: pixel coordinates of the dense soft target when ``sample_ind`` is only
-    a gather index (row mode, see ``fmap_losses_rows``)."""
+    a gather index (row mode, see ``fmap_losses_rows``).  ``gemm_dtype='bf16'``: the dense and SCL
+    contractions on the bf16 matrix cores (BASELINE config 5; fp32 accumulation)."""
+    if gemm_dtype not in ('fp32', 'bf16'):
+        raise ValueError('gemm_dtype must be fp32 or bf16')
     return _FmapLosses.apply(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
-                             temperature, do_dense, do_joint, do_scl, coord_ind, coord_w)
+                             temperature, do_dense, do_joint, do_scl, coord_ind, coord_w, gemm_dtype)
 
 
 # --------------------------------------------------------------------------- #
@@ -440,7 +445,8 @@ def sampled_projection(weight, bias, pix, maps, sampling=None):
     return torch.nn.functional.linear(xs, weight.reshape(weight.shape[0], -1), bias)
 
 
-def fmap_losses_rows(rows1, rows2, feat3, S, coord_ind, coord_w, keep, joints_vis, use_depth, use_rgb, temperature):
+def fmap_losses_rows(rows1, rows2, feat3, S, coord_ind, coord_w, keep, joints_vis, use_depth, use_rgb, temperature,
+                     gemm_dtype='fp32'):
     """The three feature-map losses on already-sampled rows [B, S+J, 128] (first S: dense samples,
     last J: joints).  The row matrix is handed to the same kernels as a [B,128,1,S+J] channels-last
     "map" whose pixel index is the row position, so every gather is one 512-byte line."""
@@ -452,7 +458,7 @@ def fmap_losses_rows(rows1, rows2, feat3, S, coord_ind, coord_w, keep, joints_vi
     gather_dense = ar[:, :S].contiguous()
     gather_joint = ar[:, S:].contiguous()
     return fmap_losses(m1, m2, feat3, gather_dense, keep, gather_joint, joints_vis, use_depth, use_rgb, temperature,
-                       coord_ind=coord_ind.contiguous(), coord_w=coord_w)
+                       coord_ind=coord_ind.contiguous(), coord_w=coord_w, gemm_dtype=gemm_dtype)
 
 
 # --------------------------------------------------------------------------- #

@@ -28,7 +28,7 @@ from .util import AverageMeter
 class ContrastTrainer(BaseTrainer):
     def __init__(self, args, engine=None, force_collectives=None):
         super().__init__(args)
-        self.engine = engine if engine is not None else HipLossEngine()
+        self.engine = engine if engine is not None else HipLossEngine(getattr(args, 'fmap_dtype', 'fp32'))
         self.grad_sync = None        # learning/grad_sync.py:GradSync when this class averages the gradients itself
         self.async_wgrad = None      # torch.ops.hcmoco namespace once deferred weight gradients are on
         self._find_done = False      # the first training step runs single-stream (quiet MIOpen Find)

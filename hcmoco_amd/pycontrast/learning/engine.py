@@ -14,6 +14,13 @@ from ... import hip_ops
 class HipLossEngine(object):
     name = 'hip'
 
+    def __init__(self, fmap_dtype='fp32'):
+        """``fmap_dtype='bf16'`` (``--fmap_dtype bf16``, BASELINE config 5): the dense and SCL similarity /
+        gradient contractions run on the bf16 matrix cores with fp32 accumulation."""
+        if fmap_dtype not in ('fp32', 'bf16'):
+            raise ValueError('fmap_dtype must be fp32 or bf16')
+        self.fmap_dtype = fmap_dtype
+
     # ---- SURVEY 8a rows 1-4 -------------------------------------------------------------
     def bank(self, contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
              use_depth=None, use_rgb=None, idx=None):
@@ -46,7 +53,8 @@ class HipLossEngine(object):
             sample_ind, keep = self.dense_samples(depth_mask, h, w, num_samples, use_depth)
         pix = hip_ops.joint_pixels(joints2d, h)
         ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=map1.device)
-        return hip_ops.fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, ud, use_rgb, temperature)
+        return hip_ops.fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, ud, use_rgb, temperature,
+                                   gemm_dtype=self.fmap_dtype)
 
     # ---- rows 5-8 fused at the sampled pixels ---------------------------------
     def fmap_sampled(self, branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
@@ -67,4 +75,4 @@ class HipLossEngine(object):
         rows2 = hip_ops.sampled_projection(proj2.weight, proj2.bias, pix, list(branches2), S)
         ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=pix.device)
         return hip_ops.fmap_losses_rows(rows1, rows2, feat3, sample_ind.shape[1], sample_ind, w, keep, joints_vis,
-                                        ud, use_rgb, temperature)
+                                        ud, use_rgb, temperature, gemm_dtype=self.fmap_dtype)

@@ -108,6 +108,9 @@ BASE_FLAGS = [
                                  'all-reduces of the encoders\' flat gradient buffers, launched chunk by chunk while '
                                  'backward is still running (learning/grad_sync.py); flat = ONE all-reduce after '
                                  'backward; auto = overlap on ROCm, ddp on CPU')),
+    (('--fmap_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
+                             help='arithmetic of the dense / SCL feature-map contractions: fp32 MFMA (the reference\'s '
+                                  'arithmetic) or bf16 MFMA with fp32 accumulation (BASELINE config 5)')),
     (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
                              help='storage type of the memory banks (bf16: BASELINE config 5)')),
 ]

@@ -161,6 +161,20 @@ int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
             float temperature, float* out1, float* gmap1, float* gmap2,
             void* workspace, size_t workspace_bytes, hcm_stream_t stream);
 
+/* BASELINE config 5 ("bf16 feature-map GEMMs"): the same two losses with both contractions of the strip
+ * kernel (Q K^T and G K) on the bf16 matrix cores -- operands rounded to bf16 in registers, fp32
+ * accumulation, everything else fp32; same arguments, same workspaces.  Parity vs the fp32 path / oracle:
+ * 1e-2 relative on the losses, 2e-2 relative L2 on the gradients (tests/test_fmap_gpu.py). */
+int hcm_dense_soft_nce_coords_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                                   int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                                   int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                                   float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                                   hcm_stream_t stream);
+int hcm_scl_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                 const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+                 float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+                 size_t workspace_bytes, hcm_stream_t stream);
+
 /* joint_pixels: pix[b,j] = clamp(floor(j2d[b,j,0]/4),0,h-1)*h + clamp(floor(j2d[b,j,1]/4),0,h-1)
  * (contrast_trainer.py:757-761).  joints2d [B, J, 2] fp32. */
 int hcm_joint_pixels(const float* joints2d, int BJ, int h, int64_t* pix, hcm_stream_t stream);

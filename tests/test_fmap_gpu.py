@@ -309,3 +309,38 @@ def test_sampled_loss_section_is_bitwise_deterministic():
         runs.append([t.detach().clone(), m.clone()] + [g_.clone() for g_ in torch.autograd.grad(t, leaves)])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,h,S,J', [(3, 12, 17, 5), (4, 16, 100, 17), (32, 64, 400, 17)])
+def test_bf16_mfma_contractions_vs_fp32_oracle(B, h, S, J):
+    """BASELINE config 5: dense + SCL with both strip-kernel contractions on the bf16 matrix cores
+    (gemm_dtype='bf16'), against the fp32 oracle at the restated tolerance -- losses 1e-2 relative, accuracies
+    within one sample, gradients 2e-2 relative L2 -- and against the oracle evaluated on correspondingly
+    perturbed inputs is NOT needed: the fp32 softmax statistics keep the error at operand-rounding level
+    (2^-9 per logit / tau).  Last case = bench size (B=32, 64x64 maps, S=400, J=17)."""
+    torch.manual_seed(B * 10 + S)
+    C, temp = 128, 0.07
+    m1, m2 = torch.randn(B, C, h, h), torch.randn(B, C, h, h)
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[1] = False
+    ud = keep.clone().int()
+    ind = torch.randint(0, h * h, (B, S))
+    ind[0, S // 2] = ind[0, 0]
+    j2d = torch.rand(B, J, 2) * 4 * h
+    pix = O.joint_pixels(j2d, h)
+    vis = torch.ones(B, J).int()
+    total, met, g1, g2, _ = run(m1, m2, None, ind, keep.int(), pix, vis, ud, None, temp, 'channels_last',
+                                do_joint=False, gemm_dtype='bf16')
+    _, met32, f1, f2, _ = run(m1, m2, None, ind, keep.int(), pix, vis, ud, None, temp, 'channels_last', do_joint=False)
+    ld, ad, d1, d2 = O.dense_soft_nce(m1, m2, ind[keep], keep, temp, ud)
+    ls, s1, s2, _ = O.scl(m1, m2, j2d, temp, ud, None)
+    assert torch.allclose(met[0:2], ld, rtol=1e-2, atol=1e-4), (met[0:2], ld)
+    assert float((met[2:4] - ad).abs().max()) <= 2.0 / (int(keep.sum()) * S) + 1e-6
+    assert abs(float(met[8]) - float(ls)) < 1e-2 * abs(float(ls)) + 1e-4
+    assert rel_l2(g1, d1 + s1) < 2e-2 and rel_l2(g2, d2 + s2) < 2e-2, (rel_l2(g1, d1 + s1), rel_l2(g2, d2 + s2))
+    # it really is a different arithmetic (not the fp32 path under another name) ...
+    assert not torch.equal(g1, f1)
+    # ... and deterministic
+    again = run(m1, m2, None, ind, keep.int(), pix, vis, ud, None, temp, 'channels_last', do_joint=False,
+                gemm_dtype='bf16')
+    assert torch.equal(again[1], met) and torch.equal(again[2], g1) and torch.equal(again[3], g2)
