@@ -15,10 +15,17 @@ JSON line; `value` is whole-job samples/s = B*N*K / max-over-ranks(time of K ste
 roofline    : the dominant hand-written kernel (the bank gather pass, HBM-bound).  `achieved` =
               algorithmic bytes per launch / mean launch duration measured with hipEvents placed
               around that kernel, on its stream, INSIDE the timed steps (hcm_prof_enable/read).
+roofline_secondary: the MFMA-bound loss kernels (dense soft-InfoNCE, cross-subject SCL: algorithmic flops of
+              SURVEY 8d / launch duration against the fp32 -- or bf16 -- MFMA peak) and the SemGCN layer
+              kernels (latency class; bytes / duration reported for scale), timed the same way.
 cpu_baseline: the same training step on the host CPU (model in torch-CPU, losses by the oracle =
-              a port of the reference math), rank 0 / N=1 only, on a bounded sample (batch 4, ~20 s
-              of steps, <=16 threads) in a CPU-only subprocess with a hard timeout.  A reported
-              baseline, never the thing measured.
+              a port of the reference math), rank 0 / N=1 only, in CPU-only subprocesses with hard
+              timeouts: (a) all host threads at the bench's OWN batch (32): 1 warm-up + as many timed steps
+              as fit ~25 s (SURVEY 8d asks 3 + 10 steps; at ~5 s per step that is minutes, so the sample
+              is bounded and its size reported); (b) ONE thread at batch 4 for a per-core figure.  A
+              reported baseline, never the thing measured.
+ms_per_step : wall clock (perf_counter around K steps, barrier + synchronize on both sides); the
+              hipEvent-timed duration of the same K steps on the main stream is `ms_per_step_hipevent`.
 """
 import argparse
 import json
@@ -33,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFS = 157.3      # fp32-input MFMA = the fp32 vector rate (same guide)
+MFMA_BF16_PEAK_TFS = 2500.0    # dense bf16 MFMA peak
 
 
 def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, sampled=1, arch='HRNet', width=18,
@@ -73,7 +82,7 @@ def build(args, trainer, engine_device):
     return model, contrast, opt, data
 
 
-def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s):
+def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s, max_steps):
     """Runs in a fresh CPU-only process (see cpu_baseline): same step, same config, oracle losses."""
     import tempfile
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
@@ -89,26 +98,36 @@ def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s):
     trainer.train_step(next(it), model, contrast, opt, stage2=True)          # warm-up
     warm = time.perf_counter() - t0
     steps, t0 = 0, time.perf_counter()
-    while steps < 1 or (time.perf_counter() - t0 + warm < budget_s and steps < 8):
+    while steps < 1 or (time.perf_counter() - t0 + warm + (time.perf_counter() - t0) / steps < budget_s
+                        and steps < max_steps):
         trainer.train_step(next(it), model, contrast, opt, stage2=True)
         steps += 1
     dt = time.perf_counter() - t0
     return {'value': round(batch * steps / dt, 3), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'ms_per_step': round(1e3 * dt / steps, 1), 'batch': batch, 'timed_steps': steps, 'warmup_steps': 1,
             'sample': '%d timed step(s) after 1 warm-up of the same stage-2 step at batch %d, K=%d, %dx%d, '
-                      'torch-CPU model + oracle losses, %d threads' % (steps, batch, nce_k, size, size, threads)}
+                      'torch-CPU model + oracle losses, %d thread(s)' % (steps, batch, nce_k, size, size, threads)}
 
 
-def cpu_baseline(nce_k, n_data, size, skeleton, batch=4, budget_s=20.0, timeout_s=240):
-    """Bounded CPU leg in a subprocess (clean thread pool, hard timeout) -> dict or None."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _cpu_leg(nce_k, n_data, size, skeleton, batch, threads, budget_s, max_steps, timeout_s):
     import subprocess
-    threads = max(1, min(os.cpu_count() or 1, 16))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='',
                ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'HCM_FORCE_COLLECTIVES'):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu_baseline_worker', '--nce_k', str(nce_k), '--n_data',
            str(n_data), '--size', str(size), '--skeleton', skeleton, '--batch_per_gpu', str(batch),
-           '--cpu_budget_s', str(budget_s)]
+           '--cpu_budget_s', str(budget_s), '--cpu_max_steps', str(max_steps)]
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
         for line in reversed(res.stdout.splitlines()):
@@ -119,6 +138,17 @@ def cpu_baseline(nce_k, n_data, size, skeleton, batch=4, budget_s=20.0, timeout_
     except subprocess.TimeoutExpired:
         return {'value': None, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
                 'sample': 'cpu leg exceeded %d s and was stopped' % timeout_s}
+
+
+def cpu_baseline(nce_k, n_data, size, skeleton, batch):
+    """Bounded CPU legs in subprocesses (clean thread pools, hard timeouts) -> dict."""
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    out = _cpu_leg(nce_k, n_data, size, skeleton, batch, threads, budget_s=25.0, max_steps=10, timeout_s=300)
+    out['cpu_model'] = cpu_model()
+    out['host_threads_available'] = os.cpu_count()
+    one = _cpu_leg(nce_k, n_data, size, skeleton, 4, 1, budget_s=20.0, max_steps=3, timeout_s=240)
+    out['one_thread'] = {k: one.get(k) for k in ('value', 'unit', 'cores', 'ms_per_step', 'batch', 'timed_steps', 'sample')}
+    return out
 
 
 def main():
@@ -134,6 +164,7 @@ def main():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_baseline_worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu_budget_s', type=float, default=20.0)
+    ap.add_argument('--cpu_max_steps', type=int, default=10, help=argparse.SUPPRESS)
     ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
     ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
     ap.add_argument('--arch', type=str, default='HRNet', choices=['HRNet', 'HRNetPN'],
@@ -150,7 +181,8 @@ def main():
                          'multi-rank control flow be exercised on a single-GPU box')
     a = ap.parse_args()
     if a.cpu_baseline_worker:
-        print(json.dumps(cpu_baseline_worker(a.nce_k, a.n_data, a.size, a.skeleton, a.batch_per_gpu, a.cpu_budget_s)))
+        print(json.dumps(cpu_baseline_worker(a.nce_k, a.n_data, a.size, a.skeleton, a.batch_per_gpu, a.cpu_budget_s,
+                                             a.cpu_max_steps)))
         return
 
     rank = int(os.environ.get('RANK', '0'))
@@ -191,16 +223,23 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     last = None
     for _ in range(a.steps):
         last = trainer.train_step(next(it), model, contrast, opt, stage2=True)
+    ev1.record()                 # main stream: it is ordered behind the side streams / RCCL at the end of a step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
     kern_ms, kern_n = hip_ops.prof_read()
+    secondary_raw = {tag: hip_ops.prof_read(tag) for tag in ('dense_stats', 'dense_grad', 'scl_stats', 'scl_grad',
+                                                               'sgc_fwd', 'sgc_bwd')}
     hip_ops.prof_enable(False)
+    kept_per_step = float(sum(int(b[6].sum()) for b in data.pool)) / len(data.pool)    # images with depth: B' of the dense loss
     tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
@@ -228,11 +267,42 @@ def main():
                 traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_bank_pass_pmc.json'
         except (OSError, KeyError, ValueError):
             pass
+        # secondary rooflines: algorithmic flops of one launch / mean launch duration
+        from hcmoco_amd.pycontrast.networks.sgcn import num_joints
+        S, J = 400, num_joints(a.skeleton)
+        mfma_peak = MFMA_BF16_PEAK_TFS if a.fmap_dtype == 'bf16' else MFMA_F32_PEAK_TFS
+        dense_gemm = 2.0 * (2.0 * kept_per_step * S * S * D)        # both orientations of Q K^T
+        scl_gemm = 2.0 * (2 * B * J) ** 2 * D
+        sgc_fwd_bytes = B * J * (2 * D + 2 * D) * 4                  # read H [B*J, 2C]; write out + xhat [B*J, C]
+        sgc_bwd_bytes = B * J * (2 * D + 3 * D + 2 * D) * 4          # read H, dOut, out, xhat; write dH [B*J, 2C]
+        spec = [('dense_stats', 'strip_kernel<Dense, stats> (S x S similarity + online softmax / soft targets)', 'mfma', dense_gemm),
+                ('dense_grad', 'strip_kernel<Dense, grad> (similarity re-formed + G K contraction)', 'mfma', 2 * dense_gemm),
+                ('scl_stats', 'strip_kernel<Scl, stats> + chunk merge (N x N, N = 2BJ)', 'mfma', scl_gemm),
+                ('scl_grad', 'strip_kernel<Scl, grad> + chunk merge', 'mfma', 2 * scl_gemm),
+                ('sgc_fwd', 'SemGCN layer forward (sgc_mix + sgc_norm), per layer', 'latency', sgc_fwd_bytes),
+                ('sgc_bwd', 'SemGCN layer backward (stats + bwd + finish), per layer', 'latency', sgc_bwd_bytes)]
+        secondary = []
+        for tag, name, bound, work in spec:
+            ms, n = secondary_raw[tag]
+            if not n:
+                continue
+            avg = ms / n
+            if bound == 'mfma':
+                ach = work / (avg * 1e-3) / 1e12
+                secondary.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak,
+                                  'unit': 'TFLOP/s', 'frac': round(ach / mfma_peak, 4), 'flops_per_launch': int(work),
+                                  'avg_launch_ms': round(avg, 5), 'launches_timed': n})
+            else:
+                ach = work / (avg * 1e-3) / 1e9
+                secondary.append({'kernel': name, 'bound': 'latency', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                                  'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'bytes_per_launch': int(work),
+                                  'avg_launch_ms': round(avg, 5), 'launches_timed': n})
         out = {
             'metric': 'pretrain samples/sec (RGB+depth+kpt triples) HRNet-w18',
             'value': round(B * world * a.steps / dt, 3), 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(1e3 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * dt / a.steps, 3), 'ms_per_step_hipevent': round(ev_ms / a.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'second-stage HCMoCo step (bank NCE + dense + joint + SCL losses, fwd+bwd+SGD+bank '
                                    'update), %s + SemGCN, %dx%d RGB+depth+%s keypoints'
@@ -251,8 +321,9 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
         }
+        out['roofline_secondary'] = secondary
         if world == 1 and not a.no_cpu_baseline and a.arch == 'HRNet':
-            out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton)
+            out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton, B)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)

@@ -843,6 +843,70 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float*
   }
 }
 
+// Separable form of the same backward, one workgroup per plane (used whenever the intermediate fits LDS --
+// every HRNet fuse layer): dx = Wy^T (G Wx).  Stage 1 contracts the columns, T[yo][xi] = sum_xo wx G[yo][xo]
+// (Ho*Wi outputs: 8x the parallelism of the per-input-pixel form at scale factor 8, and ~2S taps each instead of
+// (2S)^2); stage 2 contracts the rows out of LDS.  Stencils come from per-workgroup tables built with the
+// forward's float expressions; both sums run in ascending output order: deterministic.
+__global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_plane_kernel(const float* __restrict__ g,
+                                                                          float* __restrict__ dx, int Hi, int Wi,
+                                                                          int Ho, int Wo, float sy, float sx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* T = smem;                                   // [Ho][Wi]
+  float* lxt = T + Ho * Wi;                          // [Wo] lambda of output column
+  float* lyt = lxt + Wo;                             // [Ho]
+  int* x0t = reinterpret_cast<int*>(lyt + Ho);       // [Wo] source floor of output column
+  int* y0t = x0t + Wo;                               // [Ho]
+  int* xlo = y0t + Ho;                               // [Wi] first / last output column touching input column
+  int* xhi = xlo + Wi;
+  int* ylo = xhi + Wi;                               // [Hi]
+  int* yhi = ylo + Hi;
+  const int64_t pl = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float isy = 1.f / sy, isx = 1.f / sx;
+  for (int o = tid; o < Wo; o += kWG) {
+    const float f = fmaxf(sx * ((float)o + 0.5f) - 0.5f, 0.f);
+    const int x0 = min((int)f, Wi - 1);
+    x0t[o] = x0;
+    lxt[o] = f - (float)x0;
+  }
+  for (int o = tid; o < Ho; o += kWG) {
+    const float f = fmaxf(sy * ((float)o + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)f, Hi - 1);
+    y0t[o] = y0;
+    lyt[o] = f - (float)y0;
+  }
+  for (int i = tid; i < Wi; i += kWG) touch_range(i, sx, isx, Wi, Wo, xlo[i], xhi[i]);
+  for (int i = tid; i < Hi; i += kWG) touch_range(i, sy, isy, Hi, Ho, ylo[i], yhi[i]);
+  __syncthreads();
+  const float* gp = g + pl * Ho * Wo;
+  for (int o = tid; o < Ho * Wi; o += kWG) {
+    const int yo = o / Wi, xi = o - yo * Wi;
+    const float* grow = gp + (int64_t)yo * Wo;
+    float acc = 0.f;
+    for (int xo = xlo[xi]; xo <= xhi[xi]; ++xo) {
+      const int x0 = x0t[xo], x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+      const float lx = lxt[xo];
+      const float w = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+      acc = fmaf(w, grow[xo], acc);
+    }
+    T[o] = acc;
+  }
+  __syncthreads();
+  float* dp = dx + pl * Hi * Wi;
+  for (int o = tid; o < Hi * Wi; o += kWG) {
+    const int yi = o / Wi, xi = o - yi * Wi;
+    float acc = 0.f;
+    for (int yo = ylo[yi]; yo <= yhi[yi]; ++yo) {
+      const int y0 = y0t[yo], y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+      const float ly = lyt[yo];
+      const float w = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+      acc = fmaf(w, T[yo * Wi + xi], acc);
+    }
+    dp[o] = acc;
+  }
+}
+
 // channels-last variant: memory is [N][H][W][C]; one thread per (pixel, channel), channel fastest.
 __global__ __launch_bounds__(kWG) void upsample_bilinear_nhwc_kernel(const float* __restrict__ in,
                                                                      float* __restrict__ out, int N,
@@ -1291,11 +1355,19 @@ int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho,
 int hcm_upsample_bilinear2d_backward(const float* grad_out, int planes, int Hi, int Wi, int Ho, int Wo,
                                      float* grad_in, hcm_stream_t stream) {
   if (planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || !grad_out || !grad_in) return (int)hipErrorInvalidValue;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  const size_t lds = ((size_t)Ho * Wi + 2 * (size_t)(Wo + Ho) + 2 * (size_t)(Wi + Hi)) * sizeof(float);
+  if (lds <= 60 * 1024) {        // separable form, intermediate in LDS (all HRNet shapes)
+    upsample_bilinear_bwd_plane_kernel<<<planes, kWG, lds, (hipStream_t)stream>>>(grad_out, grad_in, Hi, Wi, Ho, Wo,
+                                                                                 sy, sx);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   const int64_t total = (int64_t)planes * Hi * Wi;
   int64_t blocks = (total + kWG - 1) / kWG;
   if (blocks > 32768) blocks = 32768;
-  upsample_bilinear_bwd_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
-      grad_out, grad_in, planes, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  upsample_bilinear_bwd_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(grad_out, grad_in, planes, Hi, Wi, Ho, Wo,
+                                                                             sy, sx);
   HCM_CHECK_LAUNCH();
   return 0;
 }

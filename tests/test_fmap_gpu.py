@@ -258,7 +258,8 @@ def test_losses_on_sampled_rows_equal_losses_on_full_maps():
 
 @pytest.mark.parametrize('shape,size', [((32, 18, 8, 8), (64, 64)), ((32, 18, 16, 16), (64, 64)), ((32, 36, 8, 8), (32, 32)),
                                         ((4, 18, 32, 32), (64, 64)), ((2, 3, 7, 5), (21, 20)), ((2, 3, 6, 6), (6, 6)),
-                                        ((1, 2, 1, 1), (4, 4)), ((2, 2, 12, 10), (5, 3))])
+                                        ((1, 2, 1, 1), (4, 4)), ((2, 2, 12, 10), (5, 3)),
+                                        ((1, 2, 128, 128), (256, 256))])     # too large for LDS: per-pixel kernel
 def test_upsample_backward_gather_form(shape, size):
     """hcm_upsample_bilinear2d_backward (row 8's backward, HRNet fuse layers): equals the float64 backward of
     F.interpolate to fp32 round-off -- up-sampling by 2/4/8, non-integer factors, identity and down-sampling --
