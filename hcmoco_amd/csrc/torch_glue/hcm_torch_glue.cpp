@@ -406,7 +406,10 @@ int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no
   static const bool on = [] { const char* e = getenv("HCM_WGRAD_KERNEL"); return !(e && e[0] == '0'); }();
   static const int64_t maxc = [] { const char* e = getenv("HCM_WGRAD_MAXC"); return e ? (int64_t)atoi(e) : (int64_t)48; }();
   static const int64_t max1 = [] { const char* e = getenv("HCM_WGRAD_MAX1X1"); return e ? (int64_t)atoi(e) : (int64_t)160; }();
-  if (!on || (g.size(3) & 3) != 0) return 0;
+  // the 3-channel stem convolution (3 -> 64, stride 2, 128x128 output) falls on the kernel's generic,
+  // non-constant-folded instantiation: 279 us per call against MIOpen's ~60 us (r02 profile)
+  static const int64_t minc = [] { const char* e = getenv("HCM_WGRAD_MINC"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+  if (!on || (g.size(3) & 3) != 0 || w.size(1) < minc) return 0;
   const bool same = g.size(2) == x.size(2) && g.size(3) == x.size(3);
   const bool half = 2 * g.size(2) == x.size(2) && 2 * g.size(3) == x.size(3);
   if (same && w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= maxc && w.size(1) <= maxc) return 3;

@@ -132,12 +132,14 @@ class GradSync(object):
         if join is not None:
             join()
         if self.mode == 'flat':
-            groups = [self.params]
+            groups = {'flat': self.params}
+        elif handled:       # the encoders went chunk by chunk: everything else is small -> ONE more collective
+            groups = {'rest': [p for p in self.params if id(p) not in handled]}
         else:
-            groups = [[p for p in g if id(p) not in handled] for g in self.groups]
-        for i, g in enumerate(groups):
+            groups = dict(enumerate(self.groups))
+        for key, g in groups.items():
             if g:
-                works.append(self._launch(self._bucket(i, g)))
+                works.append(self._launch(self._bucket(key, g)))
         for t, w in works:
             w.wait()                 # RCCL: orders the current stream behind the collective, no host block
             if not self.avg:

@@ -13,6 +13,8 @@ torch.manual_seed(0)
 B, K, n, D = 32, int(os.environ.get('K', 16384)), int(os.environ.get('N', 131072)), 128
 nrm = torch.nn.functional.normalize
 banks = [nrm(torch.randn(n, D, device=d)) for _ in range(3)]
+if os.environ.get('DTYPE', 'f32') == 'bf16':          # BASELINE config 5 bank storage
+    banks = [b.to(torch.bfloat16) for b in banks]
 xs = [nrm(torch.randn(B, D, device=d)) for _ in range(3)]
 for i in range(6):
     idx = torch.randint(0, n, (B, K + 1), device=d)
