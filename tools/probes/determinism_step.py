@@ -5,7 +5,7 @@ import os
 import sys
 import tempfile
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from hcmoco_amd import _lib
@@ -16,7 +16,9 @@ dev = torch.device('cuda:0')
 
 
 def run():
-    args = bench.make_args(8, 1024, 4096, 128, 'coco17', 'nccl', tempfile.mkdtemp(), steps + 1)
+    args = bench.make_args(int(os.environ.get('PROBE_B', 8)), int(os.environ.get('PROBE_K', 1024)),
+                           int(os.environ.get('PROBE_N', 4096)), int(os.environ.get('PROBE_SIZE', 128)), 'coco17', 'nccl',
+                           tempfile.mkdtemp(), steps + 1)
     args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
     tr = ContrastTrainer(args)
     tr.device = dev
