@@ -1,0 +1,315 @@
+"""NTU RGB-D + MPII tuple producer (``--dataset NTUMPII --modal RGBD2S``): the positional batch tuple the
+trainer indexes from image files.
+
+Reference: /root/reference/pycontrast/datasets/dataset.py:65-250 (NTU frame: RGB jpg, masked 16-bit depth png,
+parsed-skeleton pickle), :306-381 (MPII annotation records), :474-617 (the GCN variant whose ``__getitem__``
+yields the tuple) and datasets/mpii_utils.py:14-65 (centre/scale affine).  Index space as in the reference:
+``[0, len(mpii))`` are MPII images (RGB only: zero depth, ``use_depth = 0``), the rest NTU frames.
+
+The reference decodes and warps with cv2 / torchvision, neither of which is in this image; this module uses
+PIL + numpy:
+  * NTU crop / resize: ``PIL.Image.crop`` + ``resize`` -- the two calls ``torchvision.transforms.functional.
+    resized_crop`` makes on PIL images (bilinear for RGB, nearest for depth);
+  * the random crop rectangle: torchvision's ``RandomResizedCrop.get_params`` restated (``crop_params``);
+  * MPII: ``cv2.warpAffine(INTER_LINEAR)`` restated as an inverse-mapped bilinear sample with a zero border
+    (``warp_affine``) -- float interpolation, not cv2's 5-bit fixed point: pixel values can differ in the last
+    bits of uint8.
+Everything AROUND the decoding -- annotation records, joint re-ordering / normalisation / flipping,
+visibility, depth normalisation, the `scale` heuristic, the affine matrix -- is pinned against the
+reference's own functions (tests/golden/dataset_tuple.npz, tests/test_datasets_cpu.py), including the
+reference's quirk of testing ``joints2d[:, 1] < j + w`` where it means column 0 (dataset.py:591-592).
+"""
+import json
+import math
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+from PIL import Image
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float64)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float64)
+KINECT_TO_MPII = [14, 13, 12, 16, 17, 18, 0, 1, 2, 3, 6, 5, 4, 8, 9, 10]          # dataset.py:325-328
+MPII_FLIP_PAIRS = [[0, 5], [1, 4], [2, 3], [10, 15], [11, 14], [12, 13]]           # dataset.py:480
+
+
+# --------------------------------------------------------------------------- pure arithmetic (pinned)
+def mpii_records(root, image_set='train', num_joints=16):
+    """Annotation json -> list of dicts (centre / scale padded, 1-based -> 0-based; dataset.py:330-381)."""
+    with open(os.path.join(root, 'annot', image_set + '.json')) as f:
+        anno = json.load(f)
+    out = []
+    for a in anno:
+        c = np.array(a['center'], dtype=np.float64)
+        s = np.array([a['scale'], a['scale']], dtype=np.float64)
+        if c[0] != -1:                          # keep limbs inside the crop
+            c[1] = c[1] + 15 * s[1]
+            s = s * 1.25
+        c = c - 1
+        joints = np.zeros((num_joints, 3), dtype=np.float64)
+        vis = np.zeros((num_joints, 3), dtype=np.float64)
+        if image_set != 'test':
+            j = np.array(a['joints'], dtype=np.float64)
+            assert len(j) == num_joints, 'joint num diff: {} vs {}'.format(len(j), num_joints)
+            joints[:, 0:2] = j[:, 0:2] - 1
+            v = np.array(a['joints_vis'])
+            vis[:, 0] = v
+            vis[:, 1] = v
+        out.append({'image': os.path.join(root, 'images', a['image']), 'center': c, 'scale': s,
+                    'joints_3d': joints, 'joints_3d_vis': vis})
+    return out
+
+
+def kinect_to_mpii(joints25):
+    return np.asarray(joints25)[KINECT_TO_MPII].reshape(16, 2)
+
+
+def normalize_joints(joints2d, root_index=6):
+    """root-centred, (x, y) -> (y, x), scaled to max-abs 1 (dataset.py:482-488)."""
+    j = np.array(joints2d, copy=True)
+    j = j - j[root_index, :]
+    j = j[:, ::-1]
+    s = max(j.max(), np.abs(j.min()))
+    return j / s
+
+
+def flip_normalized_joints(norm_joints, pairs=MPII_FLIP_PAIRS):
+    """mirror the second coordinate and swap left/right joints, in place like the reference (:494-500)."""
+    norm_joints[:, 1] = -norm_joints[:, 1]
+    tmp = norm_joints.copy()
+    for i, j in pairs:
+        norm_joints[i, :] = tmp[j, :]
+        norm_joints[j, :] = tmp[i, :]
+    return norm_joints
+
+
+def scale_from_joints(joint2d, joint_vis):
+    """largest distance between two visible joints; 80 when there is none (dataset.py:457-472)."""
+    n = joint2d.shape[0]
+    d = joint2d.reshape(n, 1, 2) - joint2d.reshape(1, n, 2)
+    d = np.sqrt((d ** 2).sum(-1))
+    d[~joint_vis, :] = -1
+    d[:, ~joint_vis] = -1
+    m = d.max()
+    return 80 if (m == -1 or m == 0) else m
+
+
+def _rot(point, rad):
+    sn, cs = np.sin(rad), np.cos(rad)
+    return [point[0] * cs - point[1] * sn, point[0] * sn + point[1] * cs]
+
+
+def _third(a, b):
+    d = a - b
+    return b + np.array([-d[1], d[0]], dtype=np.float32)
+
+
+def affine_from_center_scale(center, scale, rot, output_size):
+    """2x3 matrix mapping the (centre, 200*scale box, rotation) source frame onto the output image
+    (mpii_utils.py:28-60; cv2.getAffineTransform = the exact solve of three point pairs)."""
+    scale_tmp = np.asarray(scale, dtype=np.float64) * 200.0
+    src_w, dst_w, dst_h = scale_tmp[0], output_size[0], output_size[1]
+    src_dir = _rot([0, src_w * -0.5], np.pi * rot / 180)
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center
+    src[1, :] = np.asarray(center) + src_dir
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
+    src[2, :] = _third(src[0, :], src[1, :])
+    dst[2, :] = _third(dst[0, :], dst[1, :])
+    a = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    for i in range(3):
+        a[2 * i] = [src[i, 0], src[i, 1], 1, 0, 0, 0]
+        a[2 * i + 1] = [0, 0, 0, src[i, 0], src[i, 1], 1]
+        b[2 * i], b[2 * i + 1] = dst[i, 0], dst[i, 1]
+    return np.linalg.solve(a, b).reshape(2, 3)
+
+
+def affine_point(pt, t):
+    return np.dot(t, np.array([pt[0], pt[1], 1.0]))[:2]
+
+
+def warp_affine(img, t, out_size):
+    """``cv2.warpAffine(img, t, out_size, flags=INTER_LINEAR)`` for an HxWxC uint8/float array: every output
+    pixel samples the source at t^-1 (x, y) bilinearly; outside the image is 0 (BORDER_CONSTANT)."""
+    w_out, h_out = out_size
+    m = np.vstack([t, [0, 0, 1]])
+    inv = np.linalg.inv(m)[:2]
+    ys, xs = np.mgrid[0:h_out, 0:w_out].astype(np.float64)
+    sx = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
+    sy = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    h, w = img.shape[:2]
+    src = img.astype(np.float64)
+
+    def at(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
+        return v * ok[..., None]
+    out = ((1 - fy) * ((1 - fx) * at(y0, x0) + fx * at(y0, x0 + 1)) + fy * ((1 - fx) * at(y0 + 1, x0) + fx * at(y0 + 1, x0 + 1)))
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8) if img.dtype == np.uint8 else out.astype(img.dtype)
+
+
+def crop_params(width, height, scale, ratio, rng=random):
+    """torchvision.transforms.RandomResizedCrop.get_params restated: ten tries of (area fraction ~ U(scale),
+    log-aspect ~ U(log ratio)), then the central crop at the clamped aspect.  Returns (top, left, h, w)."""
+    area = height * width
+    log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
+    for _ in range(10):
+        target = area * rng.uniform(scale[0], scale[1])
+        aspect = math.exp(rng.uniform(log_ratio[0], log_ratio[1]))
+        w = int(round(math.sqrt(target * aspect)))
+        h = int(round(math.sqrt(target / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            return rng.randint(0, height - h), rng.randint(0, width - w), h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w, h = width, int(round(width / min(ratio)))
+    elif in_ratio > max(ratio):
+        h, w = height, int(round(height * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip):
+    """Items 0-8 of the tuple for an NTU frame, from the decoded (cropped, resized, flipped, normalised) frame
+    ``rgbd`` [6, size, size], the 25 Kinect depth-image joints ``d_loc`` and the crop rectangle
+    ``resize_param = (i, j, h, w, need_flip, original_h, original_w)`` (dataset.py:578-617)."""
+    joints2d = kinect_to_mpii(np.array(d_loc, dtype=np.float32))
+    i, j, h, w, need_flip = resize_param[:5]
+    norm = normalize_joints(joints2d)
+    if random_flip and need_flip:
+        norm = flip_normalized_joints(norm)
+    # the reference compares column 1 against j + w in the last test (it means column 0); mirrored for parity
+    vis = np.logical_and(np.logical_and(joints2d[:, 1] > i, joints2d[:, 1] < i + h),
+                         np.logical_and(joints2d[:, 0] > j, joints2d[:, 1] < j + w))
+    original = joints2d[:, ::-1].copy()
+    original[:, 0] = (original[:, 0] - i) / h * size
+    original[:, 1] = (original[:, 1] - j) / w * size
+    depth = rgbd[3]
+    mask = depth > 0
+    mean = depth.sum() / mask.sum()
+    centred = depth - mean
+    centred[~mask] = 0
+    rgbd = rgbd.clone()
+    rgbd[3:] = centred.unsqueeze(0)
+    original[np.logical_not(vis), :] = 0
+    norm[np.logical_not(vis), :] = 0
+    scale = scale_from_joints(original, vis)
+    return (rgbd, index, torch.from_numpy(norm.copy().astype(np.float32)), joints3d, torch.from_numpy(original.copy()),
+            torch.from_numpy(vis.astype(np.int32).copy()), 1, mask.float(), scale)
+
+
+def _to_tensor_normalised(img_uint8_hwc):
+    x = torch.from_numpy(np.array(img_uint8_hwc, dtype=np.float32))
+    x /= 255.0
+    x -= torch.from_numpy(IMAGENET_MEAN)
+    x /= torch.from_numpy(IMAGENET_STD)
+    return x.permute(2, 0, 1)
+
+
+# --------------------------------------------------------------------------- the dataset
+class NTUMPIIContrastDataset(torch.utils.data.Dataset):
+    """``modal2Dataset['NTUMPIIRGBD2S']`` (= NTUMPIIRGBD3D2DSkeletonGCN): MPII images first, then NTU frames."""
+
+    def __init__(self, ntu_root, ntu_file_list, mpii_root, mpii_image_set='train', size=256, random_flip=False,
+                 random_resized_crop=False):
+        self.root = ntu_root
+        self.file_list = [f.strip() for f in open(ntu_file_list)] if ntu_file_list else []
+        self.size = (size, size)
+        self.random_flip, self.random_resized_crop = random_flip, random_resized_crop
+        self.image_list = [os.path.join(ntu_root, f) for f in self.file_list]
+        self.depth_list = [os.path.join(ntu_root, self._sibling(f, 'HumanRGBD/NTURGBD/nturgb+d_depth_masked', 'MDepth', 'png'))
+                           for f in self.file_list]
+        self.skeleton_list = [os.path.join(ntu_root, self._skeleton_name(f)) for f in self.file_list]
+        self.db = mpii_records(mpii_root, mpii_image_set) if mpii_root else []
+        self.num_joints = 25
+
+    @staticmethod
+    def _sibling(f, prefix, tag, ext):
+        return f.replace('nturgb+d_rgb_warped_correction', prefix).replace('WRGB', tag).replace('jpg', ext)
+
+    @classmethod
+    def _skeleton_name(cls, f):
+        f = cls._sibling(f, 'HumanRGBD/NTURGBD/nturgb+d_parsed_skeleton', 'Skeleton', 'pkl')
+        num = int(f[-12:-4])                     # skeleton frames are numbered from 0, images from 1 (:165-172)
+        return f[:-12] + str(num - 1).zfill(8) + f[-4:]
+
+    def __len__(self):
+        return len(self.db) + len(self.image_list)
+
+    # ---- MPII image -> items 0, 2, 4, 5 (dataset.py:502-562)
+    def _mpii(self, k):
+        rec = self.db[k]
+        img = np.array(Image.open(rec['image']).convert('RGB'))
+        joints, jvis = rec['joints_3d'].copy(), rec['joints_3d_vis']
+        c, s, r = rec['center'], rec['scale'], 0
+        if self.random_resized_crop:
+            s = s * np.clip(np.random.randn() * 0.25 + 1, 0.75, 1.25)
+            r = np.clip(np.random.randn() * 30, -60, 60) if random.random() < 0.6 else 0
+        t = affine_from_center_scale(c, s, r, self.size)
+        img = warp_affine(img, t, self.size)
+        original = joints[:, :2].copy()
+        if self.random_resized_crop:             # (the reference leaves the joints un-warped otherwise)
+            for q in range(jvis.shape[0]):
+                if jvis[q, 0] > 0.0:
+                    original[q, 0:2] = affine_point(joints[q, 0:2], t)
+        norm = normalize_joints(joints[:, :2])
+        original = original[:, ::-1]
+        if self.random_flip and random.random() <= 0.5:
+            img = np.ascontiguousarray(img[:, ::-1, :])
+            norm = flip_normalized_joints(norm)
+            original[:, 1] = self.size[1] - original[:, 1]
+        x = _to_tensor_normalised(img)
+        vis = np.logical_and(np.logical_and(np.logical_and(original[:, 0] >= 0, original[:, 0] < self.size[0]),
+                                            np.logical_and(original[:, 1] >= 0, original[:, 1] < self.size[0])), jvis[:, 0])
+        return torch.cat([x, torch.zeros_like(x)], 0), norm, original, vis
+
+    # ---- NTU frame -> decoded rgbd + crop rectangle (dataset.py:175-250)
+    def _ntu_frame(self, k):
+        img = Image.open(self.image_list[k]).convert('RGB')
+        depth = Image.open(self.depth_list[k])
+        original_h, original_w = img.size[1], img.size[0]
+        with open(self.skeleton_list[k], 'rb') as f:
+            skel = pickle.load(f)
+        body = skel['joints'][0]
+        j3 = np.array(list(body['3d_loc']), dtype=np.float32)
+        joints3d = torch.from_numpy(j3 - j3[0])
+        if self.random_resized_crop:
+            j2 = np.array(list(body['d_loc']))
+            assert not np.any(np.isnan(j2)), self.skeleton_list[k]
+            cx = random.randrange(int(j2[:, 1].min()), int(j2[:, 1].max()))
+            cy = random.randrange(int(j2[:, 0].min()), int(j2[:, 0].max()))
+            _, _, h, w = crop_params(img.size[0], img.size[1], (0.08, 1.2), (1, 1))
+            i, j = int(cx - h / 2.0), int(cy - w / 2.0)
+            box = (j, i, j + w, i + h)
+            img = img.crop(box).resize(self.size[::-1], Image.BILINEAR)
+            depth = depth.crop(box).resize(self.size[::-1], Image.NEAREST)
+        else:
+            i, j, h, w = 0, 0, img.size[0], img.size[1]
+        need_flip = random.random() >= 0.5
+        if self.random_flip and need_flip:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+            depth = depth.transpose(Image.FLIP_LEFT_RIGHT)
+        x = _to_tensor_normalised(np.array(img))
+        d = torch.from_numpy(np.array(depth).astype(np.float32) / 1000.0)
+        rgbd = torch.cat([x, torch.stack([d, d, d], 0)], 0)
+        return rgbd, joints3d, (i, j, h, w, need_flip, original_h, original_w), body['d_loc']
+
+    def __getitem__(self, index):
+        if index < len(self.db):
+            rgbd, norm, original, vis = self._mpii(index)
+            original[np.logical_not(vis), :] = 0
+            norm[np.logical_not(vis), :] = 0
+            return (rgbd, index, torch.from_numpy(norm.copy().astype(np.float32)), torch.zeros([self.num_joints, 3]),
+                    torch.from_numpy(original.copy()), torch.from_numpy(vis.astype(np.int32).copy()), 0,
+                    torch.zeros_like(rgbd[0]), scale_from_joints(original, vis))
+        rgbd, joints3d, resize_param, d_loc = self._ntu_frame(index - len(self.db))
+        return ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, self.size[0], self.random_flip)

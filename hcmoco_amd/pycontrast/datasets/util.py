@@ -1,0 +1,66 @@
+"""``build_own_contrast_loader`` for image datasets (reference: /root/reference/pycontrast/datasets/util.py:456-585):
+the source-balancing ``WeightedRandomSampler``, its distributed wrapper and the DataLoader.  Only the
+NTU + MPII combination (``--dataset NTUMPII --modal RGBD2S``) has a tuple producer in this build
+(datasets/ntu_mpii.py); the COCO / NTU-segmentation variants raise."""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+from torch.utils.data.distributed import DistributedSampler
+from torch.utils.data.sampler import WeightedRandomSampler
+
+
+class _SamplerAsDataset(Dataset):
+    def __init__(self, sampler):
+        self.sampler, self.drawn = sampler, None
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def __getitem__(self, i):
+        if self.drawn is None:
+            self.drawn = list(self.sampler)
+        return self.drawn[i]
+
+
+class DistributedSamplerWrapper(DistributedSampler):
+    """Shards the indices DRAWN by another sampler across ranks (util.py:485-528): each epoch the wrapped
+    sampler is drawn once per process, DistributedSampler picks this rank's positions of that draw."""
+
+    def __init__(self, sampler, num_replicas=None, rank=None, shuffle=True):
+        super().__init__(_SamplerAsDataset(sampler), num_replicas=num_replicas, rank=rank, shuffle=shuffle)
+        self.sampler = sampler
+
+    def __iter__(self):
+        self.dataset.drawn = list(self.sampler)
+        return iter([self.dataset.drawn[i] for i in super().__iter__()])
+
+
+def source_balancing_weights(n_first, n_second):
+    """Per-sample weights that give the two concatenated sources equal mass (util.py:558-581: MPII first)."""
+    n = n_first + n_second
+    w = np.zeros([n])
+    w[:n_first] = n_second / n
+    w[n_first:] = n_first / n
+    return w
+
+
+def build_own_contrast_loader(opt, rank=0, world=1, ngpus_per_node=1):
+    """(dataset, loader, sampler) as ``datasets/util.py:530-585``; ``--batch_size`` is the GLOBAL batch."""
+    key = (opt.dataset or '') + opt.modal
+    if key != 'NTUMPIIRGBD2S':
+        raise NotImplementedError('dataset %r: only NTUMPII + RGBD2S has a tuple producer in this build (COCO needs '
+                                  'pycocotools, the NTU segmentation split its own label files); use --synthetic' % key)
+    from .ntu_mpii import NTUMPIIContrastDataset
+    ds = NTUMPIIContrastDataset(opt.data_folder, opt.train_file_list, opt.mpii_root, 'train',
+                                size=int(getattr(opt, 'image_size', 320)), random_flip=bool(opt.random_flip),
+                                random_resized_crop=True)
+    weights = source_balancing_weights(len(ds.db), len(ds.image_list))
+    sampler = WeightedRandomSampler(weights, len(weights))
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        sampler = DistributedSamplerWrapper(sampler, num_replicas=world, rank=rank)
+    else:
+        sampler.set_epoch = lambda epoch: None
+    workers = int((opt.num_workers + ngpus_per_node - 1) / ngpus_per_node)
+    loader = torch.utils.data.DataLoader(ds, batch_size=max(1, int(opt.batch_size / max(1, world))), shuffle=False,
+                                         num_workers=workers, pin_memory=True, sampler=sampler, drop_last=True)
+    return ds, loader, sampler

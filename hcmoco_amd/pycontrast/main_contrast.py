@@ -37,13 +37,13 @@ def main_worker(gpu, ngpus_per_node, args, engine=None):
 
     model, model_ema = build_model(args)
 
-    if not args.synthetic:
-        raise NotImplementedError(
-            'only --synthetic batches are available: the NTU/MPII/COCO loaders of the reference need cv2, '
-            'torchvision and pycocotools and are outside the hot path (SURVEY 2.1 #14).  A real loader only '
-            'has to yield the positional tuple of SURVEY appendix B.')
-    train_dataset, train_loader, train_sampler = build_synthetic_contrast_loader(
-        args, trainer.device, args.rank, args.world_size)
+    if args.synthetic:
+        train_dataset, train_loader, train_sampler = build_synthetic_contrast_loader(
+            args, trainer.device, args.rank, args.world_size)
+    else:       # image files -> the positional tuple of SURVEY appendix B (datasets/ntu_mpii.py, PIL + numpy)
+        from .datasets.util import build_own_contrast_loader
+        train_dataset, train_loader, train_sampler = build_own_contrast_loader(
+            args, args.rank, args.world_size, ngpus_per_node)
 
     contrast = build_mem(args, len(train_dataset))
     contrast.to(trainer.device)

@@ -97,6 +97,8 @@ BASE_FLAGS = [
     (('--synthetic_n_data',), dict(type=_I, default=131072)),
     (('--synthetic_size',), dict(type=_I, default=256)),
     (('--synthetic_steps',), dict(type=_I, default=50, help='batches per epoch in synthetic mode')),
+    (('--image_size',), dict(type=_I, default=320, help='side of the square crops of the image datasets (the '
+                                                        'reference hard-codes its class default, 320)')),
     (('--synthetic_ntu',), dict(type=_I, default=0,
                                 help='synthetic batches carry the NTU-only items 9-15 (use_rgb at position 11)')),
     (('--synthetic_p_rgb',), dict(type=float, default=1.0, help='P(use_rgb = 1) of NTU-style synthetic samples')),

@@ -528,12 +528,137 @@ def gen_trace():
         npz('trace_stage%d' % stage, **arrays)
 
 
+# --------------------------------------------------------------------------- #
+# 10. dataset tuple producers (datasets/dataset.py:306-617, datasets/mpii_utils.py:14-65): the numpy / torch
+#     arithmetic AROUND the image decoding.  cv2 / torchvision / json_tricks / pycocotools are not in the image:
+#     process-local stub modules let `datasets.dataset` import; the functions driven here never touch them, except
+#     get_affine_transform (calls cv2.getAffineTransform = the exact solve of three point pairs, stubbed with
+#     numpy.linalg.solve) and the *_getitem__ branches whose decoded image / super().__getitem__ result is injected.
+# --------------------------------------------------------------------------- #
+def install_dataset_stubs():
+    import json
+    np.float = float                                   # numpy 2 dropped the alias the reference uses (:341-353)
+    cv2 = types.ModuleType('cv2')
+
+    def get_affine(src, dst):
+        a = np.zeros((6, 6), np.float64)
+        b = np.zeros(6, np.float64)
+        for i in range(3):
+            a[2 * i] = [src[i][0], src[i][1], 1, 0, 0, 0]
+            a[2 * i + 1] = [0, 0, 0, src[i][0], src[i][1], 1]
+            b[2 * i], b[2 * i + 1] = dst[i][0], dst[i][1]
+        return np.linalg.solve(a, b).reshape(2, 3)
+    cv2.getAffineTransform = get_affine
+    cv2.INTER_LINEAR, cv2.IMREAD_COLOR, cv2.IMREAD_IGNORE_ORIENTATION, cv2.COLOR_BGR2RGB = 1, 1, 128, 4
+    sys.modules['cv2'] = cv2
+    tv = types.ModuleType('torchvision')
+    tvd = types.ModuleType('torchvision.datasets')
+    tvd.ImageFolder = type('ImageFolder', (), {})
+    tvt = types.ModuleType('torchvision.transforms')
+    tvf = types.ModuleType('torchvision.transforms.functional')
+    tv.datasets, tv.transforms, tvt.functional = tvd, tvt, tvf
+    sys.modules.update({'torchvision': tv, 'torchvision.datasets': tvd, 'torchvision.transforms': tvt,
+                        'torchvision.transforms.functional': tvf})
+    jt = types.ModuleType('json_tricks')
+    jt.load, jt.loads, jt.dump, jt.dumps = json.load, json.loads, json.dump, json.dumps
+    sys.modules['json_tricks'] = jt
+    pc = types.ModuleType('pycocotools')
+    pcc = types.ModuleType('pycocotools.coco')
+    pcc.COCO = type('COCO', (), {})
+    pc.coco = pcc
+    sys.modules.update({'pycocotools': pc, 'pycocotools.coco': pcc})
+    for name in ('skimage', 'skimage.io', 'skimage.transform', 'h5py', 'scipy.io'):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+
+
+def gen_dataset():
+    import json
+    import tempfile
+    install_dataset_stubs()
+    # the reference's datasets/ has no __init__.py and a `datasets` distribution is installed in this image:
+    # load the directory as an explicitly-pathed package so that its relative imports resolve
+    import importlib
+    pkg = types.ModuleType('refdatasets')
+    pkg.__path__ = [os.path.join(REF, 'datasets')]
+    sys.modules['refdatasets'] = pkg
+    D = importlib.import_module('refdatasets.dataset')
+    MU = importlib.import_module('refdatasets.mpii_utils')
+    g = np.random.RandomState(77)
+    arrays = {}
+    # --- MPII annotation records (:330-381)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, 'annot'))
+    anno = []
+    for k in range(4):
+        joints = (g.rand(16, 2) * 300 + 20).round(2)
+        vis = (g.rand(16) < 0.8).astype(int)
+        anno.append({'image': 'im%d.jpg' % k, 'center': [float(150 + 10 * k), float(120 - 5 * k)] if k != 2 else [-1.0, -1.0],
+                     'scale': float(1.1 + 0.3 * k), 'joints': joints.tolist(), 'joints_vis': vis.tolist()})
+    with open(os.path.join(tmp, 'annot', 'train.json'), 'w') as f:
+        json.dump(anno, f)
+    obj = D.NTUMPIIRGBD3D2DSkeletonGCN.__new__(D.NTUMPIIRGBD3D2DSkeletonGCN)
+    db = obj._get_db(tmp, 'train', 16, 'jpg')
+    arrays['mpii_anno_json'] = np.array(json.dumps(anno))
+    arrays['mpii_center'] = np.stack([r['center'] for r in db])
+    arrays['mpii_scale'] = np.stack([r['scale'] for r in db])
+    arrays['mpii_joints'] = np.stack([r['joints_3d'] for r in db])
+    arrays['mpii_joints_vis'] = np.stack([r['joints_3d_vis'] for r in db])
+    arrays['mpii_image'] = np.array([os.path.relpath(r['image'], tmp) for r in db])
+    # --- joint bookkeeping
+    k25 = g.rand(25, 2).astype(np.float32) * 400
+    arrays['kinect25'] = k25
+    arrays['kinect2mpii'] = obj.Kinect2MPII(k25)
+    obj.flip_pairs = [[0, 5], [1, 4], [2, 3], [10, 15], [11, 14], [12, 13]]
+    j16 = g.rand(16, 2).astype(np.float32) * 200
+    arrays['joints16'] = j16
+    arrays['norm_myway'] = obj.normalize_joints_myway(j16)
+    arrays['norm_flipped'] = obj.flip_normalized_joints(obj.normalize_joints_myway(j16).copy())
+    vis = g.rand(16) < 0.7
+    arrays['vis16'] = vis
+    arrays['scale_mpii'] = np.float64(D.generate_scale_mpii(j16.astype(np.float64), vis))
+    arrays['scale_mpii_none'] = np.float64(D.generate_scale_mpii(j16.astype(np.float64), np.zeros(16, bool)))
+    # --- affine helpers (mpii_utils.py:14-65)
+    for k, (c, s, r) in enumerate([((150., 120.), (1.2, 1.2), 0.0), ((88.5, 240.25), (2.0, 2.0), 17.5),
+                                   ((10., 10.), (0.7, 0.7), -41.0)]):
+        t = MU.get_affine_transform(np.array(c), np.array(s), r, (256, 256))
+        arrays['affine%d_in' % k] = np.array([c[0], c[1], s[0], s[1], r])
+        arrays['affine%d' % k] = t
+        arrays['affine%d_pt' % k] = MU.affine_transform(np.array([31.0, 77.0]), t)
+    # --- NTU branch of the GCN tuple (:570-617) with the decoded frame injected
+    size = 64
+    obj.size, obj.random_flip, obj.random_resized_crop = (size, size), True, True
+    obj.db, obj.mpii_num_joints, obj.num_joints = [], 16, 25
+    depth = torch.from_numpy((g.rand(size, size) * 3000).astype(np.float32) / 1000.0)
+    depth[:, :20] = 0
+    rgbd = torch.cat([torch.from_numpy(g.randn(3, size, size).astype(np.float32)), torch.stack([depth] * 3)], 0)
+    dloc = (g.rand(25, 2) * np.array([400, 300]) + np.array([500, 300])).astype(np.float32)
+    joints3d = torch.from_numpy(g.randn(25, 3).astype(np.float32))
+    resize_param = (350, 520, 380, 380, True, 1080, 1920)
+    skel = {'joints': [{'d_loc': [list(map(float, p)) for p in dloc]}]}
+    orig = D.NTURGBD3DSkeleton.__getitem__
+    D.NTURGBD3DSkeleton.__getitem__ = lambda self, index, return_resize_param=False: (rgbd.clone(), index, joints3d, resize_param, skel)
+    try:
+        out = obj[5]
+    finally:
+        D.NTURGBD3DSkeleton.__getitem__ = orig
+    arrays.update(ntu_rgbd_in=rgbd, ntu_dloc=dloc, ntu_joints3d=joints3d, ntu_resize_param=np.array(resize_param[:4] + resize_param[5:]),
+                  ntu_need_flip=resize_param[4], ntu_size=size)
+    names = ['rgbd', 'index', 'norm_joints', 'joints3d', 'original_joints2d', 'joints_vis', 'true_depth', 'depth_mask', 'scale']
+    for n, v in zip(names, out):
+        arrays['ntu_out_' + n] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+    npz('dataset_tuple', **arrays)
+
+
 if __name__ == '__main__':
     install_shims()
     only = set(sys.argv[1:])
     sys.argv = sys.argv[:1]
     gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
-                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options, trace=gen_trace)
+                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options, trace=gen_trace, dataset=gen_dataset)
     for name, fn in gens.items():
         if not only or name in only:
             fn()

@@ -1,0 +1,198 @@
+"""Dataset tuple producers (reference datasets/dataset.py:306-617, datasets/mpii_utils.py:14-65).
+(1) the arithmetic around the image decoding against vectors recorded from the reference's own functions
+    (tests/golden/gen_golden.py:gen_dataset -> dataset_tuple.npz), bit-exact;
+(2) a miniature NTU + MPII tree written to disk with PIL: the dataset, the source-balancing sampler, the loader and
+    two trainer steps through ``main_contrast.main`` (oracle engine, CPU)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import load_golden
+from hcmoco_amd.pycontrast.datasets import ntu_mpii as N
+from hcmoco_amd.pycontrast.datasets.util import DistributedSamplerWrapper, source_balancing_weights
+
+
+def npz():
+    return load_golden('dataset_tuple')
+
+
+def test_mpii_records_match_reference(tmp_path):
+    g = npz()
+    os.makedirs(tmp_path / 'annot')
+    (tmp_path / 'annot' / 'train.json').write_text(str(g['mpii_anno_json']))
+    db = N.mpii_records(str(tmp_path), 'train')
+    assert np.array_equal(np.stack([r['center'] for r in db]), g['mpii_center'].numpy())
+    assert np.array_equal(np.stack([r['scale'] for r in db]), g['mpii_scale'].numpy())
+    assert np.array_equal(np.stack([r['joints_3d'] for r in db]), g['mpii_joints'].numpy())
+    assert np.array_equal(np.stack([r['joints_3d_vis'] for r in db]), g['mpii_joints_vis'].numpy())
+    assert [os.path.relpath(r['image'], tmp_path) for r in db] == [str(s) for s in g['mpii_image']]
+
+
+def test_joint_bookkeeping_matches_reference():
+    g = npz()
+    assert np.array_equal(N.kinect_to_mpii(g['kinect25'].numpy()), g['kinect2mpii'].numpy())
+    j16 = g['joints16'].numpy()
+    assert np.array_equal(N.normalize_joints(j16), g['norm_myway'].numpy())
+    assert np.array_equal(N.flip_normalized_joints(N.normalize_joints(j16).copy()), g['norm_flipped'].numpy())
+    vis = g['vis16'].numpy().astype(bool)
+    assert float(N.scale_from_joints(j16.astype(np.float64), vis)) == float(g['scale_mpii'])
+    assert float(N.scale_from_joints(j16.astype(np.float64), np.zeros(16, bool))) == float(g['scale_mpii_none']) == 80.0
+
+
+def test_affine_matches_reference():
+    g = npz()
+    for k in range(3):
+        cx, cy, sx, sy, r = [float(v) for v in g['affine%d_in' % k]]
+        t = N.affine_from_center_scale(np.array([cx, cy]), np.array([sx, sy]), r, (256, 256))
+        assert np.allclose(t, g['affine%d' % k].numpy(), rtol=0, atol=1e-12)
+        assert np.allclose(N.affine_point(np.array([31.0, 77.0]), t), g['affine%d_pt' % k].numpy(), atol=1e-10)
+    # the matrix maps the box centre to the image centre and keeps distances scaled by out / (200 * scale)
+    t = N.affine_from_center_scale(np.array([100.0, 60.0]), np.array([1.0, 1.0]), 0.0, (256, 256))
+    assert np.allclose(N.affine_point([100.0, 60.0], t), [128.0, 128.0])
+    assert np.allclose(N.affine_point([200.0, 60.0], t), [128.0 + 100 * 256 / 200.0, 128.0])
+
+
+def test_ntu_tuple_matches_reference():
+    """Items 0-8 for an NTU frame from an injected decoded frame: normalised depth, mask, joint re-ordering,
+    visibility (with the reference's column quirk), flipped normalised skeleton, crop-relative pixel joints, scale."""
+    g = npz()
+    rp = [int(v) for v in g['ntu_resize_param']]
+    resize_param = (rp[0], rp[1], rp[2], rp[3], bool(g['ntu_need_flip']), rp[4], rp[5])
+    out = N.ntu_tuple(g['ntu_rgbd_in'].clone(), 5, g['ntu_joints3d'], resize_param, g['ntu_dloc'].numpy(),
+                      int(g['ntu_size']), random_flip=True)
+    names = ['rgbd', 'index', 'norm_joints', 'joints3d', 'original_joints2d', 'joints_vis', 'true_depth', 'depth_mask', 'scale']
+    for n, v in zip(names, out):
+        want = g['ntu_out_' + n]
+        if isinstance(want, torch.Tensor):
+            got = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            assert got.dtype == want.dtype and torch.equal(got, want), n
+        else:
+            assert float(v) == float(want), n
+    assert int(out[5].sum()) not in (0, 16)            # the fixture has visible and invisible joints
+
+
+def test_warp_affine_identity_shift_and_border():
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 255, (20, 30, 3)).astype(np.uint8)
+    ident = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    assert np.array_equal(N.warp_affine(img, ident, (30, 20)), img)
+    shift = np.array([[1.0, 0, 3], [0, 1.0, -2]])              # dst(x, y) = src(x - 3, y + 2)
+    out = N.warp_affine(img, shift, (30, 20))
+    assert np.array_equal(out[0:18, 3:30], img[2:20, 0:27]) and int(out[:, :3].sum()) == 0 and int(out[18:].sum()) == 0
+    half = np.array([[0.5, 0, 0], [0, 0.5, 0]])                # down-scale by 2: samples every second pixel exactly
+    assert np.array_equal(N.warp_affine(img, half, (15, 10)), img[::2, ::2])
+
+
+def test_crop_params_stay_inside_and_respect_ratio():
+    import random
+    rng = random.Random(3)
+    for _ in range(200):
+        top, left, h, w = N.crop_params(1920, 1080, (0.08, 1.0), (1, 1), rng)
+        assert 0 <= top <= 1080 - h and 0 <= left <= 1920 - w and h == w and h > 0
+    top, left, h, w = N.crop_params(1920, 1080, (3.0, 4.0), (1, 1), rng)       # impossible area: central fallback
+    assert (h, w) == (1080, 1080) and top == 0 and left == (1920 - 1080) // 2
+
+
+def test_sampler_weights_and_distributed_wrapper():
+    w = source_balancing_weights(3, 9)
+    assert np.isclose(w[:3].sum(), w[3:].sum())                # both sources carry the same probability mass
+    base = torch.utils.data.WeightedRandomSampler(w, 12)
+    a = DistributedSamplerWrapper(base, num_replicas=2, rank=0, shuffle=False)
+    b = DistributedSamplerWrapper(base, num_replicas=2, rank=1, shuffle=False)
+    torch.manual_seed(5)
+    ia = list(a)
+    torch.manual_seed(5)
+    ib = list(b)
+    torch.manual_seed(5)
+    drawn = list(base)
+    assert len(ia) == len(ib) == 6 and sorted(ia + ib) == sorted(drawn)        # the two ranks split ONE draw
+
+
+def _write_tree(root, n_ntu=5, n_mpii=3, seed=0):
+    """A miniature copy of the on-disk layout the reference expects (dataset.py:85-93, :165-172, :330-381)."""
+    rng = np.random.RandomState(seed)
+    rel = []
+    for k in range(n_ntu):
+        name = 'nturgb+d_rgb_warped_correction/S001C001P001R001A001/WRGB-%08d.jpg' % (k + 1)
+        rel.append(name)
+        rgb = (rng.rand(108, 192, 3) * 255).astype(np.uint8)
+        depth = np.zeros((108, 192), np.uint16)
+        depth[20:90, 60:130] = (2000 + rng.rand(70, 70) * 1500).astype(np.uint16)
+        skel = {'joints': [{'3d_loc': (rng.randn(25, 3)).tolist(),
+                            'd_loc': (np.array([60, 20]) + rng.rand(25, 2) * np.array([70, 70])).tolist()}]}
+        for path, writer in ((name, lambda p: Image.fromarray(rgb).save(p, quality=95)),
+                             (N.NTUMPIIContrastDataset._sibling(name, 'HumanRGBD/NTURGBD/nturgb+d_depth_masked', 'MDepth', 'png'),
+                              lambda p: Image.fromarray(depth).save(p)),
+                             (N.NTUMPIIContrastDataset._skeleton_name(name), lambda p: pickle.dump(skel, open(p, 'wb')))):
+            full = os.path.join(root, path)
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            writer(full)
+    flist = os.path.join(root, 'flist.txt')
+    open(flist, 'w').write('\n'.join(rel) + '\n')
+    mpii = os.path.join(root, 'mpii')
+    os.makedirs(os.path.join(mpii, 'annot'))
+    os.makedirs(os.path.join(mpii, 'images'))
+    anno = []
+    for k in range(n_mpii):
+        Image.fromarray((rng.rand(120, 160, 3) * 255).astype(np.uint8)).save(os.path.join(mpii, 'images', 'm%d.jpg' % k))
+        anno.append({'image': 'm%d.jpg' % k, 'center': [80.0, 55.0], 'scale': 0.5,
+                     'joints': (np.array([30, 10]) + rng.rand(16, 2) * 100).tolist(), 'joints_vis': [1] * 14 + [0, 1]})
+    json.dump(anno, open(os.path.join(mpii, 'annot', 'train.json'), 'w'))
+    return flist, mpii
+
+
+def test_dataset_yields_the_positional_tuple(tmp_path):
+    flist, mpii = _write_tree(str(tmp_path))
+    ds = N.NTUMPIIContrastDataset(str(tmp_path), flist, mpii, 'train', size=64, random_flip=True, random_resized_crop=True)
+    assert len(ds) == 8 and len(ds.db) == 3
+    for index in (0, 2, 3, 7):
+        t = ds[index]
+        assert len(t) == 9
+        rgbd, idx, norm, j3, orig, vis, true_depth, mask, scale = t
+        assert rgbd.shape == (6, 64, 64) and rgbd.dtype == torch.float32 and idx == index
+        assert norm.shape == (16, 2) and norm.dtype == torch.float32 and float(norm.abs().max()) <= 1.0 + 1e-6
+        assert j3.shape == (25, 3) and orig.shape == (16, 2) and vis.shape == (16,) and vis.dtype == torch.int32
+        assert mask.shape == (64, 64) and mask.dtype == torch.float32 and float(scale) > 0
+        assert bool((orig[vis == 0] == 0).all()) and bool((norm[vis == 0] == 0).all())
+        if index < 3:              # MPII: RGB only
+            assert true_depth == 0 and float(mask.sum()) == 0 and float(rgbd[3:].abs().sum()) == 0 and int(vis[14]) == 0
+        else:                      # NTU: masked, mean-centred depth replicated on three channels
+            assert true_depth == 1 and float(mask.sum()) > 0
+            d = rgbd[3]
+            assert torch.equal(rgbd[4], d) and torch.equal(rgbd[5], d) and bool((d[mask == 0] == 0).all())
+            assert abs(float(d[mask > 0].mean())) < 1e-3
+    # no augmentation: the NTU frame is decoded as is (normalised RGB, depth in metres minus its mean)
+    plain = N.NTUMPIIContrastDataset(str(tmp_path), flist, None, size=64)
+    rgbd = plain[0][0]
+    img = np.array(Image.open(plain.image_list[0]).convert('RGB'), dtype=np.float32) / 255.0
+    want = (torch.from_numpy(img) - torch.tensor([0.485, 0.456, 0.406])) / torch.tensor([0.229, 0.224, 0.225])
+    assert torch.allclose(rgbd[:3], want.permute(2, 0, 1).float(), atol=1e-6)
+
+
+def test_image_dataset_drives_the_training_loop(tmp_path, monkeypatch):
+    """``main_contrast.py --dataset NTUMPII`` (no --synthetic): files -> loader -> positional tuple -> two stage-2
+    steps of the real trainer (oracle loss engine on CPU); MPII samples enter with use_depth = 0."""
+    from hcmoco_amd.pycontrast import main_contrast
+    from oracle.oracle_engine import OracleLossEngine
+    flist, mpii = _write_tree(str(tmp_path / 'data'), n_ntu=6, n_mpii=4)
+    monkeypatch.setenv('MASTER_PORT', str(26000 + os.getpid() % 2000))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
+        monkeypatch.delenv(k, raising=False)
+    argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list',
+            '3,3', '--batch_size', '4', '--nce_k', '8', '--world-size', '1', '--dist-backend', 'gloo', '--dataset', 'NTUMPII',
+            '--data_folder', str(tmp_path / 'data'), '--train_file_list', flist, '--mpii_root', mpii, '--image_size', '64',
+            '--num_workers', '0', '--epochs', '1', '--print_freq', '1', '--save_freq', '1', '--model_path', str(tmp_path),
+            '--tb_path', str(tmp_path), '--seed', '1', '--learning_rate', '0.01', '--linear_feat_map', '1',
+            '--modality_missing', '1', '--pri3d_num_samples_per_image', '8', '--skeleton_meta_name', 'mpii', '--random_flip', '1']
+    try:
+        outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    assert len(outs) == 4 and outs[0] == outs[0]
+    assert contrast.memory_1.shape[0] == 10              # the bank is sized by len(train_dataset) (main_contrast.py:49)

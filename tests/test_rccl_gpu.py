@@ -204,3 +204,50 @@ def test_two_ranks_on_one_gpu_stay_bit_identical(mode, tmp_path):
         assert r0['launched'] == [2 * 4 + 1] * 3, r0['launched']
     else:
         assert r0['launched'] == [1, 1, 1]
+
+
+def test_hrnetpn_under_a_one_rank_rccl_group(tmp_path):
+    """Config 4's model (HRNet + PointNet++ + SemGCN) through the N>1 control path on RCCL: one HRNet goes chunk by
+    chunk, the PointNet++ shared MLPs (deferred weight gradients on their own stream) are joined before they
+    travel in the rest bucket.  One rank => every collective is the identity => gradients unchanged by reduce()."""
+    import bench
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    dev = torch.device('cuda:0')
+    args = bench.make_args(4, 1024, 4096, 64, 'coco17', 'nccl', str(tmp_path), 3, arch='HRNetPN', width=18)
+    args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
+    args.grad_sync = 'overlap'
+    os.environ['HCM_GRAD_CHUNKS'] = str(CHUNKS)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % (27000 + os.getpid() % 2000), rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        tr = ContrastTrainer(args, force_collectives=True)
+        tr.device = dev
+        model, contrast, opt, data = bench.build(args, tr, dev)
+        sync, bad, launched = tr.grad_sync, [], []
+        real = sync.reduce
+
+        def checked(join=None):
+            if join is not None:
+                join()
+            torch.cuda.synchronize()
+            snap = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+            n = real(None)
+            torch.cuda.synchronize()
+            bad.extend(k for k, p in model.named_parameters()
+                       if (snap[k] is None and float(p.grad.abs().max()) != 0.0)
+                       or (snap[k] is not None and not torch.equal(p.grad, snap[k])))
+            launched.append(n)
+            return n
+        sync.reduce = checked
+        it = iter(data)
+        for _ in range(2):
+            out = tr.train_step(next(it), model, contrast, opt, True)
+        torch.cuda.synchronize()
+        assert bad == [] and launched == [CHUNKS + 1, CHUNKS + 1], (bad[:5], launched)
+        assert bool(torch.isfinite(out['loss']))
+    finally:
+        _lib.torch_glue().set_async_wgrad(False)
+        _lib.torch_glue().set_grad_chunks(0)
+        if dist.is_initialized():
+            dist.destroy_process_group()
