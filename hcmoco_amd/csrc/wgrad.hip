@@ -25,6 +25,9 @@
 // K real dY rows (+ one shared zero row for the padded channels) in LDS lets four workgroups share a CU.
 // A first attempt fed dY through the scalar cache into packed VALU FMAs (one lane per (c,tap), K
 // accumulators): correct, but every 4 pixels waited on ~9 scalar-load round trips -- 111 us at 18ch@64^2.
+#include <cstdio>
+#include <cstdlib>
+
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
 
@@ -200,7 +203,16 @@ __global__ __launch_bounds__(1024) void wgrad3x3_reduce_kernel(const float* __re
 // (MT, NTW) instantiations: K <= 16*MT, at most ~24 tiles (96 accumulator registers) per wave
 // (MT, NTW, waves across N) per K: few N tiles per workgroup where K is small (more workgroups across
 // N, fewer and smaller partials), at most ~24 tiles (96 accumulator registers) per wave
+bool pick_tiles_default(int mt, int& ntw, int& wn_max);
+// HCM_WGRAD_WN<mt>=<waves across N> overrides the table below (tuning sweeps, tools/bench_wgrad.py)
 bool pick_tiles(int mt, int& ntw, int& wn_max) {
+  if (!pick_tiles_default(mt, ntw, wn_max)) return false;
+  char name[32];
+  snprintf(name, sizeof(name), "HCM_WGRAD_WN%d", mt);
+  if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= 1 && v <= 8) wn_max = v; }
+  return true;
+}
+bool pick_tiles_default(int mt, int& ntw, int& wn_max) {
   wn_max = 4;
   switch (mt) {
     case 1: ntw = 12; return true;
@@ -235,7 +247,8 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g)
   for (;;) {
     g.dstride = rb * W + 4;
     size_t bytes = ((size_t)g.cmax * (st * rb + 2) * (st * W + 8) + (size_t)(K + 1) * g.dstride) * 4;
-    if (bytes <= 48 * 1024 || rb == 1) break;
+    static const size_t cap = (size_t)(getenv("HCM_WGRAD_LDS_KB") ? atoi(getenv("HCM_WGRAD_LDS_KB")) : 48) * 1024;
+    if (bytes <= cap || rb == 1) break;
     rb = (rb + 1) / 2;
   }
   g.rb = rb;
@@ -250,7 +263,14 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g)
   size_t red = (size_t)(wp - 1) * wn * g.mt * g.ntw * 64 * 16;
   g.lds_bytes = tile > red ? tile : red;
   if (g.lds_bytes > 150 * 1024) return false;
-  int want = 1024 / g.ngroups;
+  // workgroups along the reduction.  r02 sweep (tools/sweep_wgrad.sh): for the wide layers (K >= 65) 256 instead of
+  // 1024 and two waves across N make the ISOLATED kernel faster than MIOpen's five launches (72ch@16x16: 28 -> 21.7 us
+  // vs 30.8; 144ch@8x8 27.7 vs 28.7), but routing those layers here is SLOWER in the step (625 vs 632 samples/s:
+  // 512-thread workgroups with 30-50 KB of LDS crowd out the other encoder's stream) -- the defaults stay as in r01
+  // and the wide layers stay on MIOpen; HCM_WGRAD_WANT_WIDE / HCM_WGRAD_WN<mt> / HCM_WGRAD_LDS_KB keep the sweep runnable
+  static const int target = getenv("HCM_WGRAD_WANT") ? atoi(getenv("HCM_WGRAD_WANT")) : 1024;
+  static const int target_wide = getenv("HCM_WGRAD_WANT_WIDE") ? atoi(getenv("HCM_WGRAD_WANT_WIDE")) : 1024;
+  int want = (g.mt >= 5 ? target_wide : target) / g.ngroups;
   if (want < 1) want = 1;
   if (want > g.units) want = g.units;
   g.per = (g.units + want - 1) / want;

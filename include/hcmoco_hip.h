@@ -56,6 +56,9 @@ int hcm_alias_draw(const float* prob, const int64_t* alias, int64_t n,
  * the six logit sets averages over (contrast_trainer.py:223-250; sets are ordered
  * 12,21,23,32,13,31).  Outputs: losses[6], accs[6] (percent), gx1..gx3 [B, D]
  * (d sum(losses) / d x), all fp32.  logits are never materialised.
+ * Every value of idx (and of all_y in hcm_bank_update) must lie in [0, n): like a raw gather the kernels do
+ * not range-check -- torch's index_select / index_copy_ would device-assert.  The host mirror
+ * (memory/mem_bank.py:CMCMem3) clamps what it passes and raises from check_indices().
  * ------------------------------------------------------------------------ */
 size_t hcm_bank_nce_workspace_bytes(int B, int K1, int D);
 int hcm_bank_nce_fused(const float* bank1, const float* bank2, const float* bank3, int64_t n,
