@@ -1,4 +1,4 @@
-"""NTU RGB-D + MPII tuple producer (``--dataset NTUMPII --modal RGBD2S``): the positional batch tuple the
+"""NTU RGB-D + MPII / COCO tuple producers (``--dataset NTUMPII | NTUCOCO --modal RGBD2S``): the positional batch tuple the
 trainer indexes from image files.
 
 Reference: /root/reference/pycontrast/datasets/dataset.py:65-250 (NTU frame: RGB jpg, masked 16-bit depth png,
@@ -178,15 +178,17 @@ def crop_params(width, height, scale, ratio, rng=random):
     return (height - h) // 2, (width - w) // 2, h, w
 
 
-def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip):
+def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip, select=KINECT_TO_MPII,
+              flip_pairs=MPII_FLIP_PAIRS):
     """Items 0-8 of the tuple for an NTU frame, from the decoded (cropped, resized, flipped, normalised) frame
     ``rgbd`` [6, size, size], the 25 Kinect depth-image joints ``d_loc`` and the crop rectangle
-    ``resize_param = (i, j, h, w, need_flip, original_h, original_w)`` (dataset.py:578-617)."""
-    joints2d = kinect_to_mpii(np.array(d_loc, dtype=np.float32))
+    ``resize_param = (i, j, h, w, need_flip, original_h, original_w)`` (dataset.py:578-617; :924-955 for the
+    13-joint COCO skeleton: ``select`` = KinectReduce, ``flip_pairs`` = the COCO pairs)."""
+    joints2d = np.array(d_loc, dtype=np.float32)[select].reshape(len(select), 2)
     i, j, h, w, need_flip = resize_param[:5]
     norm = normalize_joints(joints2d)
     if random_flip and need_flip:
-        norm = flip_normalized_joints(norm)
+        norm = flip_normalized_joints(norm, flip_pairs)
     # the reference compares column 1 against j + w in the last test (it means column 0); mirrored for parity
     vis = np.logical_and(np.logical_and(joints2d[:, 1] > i, joints2d[:, 1] < i + h),
                          np.logical_and(joints2d[:, 0] > j, joints2d[:, 1] < j + w))
@@ -218,6 +220,14 @@ def _to_tensor_normalised(img_uint8_hwc):
 # --------------------------------------------------------------------------- the dataset
 class NTUMPIIContrastDataset(torch.utils.data.Dataset):
     """``modal2Dataset['NTUMPIIRGBD2S']`` (= NTUMPIIRGBD3D2DSkeletonGCN): MPII images first, then NTU frames."""
+    KINECT_SELECT = KINECT_TO_MPII       # Kinect joints that make up this skeleton, in its order
+    FLIP_PAIRS = MPII_FLIP_PAIRS         # left/right pairs of the 2-D pose source's own joint order
+
+    def _records(self, root, image_set):
+        return mpii_records(root, image_set)
+
+    def _reduce(self, norm, original, vis):
+        return norm, original, vis
 
     def __init__(self, ntu_root, ntu_file_list, mpii_root, mpii_image_set='train', size=256, random_flip=False,
                  random_resized_crop=False):
@@ -229,7 +239,7 @@ class NTUMPIIContrastDataset(torch.utils.data.Dataset):
         self.depth_list = [os.path.join(ntu_root, self._sibling(f, 'HumanRGBD/NTURGBD/nturgb+d_depth_masked', 'MDepth', 'png'))
                            for f in self.file_list]
         self.skeleton_list = [os.path.join(ntu_root, self._skeleton_name(f)) for f in self.file_list]
-        self.db = mpii_records(mpii_root, mpii_image_set) if mpii_root else []
+        self.db = self._records(mpii_root, mpii_image_set) if mpii_root else []
         self.num_joints = 25
 
     @staticmethod
@@ -265,7 +275,7 @@ class NTUMPIIContrastDataset(torch.utils.data.Dataset):
         original = original[:, ::-1]
         if self.random_flip and random.random() <= 0.5:
             img = np.ascontiguousarray(img[:, ::-1, :])
-            norm = flip_normalized_joints(norm)
+            norm = flip_normalized_joints(norm, self.FLIP_PAIRS)
             original[:, 1] = self.size[1] - original[:, 1]
         x = _to_tensor_normalised(img)
         vis = np.logical_and(np.logical_and(np.logical_and(original[:, 0] >= 0, original[:, 0] < self.size[0]),
@@ -306,10 +316,91 @@ class NTUMPIIContrastDataset(torch.utils.data.Dataset):
     def __getitem__(self, index):
         if index < len(self.db):
             rgbd, norm, original, vis = self._mpii(index)
+            norm, original, vis = self._reduce(norm, original, vis)
             original[np.logical_not(vis), :] = 0
             norm[np.logical_not(vis), :] = 0
             return (rgbd, index, torch.from_numpy(norm.copy().astype(np.float32)), torch.zeros([self.num_joints, 3]),
                     torch.from_numpy(original.copy()), torch.from_numpy(vis.astype(np.int32).copy()), 0,
                     torch.zeros_like(rgbd[0]), scale_from_joints(original, vis))
         rgbd, joints3d, resize_param, d_loc = self._ntu_frame(index - len(self.db))
-        return ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, self.size[0], self.random_flip)
+        if self.random_flip and resize_param[4] and max(max(p) for p in self.FLIP_PAIRS) >= len(self.KINECT_SELECT):
+            # the reference applies the 17-joint COCO pairs to its 13-joint NTU skeleton here and dies with an
+            # IndexError (dataset.py:820-826, :936-937); its scripts never pass --random_flip for this dataset
+            raise IndexError('flip pairs of the 2-D pose source do not fit the %d-joint NTU skeleton '
+                             '(same failure as the reference; run without --random_flip)' % len(self.KINECT_SELECT))
+        return ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, self.size[0], self.random_flip,
+                         self.KINECT_SELECT, self.FLIP_PAIRS)
+
+
+# --------------------------------------------------------------------------- NTU + COCO (13-joint skeleton)
+COCO_FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]      # dataset.py:651-652
+COCO_TO_REDUCED = [16, 14, 12, 11, 13, 15, 0, 10, 8, 6, 5, 7, 9]                                # COCOReduce, :889-903
+KINECT_TO_REDUCED = [14, 13, 12, 16, 17, 18, 3, 6, 5, 4, 8, 9, 10]                              # KinectReduce, :905-907
+
+
+def box_to_center_scale(x, y, w, h, aspect_ratio=1.0, pixel_std=200):
+    """COCO box -> (centre, scale) of the crop (dataset.py:776-791)."""
+    center = np.zeros((2), dtype=np.float32)
+    center[0] = x + w * 0.5
+    center[1] = y + h * 0.5
+    if w > aspect_ratio * h:
+        h = w * 1.0 / aspect_ratio
+    elif w < aspect_ratio * h:
+        w = h * aspect_ratio
+    scale = np.array([w * 1.0 / pixel_std, h * 1.0 / pixel_std], dtype=np.float32)
+    if center[0] != -1:
+        scale = scale * 1.25
+    return center, scale
+
+
+def coco_records(root, image_set='train2014', num_joints=17):
+    """person_keypoints_<set>.json -> one record per annotated person (dataset.py:698-770), read with ``json``
+    instead of pycocotools: images in id order, their non-crowd annotations in file order, boxes clipped to the
+    image, persons without any labelled keypoint dropped."""
+    prefix = 'person_keypoints' if 'test' not in image_set else 'image_info'
+    with open(os.path.join(root, 'annotations', prefix + '_' + image_set + '.json')) as f:
+        data = json.load(f)
+    person = [c['id'] for c in data['categories']][0]            # class index 1 = the first category
+    by_image = {}
+    for a in data.get('annotations', []):
+        if not a.get('iscrowd', 0):
+            by_image.setdefault(a['image_id'], []).append(a)
+    out = []
+    for im in data['images']:
+        width, height = im['width'], im['height']
+        for obj in by_image.get(im['id'], []):
+            x, y, w, h = obj['bbox']
+            x1, y1 = np.max((0, x)), np.max((0, y))
+            x2 = np.min((width - 1, x1 + np.max((0, w - 1))))
+            y2 = np.min((height - 1, y1 + np.max((0, h - 1))))
+            if not (obj['area'] > 0 and x2 >= x1 and y2 >= y1):
+                continue
+            if obj['category_id'] != person or max(obj['keypoints']) == 0:
+                continue
+            joints = np.zeros((num_joints, 3), dtype=np.float64)
+            vis = np.zeros((num_joints, 3), dtype=np.float64)
+            for k in range(num_joints):
+                joints[k, 0], joints[k, 1] = obj['keypoints'][3 * k], obj['keypoints'][3 * k + 1]
+                v = min(obj['keypoints'][3 * k + 2], 1)
+                vis[k, 0], vis[k, 1] = v, v
+            center, scale = box_to_center_scale(x1, y1, x2 - x1, y2 - y1)
+            name = '%012d.jpg' % im['id']
+            if '2014' in image_set:
+                name = 'COCO_%s_' % image_set + name
+            folder = 'test2017' if 'test' in image_set else image_set
+            out.append({'image': os.path.join(root, 'images', folder, name), 'center': center, 'scale': scale,
+                        'joints_3d': joints, 'joints_3d_vis': vis})
+    return out
+
+
+class NTUCOCOContrastDataset(NTUMPIIContrastDataset):
+    """``modal2Dataset['NTUCOCORGBD2S']`` (= NTUCOCORGBD3D2DSkeletonGCN, dataset.py:622-955): COCO persons first
+    (17 keypoints reduced to the 13-joint ``coco_reduce`` skeleton after augmentation), then NTU frames."""
+    KINECT_SELECT = KINECT_TO_REDUCED
+    FLIP_PAIRS = COCO_FLIP_PAIRS
+
+    def _records(self, root, image_set):
+        return coco_records(root, image_set)
+
+    def _reduce(self, norm, original, vis):
+        return (norm[COCO_TO_REDUCED].reshape(13, 2), original[COCO_TO_REDUCED].reshape(13, 2), vis[COCO_TO_REDUCED])

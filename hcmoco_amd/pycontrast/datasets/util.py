@@ -1,7 +1,7 @@
 """``build_own_contrast_loader`` for image datasets (reference: /root/reference/pycontrast/datasets/util.py:456-585):
-the source-balancing ``WeightedRandomSampler``, its distributed wrapper and the DataLoader.  Only the
-NTU + MPII combination (``--dataset NTUMPII --modal RGBD2S``) has a tuple producer in this build
-(datasets/ntu_mpii.py); the COCO / NTU-segmentation variants raise."""
+the source-balancing ``WeightedRandomSampler``, its distributed wrapper and the DataLoader.  NTU + MPII and
+NTU + COCO (``--dataset NTUMPII | NTUCOCO --modal RGBD2S``) have tuple producers in this build
+(datasets/ntu_mpii.py); the NTU-segmentation variant raises."""
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -47,13 +47,17 @@ def source_balancing_weights(n_first, n_second):
 def build_own_contrast_loader(opt, rank=0, world=1, ngpus_per_node=1):
     """(dataset, loader, sampler) as ``datasets/util.py:530-585``; ``--batch_size`` is the GLOBAL batch."""
     key = (opt.dataset or '') + opt.modal
-    if key != 'NTUMPIIRGBD2S':
-        raise NotImplementedError('dataset %r: only NTUMPII + RGBD2S has a tuple producer in this build (COCO needs '
-                                  'pycocotools, the NTU segmentation split its own label files); use --synthetic' % key)
-    from .ntu_mpii import NTUMPIIContrastDataset
-    ds = NTUMPIIContrastDataset(opt.data_folder, opt.train_file_list, opt.mpii_root, 'train',
-                                size=int(getattr(opt, 'image_size', 320)), random_flip=bool(opt.random_flip),
-                                random_resized_crop=True)
+    from .ntu_mpii import NTUCOCOContrastDataset, NTUMPIIContrastDataset
+    size = int(getattr(opt, 'image_size', 320))
+    if key == 'NTUMPIIRGBD2S':
+        ds = NTUMPIIContrastDataset(opt.data_folder, opt.train_file_list, opt.mpii_root, 'train', size=size,
+                                    random_flip=bool(opt.random_flip), random_resized_crop=True)
+    elif key == 'NTUCOCORGBD2S':
+        ds = NTUCOCOContrastDataset(opt.data_folder, opt.train_file_list, opt.coco_root, 'train2014', size=size,
+                                    random_flip=bool(opt.random_flip), random_resized_crop=True)
+    else:
+        raise NotImplementedError('dataset %r: NTUMPII and NTUCOCO (+ RGBD2S) have tuple producers in this build; the NTU '
+                                  'segmentation split needs its own label files; use --synthetic' % key)
     weights = source_balancing_weights(len(ds.db), len(ds.image_list))
     sampler = WeightedRandomSampler(weights, len(weights))
     if torch.distributed.is_available() and torch.distributed.is_initialized():

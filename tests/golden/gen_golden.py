@@ -650,6 +650,81 @@ def gen_dataset():
     names = ['rgbd', 'index', 'norm_joints', 'joints3d', 'original_joints2d', 'joints_vis', 'true_depth', 'depth_mask', 'scale']
     for n, v in zip(names, out):
         arrays['ntu_out_' + n] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+
+    # --- NTU + COCO variant (:622-955): annotation records through the reference's own loader (the pycocotools API
+    #     it calls is replaced by a minimal reader of the same json), box -> centre/scale, the two joint reductions,
+    #     and the NTU branch of its __getitem__ with the decoded frame injected
+    coco_json = {'categories': [{'id': 1, 'name': 'person'}, {'id': 7, 'name': 'other'}], 'images': [], 'annotations': []}
+    aid = 0
+    for im_id, (w_, h_) in ((9, (640, 480)), (3, (500, 375)), (12, (320, 240))):
+        coco_json['images'].append({'id': im_id, 'width': w_, 'height': h_})
+        for k in range(3):
+            kp = []
+            for q in range(17):
+                kp += [float(g.randint(0, w_)), float(g.randint(0, h_)), int(g.randint(0, 3))]
+            if im_id == 3 and k == 1:
+                kp = [0] * 51                                  # person without keypoints: dropped
+            box = [float(g.randint(-20, w_ - 50)), float(g.randint(-10, h_ - 50)), float(g.randint(30, 300)), float(g.randint(30, 300))]
+            coco_json['annotations'].append({'id': aid, 'image_id': im_id, 'category_id': 7 if (im_id == 12 and k == 0) else 1,
+                                             'iscrowd': int(im_id == 9 and k == 2), 'area': 0.0 if (im_id == 12 and k == 2) else 900.0,
+                                             'bbox': box, 'keypoints': kp})
+            aid += 1
+    os.makedirs(os.path.join(tmp, 'annotations'))
+    with open(os.path.join(tmp, 'annotations', 'person_keypoints_train2014.json'), 'w') as f:
+        json.dump(coco_json, f)
+
+    class MiniCOCO(object):                                     # the five pycocotools calls of dataset.py:631-722
+        def __init__(self, path):
+            self.d = json.load(open(path))
+
+        def getCatIds(self):
+            return [c['id'] for c in self.d['categories']]
+
+        def loadCats(self, ids):
+            return [c for c in self.d['categories'] if c['id'] in ids]
+
+        def getImgIds(self):
+            return [i['id'] for i in self.d['images']]
+
+        def loadImgs(self, i):
+            return [im for im in self.d['images'] if im['id'] == i]
+
+        def getAnnIds(self, imgIds, iscrowd=None):
+            return [a['id'] for a in self.d['annotations'] if a['image_id'] == imgIds and (iscrowd is None or bool(a['iscrowd']) == iscrowd)]
+
+        def loadAnns(self, ids):
+            return [a for a in self.d['annotations'] if a['id'] in ids]
+    D.COCO = MiniCOCO
+    cobj = D.NTUCOCORGBD3D2DSkeletonGCN.__new__(D.NTUCOCORGBD3D2DSkeletonGCN)
+    cobj.coco_root, cobj.coco_image_set = tmp, 'train2014'
+    cobj.coco = MiniCOCO(cobj._get_ann_file_keypoint())
+    cats = [c['name'] for c in cobj.coco.loadCats(cobj.coco.getCatIds())]
+    cobj.classes = ['__background__'] + cats
+    cobj._class_to_ind = dict(zip(cobj.classes, range(len(cobj.classes))))
+    cobj._class_to_coco_ind = dict(zip(cats, cobj.coco.getCatIds()))
+    cobj._coco_ind_to_class_ind = dict([(cobj._class_to_coco_ind[c], cobj._class_to_ind[c]) for c in cobj.classes[1:]])
+    cobj.image_set_index = cobj._load_image_set_index()
+    cobj.coco_num_joints, cobj.is_train, cobj.aspect_ratio, cobj.pixel_std, cobj.data_format = 17, True, 1.0, 200, 'jpg'
+    cdb = cobj._get_db()
+    arrays['coco_anno_json'] = np.array(json.dumps(coco_json))
+    arrays['coco_center'] = np.stack([r['center'] for r in cdb])
+    arrays['coco_scale'] = np.stack([r['scale'] for r in cdb])
+    arrays['coco_joints'] = np.stack([r['joints_3d'] for r in cdb])
+    arrays['coco_joints_vis'] = np.stack([r['joints_3d_vis'] for r in cdb])
+    arrays['coco_image'] = np.array([os.path.relpath(r['image'], tmp) for r in cdb])
+    n17, o17, v17 = g.rand(17, 2), g.rand(17, 2) * 100, g.rand(17) < 0.6
+    r = cobj.COCOReduce(n17, o17, v17)
+    arrays.update(coco_in_norm=n17, coco_in_orig=o17, coco_in_vis=v17, coco_red_norm=r[0], coco_red_orig=r[1], coco_red_vis=r[2],
+                  kinect_reduce=cobj.KinectReduce(k25))
+    cobj.size, cobj.random_flip, cobj.random_resized_crop, cobj.db, cobj.num_joints = (size, size), False, True, [], 25
+    cobj.flip_pairs = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+    D.NTURGBD3DSkeleton.__getitem__ = lambda self, index, return_resize_param=False: (rgbd.clone(), index, joints3d, resize_param, skel)
+    try:
+        cout = cobj[2]
+    finally:
+        D.NTURGBD3DSkeleton.__getitem__ = orig
+    for n, v in zip(names, cout):
+        arrays['ntucoco_out_' + n] = v if isinstance(v, torch.Tensor) else np.asarray(v)
     npz('dataset_tuple', **arrays)
 
 

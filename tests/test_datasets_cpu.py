@@ -196,3 +196,91 @@ def test_image_dataset_drives_the_training_loop(tmp_path, monkeypatch):
             torch.distributed.destroy_process_group()
     assert len(outs) == 4 and outs[0] == outs[0]
     assert contrast.memory_1.shape[0] == 10              # the bank is sized by len(train_dataset) (main_contrast.py:49)
+
+
+# ---------------------------------------------------------------------------------- NTU + COCO (13 joints)
+def test_coco_records_and_reductions_match_reference(tmp_path):
+    """person_keypoints json -> records through the reference's own loader (dataset.py:698-770, with the five
+    pycocotools calls replaced by a json reader) vs ``coco_records`` reading the json directly: crowd, non-person,
+    zero-area and keypoint-less annotations dropped, boxes clipped, centre/scale; COCOReduce / KinectReduce."""
+    g = npz()
+    os.makedirs(tmp_path / 'annotations')
+    (tmp_path / 'annotations' / 'person_keypoints_train2014.json').write_text(str(g['coco_anno_json']))
+    db = N.coco_records(str(tmp_path), 'train2014')
+    assert [os.path.relpath(r['image'], tmp_path) for r in db] == [str(s) for s in g['coco_image']]
+    assert np.array_equal(np.stack([r['center'] for r in db]), g['coco_center'].numpy())
+    assert np.array_equal(np.stack([r['scale'] for r in db]), g['coco_scale'].numpy())
+    assert np.array_equal(np.stack([r['joints_3d'] for r in db]), g['coco_joints'].numpy())
+    assert np.array_equal(np.stack([r['joints_3d_vis'] for r in db]), g['coco_joints_vis'].numpy())
+    ds = N.NTUCOCOContrastDataset.__new__(N.NTUCOCOContrastDataset)
+    n, o, v = ds._reduce(g['coco_in_norm'].numpy(), g['coco_in_orig'].numpy(), g['coco_in_vis'].numpy())
+    assert np.array_equal(n, g['coco_red_norm'].numpy()) and np.array_equal(o, g['coco_red_orig'].numpy())
+    assert np.array_equal(v, g['coco_red_vis'].numpy())
+    k = g['kinect25'].numpy()[N.KINECT_TO_REDUCED].reshape(13, 2)
+    assert np.array_equal(k, g['kinect_reduce'].numpy())
+
+
+def test_ntucoco_tuple_matches_reference():
+    g = npz()
+    rp = [int(v) for v in g['ntu_resize_param']]
+    resize_param = (rp[0], rp[1], rp[2], rp[3], bool(g['ntu_need_flip']), rp[4], rp[5])
+    out = N.ntu_tuple(g['ntu_rgbd_in'].clone(), 2, g['ntu_joints3d'], resize_param, g['ntu_dloc'].numpy(),
+                      int(g['ntu_size']), random_flip=False, select=N.KINECT_TO_REDUCED, flip_pairs=N.COCO_FLIP_PAIRS)
+    names = ['rgbd', 'index', 'norm_joints', 'joints3d', 'original_joints2d', 'joints_vis', 'true_depth', 'depth_mask', 'scale']
+    for n, v in zip(names, out):
+        want = g['ntucoco_out_' + n]
+        if isinstance(want, torch.Tensor):
+            got = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            assert got.dtype == want.dtype and torch.equal(got, want), n
+        else:
+            assert float(v) == float(want), n
+    assert out[2].shape == (13, 2)
+
+
+def test_ntucoco_dataset_end_to_end(tmp_path, monkeypatch):
+    """A miniature COCO + NTU tree -> 13-joint tuples -> two stage-2 steps with the coco_reduce skeleton."""
+    from hcmoco_amd.pycontrast import main_contrast
+    from oracle.oracle_engine import OracleLossEngine
+    root = str(tmp_path / 'data')
+    flist, _ = _write_tree(root, n_ntu=5, n_mpii=1)
+    coco = os.path.join(root, 'coco')
+    os.makedirs(os.path.join(coco, 'annotations'))
+    os.makedirs(os.path.join(coco, 'images', 'train2014'))
+    rng = np.random.RandomState(1)
+    data = {'categories': [{'id': 1, 'name': 'person'}], 'images': [], 'annotations': []}
+    for k in range(3):
+        Image.fromarray((rng.rand(120, 160, 3) * 255).astype(np.uint8)).save(
+            os.path.join(coco, 'images', 'train2014', 'COCO_train2014_%012d.jpg' % (k + 1)))
+        data['images'].append({'id': k + 1, 'width': 160, 'height': 120})
+        kp = []
+        for q in range(17):
+            kp += [float(20 + rng.rand() * 100), float(10 + rng.rand() * 90), 2 if q != 3 else 0]
+        data['annotations'].append({'id': k, 'image_id': k + 1, 'category_id': 1, 'iscrowd': 0, 'area': 5000.0,
+                                    'bbox': [15.0, 5.0, 120.0, 100.0], 'keypoints': kp})
+    json.dump(data, open(os.path.join(coco, 'annotations', 'person_keypoints_train2014.json'), 'w'))
+    ds = N.NTUCOCOContrastDataset(root, flist, coco, 'train2014', size=64, random_resized_crop=True)
+    assert len(ds) == 8 and len(ds.db) == 3
+    t = ds[0]
+    assert t[2].shape == (13, 2) and t[4].shape == (13, 2) and t[5].shape == (13,) and t[6] == 0
+    assert ds[5][2].shape == (13, 2) and ds[5][6] == 1
+    flip = N.NTUCOCOContrastDataset(root, flist, coco, 'train2014', size=64, random_flip=True, random_resized_crop=True)
+    import random
+    random.seed(0)
+    with pytest.raises(IndexError, match='flip pairs'):          # the reference fails the same way (:820-826, :936-937)
+        for _ in range(20):
+            flip[6]
+    monkeypatch.setenv('MASTER_PORT', str(26500 + os.getpid() % 2000))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
+        monkeypatch.delenv(k, raising=False)
+    argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list',
+            '3,3', '--batch_size', '4', '--nce_k', '6', '--world-size', '1', '--dist-backend', 'gloo', '--dataset', 'NTUCOCO',
+            '--data_folder', root, '--train_file_list', flist, '--coco_root', coco, '--image_size', '64', '--num_workers', '0',
+            '--epochs', '1', '--print_freq', '1', '--save_freq', '1', '--model_path', str(tmp_path), '--tb_path', str(tmp_path),
+            '--seed', '1', '--learning_rate', '0.01', '--linear_feat_map', '1', '--modality_missing', '1',
+            '--pri3d_num_samples_per_image', '8', '--skeleton_meta_name', 'coco_reduce']
+    try:
+        outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    assert len(outs) == 4 and outs[0] == outs[0] and contrast.memory_1.shape[0] == 8
