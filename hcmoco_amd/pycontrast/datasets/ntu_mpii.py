@@ -179,7 +179,7 @@ def crop_params(width, height, scale, ratio, rng=random):
 
 
 def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip, select=KINECT_TO_MPII,
-              flip_pairs=MPII_FLIP_PAIRS):
+              flip_pairs=MPII_FLIP_PAIRS, empty_ok=False, with_mean=False):
     """Items 0-8 of the tuple for an NTU frame, from the decoded (cropped, resized, flipped, normalised) frame
     ``rgbd`` [6, size, size], the 25 Kinect depth-image joints ``d_loc`` and the crop rectangle
     ``resize_param = (i, j, h, w, need_flip, original_h, original_w)`` (dataset.py:578-617; :924-955 for the
@@ -197,7 +197,7 @@ def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip, sel
     original[:, 1] = (original[:, 1] - j) / w * size
     depth = rgbd[3]
     mask = depth > 0
-    mean = depth.sum() / mask.sum()
+    mean = 0.0 if (empty_ok and mask.sum() == 0) else depth.sum() / mask.sum()     # (:1068-1071 guards the empty frame)
     centred = depth - mean
     centred[~mask] = 0
     rgbd = rgbd.clone()
@@ -205,8 +205,9 @@ def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip, sel
     original[np.logical_not(vis), :] = 0
     norm[np.logical_not(vis), :] = 0
     scale = scale_from_joints(original, vis)
-    return (rgbd, index, torch.from_numpy(norm.copy().astype(np.float32)), joints3d, torch.from_numpy(original.copy()),
-            torch.from_numpy(vis.astype(np.int32).copy()), 1, mask.float(), scale)
+    out = (rgbd, index, torch.from_numpy(norm.copy().astype(np.float32)), joints3d, torch.from_numpy(original.copy()),
+           torch.from_numpy(vis.astype(np.int32).copy()), 1, mask.float(), scale)
+    return out + (mean,) if with_mean else out
 
 
 def _to_tensor_normalised(img_uint8_hwc):
@@ -404,3 +405,95 @@ class NTUCOCOContrastDataset(NTUMPIIContrastDataset):
 
     def _reduce(self, norm, original, vis):
         return (norm[COCO_TO_REDUCED].reshape(13, 2), original[COCO_TO_REDUCED].reshape(13, 2), vis[COCO_TO_REDUCED])
+
+
+# --------------------------------------------------------------------------- NTU + NTU-segmentation frames (HRNetPN)
+SEG_ORIGINAL_LABELS = [0, 1, 2, 3, 6, 7, 8, 17, 18, 19, 25, 26, 27, 32, 33, 34, 38, 39, 43, 44, 46, 49, 50, 56, 58]
+
+
+def seg_label_mapper():
+    """raw annotation value -> 0..24 (dataset.py:1016-1019); values outside the list map to themselves."""
+    m = np.arange(60)
+    for i, l in enumerate(SEG_ORIGINAL_LABELS):
+        m[l] = i
+    return m
+
+
+class NTUSegContrastDataset(NTUMPIIContrastDataset):
+    """``modal2Dataset['NTUSegRGBD2S']`` (= NTURGBDSegJoint, dataset.py:957-1120): the NTU frames of the file list
+    followed by the frames of the human-parsing subset, every sample an NTU-style frame; the tuple carries seven
+    more items -- 9 ``label`` (uint8 map, 255 where there is no annotation), 10 ``true_label``, 11 ``true_rgb``,
+    12 ``grid_xy`` (source pixel of every crop pixel, what HRNetPN back-projects with), 13/14 the frame size,
+    15 the mean depth that was subtracted.  ``mask_seg_depth`` / ``mask_seg_rgb`` blank one modality of the
+    parsing frames (the "versatility" settings)."""
+
+    def __init__(self, ntu_root, ntu_file_list, seg_root, seg_image_set, size=256, random_flip=False,
+                 random_resized_crop=False, only_seg=False, mask_seg_depth=False, mask_seg_rgb=False,
+                 skeleton_root='./data/NTURGBD'):
+        super().__init__(ntu_root, ntu_file_list, None, size=size, random_flip=random_flip,
+                         random_resized_crop=random_resized_crop)
+        assert not random_flip, 'the parsing labels are not flipped (dataset.py:1089)'
+        self.only_seg, self.mask_seg_depth, self.mask_seg_rgb = only_seg, mask_seg_depth, mask_seg_rgb
+        lines = sorted(l.strip() for l in open(seg_image_set))
+        stem = lambda fn: fn.split('/')[1].split('.')[0]
+        seg_images = [os.path.join(seg_root, l) for l in lines]
+        seg_depth = [os.path.join(seg_root, 'depth', 'MDepth-' + stem(l) + '.png') for l in lines]
+        self.seg_gt_list = [os.path.join(seg_root, 'png_annotation_v2', stem(l) + '.png') for l in lines]
+        seg_skel = [self._seg_skeleton(l, skeleton_root) for l in lines]
+        self.split = len(self.image_list)
+        if only_seg:
+            self.image_list, self.depth_list, self.skeleton_list = seg_images, seg_depth, seg_skel
+        else:
+            self.image_list = self.image_list + seg_images
+            self.depth_list = self.depth_list + seg_depth
+            self.skeleton_list = self.skeleton_list + seg_skel
+        self.label_mapper = seg_label_mapper()
+
+    @staticmethod
+    def _seg_skeleton(fn, skeleton_root):
+        import re
+        m = re.match(r'.*S(\d{3})C(\d{3})P(\d{3})R(\d{3})A(\d{3})F(\d{3}).*', fn)
+        setup, frame = int(m.group(1)), int(m.group(6))
+        tag = fn.split('/')[-1][:-8]                    # strip 'Fnnn.ext'
+        return os.path.join(skeleton_root, 'NTURGBD' if setup < 18 else 'NTURGBD120', 'nturgb+d_parsed_skeleton', tag,
+                            'Skeleton-{:08d}.pkl'.format(frame))
+
+    def __len__(self):
+        return len(self.image_list)
+
+    def _crop_nearest(self, pil, resize_param):
+        i, j, h, w = resize_param[:4]           # unconditional, as in the reference (labels and grid are always cropped)
+        return pil.crop((j, i, j + w, i + h)).resize(self.size[::-1], Image.NEAREST)
+
+    def seg_items(self, index, rgbd, mask, resize_param, label_image=None):
+        """items 6-7 (possibly blanked) and 9-14 for frame ``index`` (dataset.py:1082-1116)."""
+        i, j, h, w, _, original_h, original_w = resize_param
+        true_depth, true_rgb = 1, 1
+        parsing = index >= self.split or self.only_seg
+        if parsing:
+            if label_image is None:
+                label_image = Image.open(self.seg_gt_list[index if self.only_seg else index - self.split])
+            label = torch.from_numpy(self.label_mapper[np.array(self._crop_nearest(label_image, resize_param)).astype(np.uint8)])
+            true_label = 1
+        else:
+            label = torch.zeros_like(rgbd[0], dtype=torch.uint8) + 255
+            true_label = 0
+        if self.mask_seg_depth and index >= self.split and not self.only_seg:
+            true_depth, mask = 0, torch.zeros_like(rgbd[0])
+            rgbd = torch.cat([rgbd[:3], torch.zeros_like(rgbd[:3])], 0)
+        if self.mask_seg_rgb and index >= self.split and not self.only_seg:
+            true_rgb = 0
+            rgbd = torch.cat([torch.zeros_like(rgbd[:3]), rgbd[3:]], 0)
+        gx, gy = torch.meshgrid(torch.arange(original_h), torch.arange(original_w), indexing='ij')
+        gx = self._crop_nearest(Image.fromarray(gx.numpy().astype(np.uint16)), resize_param)
+        gy = self._crop_nearest(Image.fromarray(gy.numpy().astype(np.uint16)), resize_param)
+        grid_xy = torch.from_numpy(np.stack([np.array(gx), np.array(gy)], -1).astype(np.int32))
+        return rgbd, true_depth, mask, label, true_label, true_rgb, grid_xy, int(original_h), int(original_w)
+
+    def __getitem__(self, index):
+        rgbd, joints3d, resize_param, d_loc = self._ntu_frame(index)
+        t = ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, self.size[0], self.random_flip, self.KINECT_SELECT,
+                      self.FLIP_PAIRS, empty_ok=True, with_mean=True)
+        rgbd, true_depth, mask, label, true_label, true_rgb, grid_xy, oh, ow = self.seg_items(index, t[0], t[7], resize_param)
+        return (rgbd, index, t[2], t[3], t[4], t[5], true_depth, mask.float(), t[8], label, true_label, true_rgb, grid_xy,
+                oh, ow, float(t[9]))

@@ -1,7 +1,7 @@
 """``build_own_contrast_loader`` for image datasets (reference: /root/reference/pycontrast/datasets/util.py:456-585):
-the source-balancing ``WeightedRandomSampler``, its distributed wrapper and the DataLoader.  NTU + MPII and
-NTU + COCO (``--dataset NTUMPII | NTUCOCO --modal RGBD2S``) have tuple producers in this build
-(datasets/ntu_mpii.py); the NTU-segmentation variant raises."""
+the source-balancing ``WeightedRandomSampler``, its distributed wrapper and the DataLoader for the three
+second-stage datasets of the reference's scripts (``--dataset NTUMPII | NTUCOCO | NTUSeg --modal RGBD2S``,
+datasets/ntu_mpii.py)."""
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -55,10 +55,18 @@ def build_own_contrast_loader(opt, rank=0, world=1, ngpus_per_node=1):
     elif key == 'NTUCOCORGBD2S':
         ds = NTUCOCOContrastDataset(opt.data_folder, opt.train_file_list, opt.coco_root, 'train2014', size=size,
                                     random_flip=bool(opt.random_flip), random_resized_crop=True)
+    elif key == 'NTUSegRGBD2S':
+        from .ntu_mpii import NTUSegContrastDataset
+        ds = NTUSegContrastDataset(opt.data_folder, opt.train_file_list, opt.seg_root, opt.seg_file_list, size=size,
+                                   random_flip=bool(opt.random_flip), random_resized_crop=True,
+                                   mask_seg_depth=bool(opt.mask_seg_depth), mask_seg_rgb=bool(opt.mask_seg_rgb))
     else:
-        raise NotImplementedError('dataset %r: NTUMPII and NTUCOCO (+ RGBD2S) have tuple producers in this build; the NTU '
-                                  'segmentation split needs its own label files; use --synthetic' % key)
-    weights = source_balancing_weights(len(ds.db), len(ds.image_list))
+        raise NotImplementedError('dataset %r: NTUMPII, NTUCOCO and NTUSeg (+ RGBD2S) have tuple producers in this build; '
+                                  'use --synthetic otherwise' % key)
+    if key == 'NTUSegRGBD2S':       # NTU frames first, parsing frames second (util.py:575-577)
+        weights = source_balancing_weights(ds.split, len(ds) - ds.split)
+    else:
+        weights = source_balancing_weights(len(ds.db), len(ds.image_list))
     sampler = WeightedRandomSampler(weights, len(weights))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         sampler = DistributedSamplerWrapper(sampler, num_replicas=world, rank=rank)

@@ -725,6 +725,34 @@ def gen_dataset():
         D.NTURGBD3DSkeleton.__getitem__ = orig
     for n, v in zip(names, cout):
         arrays['ntucoco_out_' + n] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+
+    # --- NTU-segmentation variant (:957-1120): label mapping, modality masking, grid_xy, mean -- the tail of its
+    #     __getitem__ with the decoded frame injected; TF.resized_crop on PIL images = crop + resize (stubbed so)
+    from PIL import Image as PILImage
+    D.TF.resized_crop = lambda img, i, j, h, w, size, interpolation=PILImage.BILINEAR: img.crop((j, i, j + w, i + h)).resize(
+        tuple(size[::-1]), interpolation)
+    lab = np.kron(g.choice(np.array([0, 1, 2, 3, 6, 7, 8, 17, 18, 19, 25, 26, 27, 32, 33, 34, 38, 39, 43, 44, 46, 49, 50, 56, 58]),
+                           size=(36, 64)), np.ones((30, 30), np.int64)).astype(np.uint8)          # 1080 x 1920 in 30-pixel blocks
+    lab_path = os.path.join(tmp, 'label.png')
+    PILImage.fromarray(lab).save(lab_path)
+    sobj = D.NTURGBDSegJoint.__new__(D.NTURGBDSegJoint)
+    sobj.size, sobj.random_flip, sobj.random_resized_crop, sobj.mpii_num_joints = (size, size), False, True, 16
+    sobj.only_seg, sobj.split, sobj.seg_gt_list = False, 3, [lab_path, lab_path]
+    sobj.label_mapper = np.arange(60)
+    for i_, l_ in enumerate([0, 1, 2, 3, 6, 7, 8, 17, 18, 19, 25, 26, 27, 32, 33, 34, 38, 39, 43, 44, 46, 49, 50, 56, 58]):
+        sobj.label_mapper[l_] = i_
+    D.NTURGBD3DSkeleton.__getitem__ = lambda self, index, return_resize_param=False: (rgbd.clone(), index, joints3d, resize_param, skel)
+    seg_names = names + ['label', 'true_label', 'true_rgb', 'grid_xy', 'original_h', 'original_w', 'mean']
+    try:
+        for tag, idx, md, mr in (('plain', 1, False, False), ('parsing', 4, False, False), ('nodepth', 4, True, False),
+                                 ('norgb', 3, False, True)):
+            sobj.mask_seg_depth, sobj.mask_seg_rgb = md, mr
+            sout = sobj[idx]
+            for n, v in zip(seg_names, sout):
+                arrays['seg_%s_%s' % (tag, n)] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+    finally:
+        D.NTURGBD3DSkeleton.__getitem__ = orig
+    arrays['seg_label_png'] = lab
     npz('dataset_tuple', **arrays)
 
 

@@ -284,3 +284,74 @@ def test_ntucoco_dataset_end_to_end(tmp_path, monkeypatch):
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
     assert len(outs) == 4 and outs[0] == outs[0] and contrast.memory_1.shape[0] == 8
+
+
+# ---------------------------------------------------------------------------------- NTU segmentation frames (HRNetPN)
+@pytest.mark.parametrize('tag,index,mask_depth,mask_rgb', [('plain', 1, False, False), ('parsing', 4, False, False),
+                                                           ('nodepth', 4, True, False), ('norgb', 3, False, True)])
+def test_ntuseg_tuple_matches_reference(tag, index, mask_depth, mask_rgb, tmp_path):
+    """The 16-item tuple of NTURGBDSegJoint.__getitem__ (dataset.py:1037-1116) from an injected decoded frame: label
+    mapping of the parsing frames (255 elsewhere), true_label / true_depth / true_rgb with the two masking modes,
+    grid_xy, frame size and the subtracted mean depth."""
+    g = npz()
+    rp = [int(v) for v in g['ntu_resize_param']]
+    resize_param = (rp[0], rp[1], rp[2], rp[3], bool(g['ntu_need_flip']), rp[4], rp[5])
+    size = int(g['ntu_size'])
+    ds = N.NTUSegContrastDataset.__new__(N.NTUSegContrastDataset)
+    ds.size, ds.random_flip, ds.random_resized_crop, ds.only_seg, ds.split = (size, size), False, True, False, 3
+    ds.mask_seg_depth, ds.mask_seg_rgb, ds.label_mapper = mask_depth, mask_rgb, N.seg_label_mapper()
+    t = N.ntu_tuple(g['ntu_rgbd_in'].clone(), index, g['ntu_joints3d'], resize_param, g['ntu_dloc'].numpy(), size, False,
+                    empty_ok=True, with_mean=True)
+    label_img = Image.fromarray(g['seg_label_png'].numpy().astype(np.uint8))
+    rgbd, true_depth, mask, label, true_label, true_rgb, grid_xy, oh, ow = ds.seg_items(index, t[0], t[7], resize_param, label_img)
+    got = (rgbd, index, t[2], t[3], t[4], t[5], true_depth, mask.float(), t[8], label, true_label, true_rgb, grid_xy, oh, ow,
+           float(t[9]))
+    names = ['rgbd', 'index', 'norm_joints', 'joints3d', 'original_joints2d', 'joints_vis', 'true_depth', 'depth_mask', 'scale',
+             'label', 'true_label', 'true_rgb', 'grid_xy', 'original_h', 'original_w', 'mean']
+    for n, v in zip(names, got):
+        want = g['seg_%s_%s' % (tag, n)]
+        if isinstance(want, torch.Tensor):
+            v = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            assert v.dtype == want.dtype and torch.equal(v, want), (tag, n)
+        else:
+            assert float(v) == float(want), (tag, n)
+    assert (true_label == 1) == (index >= 3) and int(label.max()) <= (24 if index >= 3 else 255)
+
+
+def test_ntuseg_dataset_feeds_the_hrnetpn_tuple(tmp_path):
+    """Files on disk -> the 16-item tuple HRNetPN's trainer path consumes (items 12-15 = grid_xy, frame size, mean)."""
+    root = str(tmp_path / 'data')
+    flist, _ = _write_tree(root, n_ntu=3, n_mpii=1)
+    seg = os.path.join(root, 'seg')
+    rng = np.random.RandomState(4)
+    lines = []
+    for k in range(2):
+        stem = 'S001C002P003R001A0%02dF%03d' % (k + 1, k + 5)
+        lines.append('images/%s.jpg' % stem)
+        skel_path = N.NTUSegContrastDataset._seg_skeleton(lines[-1], os.path.join(root, 'skel'))
+        depth = np.zeros((108, 192), np.uint16)
+        depth[30:80, 70:120] = 2500
+        for path, writer in ((os.path.join(seg, 'images', stem + '.jpg'), lambda p: Image.fromarray((rng.rand(108, 192, 3) * 255).astype(np.uint8)).save(p)),
+                             (os.path.join(seg, 'depth', 'MDepth-' + stem + '.png'), lambda p: Image.fromarray(depth).save(p)),
+                             (os.path.join(seg, 'png_annotation_v2', stem + '.png'),
+                              lambda p: Image.fromarray(rng.choice(np.array(N.SEG_ORIGINAL_LABELS), size=(108, 192)).astype(np.uint8)).save(p)),
+                             (skel_path, lambda p: pickle.dump({'joints': [{'3d_loc': rng.randn(25, 3).tolist(),
+                                                                            'd_loc': (np.array([70, 30]) + rng.rand(25, 2) * 50).tolist()}]},
+                                                               open(p, 'wb')))):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            writer(path)
+    seg_list = os.path.join(seg, 'train.txt')
+    open(seg_list, 'w').write('\n'.join(reversed(lines)) + '\n')
+    ds = N.NTUSegContrastDataset(root, flist, seg, seg_list, size=64, random_resized_crop=True, mask_seg_rgb=True,
+                                 skeleton_root=os.path.join(root, 'skel'))
+    assert len(ds) == 5 and ds.split == 3 and ds.skeleton_list[3].endswith('S001C002P003R001A001/Skeleton-00000005.pkl')
+    plain, parsing = ds[0], ds[4]
+    assert len(plain) == len(parsing) == 16
+    assert plain[10] == 0 and plain[11] == 1 and int(plain[9].min()) == 255
+    assert parsing[10] == 1 and parsing[11] == 0 and int(parsing[9].max()) <= 24 and float(parsing[0][:3].abs().sum()) == 0
+    gxy = parsing[12]
+    assert gxy.shape == (64, 64, 2) and gxy.dtype == torch.int32 and parsing[13] == 108 and parsing[14] == 192
+    assert bool((gxy[..., 0][1:] >= gxy[..., 0][:-1]).all()) and bool((gxy[..., 1][:, 1:] >= gxy[..., 1][:, :-1]).all())
+    assert isinstance(parsing[15], float) and parsing[15] > 0
+    batch = torch.utils.data.default_collate([ds[3], ds[4]])
+    assert batch[12].shape == (2, 64, 64, 2) and batch[13].tolist() == [108, 108] and batch[15].dtype == torch.float64
