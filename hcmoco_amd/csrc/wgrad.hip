@@ -248,13 +248,15 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g)
     g.dstride = rb * W + 4;
     size_t bytes = ((size_t)g.cmax * (st * rb + 2) * (st * W + 8) + (size_t)(K + 1) * g.dstride) * 4;
     static const size_t cap = (size_t)(getenv("HCM_WGRAD_LDS_KB") ? atoi(getenv("HCM_WGRAD_LDS_KB")) : 48) * 1024;
-    if (bytes <= cap || rb == 1) break;
+    static const size_t cap_wide = getenv("HCM_WGRAD_LDS_KB_WIDE") ? (size_t)atoi(getenv("HCM_WGRAD_LDS_KB_WIDE")) * 1024 : cap;
+    if (bytes <= (g.mt >= 5 ? cap_wide : cap) || rb == 1) break;
     rb = (rb + 1) / 2;
   }
   g.rb = rb;
   g.rblocks = (H + rb - 1) / rb;
   g.units = N * g.rblocks;
-  int wp = 8 / wn;
+  static const int waves_wide = getenv("HCM_WGRAD_WAVES_WIDE") ? atoi(getenv("HCM_WGRAD_WAVES_WIDE")) : 8;
+  int wp = (g.mt >= 5 ? waves_wide : 8) / wn;
   if (wp > rb) wp = rb;
   if (wp < 1) wp = 1;
   g.wp = wp;
