@@ -4,15 +4,19 @@
  *
  * Plain-C sequential restatement of the nine CUDA kernels of the reference
  * (/root/reference/pycontrast/networks/pointnet2/src/*.cu), one function per kernel, citing the
- * lines it follows.  The kernels cannot be executed in the build container (no nvcc / GPU) and
- * the reference ships no tests or fixtures for them: PARITY UNPINNED by the reference.  It is
- * pinned instead by hand-checkable known-answer tests (tests/test_pointnet2_oracle.py).
+ * lines it follows.  The reference ships no tests or fixtures for these ops and its extension does not
+ * build against a current PyTorch (THC), but its kernel files compile for gfx950 from where they lie
+ * (oracle/build_ref_pointnet2.py -> oracle/_ref/libpointnet2_ref_{ieee,fma}.so).  PINNED on the GPU by
+ * tests/test_pointnet2_ref_gpu.py: every function below is bit-identical to the reference's own kernel
+ * (indices, distances, forwards; duplicate-free backwards), in both arithmetic contracts.  On CPU it is
+ * additionally held by hand-checkable known-answer tests (tests/test_pointnet2_oracle.py).
  *
  * Arithmetic contract (oracle_set_contract): the reference source evaluates  a*a + b*b + c*c  and is
  * built with `nvcc -O2` (networks/pointnet2/setup.py:20, --fmad=true by default).  Mode 1 (default)
- * restates the contracted form every LLVM / GNU compiler here produces for that source,
- * fma(c, c, fma(a, a, b*b)) -- taken as the reference's real arithmetic; mode 0 is the un-fused
- * ((a*a + b*b) + c*c) of an --fmad=false / CPU build.  Compiled with -ffp-contract=off: only the
+ * restates LLVM's scalar contraction of that source, fma(c, c, fma(a, a, b*b)) (what the reference's
+ * kernels compute when built with contraction on and no packed-fp32 vectorisation, i.e. what NVPTX gets)
+ * -- taken as the reference's real arithmetic; mode 0 is the un-fused ((a*a + b*b) + c*c) of an
+ * --fmad=false / -ffp-contract=off build.  Compiled with -ffp-contract=off: only the
  * fmaf() calls below fuse.
  */
 #include <math.h>

@@ -119,3 +119,26 @@ def test_arithmetic_contracts_are_distinguishable():
         assert o_ieee == float(want_ieee) and o_fma == float(want_fma)
     finally:
         P.set_contract('fma')
+
+
+
+def test_reference_kernel_build_exports_the_nine_launchers():
+    """oracle/_ref (the reference's own kernels for gfx950, oracle/build_ref_pointnet2.py): where the reference is
+    present the recipe must have produced both builds; anywhere, a present build must carry every launcher
+    oracle/pointnet2_ref.py binds.  (No device code runs here; the GPU comparison is tests/test_pointnet2_ref_gpu.py.)"""
+    import json
+    import os
+    import subprocess
+    from oracle import build_ref_pointnet2 as B
+    from oracle import pointnet2_ref as R
+    if os.path.isdir(B.REF_SRC):
+        assert B.build() is not None and R.available()
+    if not R.available():
+        pytest.skip('oracle/_ref not built and no reference to build it from')
+    with open(R.SYMS) as f:
+        table = json.load(f)
+    assert sorted(table) == sorted(B.LAUNCHERS) == sorted(R._SIGS)
+    for so in R.SOS.values():
+        nm = subprocess.run(['nm', '-D', '--defined-only', so], capture_output=True, text=True, check=True).stdout
+        for sym in table.values():
+            assert sym in nm, (so, sym)
