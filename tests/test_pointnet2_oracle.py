@@ -1,5 +1,6 @@
 """Known-answer tests pinning oracle/pointnet2_oracle.c (the reference ships no fixtures for its
 CUDA kernels).  Hand-checkable tiny clouds.  CPU only."""
+import pytest
 import torch
 
 from oracle import pointnet2_oracle as P
