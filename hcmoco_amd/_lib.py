@@ -76,6 +76,9 @@ SIGNATURES = {
     'hcm_bn_act_stats_floats': (C.c_size_t, [_i, _i, _i]),
     'hcm_bn_act_forward': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3),
     'hcm_bn_act_backward': (_i, [_p] * 6 + [_i] * 4 + [_p] * 4),
+    'hcm_conv3x3_supported': (_i, [_i] * 4),
+    'hcm_conv3x3_forward': (_i, [_p] * 3 + [_i] * 5 + [_p]),
+    'hcm_conv3x3_backward_data': (_i, [_p] * 3 + [_i] * 5 + [_p]),
     'hcm_bn_act_backward_ws': (_i, [_p] * 6 + [_i] * 4 + [_p] * 5),
     'hcm_conv3x3_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
     'hcm_conv3x3_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),

@@ -225,11 +225,27 @@ ConvKey key_of(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
                  (int)w.size(0), (int)w.size(2), (int)w.size(3), (int)stride, (int)pad};
 }
 
+// hcm_conv3x3_forward / _backward_data (csrc/conv.hip) serve the 3x3 stride-1 convolutions of the two
+// high-resolution branches (18ch@64-wide, 36ch@32-wide: 14 us against MIOpen's 25 / 21 us); everything else
+// stays on MIOpen.  HCM_CONV_KERNEL=0 keeps every layer there.
+bool own_conv(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
+  static const bool on = !(getenv("HCM_CONV_KERNEL") && getenv("HCM_CONV_KERNEL")[0] == '0');
+  return on && stride == 1 && pad == 1 && w.size(2) == 3 && w.size(3) == 3 &&
+         hcm_conv3x3_supported((int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3)) == 1;
+}
+
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
                   w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
                   w.is_contiguous(),
               "hcmoco::conv2d needs contiguous fp32 ROCm tensors x [N,C,H,W], w [K,C,R,S] (groups = dilation = 1, no bias)");
+  if (own_conv(x, w, stride, pad)) {
+    Tensor y = at::empty({x.size(0), w.size(0), x.size(2), x.size(3)}, x.options());
+    check_rc(hcm_conv3x3_forward(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), (int)x.size(0),
+                                 (int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3), current_stream(x)),
+             "hcm_conv3x3_forward");
+    return y;
+  }
   const ConvKey k = key_of(x, w, stride, pad);
   ConvPlan* p = get_plan(k);
   hipStream_t st = (hipStream_t)current_stream(x);
@@ -367,7 +383,12 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   miopenHandle_t h = thread_handle(k.dev, st);
   const float one = 1.f, zero = 0.f;
   ConvGrads o;
-  if (need_dx) {
+  if (need_dx && own_conv(x, w, stride, pad)) {
+    o.dx = at::empty_like(x);
+    check_rc(hcm_conv3x3_backward_data(g.data_ptr<float>(), w.data_ptr<float>(), o.dx.data_ptr<float>(), (int)x.size(0),
+                                       (int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3), st),
+             "hcm_conv3x3_backward_data");
+  } else if (need_dx) {
     o.dx = at::empty_like(x);
     HandlePlan& hp = handle_plan(h, p);
     if (!(hp.found & kFoundBwdData)) {
@@ -844,7 +865,14 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
       const bool need_dx = a != 0 || T.need_dx0;
       ConvPlan* p = get_plan(key_of(x, T.w[L], I[5], I[6]));
       hipStream_t st = (hipStream_t)current_stream(x);
-      if (need_dx) {
+      if (need_dx && own_conv(x, T.w[L], I[5], I[6])) {
+        Tensor dx = at::empty_like(x);
+        check_rc(hcm_conv3x3_backward_data(dzc.data_ptr<float>(), T.w[L].data_ptr<float>(), dx.data_ptr<float>(),
+                                           (int)x.size(0), (int)x.size(1), (int)T.w[L].size(0), (int)x.size(2),
+                                           (int)x.size(3), st),
+                 "hcm_conv3x3_backward_data");
+        accumulate(S, G[a], dx, true);
+      } else if (need_dx) {
         miopenHandle_t h = thread_handle((int)x.get_device(), st);
         Tensor dx = at::empty_like(x);
         const float one = 1.f, zero = 0.f;
