@@ -24,10 +24,9 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;
 
 // CG: groups of 4 input channels (padded), MT: tiles of 16 output channels on the matrix cores, WT: map width,
-// RB: rows per workgroup (one row per wave: RB == 4), LO: output channels beyond 16*MT computed on the vector ALU
+// RB: rows per workgroup = waves per workgroup (one row per wave), LO: output channels beyond 16*MT computed on the vector ALU
 // (0, or the capacity 2 * 64 / WT: two per lane), FLIP: data gradient.
 //
 // Why LO: 18 = 16 + 2 and 36 = 32 + 4.  A second / third MFMA tile for 2 / 4 channels is 44 % / 25 % of the
@@ -35,14 +34,14 @@ constexpr int kThreads = 256;
 // channels and do them as plain FMAs -- x from the same LDS tile (lane = pixel: conflict-free), the two weights
 // of the pair from a small LDS table (broadcast read) -- in the shadow of the MFMAs, which run 32 cycles each.
 template <int CG, int MT, int WT, int RB, int LO, bool FLIP>
-__global__ __launch_bounds__(kThreads) void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+__global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                 float* __restrict__ y, int C, int K, int H) {
   constexpr int LW = WT + 8;                       // [3 unused][left halo][WT][right halo][3 unused]
   constexpr int LH = RB + 2;
   constexpr int PLANE = LH * LW;
   constexpr int STEPS = 9 * CG;
   constexpr int P = WT / 16;                       // pixel tiles of a row
-  static_assert(RB == 4, "one row per wave");
+  constexpr int kThreads = 64 * RB;               // one row per wave
   static_assert(LO == 0 || LO == 2 * (64 / WT), "leftover capacity: two channels per lane");
   extern __shared__ float lds[];
   float* Xs = lds;                                 // [4*CG][LH][LW]
@@ -180,21 +179,20 @@ __global__ __launch_bounds__(kThreads) void conv3x3_mfma_kernel(const float* __r
   }
 }
 
-template <int CG, int MT, int WT, int LO>
+template <int CG, int MT, int WT, int RB, int LO>
 int launch(const float* x, const float* w, float* y, int N, int C, int K, int H, bool flip, hipStream_t st) {
-  constexpr int RB = 4;
   constexpr size_t lds = ((size_t)4 * CG * (RB + 2) * (WT + 8) + (size_t)9 * CG * MT * 64 + (size_t)4 * CG * 9 * LO) * sizeof(float);
   const dim3 grid(N * (H / RB));
   if (flip) {
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true><<<grid, kThreads, lds, st>>>(x, w, y, C, K, H);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H);
   } else {
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false><<<grid, kThreads, lds, st>>>(x, w, y, C, K, H);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H);
   }
   HCM_CHECK_LAUNCH();
   return 0;
@@ -204,10 +202,12 @@ int launch(const float* x, const float* w, float* y, int N, int C, int K, int H,
 int dispatch(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, bool flip, hipStream_t st) {
   if (N <= 0 || C != K || !x || !w || !y || H % 4 != 0) return (int)hipErrorInvalidValue;
   static const bool hybrid = !(getenv("HCM_CONV_HYBRID") && getenv("HCM_CONV_HYBRID")[0] == '0');
-  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 2>(x, w, y, N, C, K, H, flip, st);
-  if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 0>(x, w, y, N, C, K, H, flip, st);
-  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4>(x, w, y, N, C, K, H, flip, st);
-  if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 0>(x, w, y, N, C, K, H, flip, st);
+  // 4-row bands (4 waves): 8-row bands with 8 waves halve the workgroup count and the weight re-reads, but the
+  // kernel gets slower (36ch: 14.6 -> 19.5 us) and so does the step (654 -> 642 samples/s)
+  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st);
+  if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 4, 0>(x, w, y, N, C, K, H, flip, st);
+  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st);
+  if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 4, 0>(x, w, y, N, C, K, H, flip, st);
   return (int)hipErrorInvalidValue;
 }
 
