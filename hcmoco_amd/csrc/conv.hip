@@ -54,24 +54,37 @@ __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __re
 
   // ---- weights -> operand order: As[step = tap*CG + g][mt][lane] = W(out = 16mt + np, in = 4g + kq, tap) ----
   // forward: W(out, in, tap) = wt[out][in][tap]; data gradient: out runs over C, in over K, wt[in][out][8 - tap]
-  // One (out, in) pair of the PADDED operand per thread and trip: its nine taps are contiguous in memory, the
-  // decode divides by compile-time constants only, padded pairs are written as zeros (no separate clear).
+  // Per thread and trip one (out, in) pair of the PADDED operand: its nine taps are contiguous in memory, padded
+  // pairs are written as zeros (no separate clear).
   // Every global load of the prologue (weights and the band of the input) is issued before the first LDS store:
   // one memory round trip instead of one per loop trip.
   const int n_out = FLIP ? C : K, n_in = FLIP ? K : C;
-  constexpr int WPAIRS = (16 * MT + LO) * 4 * CG, WTRIPS = (WPAIRS + kThreads - 1) / kThreads;
+  // weights: a wave's 64 lanes are the 64 entries (4 input channels x 16 output channels) of ONE operand row, so
+  // each of its nine LDS stores fills a row (conflict-free) and its global reads fall into 16 short runs
+  constexpr int WROWS = CG * MT * 64, WTRIPS = (WROWS + kThreads - 1) / kThreads;
+  constexpr int LPAIRS = 4 * CG * LO, LTRIPS = (LPAIRS + kThreads - 1) / kThreads;
   constexpr int Q = WT / 4;                        // float4 per row
   constexpr int XQ = 4 * CG * LH * Q, XTRIPS = (XQ + kThreads - 1) / kThreads;
-  float wv[WTRIPS][9];
+  float wv[WTRIPS][9], lv[LTRIPS > 0 ? LTRIPS : 1][9];
   float4 xv4[XTRIPS];
+  auto wsrc = [&](int o, int i) { return wt + (FLIP ? ((size_t)i * C + o) : ((size_t)o * C + i)) * 9; };
 #pragma unroll
   for (int t = 0; t < WTRIPS; ++t) {
     const int e = tid + t * kThreads;
-    const int i = e % (4 * CG), o = e / (4 * CG);
-    const bool real = e < WPAIRS && o < n_out && i < n_in;
-    const float* src = wt + (FLIP ? ((size_t)i * C + o) : ((size_t)o * C + i)) * 9;
+    const int i = 4 * ((e >> 6) / MT) + (e & 3), o = 16 * ((e >> 6) % MT) + ((e >> 2) & 15);
+    const bool real = e < WROWS && o < n_out && i < n_in;
+    const float* src = wsrc(o, i);
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[t][k] = real ? src[k] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < LTRIPS; ++t) {
+    const int e = tid + t * kThreads;
+    const int o = 16 * MT + e % (LO ? LO : 1), i = e / (LO ? LO : 1);
+    const bool real = e < LPAIRS && o < n_out && i < n_in;
+    const float* src = wsrc(o, i);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) lv[t][k] = real ? src[k] : 0.f;
   }
   const float* xin = x + (size_t)img * n_in * H * WT;
 #pragma unroll
@@ -84,18 +97,20 @@ __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __re
   }
 #pragma unroll
   for (int t = 0; t < WTRIPS; ++t) {
+    const int e = tid + t * kThreads;              // As[tap*CG + g][mt][kq*16 + np] with (g, mt) = e >> 6
+    if (e < WROWS) {
+      float* dst = As + (e >> 6) * 64 + (e & 3) * 16 + ((e >> 2) & 15);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dst[(FLIP ? 8 - k : k) * CG * MT * 64] = wv[t][k];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < LTRIPS; ++t) {
     const int e = tid + t * kThreads;
-    const int i = e % (4 * CG), o = e / (4 * CG);
-    if (e < WPAIRS) {
-      if (o < 16 * MT) {
-        float* dst = As + ((i >> 2) * MT + (o >> 4)) * 64 + (i & 3) * 16 + (o & 15);
+    if (e < LPAIRS) {
+      float* dst = Ls + (e / (LO ? LO : 1)) * 9 * LO + e % (LO ? LO : 1);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dst[(FLIP ? 8 - k : k) * CG * MT * 64] = wv[t][k];
-      } else {
-        float* dst = Ls + i * 9 * LO + (o - 16 * MT);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dst[(FLIP ? 8 - k : k) * LO] = wv[t][k];
-      }
+      for (int k = 0; k < 9; ++k) dst[(FLIP ? 8 - k : k) * LO] = lv[t][k];
     }
   }
 #pragma unroll
