@@ -78,10 +78,16 @@ __global__ __launch_bounds__(kWG) void gather_norm_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 struct DensePolicy {
   // soft target exp(-|q_r - q_c|_2) from integer pixel coordinates (contrast_trainer.py:702-706)
+  // meta arrives as the flat pixel index; pack() turns it into (row << 16 | column) ONCE per query row and once
+  // per staged key (the divisions by the run-time map width used to sit in weight(): 16 integer divisions per
+  // lane and key tile, more VALU time than the tile's 32 MFMAs)
   int w;
+  __device__ __forceinline__ int pack(int m) const { return ((m / w) << 16) | (m % w); }
   __device__ __forceinline__ float weight(int mr, int mc, int r, int c) const {
-    const float dy = (float)(mr / w - mc / w), dx = (float)(mr % w - mc % w);
-    return __expf(-sqrtf(dy * dy + dx * dx));
+    const float dy = (float)((mr >> 16) - (mc >> 16)), dx = (float)((mr & 0xffff) - (mc & 0xffff));
+    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf (a dozen instructions): the argument is a small exact
+    // integer and the result only feeds exp(-d)
+    return __expf(-__builtin_amdgcn_sqrtf(dy * dy + dx * dx));
   }
   // row statistics -> (loss term, alpha, beta):  G = alpha*softmax - beta*weight
   __device__ __forceinline__ void finish(float lse, float tdot, float z, float& loss, float& alpha,
@@ -94,6 +100,7 @@ struct DensePolicy {
 struct SclPolicy {
   // positives: same joint id, different row, both rows' modality present (:873-885)
   // meta = joint id | (valid << 16)
+  __device__ __forceinline__ int pack(int m) const { return m; }
   __device__ __forceinline__ float weight(int mr, int mc, int r, int c) const {
     return ((mr & 0xffff) == (mc & 0xffff) && r != c && (mr >> 16) && (mc >> 16)) ? 1.f : 0.f;
   }
@@ -115,6 +122,7 @@ struct StripArgs {
   int nbatch;
   int symmetric;        // 1: SCL (Q = K = all 2*nbatch*S rows, one problem); 0: dense
   float inv_tau;
+  int bounded;          // 1: rows are unit vectors and exp(-2/tau) is representable: softmax around the bound 1/tau
   const float* gscale;  // device scalar: 1/(B'S) or 1/N (0 disables the loss)
   float* stat;          // [norient][rows][4] = lse, alpha, beta, unused
   float* rowloss;       // [norient][rows]
@@ -129,7 +137,11 @@ struct StripArgs {
   float* pdq;           // [nkc][N][128]
 };
 
-constexpr int kKS = 144;  // LDS row stride of the key tile (16 mod 32 -> conflict-free b32 reads)
+// LDS row stride of the key tile: 148 = 20 mod 32.  GEMM 1 reads a float4 per lane with lane = key ROW (np): eight
+// consecutive rows must start in eight different bank quads (np*20 mod 32 = 0,20,8,28,16,4,24,12); with the earlier
+// 144 (16 mod 32, ideal for GEMM 2's b32 reads of four rows) those reads were 4-way conflicts and the LDS pipe,
+// shared by the CU's waves, took longer per tile than the 32 MFMAs.  GEMM 2's reads become 3 lanes per bank instead of 2.
+constexpr int kKS = 148;
 
 // BF16 (BASELINE config 5, "bf16 feature-map GEMMs"): both contractions run on the bf16 matrix cores with
 // fp32 accumulation -- the similarity P = Q K^T as 4 x v_mfma_f32_16x16x32_bf16 per tile (32 fp32 MFMAs
@@ -137,12 +149,20 @@ constexpr int kKS = 144;  // LDS row stride of the key tile (16 mod 32 -> confli
 // are rounded to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) in registers on their way from the
 // fp32 unit rows / the fp32 LDS tile into the MFMA; everything else (softmax statistics, targets,
 // normalisation backward) stays fp32.  Parity is stated against the fp32 oracle at 1e-2.
-template <class Policy, bool GRAD, bool BF16>
+template <class Policy, bool GRAD, bool BF16, bool BND>
 __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
-  __shared__ __attribute__((aligned(16))) float sK[16 * kKS];
+  // Software pipeline over the key tiles, three LDS buffers, ONE barrier per tile: while tile t is in its element-wise
+  // phase (softmax / targets / gradient entries) the similarity of tile t+1 has already been issued and tile t+2 is
+  // travelling global -> registers, so no phase waits for a load or for a matrix result.
+  // What this does NOT buy (r02, PMC of the dense stats pass: per wave 25.6 k cycles of fp32-MFMA busy time + 26.6 k
+  // of VALU busy time in 113 k cycles, two waves per SIMD): on this part the fp32 MFMAs and the VALU instructions of a
+  // SIMD's waves do not overlap -- their times ADD (removing either phase removes its full time; interleaving them
+  // in the instruction stream, independent accumulators, conflict-free LDS strides each changed nothing).  The pass is
+  // bounded by (MFMA + VALU) instruction time: fewer VALU instructions per element is the only lever left in fp32.
+  __shared__ __attribute__((aligned(16))) float sKb[3][16 * kKS];
   __shared__ float sG[4][16][17];
-  __shared__ int sMetaC[16];
-  __shared__ float sStatC[16][3];
+  __shared__ int sMetaCb[3][16];
+  __shared__ float sStatCb[3][16][3];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int np = lane & 15, g = lane >> 4;
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = row0 + 4 * g + q;
-    mrow[q] = (r < S) ? metaQ[r] : 0;
+    mrow[q] = (r < S) ? pol.pack(metaQ[r]) : 0;
     if (GRAD) {
       lse_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 0] : 0.f;
       al_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 1] : 0.f;
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   v4f dq[8];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    m[q] = -1.0e30f; ssum[q] = 0.f; td[q] = 0.f; z[q] = 0.f; best[q] = -3.0e38f; bestc[q] = 0;
+    m[q] = BND ? a.inv_tau : -1.0e30f; ssum[q] = 0.f; td[q] = 0.f; z[q] = 0.f; best[q] = -3.0e38f; bestc[q] = 0;
   }
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) dq[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -216,86 +236,129 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   const int ntiles = (S + 15) / 16;
   const int tiles_per = (ntiles + a.nkc - 1) / a.nkc;
   const int tile_lo = kc * tiles_per, tile_hi = min(ntiles, tile_lo + tiles_per);
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+  // fetch: this thread's share of a key tile (16 rows x 32 float4 = 2 float4 per thread; threads < 16 also the
+  // tile's meta / stats of the other orientation)
+  float4 kreg[2];
+  int mreg = 0;
+  float sreg[3] = {0.f, 0.f, 0.f};
+  auto fetch = [&](int tile) {
     const int c0 = tile * 16;
-    __syncthreads();  // previous tile fully consumed
-    {
-      // cooperative load of K[c0 .. c0+16) into LDS: 16 rows x 32 float4 = 512 float4, 2 per thread
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int e = threadIdx.x + h * kWG;
-        const int rr = e >> 5, cc = (e & 31) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + rr < S) v = *reinterpret_cast<const float4*>(K + (int64_t)(c0 + rr) * kC + cc);
-        *reinterpret_cast<float4*>(&sK[rr * kKS + cc]) = v;
-      }
-      if (threadIdx.x < 16) {
-        const int c = c0 + threadIdx.x;
-        sMetaC[threadIdx.x] = (c < S) ? metaK[c] : 0;
-        if (GRAD) {
-          sStatC[threadIdx.x][0] = (c < S) ? a.stat[(statK + c) * 4 + 0] : 0.f;
-          sStatC[threadIdx.x][1] = (c < S) ? a.stat[(statK + c) * 4 + 1] : 0.f;
-          sStatC[threadIdx.x][2] = (c < S) ? a.stat[(statK + c) * 4 + 2] : 0.f;
-        }
+    for (int h = 0; h < 2; ++h) {
+      const int e = threadIdx.x + h * kWG;
+      const int rr = e >> 5, cc = (e & 31) * 4;
+      kreg[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + rr < S) kreg[h] = *reinterpret_cast<const float4*>(K + (int64_t)(c0 + rr) * kC + cc);
+    }
+    if (threadIdx.x < 16) {
+      const int c = c0 + threadIdx.x;
+      mreg = (c < S) ? pol.pack(metaK[c]) : 0;
+      if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sreg[i] = (c < S) ? a.stat[(statK + c) * 4 + i] : 0.f;
       }
     }
-    __syncthreads();
-
-    // GEMM 1: P[16 x 16] = Qstrip . Ktile^T   (32 x v_mfma_f32_16x16x4_f32)
-    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = threadIdx.x + h * kWG;
+      *reinterpret_cast<float4*>(&sKb[buf][(e >> 5) * kKS + (e & 31) * 4]) = kreg[h];
+    }
+    if (threadIdx.x < 16) {
+      sMetaCb[buf][threadIdx.x] = mreg;
+      if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sStatCb[buf][threadIdx.x][i] = sreg[i];
+      }
+    }
+  };
+  // GEMM 1: P[16 x 16] = Qstrip . Ktile^T   (32 x v_mfma_f32_16x16x4_f32) into four independent accumulators
+  auto gemm1 = [&](const float* sK, v4f (&ap)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] = (v4f){0.f, 0.f, 0.f, 0.f};
     if constexpr (BF16) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 lo = *reinterpret_cast<const float4*>(&sK[np * kKS + 32 * j + 8 * g]);
         const float4 hi = *reinterpret_cast<const float4*>(&sK[np * kKS + 32 * j + 8 * g + 4]);
         const v8f kv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], __builtin_convertvector(kv, v8bf), acc, 0, 0, 0);
+        ap[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], __builtin_convertvector(kv, v8bf), ap[j], 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float4 kb = *reinterpret_cast<const float4*>(&sK[np * kKS + 16 * j + 4 * g]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, acc, 0, 0, 0);
+        ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, ap[0], 0, 0, 0);
+        ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, ap[1], 0, 0, 0);
+        ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, ap[2], 0, 0, 0);
+        ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, ap[3], 0, 0, 0);
       }
     }
+  };
+  v4f apn[4];                                       // similarity of the NEXT tile (in flight)
+  if (tile_lo < tile_hi) {
+    fetch(tile_lo);
+    commit(0);
+  }
+  __syncthreads();
+  gemm1(sKb[0], apn);
+  if (tile_lo + 1 < tile_hi) fetch(tile_lo + 1);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int c0 = tile * 16;
+    const int ib = (tile - tile_lo) % 3, nb = (ib + 1) % 3;
+    const float* sK = sKb[ib];
+    const int* sMetaC = sMetaCb[ib];
+    const float (*sStatC)[3] = sStatCb[ib];
+    const v4f acc = (apn[0] + apn[1]) + (apn[2] + apn[3]);
+    if (tile + 1 < tile_hi) commit(nb);             // buffer nb was last read two barriers ago
+    __syncthreads();                                // tile t+1 is in LDS
+    if (tile + 2 < tile_hi) fetch(tile + 2);
+    gemm1(sKb[nb], apn);                            // unconditional (a stale buffer after the last tile): keeps the
+                                                    // MFMAs and the element-wise code below in one basic block
     // C layout: acc[q] = P[row0 + 4g + q][c0 + np]
     const int c = c0 + np;
     const bool cvalid = c < S;
     const int mc = sMetaC[np];
 
+    // Element-wise part, branch-free (selects): with divergent branches and a two-exp online softmax it cost as many
+    // VALU cycles per tile as the tile's 32 MFMAs.  Unit rows bound every logit by 1/tau, so when exp(-2/tau) is
+    // far from underflow (a.bounded; tau = 0.07: 4e-13) the row maximum is replaced by that bound -- one exp per
+    // element, no rescaling; otherwise the running-maximum form.
     if (!GRAD) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = row0 + 4 * g + q;
-        if (cvalid && r < S) {
-          const float P = acc[q] * a.inv_tau;
-          const float wgt = pol.weight(mrow[q], mc, r, c);
-          const float mn = fmaxf(m[q], P);
-          ssum[q] = ssum[q] * __expf(m[q] - mn) + __expf(P - mn);
+        const bool ok = cvalid && r < S;
+        const float okf = ok ? 1.f : 0.f;            // multiplied in, not selected: a select on an expensive value is
+        const float P = acc[q] * a.inv_tau;          // turned back into a divergent branch, and a branch ends the block
+        const float wgt = pol.weight(mrow[q], mc, r, c) * okf;
+        if (BND) {
+          ssum[q] = fmaf(__expf(P - a.inv_tau), okf, ssum[q]);
+        } else {
+          const float mn = ok ? fmaxf(m[q], P) : m[q];
+          ssum[q] = fmaf(__expf(P - mn), okf, ssum[q] * __expf(m[q] - mn));
           m[q] = mn;
-          td[q] = fmaf(wgt, P, td[q]);
-          z[q] += wgt;
-          if (P > best[q]) { best[q] = P; bestc[q] = c; }
         }
+        td[q] = fmaf(wgt, P, td[q]);
+        z[q] += wgt;
+        const bool better = ok && P > best[q];
+        best[q] = better ? P : best[q];
+        bestc[q] = better ? c : bestc[q];
       }
     } else {
       const float lse_c = sStatC[np][0], al_c = sStatC[np][1], be_c = sStatC[np][2];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = row0 + 4 * g + q;
-        float G = 0.f;
-        if (cvalid && r < S) {
-          const float P = acc[q] * a.inv_tau;
-          const float wgt = pol.weight(mrow[q], mc, r, c);
-          G = al_r[q] * __expf(P - lse_r[q]) - be_r[q] * wgt + al_c * __expf(P - lse_c) - be_c * wgt;
-          G *= gs * a.inv_tau;
-        }
+        const float okf = (cvalid && r < S) ? gs * a.inv_tau : 0.f;
+        const float P = fminf(acc[q] * a.inv_tau, 2.f * a.inv_tau);      // (clamp: padded rows must not make inf * 0)
+        const float wgt = pol.weight(mrow[q], mc, r, c);
+        float G = al_r[q] * __expf(P - lse_r[q]) - be_r[q] * wgt + al_c * __expf(P - lse_c) - be_c * wgt;
+        G *= okf;
         sG[wave][4 * g + q][np] = G;
       }
-      __syncthreads();  // sG visible (also orders the LDS traffic of the four waves)
+      __builtin_amdgcn_wave_barrier();  // sG[wave] is written and read by this wave only; LDS operations of a wave execute in order
       // GEMM 2: dQ[16 x 128] += G[16 x 16] . Ktile[16 x 128]   (4 k-steps x 8 channel tiles)
       if constexpr (BF16) {
         // A = G[np][4g + i], B = Ktile[4g + i][16nt + np], i < 4: one 16-key contraction per channel tile
@@ -1202,22 +1265,27 @@ static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int
   HCM_CHECK_LAUNCH();
   StripArgs a;
   a.F = ws.F; a.invn = ws.invn; a.meta = ws.meta; a.keep = keep; a.S = S; a.nbatch = B;
-  a.symmetric = 0; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
+  a.symmetric = 0; a.inv_tau = (float)(1.0 / (double)temperature); a.bounded = 2.0 / (double)temperature < 80.0 ? 1 : 0; a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
   a.nkc = 1; a.pstat = nullptr; a.pdq = nullptr;
   const dim3 grid((S + 63) / 64, B, 2);
   DensePolicy pol{coord_w};
   {
     ProfSpan span(HCM_PROF_DENSE_STATS, s);
-    if (bf16) strip_kernel<DensePolicy, false, true><<<grid, kWG, 0, s>>>(a, pol);
-    else strip_kernel<DensePolicy, false, false><<<grid, kWG, 0, s>>>(a, pol);
+    if (a.bounded) {
+      if (bf16) strip_kernel<DensePolicy, false, true, true><<<grid, kWG, 0, s>>>(a, pol);
+      else strip_kernel<DensePolicy, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
+    } else {
+      if (bf16) strip_kernel<DensePolicy, false, true, false><<<grid, kWG, 0, s>>>(a, pol);
+      else strip_kernel<DensePolicy, false, false, false><<<grid, kWG, 0, s>>>(a, pol);
+    }
     HCM_CHECK_LAUNCH();
     span.stop();
   }
   {
     ProfSpan span(HCM_PROF_DENSE_GRAD, s);
-    if (bf16) strip_kernel<DensePolicy, true, true><<<grid, kWG, 0, s>>>(a, pol);
-    else strip_kernel<DensePolicy, true, false><<<grid, kWG, 0, s>>>(a, pol);
+    if (bf16) strip_kernel<DensePolicy, true, true, false><<<grid, kWG, 0, s>>>(a, pol);
+    else strip_kernel<DensePolicy, true, false, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     span.stop();
   }
@@ -1273,15 +1341,20 @@ static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B
   HCM_CHECK_LAUNCH();
   StripArgs a;
   a.F = ws.F; a.invn = ws.invn; a.meta = ws.meta; a.keep = nullptr; a.S = J; a.nbatch = B;
-  a.symmetric = 1; a.inv_tau = (float)(1.0 / (double)temperature); a.gscale = ws.gscale;
+  a.symmetric = 1; a.inv_tau = (float)(1.0 / (double)temperature); a.bounded = 2.0 / (double)temperature < 80.0 ? 1 : 0; a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
   a.nkc = ws.nkc; a.pstat = ws.pstat; a.pdq = ws.pdq;
   const dim3 grid((N + 63) / 64, ws.nkc, 1);
   SclPolicy pol;
   {
     ProfSpan span(HCM_PROF_SCL_STATS, s);
-    if (bf16) strip_kernel<SclPolicy, false, true><<<grid, kWG, 0, s>>>(a, pol);
-    else strip_kernel<SclPolicy, false, false><<<grid, kWG, 0, s>>>(a, pol);
+    if (a.bounded) {
+      if (bf16) strip_kernel<SclPolicy, false, true, true><<<grid, kWG, 0, s>>>(a, pol);
+      else strip_kernel<SclPolicy, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
+    } else {
+      if (bf16) strip_kernel<SclPolicy, false, true, false><<<grid, kWG, 0, s>>>(a, pol);
+      else strip_kernel<SclPolicy, false, false, false><<<grid, kWG, 0, s>>>(a, pol);
+    }
     HCM_CHECK_LAUNCH();
     if (ws.nkc > 1) {
       strip_merge_stats_kernel<SclPolicy><<<(N + kWG - 1) / kWG, kWG, 0, s>>>(a, pol, N);
@@ -1291,8 +1364,8 @@ static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B
   }
   {
     ProfSpan span(HCM_PROF_SCL_GRAD, s);
-    if (bf16) strip_kernel<SclPolicy, true, true><<<grid, kWG, 0, s>>>(a, pol);
-    else strip_kernel<SclPolicy, true, false><<<grid, kWG, 0, s>>>(a, pol);
+    if (bf16) strip_kernel<SclPolicy, true, true, false><<<grid, kWG, 0, s>>>(a, pol);
+    else strip_kernel<SclPolicy, true, false, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     if (ws.nkc > 1) {
       strip_merge_grad_kernel<<<(N + 3) / 4, kWG, 0, s>>>(a, N);

@@ -4,7 +4,9 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hcmoco_amd import hip_ops
+from hcmoco_amd import _lib, hip_ops
+if os.environ.get('HCM_LIB'):                 # a diagnostic build of the library
+    _lib.LIB_PATH = os.environ['HCM_LIB']
 
 d = torch.device('cuda:0')
 torch.manual_seed(0)

@@ -95,3 +95,13 @@ for length, a, b in holes[:3]:
         agg[n][1] += 1
     for n, (v, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
         print('    %7.1f us %3d x  %s' % (v / 1e3, c, n[:100]))
+
+# the long kernels: everything above 40 us in the window, by name
+long_ = defaultdict(lambda: [0, 0])
+for s, e, n, q in win:
+    if e - s > 40000:
+        long_[n][0] += e - s
+        long_[n][1] += 1
+print('kernels longer than 40 us: %.2f ms in %d launches' % (sum(v[0] for v in long_.values()) / 1e6, sum(v[1] for v in long_.values())))
+for n, (v, c) in sorted(long_.items(), key=lambda kv: -kv[1][0])[:25]:
+    print('  %8.1f us  %4d x %6.1f us  %s' % (v / 1e3, c, v / c / 1e3, n[:100]))
