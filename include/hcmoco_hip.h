@@ -403,8 +403,8 @@ int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host);
  * branches (reference: networks/official_hrnet.py:40-70 `conv3x3` -> nn.Conv2d(bias=False); replaces the
  * cudnn/MIOpen call behind F.conv2d and its data gradient).  x [N,C,H,W], w [K,C,3,3], y [N,K,H,W];
  * backward_data: dy [N,K,H,W] -> dx [N,C,H,W] = conv of dy with the transposed, flipped filter.
- * hcm_conv3x3_supported: 1 for the shapes with a kernel instance (C == K in 17..20 or 29..32 on 64-wide maps,
- * 33..36 on 32-wide maps, H % 4 == 0); anything else returns hipErrorInvalidValue and the caller keeps its library path. */
+ * hcm_conv3x3_supported: 1 for the shapes with a kernel instance (C == K in 17..20 on 64-wide maps, 33..36 on
+ * 32-wide maps, H % 4 == 0); anything else returns hipErrorInvalidValue and the caller keeps its library path. */
 int hcm_conv3x3_supported(int C, int K, int H, int W);
 int hcm_conv3x3_forward(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, hcm_stream_t stream);
 int hcm_conv3x3_backward_data(const float* dy, const float* w, float* dx, int N, int C, int K, int H, int W,

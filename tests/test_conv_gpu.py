@@ -20,7 +20,7 @@ def _call(name, a, w, N, Cc, K, H, W):
 
 
 @pytest.mark.parametrize('N,Cc,H,W', [(32, 18, 64, 64), (32, 36, 32, 32), (3, 18, 8, 64), (2, 20, 12, 64), (1, 17, 4, 64),
-                                      (5, 36, 4, 32), (2, 33, 20, 32), (1, 34, 32, 32), (4, 32, 64, 64), (2, 30, 8, 64)])
+                                      (5, 36, 4, 32), (2, 33, 20, 32), (1, 34, 32, 32)])
 def test_conv3x3_forward_and_data_gradient_match_conv2d(N, Cc, H, W):
     from hcmoco_amd import _lib
     assert _lib.lib().hcm_conv3x3_supported(Cc, Cc, H, W) == 1
@@ -48,7 +48,7 @@ def test_conv3x3_is_deterministic_and_refuses_other_shapes():
     b = _call('hcm_conv3x3_forward', x, w, 4, 18, 18, 64, 64)
     assert torch.equal(a, b)
     L = _lib.lib()
-    for shape in [(72, 72, 16, 16), (18, 36, 64, 64), (18, 18, 62, 64), (18, 18, 64, 48), (16, 16, 64, 64)]:
+    for shape in [(72, 72, 16, 16), (18, 36, 64, 64), (18, 18, 62, 64), (18, 18, 64, 48), (16, 16, 64, 64), (32, 32, 64, 64)]:
         assert L.hcm_conv3x3_supported(*shape) == 0
     with pytest.raises(_lib.HipError):
         _call('hcm_conv3x3_forward', torch.randn(1, 72, 16, 16, device=dev), torch.randn(72, 72, 3, 3, device=dev),
