@@ -91,6 +91,11 @@ class ContrastTrainer(BaseTrainer):
                 glue = _lib.torch_glue()
             self.grad_sync = GradSync(model, [p for g in optimizer.param_groups for p in g['params']], mode=sync,
                                       chunks=int(os.environ.get('HCM_GRAD_CHUNKS', '4')), glue=glue)
+        if (deferred and os.environ.get('HCM_FLAT_SGD', '1') != '0' and isinstance(optimizer, torch.optim.SGD)):
+            # one update launch per encoder instead of ~40 per step (learning/flat_sgd.py); checkpoints keep the
+            # reference's per-parameter layout
+            from .flat_sgd import FlatParamSGD
+            optimizer = FlatParamSGD(optimizer, model)
         if multi and self.grad_sync is None:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # stage 1 never touches the 1x1 feature-map projections when --linear_feat_map 1 is set

@@ -211,3 +211,31 @@ def test_transfer_ckpt_roundtrip_into_backbone():
     net = get_hrnet_w18_backbone()
     net.load_state_dict(torch.load(dst))                       # strict: every key present, none extra
     assert torch.equal(net.conv1.weight, model.encoder2.conv1.weight.detach().cpu())
+
+
+def test_flat_param_sgd_without_encoder_programs_is_a_transparent_wrapper():
+    """learning/flat_sgd.py on a model with no encoder program (CPU, or any module path): same parameters, same
+    state_dict as the optimizer it wraps; lr edits through param_groups reach the inner optimizer."""
+    import copy
+    from hcmoco_amd.pycontrast.learning.flat_sgd import FlatParamSGD
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2))
+    t = copy.deepcopy(m)
+    kw = dict(lr=0.1, momentum=0.9, weight_decay=1e-3)
+    a = FlatParamSGD(torch.optim.SGD(m.parameters(), **kw), m)
+    b = torch.optim.SGD(t.parameters(), **kw)
+    x = torch.randn(7, 5)
+    for i in range(3):
+        for net, opt in ((m, a), (t, b)):
+            opt.zero_grad(set_to_none=True)
+            net(x).square().mean().backward()
+            opt.step()
+        a.param_groups[0]['lr'] = b.param_groups[0]['lr'] = 0.05
+    for p, q in zip(m.parameters(), t.parameters()):
+        assert torch.equal(p, q)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa['param_groups'] == sb['param_groups']
+    for k in sb['state']:
+        assert torch.equal(sa['state'][k]['momentum_buffer'], sb['state'][k]['momentum_buffer'])
+    a.load_state_dict(sb)
+    assert a.inner.param_groups[0]['lr'] == 0.05

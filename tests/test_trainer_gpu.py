@@ -181,3 +181,52 @@ def test_stage2_loop_on_the_hip_engine_through_main(_pg_env):
     torch.cuda.synchronize()
     assert len(outs) == 4 and outs[0] == outs[0]
     assert eng.calls['bank'] == 2 and eng.calls['fmap'] == 2 and eng.calls['regimes'] == {(True, False)}
+
+
+def test_flat_parameter_sgd_is_the_same_update_and_keeps_the_reference_checkpoint_layout():
+    """learning/flat_sgd.py: after the first step every encoder parameter is a view of one flat tensor, the step it
+    took is bit-identical to torch.optim.SGD on the separate tensors with the same gradients, and state_dict() is
+    the per-parameter layout a plain SGD over model.parameters() loads."""
+    import copy
+    from hcmoco_amd.pycontrast.learning.flat_sgd import FlatParamSGD
+    from hcmoco_amd.pycontrast.networks.hrnet import HighResolutionNet
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    net = HighResolutionNet(18).to(dev).train()
+    head = torch.nn.Linear(18, 4).to(dev)
+    model = torch.nn.ModuleDict({'enc': net, 'head': head})
+    kw = dict(lr=0.03, momentum=0.9, weight_decay=1e-4)
+    opt = FlatParamSGD(torch.optim.SGD(model.parameters(), fused=True, **kw), model)
+    twin = copy.deepcopy(model)
+    ref = torch.optim.SGD(twin.parameters(), fused=True, **kw)
+    x = torch.randn(2, 3, 64, 64, device=dev)
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        maps = net(x)
+        loss = sum(m.square().mean() for m in maps) + head(maps[0].mean((2, 3))).sum()
+        loss.backward()
+        from hcmoco_amd import _lib
+        _lib.torch_glue().wgrad_join()
+        for p, q in zip(model.parameters(), twin.parameters()):       # the twin takes the SAME gradients
+            q.grad = None if p.grad is None else p.grad.detach().clone()
+        opt.step()
+        ref.step()
+        assert len(opt._flat) == 1 and opt._flat[0][1].numel() == sum(p.numel() for p in net.last_program.params)
+        for p, q in zip(model.parameters(), twin.parameters()):
+            assert torch.equal(p, q)
+        for p in net.last_program.params:
+            assert p.untyped_storage().data_ptr() == opt._flat[0][1].untyped_storage().data_ptr()
+    assert len(opt.param_groups[0]['params']) == 1 + sum(1 for p in model.parameters()
+                                                          if all(p is not q for q in net.last_program.params))
+    sd, rd = opt.state_dict(), ref.state_dict()
+    assert sd['param_groups'][0]['params'] == rd['param_groups'][0]['params']
+    assert sorted(sd['state']) == sorted(rd['state'])
+    for k in rd['state']:
+        assert torch.equal(sd['state'][k]['momentum_buffer'], rd['state'][k]['momentum_buffer'])
+    # a plain optimizer loads it; the wrapper loads a plain optimizer's
+    fresh = torch.optim.SGD(copy.deepcopy(twin).parameters(), fused=True, **kw)
+    fresh.load_state_dict(sd)
+    opt.load_state_dict(rd)
+    sd2 = opt.state_dict()
+    for k in rd['state']:
+        assert torch.equal(sd2['state'][k]['momentum_buffer'], rd['state'][k]['momentum_buffer'])
