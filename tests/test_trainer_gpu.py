@@ -230,3 +230,45 @@ def test_flat_parameter_sgd_is_the_same_update_and_keeps_the_reference_checkpoin
     sd2 = opt.state_dict()
     for k in rd['state']:
         assert torch.equal(sd2['state'][k]['momentum_buffer'], rd['state'][k]['momentum_buffer'])
+
+
+def test_flat_parameter_sgd_resumes_from_a_reference_layout_checkpoint():
+    """A per-parameter optimizer state loaded BEFORE the first step (resume_model's order) moves into the flat
+    momentum buffer when the parameters are flattened: the next steps equal a plain SGD that simply continued."""
+    import copy
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.learning.flat_sgd import FlatParamSGD
+    from hcmoco_amd.pycontrast.networks.hrnet import HighResolutionNet
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    net = HighResolutionNet(18).to(dev).train()
+    kw = dict(lr=0.03, momentum=0.9, weight_decay=1e-4)
+    plain = torch.optim.SGD(net.parameters(), fused=True, **kw)
+    x = torch.randn(2, 3, 64, 64, device=dev)
+
+    def backward(n):
+        sum(m.square().mean() for m in n(x)).backward()
+        _lib.torch_glue().wgrad_join()
+
+    for _ in range(2):                                   # two plain steps: momentum buffers exist
+        plain.zero_grad(set_to_none=True)
+        backward(net)
+        plain.step()
+    twin = copy.deepcopy(net)
+    cont = torch.optim.SGD(twin.parameters(), fused=True, **kw)
+    cont.load_state_dict(copy.deepcopy(plain.state_dict()))
+    flat = FlatParamSGD(torch.optim.SGD(net.parameters(), fused=True, **kw), net)
+    flat.load_state_dict(copy.deepcopy(plain.state_dict()))            # before its first step
+    for _ in range(2):
+        flat.zero_grad(set_to_none=True)
+        backward(net)
+        for p, q in zip(net.parameters(), twin.parameters()):
+            q.grad = p.grad.detach().clone()
+        flat.step()
+        cont.step()
+        assert len(flat._flat) == 1
+        for p, q in zip(net.parameters(), twin.parameters()):
+            assert torch.equal(p, q)
+    a, b = flat.state_dict(), cont.state_dict()
+    for k in b['state']:
+        assert torch.equal(a['state'][k]['momentum_buffer'], b['state'][k]['momentum_buffer'])
