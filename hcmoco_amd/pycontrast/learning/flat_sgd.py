@@ -137,7 +137,15 @@ class FlatParamSGD(object):
                 self.inner.load_state_dict(self._pending_state)
                 self._pending_state = None
             self._flatten()
-        for enc, flat, params, _ in self._flat:
+        for enc, flat, params, offs in self._flat:
+            # someone re-allocated the parameters (model.to(...), .float(), load with assign=True): take their current
+            # values back into the flat tensor and re-bind, or the update below would go to memory nobody reads
+            if (params[0].data_ptr() != flat.data_ptr()
+                    or params[-1].data_ptr() != flat.data_ptr() + offs[-1] * flat.element_size()):
+                with torch.no_grad():
+                    for p, off in zip(params, offs):
+                        flat[off:off + p.numel()].copy_(p.reshape(-1))
+                        p.data = flat[off:off + p.numel()].view(p.shape)
             fg = self._flat_grad(params, flat.numel(), full_check=False)
             if fg is None:
                 # this step's forward did not run as an encoder program (module path, another input shape): gather

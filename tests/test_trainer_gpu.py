@@ -272,3 +272,15 @@ def test_flat_parameter_sgd_resumes_from_a_reference_layout_checkpoint():
     a, b = flat.state_dict(), cont.state_dict()
     for k in b['state']:
         assert torch.equal(a['state'][k]['momentum_buffer'], b['state'][k]['momentum_buffer'])
+    # parameters re-allocated behind the optimizer's back (model.to / .float()): re-bound at the next step
+    for p in net.parameters():
+        p.data = p.data.clone()
+    flat.zero_grad(set_to_none=True)
+    backward(net)
+    for p, q in zip(net.parameters(), twin.parameters()):
+        q.grad = p.grad.detach().clone()
+    flat.step()
+    cont.step()
+    for p, q in zip(net.parameters(), twin.parameters()):
+        assert torch.equal(p, q)
+    assert net.last_program.params[0].data_ptr() == flat._flat[0][1].data_ptr()
