@@ -331,9 +331,15 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton, B)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which is block-
+        # buffered on a pipe and would otherwise come out at process exit, after python's own (flushed) print
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
