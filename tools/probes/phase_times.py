@@ -16,7 +16,13 @@ import bench                                                             # noqa:
 
 def main():
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    import torch.distributed as dist
     dev = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    if os.environ.get('HCM_FORCE_COLLECTIVES', '0') != '0':        # the N>1 control path on a 1-rank RCCL group
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     args = bench.make_args(32, 16384, 131072, 256, os.environ.get('SKELETON', 'coco17'), 'nccl',
                            tempfile.mkdtemp(), 10 ** 6)
     args.rank, args.world_size, args.local_rank, args.gpu = 0, 1, 0, 0
@@ -40,10 +46,14 @@ def main():
         if hasattr(eng, nm):
             f = getattr(eng, nm)
             setattr(eng, nm, (lambda f, nm: lambda *a, **k: (lambda out: (mark('loss_' + nm), out)[1])(f(*a, **k)))(f, nm))
+    if trainer.grad_sync is not None:
+        red0 = trainer.grad_sync.reduce
+        trainer.grad_sync.reduce = lambda join=None: (mark('backward_returned'), red0(join), mark('reduced'))[1]
     join0 = trainer.async_wgrad.wgrad_join if trainer.async_wgrad is not None else None
     if join0 is not None:
         def join():
-            mark('backward_returned')
+            if trainer.grad_sync is None:
+                mark('backward_returned')
             join0()
             mark('joined')
         trainer.async_wgrad.wgrad_join = join
