@@ -23,6 +23,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        if os.environ.get('HCM_PROBE_NO_ALLREDUCE'):              # how much of the control path's cost is RCCL itself
+            class _Done(object):
+                def wait(self):
+                    return True
+            dist.all_reduce = lambda t, op=None, async_op=False, group=None: _Done()
     args = bench.make_args(32, 16384, 131072, 256, os.environ.get('SKELETON', 'coco17'), 'nccl',
                            tempfile.mkdtemp(), 10 ** 6)
     args.rank, args.world_size, args.local_rank, args.gpu = 0, 1, 0, 0
