@@ -798,7 +798,9 @@ __global__ void joint_pixels_kernel(const float* __restrict__ j2d, int n, int h,
 // thread four consecutive output pixels of one plane -> 16-byte coalesced stores, inputs from L1/L2.
 // Same arithmetic as at::native::upsample_bilinear2d (area_pixel_compute_source_index).
 // ------------------------------------------------------------------------------------------
+template <bool ACC, bool RELU>
 __global__ __launch_bounds__(kWG) void upsample_bilinear_kernel(const float* __restrict__ in,
+                                                                const float* __restrict__ acc,
                                                                 float* __restrict__ out, int planes,
                                                                 int Hi, int Wi, int Ho, int Wo,
                                                                 float sy, float sx) {
@@ -826,10 +828,19 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_kernel(const float* __r
       v[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
     }
     float* dst = out + (pl * Ho + oy) * Wo + 4 * q;
+    const float* asrc = ACC ? acc + (pl * Ho + oy) * Wo + 4 * q : nullptr;
     if (4 * q + 3 < Wo && ((Wo & 3) == 0)) {
+      if (ACC) {                                       // the running sum of the fuse layer + this term (+ ReLU): one launch
+        const float4 a4 = *reinterpret_cast<const float4*>(asrc);
+        v[0] = a4.x + v[0]; v[1] = a4.y + v[1]; v[2] = a4.z + v[2]; v[3] = a4.w + v[3];
+      }
+      if (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-      for (int k = 0; k < 4 && 4 * q + k < Wo; ++k) dst[k] = v[k];
+      for (int k = 0; k < 4 && 4 * q + k < Wo; ++k) {
+        float r = ACC ? asrc[k] + v[k] : v[k];
+        dst[k] = RELU ? fmaxf(r, 0.f) : r;
+      }
     }
   }
 }
@@ -911,11 +922,17 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_kernel(const float*
 // (Ho*Wi outputs: 8x the parallelism of the per-input-pixel form at scale factor 8, and ~2S taps each instead of
 // (2S)^2); stage 2 contracts the rows out of LDS.  Stencils come from per-workgroup tables built with the
 // forward's float expressions; both sums run in ascending output order: deterministic.
+// MASK: the op was fused with the ReLU that followed it (y = relu(acc + up(x))): the gradient is first masked by
+// y > 0 -- staged in LDS for the two passes and written out as the gradient of the running sum `acc`.
+template <bool MASK>
 __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_plane_kernel(const float* __restrict__ g,
+                                                                          const float* __restrict__ y,
+                                                                          float* __restrict__ gmasked,
                                                                           float* __restrict__ dx, int Hi, int Wi,
                                                                           int Ho, int Wo, float sy, float sx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* T = smem;                                   // [Ho][Wi]
+  float* Gs = smem;                                  // [Ho][Wo] masked gradient plane (MASK only)
+  float* T = smem + (MASK ? Ho * Wo : 0);            // [Ho][Wi]
   float* lxt = T + Ho * Wi;                          // [Wo] lambda of output column
   float* lyt = lxt + Wo;                             // [Ho]
   int* x0t = reinterpret_cast<int*>(lyt + Ho);       // [Wo] source floor of output column
@@ -941,11 +958,20 @@ __global__ __launch_bounds__(kWG) void upsample_bilinear_bwd_plane_kernel(const 
   }
   for (int i = tid; i < Wi; i += kWG) touch_range(i, sx, isx, Wi, Wo, xlo[i], xhi[i]);
   for (int i = tid; i < Hi; i += kWG) touch_range(i, sy, isy, Hi, Ho, ylo[i], yhi[i]);
-  __syncthreads();
   const float* gp = g + pl * Ho * Wo;
+  if (MASK) {
+    const float* yp = y + pl * Ho * Wo;
+    float* mp = gmasked + pl * Ho * Wo;
+    for (int o = tid; o < Ho * Wo; o += kWG) {
+      const float v = yp[o] > 0.f ? gp[o] : 0.f;
+      Gs[o] = v;
+      mp[o] = v;
+    }
+  }
+  __syncthreads();
   for (int o = tid; o < Ho * Wi; o += kWG) {
     const int yo = o / Wi, xi = o - yo * Wi;
-    const float* grow = gp + (int64_t)yo * Wo;
+    const float* grow = (MASK ? Gs : gp) + (int64_t)yo * Wo;
     float acc = 0.f;
     for (int xo = xlo[xi]; xo <= xhi[xi]; ++xo) {
       const int x0 = x0t[xo], x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
@@ -1419,8 +1445,33 @@ int hcm_upsample_bilinear2d(const float* in, int planes, int Hi, int Wi, int Ho,
   const int64_t total = (int64_t)planes * Ho * ((Wo + 3) / 4);
   int64_t blocks = (total + kWG - 1) / kWG;
   if (blocks > 16384) blocks = 16384;
-  upsample_bilinear_kernel<<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
-      in, out, planes, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  upsample_bilinear_kernel<false, false><<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(
+      in, nullptr, out, planes, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_upsample_bilinear2d_add(const float* in, const float* acc, int relu, int planes, int Hi, int Wi, int Ho, int Wo,
+                                float* out, hcm_stream_t stream) {
+  if (planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || !in || !acc || !out) return (int)hipErrorInvalidValue;
+  const int64_t total = (int64_t)planes * Ho * ((Wo + 3) / 4);
+  int64_t blocks = (total + kWG - 1) / kWG;
+  if (blocks > 16384) blocks = 16384;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  if (relu) upsample_bilinear_kernel<true, true><<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(in, acc, out, planes, Hi, Wi, Ho, Wo, sy, sx);
+  else upsample_bilinear_kernel<true, false><<<(int)blocks, kWG, 0, (hipStream_t)stream>>>(in, acc, out, planes, Hi, Wi, Ho, Wo, sy, sx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_upsample_bilinear2d_backward_relu(const float* grad_out, const float* y, int planes, int Hi, int Wi, int Ho, int Wo,
+                                          float* grad_in, float* grad_masked, hcm_stream_t stream) {
+  if (planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || !grad_out || !y || !grad_in || !grad_masked)
+    return (int)hipErrorInvalidValue;
+  const size_t lds = ((size_t)Ho * Wo + (size_t)Ho * Wi + 2 * (size_t)(Wo + Ho) + 2 * (size_t)(Wi + Hi)) * sizeof(float);
+  if (lds > 60 * 1024) return (int)hipErrorInvalidValue;      // caller: threshold + hcm_upsample_bilinear2d_backward
+  upsample_bilinear_bwd_plane_kernel<true><<<planes, kWG, lds, (hipStream_t)stream>>>(
+      grad_out, y, grad_masked, grad_in, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
   HCM_CHECK_LAUNCH();
   return 0;
 }
@@ -1431,8 +1482,8 @@ int hcm_upsample_bilinear2d_backward(const float* grad_out, int planes, int Hi, 
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
   const size_t lds = ((size_t)Ho * Wi + 2 * (size_t)(Wo + Ho) + 2 * (size_t)(Wi + Hi)) * sizeof(float);
   if (lds <= 60 * 1024) {        // separable form, intermediate in LDS (all HRNet shapes)
-    upsample_bilinear_bwd_plane_kernel<<<planes, kWG, lds, (hipStream_t)stream>>>(grad_out, grad_in, Hi, Wi, Ho, Wo,
-                                                                                 sy, sx);
+    upsample_bilinear_bwd_plane_kernel<false><<<planes, kWG, lds, (hipStream_t)stream>>>(grad_out, nullptr, nullptr, grad_in,
+                                                                                        Hi, Wi, Ho, Wo, sy, sx);
     HCM_CHECK_LAUNCH();
     return 0;
   }

@@ -586,7 +586,7 @@ Tensor upsample_bilinear(const Tensor& x, int64_t Ho, int64_t Wo) { return Upsam
 //   * encoder_forward_async/_wait run the forward on the helper thread of the current stream as well,
 //     so the caller can issue the other encoder meanwhile.
 // ------------------------------------------------------------------------------------------------
-enum : int64_t { kOpConvBn = 0, kOpAdd = 1, kOpRelu = 2, kOpUpsample = 3 };
+enum : int64_t { kOpConvBn = 0, kOpAdd = 1, kOpRelu = 2, kOpUpsample = 3, kOpUpsampleAdd = 4 };
 constexpr int kInstrInts = 12;   // op dst a b layer stride pad relu out_h out_w stream 0
 
 struct Tape : torch::CustomClassHolder {
@@ -686,6 +686,16 @@ Tensor upsample_forward_raw(const Tensor& x, int64_t Ho, int64_t Wo) {
   check_rc(hcm_upsample_bilinear2d(x.data_ptr<float>(), (int)(N * C), (int)Hi, (int)Wi, (int)Ho, (int)Wo,
                                    y.data_ptr<float>(), current_stream(x)),
            "hcm_upsample_bilinear2d");
+  return y;
+}
+
+// out = relu?(acc + upsample(x)): a term of a fuse layer (and its ReLU when it is the last) in one launch
+Tensor upsample_add_raw(const Tensor& x, const Tensor& acc, bool relu) {
+  Tensor y = at::empty_like(acc);
+  check_rc(hcm_upsample_bilinear2d_add(x.data_ptr<float>(), acc.data_ptr<float>(), relu ? 1 : 0, (int)(x.size(0) * x.size(1)),
+                                       (int)x.size(2), (int)x.size(3), (int)acc.size(2), (int)acc.size(3), y.data_ptr<float>(),
+                                       current_stream(x)),
+           "hcm_upsample_bilinear2d_add");
   return y;
 }
 
@@ -915,6 +925,24 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
     } else if (op == kOpUpsample) {
       const Tensor& x = T.val[a];
       accumulate(S, G[a], upsample_backward_raw(g, x.size(0), x.size(1), x.size(2), x.size(3)), true);
+    } else if (op == kOpUpsampleAdd) {
+      const Tensor& x = T.val[a];
+      if (I[7] != 0) {                                 // fused ReLU: mask by the output, the masked gradient is d acc
+        const Tensor& y = T.val[dst];
+        Tensor dx = at::empty_like(x), gm = at::empty_like(g);
+        const int rc = hcm_upsample_bilinear2d_backward_relu(g.data_ptr<float>(), y.data_ptr<float>(), (int)(x.size(0) * x.size(1)),
+                                                             (int)x.size(2), (int)x.size(3), (int)g.size(2), (int)g.size(3),
+                                                             dx.data_ptr<float>(), gm.data_ptr<float>(), current_stream(x));
+        if (rc != 0) {                                 // plane too large for the LDS form: mask, then the plain backward
+          gm = at::threshold_backward(g, y, 0);
+          dx = upsample_backward_raw(gm, x.size(0), x.size(1), x.size(2), x.size(3));
+        }
+        accumulate(S, G[a], dx, true);
+        accumulate(S, G[b], gm, true);
+      } else {
+        accumulate(S, G[a], upsample_backward_raw(g, x.size(0), x.size(1), x.size(2), x.size(3)), true);
+        accumulate(S, G[b], g, false);
+      }
     }
     S.issued();
     T.val[dst] = Tensor();
@@ -969,6 +997,8 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
         T.val[dst] = at::relu(T.val[a]);
       } else if (op == kOpUpsample) {
         T.val[dst] = upsample_forward_raw(T.val[a], I[8], I[9]);
+      } else if (op == kOpUpsampleAdd) {
+        T.val[dst] = upsample_add_raw(T.val[a], T.val[b], I[7] != 0);
       } else {
         TORCH_CHECK(false, "hcmoco::run_encoder: unknown opcode ", op);
       }

@@ -20,6 +20,7 @@ ENCODER_PROGRAM = os.environ.get('HCM_ENCODER_PROGRAM', '1') != '0'   # whole en
 # HRNet branch i on HIP stream i of the encoder.  Off: measured 530 vs 572 samples/s -- the ~300 cross-stream
 # event waits per pass cost more than the extra overlap buys (134 ms/step with GPU_MAX_HW_QUEUES=8).
 BRANCH_STREAMS = os.environ.get('HCM_BRANCH_STREAMS', '0') != '0'
+FUSE_UPSAMPLE_ADD = os.environ.get('HCM_FUSE_UPSAMPLE_ADD', '1') != '0'   # fuse-layer terms as one instruction
 
 
 def bn_act_supported(x):
@@ -139,7 +140,7 @@ class ProgramBuilder(object):
     on a helper thread).  Instructions are 12 ints ``op dst a b layer stride pad relu out_h out_w 0 0``
     over value slots; slot 0 is the input image.  ``ok`` turns False when a layer falls outside what the
     kernels cover (then the module-by-module path runs)."""
-    CONV_BN, ADD, RELU, UPSAMPLE = 0, 1, 2, 3
+    CONV_BN, ADD, RELU, UPSAMPLE, UPSAMPLE_ADD = 0, 1, 2, 3, 4
 
     def __init__(self, in_shape):
         self.instr, self.params, self.buffers = [], [], []
@@ -182,6 +183,14 @@ class ProgramBuilder(object):
     def upsample(self, a, size):
         dst = self._new((self.shapes[a][0], int(size[0]), int(size[1])))
         self.instr += [self.UPSAMPLE, dst, a, -1, 0, 0, 0, 0, int(size[0]), int(size[1]), self.sid, 0]
+        return dst
+
+    def upsample_add(self, a, acc, relu=False):
+        """relu?(acc + upsample(a)) to acc's size: a term of a fuse layer (and its ReLU when it is the last) as one
+        instruction instead of upsample + add (+ relu)."""
+        dst = self._new(self.shapes[acc])
+        _, h, w = self.shapes[acc]
+        self.instr += [self.UPSAMPLE_ADD, dst, a, acc, 0, 0, 0, int(relu), int(h), int(w), self.sid, 0]
         return dst
 
     def chain(self, seq, a):
@@ -309,17 +318,23 @@ class HighResolutionModule(nn.Module):
         for i, row in enumerate(self.fuse_layers):
             pb.on(i)
             y = xs[0] if i == 0 else pb.chain(row[0], xs[0])
+            last = self.num_branches - 1
+            done = False                       # the output's ReLU went into the last term's instruction
             for j in range(1, self.num_branches):
                 if j == i:
                     y = pb.add(y, xs[j])
                 elif j > i:
-                    y = pb.add(y, pb.upsample(row[j].emit(pb, xs[j]), pb.shapes[xs[i]][1:]))
+                    if FUSE_UPSAMPLE_ADD:      # same sum in the same order, one launch per term (two or three before)
+                        y = pb.upsample_add(row[j].emit(pb, xs[j]), y, relu=(j == last))
+                        done = j == last
+                    else:
+                        y = pb.add(y, pb.upsample(row[j].emit(pb, xs[j]), pb.shapes[xs[i]][1:]))
                 else:
                     t = xs[j]
                     for step in row[j][:-1]:
                         t = step.emit(pb, t)
                     y = row[j][-1].emit(pb, t, y)
-            outs.append(pb.relu(y))
+            outs.append(y if done else pb.relu(y))
         return outs
 
 

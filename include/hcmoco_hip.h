@@ -196,6 +196,14 @@ int hcm_upsample_bilinear2d_nhwc(const float* in, int N, int C, int Hi, int Wi, 
  * upsample_bilinear2d_backward scatters with float atomicAdd); overwrites grad_in. */
 int hcm_upsample_bilinear2d_backward(const float* grad_out, int planes, int Hi, int Wi, int Ho, int Wo,
                                      float* grad_in, hcm_stream_t stream);
+/* A term of an HRNet fuse layer in one launch (networks/official_hrnet.py:230-251: y = y + F.interpolate(f_ij(x_j));
+ * after the last term, relu): out = relu?(acc + upsample(in)).  backward_relu is the backward of the relu form:
+ * grad_masked = grad_out * (y > 0) (the gradient of `acc`), grad_in = upsample^T(grad_masked); it refuses planes
+ * whose masked gradient does not fit LDS (> 60 KB with the separable form's tables): mask, then the plain backward. */
+int hcm_upsample_bilinear2d_add(const float* in, const float* acc, int relu, int planes, int Hi, int Wi, int Ho, int Wo,
+                                float* out, hcm_stream_t stream);
+int hcm_upsample_bilinear2d_backward_relu(const float* grad_out, const float* y, int planes, int Hi, int Wi, int Ho, int Wo,
+                                          float* grad_in, float* grad_masked, hcm_stream_t stream);
 
 /* Row 8, sampled form: bilinear(x)[b, :, pix[b,r]] for one HRNet branch
  * x [B, C, hi, wi] (strides st), evaluated on the finest grid (h0 x w0, align_corners=False), written

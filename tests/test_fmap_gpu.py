@@ -345,3 +345,36 @@ def test_bf16_mfma_contractions_vs_fp32_oracle(B, h, S, J):
     again = run(m1, m2, None, ind, keep.int(), pix, vis, ud, None, temp, 'channels_last', do_joint=False,
                 gemm_dtype='bf16')
     assert torch.equal(again[1], met) and torch.equal(again[2], g1) and torch.equal(again[3], g2)
+
+
+@pytest.mark.parametrize('planes,hi,ho', [(36, 32, 64), (7, 8, 64), (18 * 3, 16, 32), (5, 4, 8), (3, 5, 12)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_upsample_add_and_its_masked_backward_equal_the_separate_ops(planes, hi, ho, relu):
+    """hcm_upsample_bilinear2d_add == (acc + hcm_upsample_bilinear2d) [+ relu] bit for bit, and
+    hcm_upsample_bilinear2d_backward_relu == threshold_backward followed by hcm_upsample_bilinear2d_backward."""
+    import ctypes as C
+    from hcmoco_amd import _lib
+    from hcmoco_amd.hip_ops import check
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(planes * 100 + hi)
+    x = torch.randn(planes, hi, hi, generator=g).to(dev)
+    acc = torch.randn(planes, ho, ho, generator=g).to(dev)
+    go = torch.randn(planes, ho, ho, generator=g).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    up = torch.empty_like(acc)
+    check(L.hcm_upsample_bilinear2d(p(x), planes, hi, hi, ho, ho, p(up), st), 'up')
+    ref = acc + up
+    if relu:
+        ref = torch.relu(ref)
+    out = torch.empty_like(acc)
+    check(L.hcm_upsample_bilinear2d_add(p(x), p(acc), int(relu), planes, hi, hi, ho, ho, p(out), st), 'up_add')
+    assert torch.equal(out, ref)
+    if relu:
+        gm_ref = torch.where(ref > 0, go, torch.zeros_like(go))
+        dx_ref = torch.empty_like(x)
+        check(L.hcm_upsample_bilinear2d_backward(p(gm_ref), planes, hi, hi, ho, ho, p(dx_ref), st), 'bwd')
+        dx, gm = torch.empty_like(x), torch.empty_like(go)
+        check(L.hcm_upsample_bilinear2d_backward_relu(p(go), p(out), planes, hi, hi, ho, ho, p(dx), p(gm), st), 'bwd_relu')
+        assert torch.equal(gm, gm_ref) and torch.equal(dx, dx_ref)
