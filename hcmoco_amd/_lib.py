@@ -78,6 +78,9 @@ SIGNATURES = {
     'hcm_bn_act_backward': (_i, [_p] * 6 + [_i] * 4 + [_p] * 4),
     'hcm_upsample_bilinear2d_add': (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     'hcm_upsample_bilinear2d_backward_relu': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _p]),
+    'hcm_conv3x3_stats_slots': (_i, [_i] * 2),
+    'hcm_conv3x3_forward_stats': (_i, [_p] * 3 + [_i] * 5 + [_p, _p]),
+    'hcm_bn_act_forward_pre': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3 + [_i, _p]),
     'hcm_conv3x3_supported': (_i, [_i] * 4),
     'hcm_conv3x3_forward': (_i, [_p] * 3 + [_i] * 5 + [_p]),
     'hcm_conv3x3_backward_data': (_i, [_p] * 3 + [_i] * 5 + [_p]),

@@ -94,15 +94,27 @@ __global__ __launch_bounds__(kBT) void bn_stats_kernel(const float* __restrict__
   }
 }
 
-template <bool RELU, bool RES>
+// PRE: the statistics pass was done by the PRODUCER of x (conv.hip's epilogue): `part` holds `nslots` partial PLAIN
+// sums (sum x, sum x^2; shift 0) per channel, [2*slot][C]; they are added in a fixed order (thread t: slots t,
+// t + 256, ...; then the block tree).
+template <bool RELU, bool RES, bool PRE>
 __global__ __launch_bounds__(kBT) void bn_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ part, Geo g, float eps, float momentum,
-    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y, int nslots) {
   const int c = blockIdx.x, s = blockIdx.y;
   float p1, p2;
-  merge_partials(part, g, c, p1, p2);
-  const float k = x[(size_t)c * g.HW];
+  if (PRE) {
+    p1 = 0.f; p2 = 0.f;
+    for (int sl = threadIdx.x; sl < nslots; sl += kBT) {
+      p1 += part[(size_t)(2 * sl) * g.C + c];
+      p2 += part[(size_t)(2 * sl + 1) * g.C + c];
+    }
+    block_sum2(p1, p2);
+  } else {
+    merge_partials(part, g, c, p1, p2);
+  }
+  const float k = PRE ? 0.f : x[(size_t)c * g.HW];
   const float invM = 1.f / (float)g.M;
   const float m1 = p1 * invM;
   const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
@@ -381,8 +393,29 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
   bn_stats_kernel<<<grid, kBT, 0, st>>>(x, g, part);
   HCM_CHECK_LAUNCH();
 #define HCM_BN_APPLY(R, S)                                                                           \
-  bn_apply_kernel<R, S><<<grid, kBT, 0, st>>>(x, residual, gamma, beta, part, g, eps, momentum,      \
-                                              running_mean, running_var, stats, y)
+  bn_apply_kernel<R, S, false><<<grid, kBT, 0, st>>>(x, residual, gamma, beta, part, g, eps, momentum, \
+                                                     running_mean, running_var, stats, y, 0)
+  if (relu) { if (residual) HCM_BN_APPLY(true, true); else HCM_BN_APPLY(true, false); }
+  else      { if (residual) HCM_BN_APPLY(false, true); else HCM_BN_APPLY(false, false); }
+#undef HCM_BN_APPLY
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_bn_act_forward_pre(const float* x, const float* residual, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           int N, int C, int HW, float* y, float* stats, const float* partial_sums, int nslots,
+                           hcm_stream_t stream) {
+  if (bad_shape(N, C, HW) || !x || !gamma || !beta || !y || !stats || !partial_sums || nslots <= 0 ||
+      (running_mean == nullptr) != (running_var == nullptr))
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(N, C, HW);
+  if (small_map(g)) return (int)hipErrorInvalidValue;       // the one-workgroup form has no separate statistics pass
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(C, g.split);
+#define HCM_BN_APPLY(R, S)                                                                                   \
+  bn_apply_kernel<R, S, true><<<grid, kBT, 0, st>>>(x, residual, gamma, beta, partial_sums, g, eps, momentum, \
+                                                    running_mean, running_var, stats, y, nslots)
   if (relu) { if (residual) HCM_BN_APPLY(true, true); else HCM_BN_APPLY(true, false); }
   else      { if (residual) HCM_BN_APPLY(false, true); else HCM_BN_APPLY(false, false); }
 #undef HCM_BN_APPLY

@@ -33,9 +33,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // matrix work spent on zeros.  A wave owns one map row; its 64 lanes are (pixel, channel pair) for the leftover
 // channels and do them as plain FMAs -- x from the same LDS tile (lane = pixel: conflict-free), the two weights
 // of the pair from a small LDS table (broadcast read) -- in the shadow of the MFMAs, which run 32 cycles each.
-template <int CG, int MT, int WT, int RB, int LO, bool FLIP>
+// STATS (forward only): the epilogue also leaves this workgroup's per-channel sums of y and y^2 in
+// stat_part[2*blockIdx.x + {0,1}][K] -- the statistics pass of the BatchNorm that follows every one of these
+// convolutions (hcm_bn_act_forward_pre), taken from the accumulators instead of re-reading y.
+template <int CG, int MT, int WT, int RB, int LO, bool FLIP, bool STATS>
 __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                                float* __restrict__ y, int C, int K, int H) {
+                                                                float* __restrict__ y, int C, int K, int H,
+                                                                float* __restrict__ stat_part) {
   constexpr int LW = WT + 8;                       // [3 unused][left halo][WT][right halo][3 unused]
   constexpr int LH = RB + 2;
   constexpr int PLANE = LH * LW;
@@ -192,38 +196,88 @@ __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __re
     if (o < n_out) yout[(size_t)o * H * WT + lpx] = lo0;
     if (o + 1 < n_out) yout[(size_t)(o + 1) * H * WT + lpx] = lo1;
   }
+  if (STATS) {
+    // this wave's row: sums over its WT pixels per channel; then the RB rows through LDS in wave order
+    float* Ss = Ls + 4 * CG * 9 * LO;                 // [RB][2][16*MT + LO]
+    constexpr int NC = 16 * MT + (LO ? LO : 0);
+    float* mine = Ss + wave * 2 * NC;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { const float v = acc[m][p][r]; s1 += v; s2 = fmaf(v, v, s2); }
+        s1 = hcm::row16_sum(s1);                      // the 16 pixels of a tile sit in one DPP row (same kq)
+        s2 = hcm::row16_sum(s2);
+        if (np == 0) { mine[16 * m + 4 * kq + r] = s1; mine[NC + 16 * m + 4 * kq + r] = s2; }
+      }
+    if (LO) {
+      float a0 = lo0, a1 = lo1, b0 = lo0 * lo0, b1 = lo1 * lo1;
+      // lanes of one channel pair: all 64 (WT = 64) or one 32-lane half (WT = 32)
+      a0 = hcm::row16_sum(a0); a1 = hcm::row16_sum(a1); b0 = hcm::row16_sum(b0); b1 = hcm::row16_sum(b1);
+      a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+      if (WT == 64) {
+        a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+      }
+      if (lpx == 0) {
+        mine[16 * MT + 2 * pair] = a0; mine[16 * MT + 2 * pair + 1] = a1;
+        mine[NC + 16 * MT + 2 * pair] = b0; mine[NC + 16 * MT + 2 * pair + 1] = b1;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * NC; e += kThreads) {
+      const int c = e % NC, which = e / NC;
+      if (c < n_out) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < RB; ++w) v += Ss[w * 2 * NC + e];
+        stat_part[(size_t)(2 * blockIdx.x + which) * n_out + c] = v;
+      }
+    }
+  }
 }
 
 template <int CG, int MT, int WT, int RB, int LO>
-int launch(const float* x, const float* w, float* y, int N, int C, int K, int H, bool flip, hipStream_t st) {
-  constexpr size_t lds = ((size_t)4 * CG * (RB + 2) * (WT + 8) + (size_t)9 * CG * MT * 64 + (size_t)4 * CG * 9 * LO) * sizeof(float);
+int launch(const float* x, const float* w, float* y, int N, int C, int K, int H, bool flip, hipStream_t st, float* stat_part = nullptr) {
+  constexpr size_t lds = ((size_t)4 * CG * (RB + 2) * (WT + 8) + (size_t)9 * CG * MT * 64 + (size_t)4 * CG * 9 * LO +
+                          (size_t)RB * 2 * (16 * MT + LO)) * sizeof(float);
   const dim3 grid(N * (H / RB));
+  if (stat_part != nullptr && !flip) {
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, true><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, stat_part);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   if (flip) {
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, nullptr);
   } else {
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, nullptr);
   }
   HCM_CHECK_LAUNCH();
   return 0;
 }
 
 // shapes with a kernel instance: C == K (BasicBlock), 64- or 32-wide maps
-int dispatch(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, bool flip, hipStream_t st) {
+int dispatch(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, bool flip, hipStream_t st,
+             float* stat_part = nullptr) {
   if (N <= 0 || C != K || !x || !w || !y || H % 4 != 0) return (int)hipErrorInvalidValue;
   static const bool hybrid = !(getenv("HCM_CONV_HYBRID") && getenv("HCM_CONV_HYBRID")[0] == '0');
   // 4-row bands (4 waves): 8-row bands with 8 waves halve the workgroup count and the weight re-reads, but the
   // kernel gets slower (36ch: 14.6 -> 19.5 us) and so does the step (654 -> 642 samples/s)
-  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st);
-  if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 4, 0>(x, w, y, N, C, K, H, flip, st);
+  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st, stat_part);
+  if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part);
   // (a padded 32-channel instance for HRNet-w32's first branch was measured: 436 vs 441 samples/s with MIOpen -- not kept)
-  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st);
-  if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 4, 0>(x, w, y, N, C, K, H, flip, st);
+  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st, stat_part);
+  if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part);
   return (int)hipErrorInvalidValue;
 }
 
@@ -240,6 +294,14 @@ int hcm_conv3x3_supported(int C, int K, int H, int W) {
 
 int hcm_conv3x3_forward(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, hcm_stream_t stream) {
   return dispatch(x, w, y, N, C, K, H, W, false, (hipStream_t)stream);
+}
+
+int hcm_conv3x3_stats_slots(int N, int H) { return (N > 0 && H > 0 && H % 4 == 0) ? N * (H / 4) : 0; }
+
+int hcm_conv3x3_forward_stats(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, float* partial_sums,
+                              hcm_stream_t stream) {
+  if (!partial_sums) return (int)hipErrorInvalidValue;
+  return dispatch(x, w, y, N, C, K, H, W, false, (hipStream_t)stream, partial_sums);
 }
 
 int hcm_conv3x3_backward_data(const float* dy, const float* w, float* dx, int N, int C, int K, int H, int W,

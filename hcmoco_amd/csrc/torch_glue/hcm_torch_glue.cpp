@@ -234,6 +234,11 @@ bool own_conv(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
          hcm_conv3x3_supported((int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3)) == 1;
 }
 
+bool stats_in_conv() {
+  static const bool on = !(getenv("HCM_CONV_STATS") && getenv("HCM_CONV_STATS")[0] == '0');
+  return on;
+}
+
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
                   w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
@@ -982,9 +987,31 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
       if (op == kOpConvBn) {
         const int64_t L = I[4];
         const Tensor& w = params[3 * L];
-        Tensor z = conv_forward_raw(T.val[a], w, I[5], I[6]);
-        BnOut o = bn_forward_raw(z, b >= 0 ? T.val[b] : Tensor(), params[3 * L + 1], params[3 * L + 2], buffers[2 * L],
-                                 buffers[2 * L + 1], momentum, eps, I[7] != 0);
+        Tensor z;
+        BnOut o;
+        if (stats_in_conv() && own_conv(T.val[a], w, I[5], I[6])) {
+          // conv.hip leaves the per-channel sums of its output in its epilogue: no statistics launch, no re-read
+          const Tensor& xin = T.val[a];
+          const int N = (int)xin.size(0), Cc = (int)xin.size(1), Kc = (int)w.size(0), H = (int)xin.size(2), W = (int)xin.size(3);
+          const int slots = hcm_conv3x3_stats_slots(N, H);
+          z = at::empty({N, Kc, H, W}, xin.options());
+          Tensor part = at::empty({2 * (int64_t)slots * Kc}, xin.options());
+          check_rc(hcm_conv3x3_forward_stats(xin.data_ptr<float>(), w.data_ptr<float>(), z.data_ptr<float>(), N, Cc, Kc, H, W,
+                                             part.data_ptr<float>(), current_stream(xin)),
+                   "hcm_conv3x3_forward_stats");
+          const Tensor res = b >= 0 ? T.val[b] : Tensor();
+          o.y = at::empty_like(z);
+          o.stats = at::empty({(int64_t)hcm_bn_act_stats_floats(N, Kc, H * W)}, z.options());
+          check_rc(hcm_bn_act_forward_pre(z.data_ptr<float>(), fptr(res), params[3 * L + 1].data_ptr<float>(),
+                                          params[3 * L + 2].data_ptr<float>(), fptr(buffers[2 * L]), fptr(buffers[2 * L + 1]),
+                                          (float)momentum, (float)eps, I[7] != 0 ? 1 : 0, N, Kc, H * W, o.y.data_ptr<float>(),
+                                          o.stats.data_ptr<float>(), part.data_ptr<float>(), slots, current_stream(z)),
+                   "hcm_bn_act_forward_pre");
+        } else {
+          z = conv_forward_raw(T.val[a], w, I[5], I[6]);
+          o = bn_forward_raw(z, b >= 0 ? T.val[b] : Tensor(), params[3 * L + 1], params[3 * L + 2], buffers[2 * L],
+                             buffers[2 * L + 1], momentum, eps, I[7] != 0);
+        }
         T.val[dst] = o.y; T.z[L] = z; T.stats[L] = o.stats; T.w[L] = w; T.gamma[L] = params[3 * L + 1];
         const int64_t C2 = 2 * params[3 * L + 1].numel();
         T.layer_off[L] = T.flat_numel;

@@ -271,6 +271,13 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
 int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
                         const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
                         float* gstats, hcm_stream_t stream);
+/* hcm_bn_act_forward whose statistics pass was done by the producer of x: partial_sums [2 * nslots][C] = per-slot
+ * plain sums of x and x^2 (hcm_conv3x3_forward_stats), added in a fixed order.  Mid-size and large maps only
+ * (N*HW per channel > 8192): hipErrorInvalidValue otherwise.  stats as for hcm_bn_act_forward. */
+int hcm_bn_act_forward_pre(const float* x, const float* residual, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           int N, int C, int HW, float* y, float* stats, const float* partial_sums, int nslots,
+                           hcm_stream_t stream);
 /* Same, with the partial-sum scratch in its own buffer (hcm_bn_act_stats_floats - 2C floats): `gstats`
  * is then exactly [dgamma C][dbeta C], so a caller can lay every parameter gradient of a network out in
  * one dense buffer (what the encoder runtime hands to RCCL in place, csrc/torch_glue). */
@@ -416,6 +423,12 @@ int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host);
 int hcm_conv3x3_supported(int C, int K, int H, int W);
 int hcm_conv3x3_forward(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, hcm_stream_t stream);
 int hcm_conv3x3_backward_data(const float* dy, const float* w, float* dx, int N, int C, int K, int H, int W,
+                              hcm_stream_t stream);
+/* The forward with the statistics pass of the BatchNorm that follows it folded into its epilogue: partial_sums
+ * [2 * hcm_conv3x3_stats_slots(N, H)][K] receives, per workgroup (slot), the sums of y and of y^2 over the slot's
+ * pixels for every output channel (plain sums, no shift); hcm_bn_act_forward_pre consumes them. */
+int hcm_conv3x3_stats_slots(int N, int H);
+int hcm_conv3x3_forward_stats(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, float* partial_sums,
                               hcm_stream_t stream);
 
 #ifdef __cplusplus

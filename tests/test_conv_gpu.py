@@ -53,3 +53,50 @@ def test_conv3x3_is_deterministic_and_refuses_other_shapes():
     with pytest.raises(_lib.HipError):
         _call('hcm_conv3x3_forward', torch.randn(1, 72, 16, 16, device=dev), torch.randn(72, 72, 3, 3, device=dev),
               1, 72, 72, 16, 16)
+
+
+@pytest.mark.parametrize('N,Cc,H,W', [(32, 18, 64, 64), (32, 36, 32, 32), (3, 17, 8, 64), (2, 20, 12, 64), (5, 34, 16, 32)])
+def test_conv3x3_forward_stats_and_the_batch_norm_that_consumes_them(N, Cc, H, W):
+    """hcm_conv3x3_forward_stats: same y as hcm_conv3x3_forward bit for bit, and per-slot sums of y / y^2 that add up
+    to the tensor's own (float64) sums; hcm_bn_act_forward_pre on those partials == hcm_bn_act_forward on y (2e-5)."""
+    from hcmoco_amd import _lib
+    from hcmoco_amd.hip_ops import check
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(N + Cc)
+    x = (torch.randn(N, Cc, H, W, generator=g) + 0.5).to(dev)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) * 0.1).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    y0 = _call('hcm_conv3x3_forward', x, w, N, Cc, Cc, H, W)
+    slots = int(L.hcm_conv3x3_stats_slots(N, H))
+    assert slots == N * H // 4
+    y = torch.empty_like(y0)
+    part = torch.full((2 * slots, Cc), float('nan'), device=dev)
+    check(L.hcm_conv3x3_forward_stats(p(x), p(w), p(y), N, Cc, Cc, H, W, p(part), st), 'forward_stats')
+    assert torch.equal(y, y0)
+    s1 = part[0::2].double().sum(0)
+    s2 = part[1::2].double().sum(0)
+    yd = y.double()
+    r1, r2 = yd.sum((0, 2, 3)), yd.square().sum((0, 2, 3))
+    assert (s1 - r1).abs().max().item() <= 1e-5 * r2.sqrt().max().item() * (N * H * W) ** 0.5
+    assert ((s2 - r2).abs() / r2).max().item() <= 1e-5
+    if N * H * W <= 8192:                                    # the one-workgroup BN form has no separate statistics pass
+        return
+    gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), torch.randn(Cc, generator=g).to(dev)
+    res = torch.randn(N, Cc, H, W, generator=g).to(dev)
+    outs = []
+    for pre in (False, True):
+        rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+        out = torch.empty_like(y)
+        stats = torch.empty(int(L.hcm_bn_act_stats_floats(N, Cc, H * W)), device=dev)
+        if pre:
+            check(L.hcm_bn_act_forward_pre(p(y), p(res), p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 1, N, Cc, H * W, p(out),
+                                           p(stats), p(part), slots, st), 'bn_pre')
+        else:
+            check(L.hcm_bn_act_forward(p(y), p(res), p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 1, N, Cc, H * W, p(out),
+                                       p(stats), st), 'bn')
+        outs.append((out, stats[:2 * Cc].clone(), rm, rv))
+    for a, b in zip(outs[0], outs[1]):
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale
