@@ -40,3 +40,12 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+def free_port():
+    """A TCP port nobody is listening on right now (bind to 0, read it back): the process-group tests used to derive
+    their port from the pid, which collides with a lingering listener or a TIME_WAIT socket once in a while."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]

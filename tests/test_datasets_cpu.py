@@ -9,6 +9,7 @@ import pickle
 
 import numpy as np
 import pytest
+from conftest import free_port
 import torch
 from PIL import Image
 
@@ -180,7 +181,7 @@ def test_image_dataset_drives_the_training_loop(tmp_path, monkeypatch):
     from hcmoco_amd.pycontrast import main_contrast
     from oracle.oracle_engine import OracleLossEngine
     flist, mpii = _write_tree(str(tmp_path / 'data'), n_ntu=6, n_mpii=4)
-    monkeypatch.setenv('MASTER_PORT', str(26000 + os.getpid() % 2000))
+    monkeypatch.setenv('MASTER_PORT', str(free_port()))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
         monkeypatch.delenv(k, raising=False)
     argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list',
@@ -269,7 +270,7 @@ def test_ntucoco_dataset_end_to_end(tmp_path, monkeypatch):
     with pytest.raises(IndexError, match='flip pairs'):          # the reference fails the same way (:820-826, :936-937)
         for _ in range(20):
             flip[6]
-    monkeypatch.setenv('MASTER_PORT', str(26500 + os.getpid() % 2000))
+    monkeypatch.setenv('MASTER_PORT', str(free_port()))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
         monkeypatch.delenv(k, raising=False)
     argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18', '--in_channel_list',

@@ -7,6 +7,7 @@ import sys
 import tempfile
 
 import pytest
+from conftest import free_port
 import torch
 
 from hcmoco_amd.pycontrast import main_contrast
@@ -28,7 +29,7 @@ def base_args(tmp, method, extra=()):
 
 @pytest.fixture(autouse=True)
 def _fresh_pg(monkeypatch):
-    monkeypatch.setenv('MASTER_PORT', str(29500 + os.getpid() % 2000))
+    monkeypatch.setenv('MASTER_PORT', str(free_port()))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
         monkeypatch.delenv(k, raising=False)
     yield
@@ -144,7 +145,7 @@ def _run_two_ranks(grad_sync):
     script = os.path.join(out, 'worker.py')
     with open(script, 'w') as f:
         f.write(WORKER % (ROOT, grad_sync, out))
-    port = str(20000 + os.getpid() % 20000)
+    port = str(free_port())
     env = dict(os.environ, OMP_NUM_THREADS='2')
     res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                           '--master-addr', '127.0.0.1', '--master-port', port, script],

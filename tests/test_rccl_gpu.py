@@ -10,6 +10,7 @@ import sys
 import tempfile
 
 import pytest
+from conftest import free_port
 import torch
 import torch.distributed as dist
 
@@ -35,7 +36,7 @@ def _run(grad_sync, steps=2, stage2=True, check_identity=False):
     if grad_sync is not None:
         args.grad_sync = grad_sync
         os.environ['HCM_GRAD_CHUNKS'] = str(CHUNKS)
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % (23000 + os.getpid() % 4000),
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % free_port(),
                                 rank=0, world_size=1, device_id=dev)
     try:
         tr = ContrastTrainer(args, force_collectives=grad_sync is not None)
@@ -191,7 +192,7 @@ def test_two_ranks_on_one_gpu_stay_bit_identical(mode, tmp_path):
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', str(25000 + os.getpid() % 3000), str(script)],
+                          '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(script)],
                          capture_output=True, text=True, env=env, timeout=800)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     r0, r1 = (torch.load(tmp_path / ('rank%d.pt' % r)) for r in (0, 1))
@@ -218,7 +219,7 @@ def test_hrnetpn_under_a_one_rank_rccl_group(tmp_path):
     args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
     args.grad_sync = 'overlap'
     os.environ['HCM_GRAD_CHUNKS'] = str(CHUNKS)
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % (27000 + os.getpid() % 2000), rank=0, world_size=1,
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % free_port(), rank=0, world_size=1,
                             device_id=dev)
     try:
         tr = ContrastTrainer(args, force_collectives=True)

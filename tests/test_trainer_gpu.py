@@ -6,6 +6,7 @@ import sys
 import tempfile
 
 import pytest
+from conftest import free_port
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -145,7 +146,7 @@ def _main_args(method, extra):
 @pytest.fixture
 def _pg_env(monkeypatch):
     monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
-    monkeypatch.setenv('MASTER_PORT', str(24000 + os.getpid() % 3000))
+    monkeypatch.setenv('MASTER_PORT', str(free_port()))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SLURM_PROCID'):
         monkeypatch.delenv(k, raising=False)
     yield
