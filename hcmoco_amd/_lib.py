@@ -78,6 +78,8 @@ SIGNATURES = {
     'hcm_bn_act_backward': (_i, [_p] * 6 + [_i] * 4 + [_p] * 4),
     'hcm_upsample_bilinear2d_add': (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     'hcm_upsample_bilinear2d_backward_relu': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _p]),
+    'hcm_conv_wgrad_partial': (_i, [_i, _p, _p] + [_i] * 5 + [_p, C.c_size_t, _p, _p]),
+    'hcm_wgrad_reduce_batch': (_i, [_p, _i, _p]),
     'hcm_conv3x3_stats_slots': (_i, [_i] * 2),
     'hcm_conv3x3_forward_stats': (_i, [_p] * 3 + [_i] * 5 + [_p, _p]),
     'hcm_bn_act_forward_pre': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3 + [_i, _p]),

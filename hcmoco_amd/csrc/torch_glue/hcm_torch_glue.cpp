@@ -758,6 +758,49 @@ Tensor& stream_workspace(hipStream_t st) {             // MIOpen workspace per (
   return ws[st];
 }
 
+// Deferred reductions of the own weight-gradient kernels (hcm_conv_wgrad_partial / hcm_wgrad_reduce_batch): the
+// partial sums of a stretch of layers are parked in an arena (per thread and stream, used in order) and reduced by
+// ONE launch per 64 layers instead of one tiny launch per layer.
+struct WgradArena {
+  Tensor buf;
+  size_t used = 0;
+  std::vector<hcm_wgrad_reduce_desc> red;
+};
+WgradArena& wgrad_arena(hipStream_t st) {
+  thread_local std::unordered_map<hipStream_t, WgradArena> arenas;
+  return arenas[st];
+}
+constexpr size_t kArenaBytes = (size_t)384 << 20;
+
+void flush_wgrad_reductions(hipStream_t st) {
+  WgradArena& A = wgrad_arena(st);
+  if (A.red.empty()) return;
+  check_rc(hcm_wgrad_reduce_batch(A.red.data(), (int)A.red.size(), st), "hcm_wgrad_reduce_batch");
+  A.red.clear();
+  A.used = 0;
+}
+
+// true: the layer's partial sums are parked and its reduction is queued on stream `st` (the current stream)
+bool defer_own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g, float* dw, hipStream_t st) {
+  static const bool on = !(getenv("HCM_WGRAD_DEFER_REDUCE") && getenv("HCM_WGRAD_DEFER_REDUCE")[0] == '0');
+  const int ks = on ? own_wgrad(x, w, g) : 0;
+  if (ks == 0) return false;
+  const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)g.size(2), W = (int)g.size(3);
+  const size_t need = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W)
+                    : ks == 1 ? hcm_conv1x1_wgrad_workspace_bytes(N, C, K, H, W) : hcm_conv3x3s2_wgrad_workspace_bytes(N, C, K, H, W);
+  if (need == 0 || need > kArenaBytes) return false;
+  WgradArena& A = wgrad_arena(st);
+  if (!A.buf.defined()) A.buf = at::empty({(int64_t)kArenaBytes}, x.options().dtype(at::kByte));
+  if (A.used + need > kArenaBytes || A.red.size() >= 64) flush_wgrad_reductions(st);
+  char* slot = static_cast<char*>(A.buf.data_ptr()) + A.used;
+  int chunks = 0;
+  check_rc(hcm_conv_wgrad_partial(ks, x.data_ptr<float>(), g.data_ptr<float>(), N, C, K, H, W, slot, need, &chunks, st),
+           "hcm_conv_wgrad_partial");
+  A.red.push_back(hcm_wgrad_reduce_desc{reinterpret_cast<const float*>(slot), dw, (int)w.numel(), chunks});
+  A.used += (need + 255) & ~(size_t)255;
+  return true;
+}
+
 // A gradient slot holds up to two tensors whose sum is the gradient: where the consumer is a conv+bn
 // instruction the sum is formed inside hcm_bn_act_backward (no add kernel); anything else resolves it.
 struct GradSlot { Tensor t, t2; bool owned = false; int sid = -1, sid2 = -1; };
@@ -835,6 +878,8 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
     while (gc->ready < (int)gc->first_layer.size() && gc->first_layer[gc->ready] >= layer_done) {
       flush_wgrads();
       const int back = S.cur;
+      S.enter(0);
+      flush_wgrad_reductions(S.st[0].stream());      // the chunk's dW must be complete before its event
       S.issued();
       for (int s2 = 1; s2 < kMaxSid; ++s2) if (S.used[s2]) { ++S.epoch[s2]; S.wait(s2, 0); }
       TORCH_CHECK(hipEventRecord(gc->ev[gc->ready], S.st[0].stream()) == hipSuccess, "hipEventRecord failed");
@@ -843,6 +888,7 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
       gc->cv.notify_all();
     }
   };
+  { WgradArena& A0 = wgrad_arena(S.st[0].stream()); A0.red.clear(); A0.used = 0; }   // nothing left over from a failed pass
   const int64_t n = (int64_t)T.prog.size() / kInstrInts;
   for (int64_t i = n - 1; i >= 0; --i) {
     const int64_t* I = &T.prog[i * kInstrInts];
@@ -914,7 +960,7 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
         // layer) never queues behind their five small launches each
         pending.push_back(PendingWgrad{p, dzc, x, fbase + T.layer_off[L], T.w[L], S.cur});
         if ((int)pending.size() >= wgrad_batch) flush_wgrads();
-      } else {
+      } else if (!(S.cur == 0 && defer_own_wgrad(x, T.w[L], dzc, fbase + T.layer_off[L], st))) {
         run_wgrad(p, dzc, x, fbase + T.layer_off[L], T.w[L], &stream_workspace(st));
       }
       T.z[L] = Tensor(); T.stats[L] = Tensor();           // release activations as the walk passes them
@@ -954,6 +1000,9 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
   }
   flush_wgrads();
   signal_chunks(0);
+  S.enter(0);
+  flush_wgrad_reductions(S.st[0].stream());
+  S.issued();
   S.finish();
 }
 

@@ -305,6 +305,15 @@ int hcm_conv1x1_wgrad(const float* x, const float* dy, int N, int C, int K, int 
 size_t hcm_conv3x3s2_wgrad_workspace_bytes(int N, int C, int K, int Ho, int Wo);
 int hcm_conv3x3s2_wgrad(const float* x, const float* dy, int N, int C, int K, int Ho, int Wo, float* dw,
                         void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+/* The two halves of the calls above, separately: hcm_conv_wgrad_partial (kind 3 = 3x3 stride 1, 1 = 1x1, 2 = 3x3
+ * stride 2; same arguments, no dw) leaves the per-workgroup partial sums in `workspace` and returns their count in
+ * *chunks; hcm_wgrad_reduce_batch sums the partials of MANY layers, each in the same fixed order as the single
+ * calls, in one launch per 64 layers -- a caller walking a network backwards parks the partials of a stretch of
+ * layers and reduces them together (dW feeds nothing but the optimizer). */
+typedef struct { const float* partial; float* dw; int total; int chunks; } hcm_wgrad_reduce_desc;   /* total = K*C*taps */
+int hcm_conv_wgrad_partial(int kind, const float* x, const float* dy, int N, int C, int K, int H, int W, void* workspace,
+                           size_t workspace_bytes, int* chunks, hcm_stream_t stream);
+int hcm_wgrad_reduce_batch(const hcm_wgrad_reduce_desc* descs, int n, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Rows 12-17 -- PointNet++ ops.  Same argument order, ownership and layouts as the

@@ -75,3 +75,48 @@ def test_wgrad_3x3_stride2_matches_aten(shape):
     got = hip_ops.conv3x3_wgrad(x, dy, ksize=3, stride=2)
     assert torch.equal(got, hip_ops.conv3x3_wgrad(x, dy, ksize=3, stride=2))
     assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_partial_plus_batched_reduction_equals_the_single_calls():
+    """hcm_conv_wgrad_partial for several layers of different kinds, then ONE hcm_wgrad_reduce_batch: every dW is
+    bit-identical to its hcm_conv{3x3,1x1,3x3s2}_wgrad call (same partial sums, same fixed-order reduction)."""
+    import ctypes as C
+    from hcmoco_amd import _lib
+    from hcmoco_amd.hip_ops import check
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    class Desc(C.Structure):
+        _fields_ = [('partial', C.c_void_p), ('dw', C.c_void_p), ('total', C.c_int), ('chunks', C.c_int)]
+
+    layers = [(3, 8, 18, 18, 64, 64), (1, 8, 36, 18, 32, 32), (2, 8, 18, 36, 32, 32), (3, 8, 36, 36, 32, 32),
+              (3, 4, 18, 18, 16, 16), (1, 4, 144, 72, 8, 8)] * 12                 # 72 layers: two launches of the batch kernel
+    keep, descs, refs, outs = [], [], [], []
+    for kind, N, Cc, K, H, W in layers:
+        s = 2 if kind == 2 else 1
+        x = torch.randn(N, Cc, s * H, s * W, generator=g).to(dev)
+        dy = torch.randn(N, K, H, W, generator=g).to(dev)
+        ks = 1 if kind == 1 else 3
+        single = {3: L.hcm_conv3x3_wgrad, 1: L.hcm_conv1x1_wgrad, 2: L.hcm_conv3x3s2_wgrad}[kind]
+        nbytes = {3: L.hcm_conv3x3_wgrad_workspace_bytes, 1: L.hcm_conv1x1_wgrad_workspace_bytes,
+                  2: L.hcm_conv3x3s2_wgrad_workspace_bytes}[kind](N, Cc, K, H, W)
+        assert nbytes > 0
+        ws1, ws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ref = torch.empty(K, Cc, ks, ks, device=dev)
+        check(single(p(x), p(dy), N, Cc, K, H, W, p(ref), p(ws1), nbytes, st), 'single')
+        out = torch.full((K, Cc, ks, ks), float('nan'), device=dev)
+        chunks = C.c_int(0)
+        check(L.hcm_conv_wgrad_partial(kind, p(x), p(dy), N, Cc, K, H, W, p(ws2), nbytes, C.byref(chunks), st), 'partial')
+        assert chunks.value > 0
+        descs.append(Desc(ws2.data_ptr(), out.data_ptr(), out.numel(), chunks.value))
+        keep += [x, dy, ws1, ws2]
+        refs.append(ref)
+        outs.append(out)
+    arr = (Desc * len(descs))(*descs)
+    check(L.hcm_wgrad_reduce_batch(C.cast(arr, C.c_void_p), len(descs), st), 'reduce_batch')
+    torch.cuda.synchronize()
+    for ref, out in zip(refs, outs):
+        assert torch.equal(ref, out)
