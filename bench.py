@@ -109,6 +109,30 @@ def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s, max_step
                       'torch-CPU model + oracle losses, %d thread(s)' % (steps, batch, nce_k, size, size, threads)}
 
 
+def check_step(records_path, timeout_s=600):
+    """The recorded step against the oracle, in a CPU-only subprocess (``python -m oracle.check_step``): this
+    process never imports the oracle.  -> the checker's report ({'checked': True, max errors ...})."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS='16', MKL_NUM_THREADS='16', HIP_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', PYTHONPATH=ROOT)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'HCM_FORCE_COLLECTIVES'):
+        env.pop(k, None)
+    try:
+        res = subprocess.run([sys.executable, '-m', 'oracle.check_step', records_path], capture_output=True, text=True,
+                             env=env, timeout=timeout_s, cwd=ROOT)
+        for line in reversed(res.stdout.splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return {'checked': False, 'error': (res.stderr.strip().splitlines() or ['checker printed nothing'])[-1][:300]}
+    except subprocess.TimeoutExpired:
+        return {'checked': False, 'error': 'checker exceeded %d s' % timeout_s}
+    finally:
+        try:
+            os.remove(records_path)
+        except OSError:
+            pass
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -154,6 +178,37 @@ def cpu_baseline(nce_k, n_data, size, skeleton, batch):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """Re-run this command line under torch.distributed.run with n ranks on this node (rendez-vous on
+    127.0.0.1, a free port).  The ranks' stdout is relayed as it comes, except that rank 0's JSON line is held
+    back and printed LAST, so the caller reads the same single line a torchrun launch would give it."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            line_json = line
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+        sys.stdout.flush()
+    return rc if rc else (0 if line_json is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,6 +220,9 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--skeleton', type=str, default='coco17')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_check', action='store_true',
+                    help='skip the whole-step oracle check (one extra UNTIMED step whose loss-kernel inputs/outputs are '
+                         're-evaluated by oracle/check_step.py in a CPU-only subprocess)')
     ap.add_argument('--cpu_baseline_worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu_budget_s', type=float, default=20.0)
     ap.add_argument('--cpu_max_steps', type=int, default=10, help=argparse.SUPPRESS)
@@ -188,6 +246,11 @@ def main():
                                              a.cpu_max_steps)))
         return
 
+    if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU, like the reference's
+        # scripts start one task per GPU (scripts/SecondStage/train_ntumpiirgbd2s_hrnet_w18.sh:8-14,
+        # learning/base_trainer.py:38-47)
+        raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -196,8 +259,12 @@ def main():
                          % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    if a.backend == 'nccl' and world > torch.cuda.device_count():
+        raise SystemExit('--gpus %d on a box with %d GPU(s): RCCL wants one device per rank (--backend gloo lets '
+                         'several ranks share a device to exercise the control flow)' % (world, torch.cuda.device_count()))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29511')
+    if 'MASTER_PORT' not in os.environ:
+        os.environ['MASTER_PORT'] = str(free_port())       # only reached with world == 1 (forced collectives)
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.device('cuda', torch.cuda.current_device())
     forced = world == 1 and os.environ.get('HCM_FORCE_COLLECTIVES', '0') != '0'
@@ -209,17 +276,37 @@ def main():
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     B = a.batch_per_gpu
     args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, a.backend, tempfile.mkdtemp(),
-                     a.steps + a.warmup, sampled=a.sampled_projection, arch=a.arch, width=a.width,
+                     a.steps + a.warmup + 2, sampled=a.sampled_projection, arch=a.arch, width=a.width,
                      bank_dtype=a.bank_dtype, fmap_dtype=a.fmap_dtype)
     args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
     args.channels_last = bool(a.channels_last)
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
-    trainer = ContrastTrainer(args)                                          # HIP loss engine
+    recorder = None
+    if not a.no_check and rank == 0:
+        # product engine + a tape of what the loss kernels saw and returned during ONE untimed step (see check_step)
+        from hcmoco_amd.pycontrast.learning.engine import RecordingEngine
+        recorder = RecordingEngine(a.fmap_dtype)
+        recorder.armed = False
+    trainer = ContrastTrainer(args, engine=recorder)                         # HIP loss engine
     trainer.device = dev
     model, contrast, opt, data = build(args, trainer, dev)
     torch.cuda.manual_seed(1234 + rank)          # per-replica pixel sampling; weights were built from seed 0
 
     it = iter(data)
+    records_path = None
+    if not a.no_check:
+        # two extra untimed steps on every rank (the collectives must match): the quiet-Find step, then a step of
+        # the default runtime that rank 0 records for the checker
+        trainer.train_step(next(it), model, contrast, opt, stage2=True)
+        if recorder is not None:
+            recorder.armed = True
+        trainer.train_step(next(it), model, contrast, opt, stage2=True)
+        if recorder is not None:
+            recorder.armed = False
+            torch.cuda.synchronize()
+            records_path = os.path.join(tempfile.mkdtemp(), 'step_records.pt')
+            torch.save(recorder.records, records_path)
+            recorder.records = []
     for _ in range(a.warmup):
         trainer.train_step(next(it), model, contrast, opt, stage2=True)
     hip_ops.prof_enable(True)
@@ -259,6 +346,14 @@ def main():
         bytes_per_sample = 3 * K1 * D * row_bytes + K1 * 8 + 12 * D * 4
         bytes_per_launch = B * bytes_per_sample
         avg_ms = kern_ms / max(kern_n, 1)
+        # the three banks of the headline configuration (201 MB) fit the 256 MiB Infinity Cache (MALL): between two
+        # steps the encoders' activations evict them, but WITHIN a launch a row fetched for one sample can be served
+        # from the MALL to the next -- the fabric-side rate can then exceed what HBM alone delivers, so the bound is
+        # labelled for what it is; profiles/r03_bank_pass_sweep.json holds the HBM-resident cases
+        bank_bytes = 3 * a.n_data * D * row_bytes
+        bound = 'hbm+mall' if bank_bytes < 256 * 2 ** 20 else 'hbm'
+        bound_note = ('banks (%.0f MB) fit the 256 MiB Infinity Cache: fabric-side bytes / peak HBM rate'
+                      % (bank_bytes / 1e6) if bound == 'hbm+mall' else 'banks exceed the Infinity Cache: HBM-resident')
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if kern_n else None
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read live);
         # reported only when the committed measurement was taken at this exact configuration
@@ -318,15 +413,24 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
                        'channels_last': bool(a.channels_last), 'sampled_projection': bool(a.sampled_projection),
+                       'grad_collectives_per_step': (trainer.grad_sync.launched if trainer.grad_sync is not None
+                                                     else (None if world > 1 else 0)),
+                       'backend': a.backend if (world > 1 or forced) else None,
                        'final_loss': round(loss, 4)},
             'roofline': {'kernel': 'bank_pass_kernel<2,fused> (gather + 6 logit sets + online softmax + d/dx)',
-                         'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
+                         'bound': bound, 'bank_bytes': bank_bytes, 'bound_note': bound_note,
+                         'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
         }
         out['roofline_secondary'] = secondary
+        if records_path is not None:
+            out['check'] = check_step(records_path)
+            out['checked'] = bool(out['check'].get('checked'))
+        else:
+            out['checked'] = False
         if world == 1 and not a.no_cpu_baseline and a.arch == 'HRNet':
             out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton, B)
         else:

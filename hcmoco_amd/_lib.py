@@ -108,6 +108,7 @@ for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]
 
 _lib = None
+ABI_VERSION = 2       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
 
 
 def build(verbose=False):
@@ -138,8 +139,9 @@ def lib():
             fn = getattr(handle, name)          # AttributeError: the library does not match the header
             fn.restype = res
             fn.argtypes = args
-        if handle.hcm_abi_version() != 1:
-            raise ImportError('libhcmoco_hip.so ABI version mismatch')
+        if handle.hcm_abi_version() != ABI_VERSION:
+            raise ImportError('libhcmoco_hip.so has ABI version %d, this package binds version %d: rebuild it '
+                              '(make -C hcmoco_amd/csrc)' % (handle.hcm_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

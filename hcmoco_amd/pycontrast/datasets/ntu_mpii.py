@@ -178,6 +178,17 @@ def crop_params(width, height, scale, ratio, rng=random):
     return (height - h) // 2, (width - w) // 2, h, w
 
 
+# The reference decides whether to mirror an NTU frame's NORMALISED skeleton by testing ``resize_param[-1]``
+# (dataset.py:589, :927, :1050) -- that is ``original_w``, always truthy -- where it means ``need_flip``
+# (resize_param[4]): under --random_flip every NTU skeleton is mirrored, whether or not the frame was.  Mirrored
+# here for parity (golden: ntu_noflip_out_norm_joints); set to False for the evidently intended behaviour.
+REFERENCE_FLIP_QUIRK = True
+
+
+def skeleton_is_mirrored(resize_param):
+    return bool(resize_param[-1]) if REFERENCE_FLIP_QUIRK else bool(resize_param[4])
+
+
 def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip, select=KINECT_TO_MPII,
               flip_pairs=MPII_FLIP_PAIRS, empty_ok=False, with_mean=False):
     """Items 0-8 of the tuple for an NTU frame, from the decoded (cropped, resized, flipped, normalised) frame
@@ -187,7 +198,7 @@ def ntu_tuple(rgbd, index, joints3d, resize_param, d_loc, size, random_flip, sel
     joints2d = np.array(d_loc, dtype=np.float32)[select].reshape(len(select), 2)
     i, j, h, w, need_flip = resize_param[:5]
     norm = normalize_joints(joints2d)
-    if random_flip and need_flip:
+    if random_flip and skeleton_is_mirrored(resize_param):
         norm = flip_normalized_joints(norm, flip_pairs)
     # the reference compares column 1 against j + w in the last test (it means column 0); mirrored for parity
     vis = np.logical_and(np.logical_and(joints2d[:, 1] > i, joints2d[:, 1] < i + h),
@@ -324,7 +335,8 @@ class NTUMPIIContrastDataset(torch.utils.data.Dataset):
                     torch.from_numpy(original.copy()), torch.from_numpy(vis.astype(np.int32).copy()), 0,
                     torch.zeros_like(rgbd[0]), scale_from_joints(original, vis))
         rgbd, joints3d, resize_param, d_loc = self._ntu_frame(index - len(self.db))
-        if self.random_flip and resize_param[4] and max(max(p) for p in self.FLIP_PAIRS) >= len(self.KINECT_SELECT):
+        if (self.random_flip and skeleton_is_mirrored(resize_param)
+                and max(max(p) for p in self.FLIP_PAIRS) >= len(self.KINECT_SELECT)):
             # the reference applies the 17-joint COCO pairs to its 13-joint NTU skeleton here and dies with an
             # IndexError (dataset.py:820-826, :936-937); its scripts never pass --random_flip for this dataset
             raise IndexError('flip pairs of the 2-D pose source do not fit the %d-joint NTU skeleton '

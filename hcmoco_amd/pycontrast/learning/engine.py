@@ -76,3 +76,111 @@ class HipLossEngine(object):
         ud = use_depth if use_depth is not None else torch.ones(B, dtype=torch.int32, device=pix.device)
         return hip_ops.fmap_losses_rows(rows1, rows2, feat3, sample_ind.shape[1], sample_ind, w, keep, joints_vis,
                                         ud, use_rgb, temperature, gemm_dtype=self.fmap_dtype)
+
+
+class RecordingEngine(object):
+    """Wrapper around a loss engine (the product's ``HipLossEngine`` unless told otherwise) that keeps CPU copies of everything one training step hands to the loss kernels and
+    everything they hand back -- bank rows before the update, the negative indices, sampled pixels, features,
+    feature maps / branch maps, projection weights, losses, accuracies, the updated bank rows and (through
+    autograd hooks) the gradients -- so that an EXTERNAL checker can re-evaluate the step
+    (``oracle/check_step.py``: the ``-m gpu`` whole-step tests and the ``--check`` leg of bench.py, which runs the
+    checker in a separate CPU process).  It computes nothing itself and imports nothing outside the product: the
+    numbers recorded are the HIP path's own.  Random draws are made by the same product code one call earlier
+    (``draw_with_positive`` / ``dense_samples``) and handed in through the ``idx=`` / ``sample_ind=`` arguments."""
+    name = 'hip+record'
+    dense_samples = staticmethod(HipLossEngine.dense_samples)
+
+    def __init__(self, fmap_dtype='fp32', inner=None):
+        self.inner = inner if inner is not None else HipLossEngine(fmap_dtype)
+        self.fmap_dtype = fmap_dtype
+        self.records = []
+        self.armed = True
+
+    @staticmethod
+    def _cpu(t):
+        if t is None:
+            return None
+        if isinstance(t, (list, tuple)):
+            return [RecordingEngine._cpu(v) for v in t]
+        return t.detach().to('cpu', copy=True)
+
+    def _grads(self, rec, total, named):
+        """d total / d t for every named tensor that takes part in autograd, through the product's own backward
+        kernels (``retain_graph``: the trainer's ``loss.backward()`` afterwards is undisturbed)."""
+        named = [(k, t) for k, t in named if t is not None and t.requires_grad]
+        if not named or not total.requires_grad:
+            return
+        gs = torch.autograd.grad(total, [t for _, t in named], retain_graph=True, allow_unused=True)
+        for (k, _), g in zip(named, gs):
+            rec['grads'][k] = None if g is None else g.detach().cpu()
+
+    def bank(self, contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+             use_depth=None, use_rgb=None, idx=None):
+        if not self.armed:
+            return self.inner.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+                                use_depth=use_depth, use_rgb=use_rgb, idx=idx)
+        c = self._cpu
+        if idx is None:
+            draw = getattr(self.inner, 'draw_indices', None)      # engines that cannot run the device sampler
+            idx = draw(contrast, index) if draw is not None else contrast.multinomial.draw_with_positive(index, contrast.K + 1)
+        before = [b.detach().clone() for b in contrast.banks()]
+        rec = {'kind': 'bank', 'T': contrast.T, 'm': contrast.m, 'banks0': c(before), 'idx': c(idx),
+               'x': c([f1, f2, f3]), 'index': c(index), 'all_x': c([all_f1, all_f2, all_f3]),
+               'all_index': c(all_index), 'use_depth': c(use_depth), 'use_rgb': c(use_rgb), 'grads': {}}
+        total, losses, accs = self.inner.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
+                                           use_depth=use_depth, use_rgb=use_rgb, idx=idx)
+        rec['losses'], rec['accs'], rec['total'] = c(losses), c(accs), c(total)
+        touched = torch.zeros(before[0].shape[0], dtype=torch.bool, device=before[0].device)
+        touched[all_index.clamp(0, before[0].shape[0] - 1)] = True
+        rec['after_rows'] = [c(b.index_select(0, all_index)) for b in contrast.banks()]
+        rec['untouched_rows_unchanged'] = [bool(torch.equal(b[~touched], b0[~touched]))
+                                           for b, b0 in zip(contrast.banks(), before)]
+        self._grads(rec, total, [('x%d' % (i + 1), f) for i, f in enumerate((f1, f2, f3))])
+        self.records.append(rec)
+        return total, losses, accs
+
+    def fmap(self, map1, map2, feat3, depth_mask, joints2d, joints_vis, use_depth, use_rgb,
+             num_samples, temperature, sample_ind=None, keep=None):
+        if not self.armed:
+            return self.inner.fmap(map1, map2, feat3, depth_mask, joints2d, joints_vis, use_depth, use_rgb,
+                                num_samples, temperature, sample_ind=sample_ind, keep=keep)
+        c = self._cpu
+        h, w = map1.shape[-2:]
+        if sample_ind is None:
+            sample_ind, keep = self.dense_samples(depth_mask, h, w, num_samples, use_depth)
+        rec = {'kind': 'fmap', 'map1': c(map1), 'map2': c(map2), 'feat3': c(feat3), 'depth_mask': c(depth_mask),
+               'joints2d': c(joints2d), 'joints_vis': c(joints_vis), 'use_depth': c(use_depth), 'use_rgb': c(use_rgb),
+               'num_samples': int(num_samples), 'temperature': float(temperature), 'sample_ind': c(sample_ind),
+               'keep': c(keep), 'fmap_dtype': self.fmap_dtype, 'grads': {}}
+        total, meters = self.inner.fmap(map1, map2, feat3, depth_mask, joints2d, joints_vis, use_depth, use_rgb,
+                                     num_samples, temperature, sample_ind=sample_ind, keep=keep)
+        rec['meters'], rec['total'] = c(meters), c(total)
+        self._grads(rec, total, [('map1', map1), ('map2', map2), ('feat3', feat3)])
+        self.records.append(rec)
+        return total, meters
+
+    def fmap_sampled(self, branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
+                     use_depth, use_rgb, num_samples, temperature, sample_ind=None, keep=None):
+        if not self.armed:
+            return self.inner.fmap_sampled(branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d, joints_vis,
+                                        use_depth, use_rgb, num_samples, temperature, sample_ind=sample_ind, keep=keep)
+        c = self._cpu
+        h, w = branches1[0].shape[-2:]
+        if sample_ind is None:
+            sample_ind, keep = self.dense_samples(depth_mask, h, w, num_samples, use_depth)
+        rec = {'kind': 'fmap_sampled', 'branches1': c(list(branches1)), 'branches2': c(list(branches2)),
+               'proj1': (c(proj1.weight), c(proj1.bias)), 'proj2': (c(proj2.weight), c(proj2.bias)),
+               'feat3': c(feat3), 'depth_mask': c(depth_mask), 'joints2d': c(joints2d), 'joints_vis': c(joints_vis),
+               'use_depth': c(use_depth), 'use_rgb': c(use_rgb), 'num_samples': int(num_samples),
+               'temperature': float(temperature), 'sample_ind': c(sample_ind), 'keep': c(keep),
+               'fmap_dtype': self.fmap_dtype, 'grads': {}}
+        total, meters = self.inner.fmap_sampled(branches1, branches2, proj1, proj2, feat3, depth_mask, joints2d,
+                                             joints_vis, use_depth, use_rgb, num_samples, temperature,
+                                             sample_ind=sample_ind, keep=keep)
+        rec['meters'], rec['total'] = c(meters), c(total)
+        named = [('b1_%d' % i, t) for i, t in enumerate(branches1)] + [('b2_%d' % i, t) for i, t in enumerate(branches2)]
+        named += [('feat3', feat3), ('proj1_w', proj1.weight), ('proj1_b', proj1.bias), ('proj2_w', proj2.weight),
+                  ('proj2_b', proj2.bias)]
+        self._grads(rec, total, named)
+        self.records.append(rec)
+        return total, meters

@@ -30,6 +30,7 @@ class FlatParamSGD(object):
         self._flat = []            # (encoder, flat parameter tensor, [params], [offsets])
         self._done = False
         self._pending_state = None
+        self._grad_ptr = {}        # id(flat parameter) -> storage address of the gradient buffer validated in full
 
     # ------------------------------------------------------------------ plain delegation
     @property
@@ -146,7 +147,16 @@ class FlatParamSGD(object):
                     for p, off in zip(params, offs):
                         flat[off:off + p.numel()].copy_(p.reshape(-1))
                         p.data = flat[off:off + p.numel()].view(p.shape)
-            fg = self._flat_grad(params, flat.numel(), full_check=False)
+            # the cheap first/last test is enough while the gradients live in the allocation that was validated
+            # piece by piece; anything else (GradSync re-bound them into a bucket in parameters() order after a
+            # module-path step, a new program) gets the full walk again -- first and last can line up while the
+            # middle is permuted
+            g0 = params[0].grad
+            ptr = None if g0 is None else g0.untyped_storage().data_ptr()
+            known = ptr is not None and self._grad_ptr.get(id(flat)) == ptr
+            fg = self._flat_grad(params, flat.numel(), full_check=not known)
+            if fg is not None:
+                self._grad_ptr[id(flat)] = ptr
             if fg is None:
                 # this step's forward did not run as an encoder program (module path, another input shape): gather
                 # the separate gradients; a parameter without one contributes zeros (it still sees weight decay)
@@ -196,8 +206,8 @@ class FlatParamSGD(object):
         if not self._done:
             try:
                 self.inner.load_state_dict(sd)         # nothing flattened yet: the reference layout IS the inner layout
-            except Exception:
-                self._pending_state = sd
+            except (ValueError, KeyError):             # group sizes do not match yet (e.g. a wrapped optimizer that
+                self._pending_state = sd               # is re-grouped before the first step): retry at step()
             return
         if not self._flat:
             self.inner.load_state_dict(sd)

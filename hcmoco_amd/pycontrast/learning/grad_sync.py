@@ -19,9 +19,10 @@ not filled yet.  ``GradSync`` keeps the overlap and drops the hooks:
   back -- the parameters' ``.grad`` are views of the buffer that was reduced.
 * **Rest bucket** -- SemGCN, heads, 1x1 projections (and anything that did not run as a program,
   which is everything on CPU): copied into one persistent flat buffer with one multi-tensor launch,
-  reduced, and ``.grad`` re-bound to views of it.  Built over a FIXED parameter list; a parameter
-  without a gradient contributes zeros and receives the average, so every replica applies the same
-  update whatever its local graph looked like.
+  reduced, and ``.grad`` re-bound to views of it.  Built over a FIXED parameter list; a parameter that
+  got no gradient on this rank contributes zeros and receives the average, so every replica applies
+  the same update whatever its local graph looked like; one that got none on ANY rank keeps
+  ``.grad = None`` (agreed once, see ``_present``), so N > 1 applies the update N = 1 applies.
 * ``optimizer.step()`` is ordered behind all of it by ``work.wait()`` on the caller's stream.
 
 ``mode='flat'`` keeps the single-bucket behaviour (one all-reduce after the join) for comparison;
@@ -77,6 +78,7 @@ class GradSync(object):
                 groups.append(stray)
             self.groups = [g for g in groups if g]
         self._flat = {}
+        self._presence = {}          # bucket key -> (local pattern, agreed pattern): see _present
         self._comm = None
         self.launched = 0            # collectives launched by the last reduce() (tests / bench read it)
 
@@ -87,9 +89,31 @@ class GradSync(object):
             return t, dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
         return t, dist.all_reduce(t, async_op=True)
 
+    def _present(self, key, group):
+        """Which parameters of ``group`` received a gradient on SOME rank.  A parameter that no rank used (stage 1
+        with ``--linear_feat_map 1``: the two 1x1 projections) must keep ``.grad = None`` -- SGD then skips it, as it
+        does with one GPU and as DistributedDataParallel does for globally unused parameters; averaging zeros into it
+        would hand it weight decay and momentum that the single-GPU run never applies.  The pattern is
+        a property of the graph, identical on every rank and from step to step, so it is agreed on ONCE per local
+        pattern (a MAX all-reduce of the presence flags + one host read, first step only) and cached."""
+        local = tuple(p.grad is not None for p in group)
+        cached = self._presence.get(key)
+        if cached is None or cached[0] != local:
+            flags = torch.tensor([1.0 if v else 0.0 for v in local], dtype=torch.float32, device=group[0].device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            cached = self._presence[key] = (local, tuple(bool(v) for v in (flags > 0).tolist()))
+        return cached[1]
+
     def _bucket(self, key, group):
-        """Copy the group's gradients into its persistent flat buffer (zeros where a parameter got no
-        gradient) and re-bind ``.grad`` to views of it; returns the buffer."""
+        """Copy the group's gradients into its persistent flat buffer and re-bind ``.grad`` to views of it; returns
+        the buffer (None when nothing in the group has a gradient anywhere).  Parameters without a gradient on ANY
+        rank are left out and keep ``.grad = None``; one that only THIS rank did not use contributes zeros and
+        receives the average."""
+        present = self._present(key, group)
+        group = [p for p, ok in zip(group, present) if ok]
+        if not group:
+            return None
+        key = (key, present)
         n = sum(p.numel() for p in group)
         flat = self._flat.get(key)
         if flat is None or flat.numel() != n or flat.device != group[0].device:
@@ -139,7 +163,9 @@ class GradSync(object):
             groups = dict(enumerate(self.groups))
         for key, g in groups.items():
             if g:
-                works.append(self._launch(self._bucket(key, g)))
+                flat = self._bucket(key, g)
+                if flat is not None:
+                    works.append(self._launch(flat))
         for t, w in works:
             w.wait()                 # RCCL: orders the current stream behind the collective, no host block
             if not self.avg:

@@ -62,11 +62,23 @@ class CMCMem3(BaseMem):
         return safe
 
     def check_indices(self):
-        if self._oob is not None:
-            bad, self._oob = bool(self._oob), None
-            if bad:
-                raise IndexError('CMCMem3: a bank row index was outside [0, %d) (dataset index / injected idx)'
-                                 % self.n_data)
+        """Raise if any index handed to the kernels since the last call had to be clamped.  With several ranks the
+        flag is MAX-reduced first, so that EVERY rank raises (one rank raising alone would leave the others hung in
+        their next collective); every rank must therefore call this at the same points of its loop -- the trainer
+        does, at ``print_freq`` and at the end of an epoch."""
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self._oob is None and not multi:
+            return
+        flag = self._oob if self._oob is not None else torch.zeros((), dtype=torch.bool, device=self.memory_1.device)
+        self._oob = None
+        if multi:
+            f = flag.to(torch.int32).reshape(1)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            flag = f[0] > 0
+        if bool(flag):
+            raise IndexError('CMCMem3: a bank row index was outside [0, %d) (dataset index / injected idx)%s'
+                             % (self.n_data, ' on some rank' if multi else ''))
 
     def _indices(self, y, idx):
         if idx is not None:

@@ -25,7 +25,9 @@ extern "C" {
 
 typedef void* hcm_stream_t; /* hipStream_t */
 
-#define HCM_ABI_VERSION 1
+/* 2 (round 3): hcm_sgc_forward/backward take a workspace, the PointNet++ index/distance ops default to the
+ * FMA arithmetic contract, new loss-section entry points.  A library and a caller must agree on this number. */
+#define HCM_ABI_VERSION 2
 int hcm_abi_version(void);
 /* hipGetErrorString() for a value returned by any entry point. */
 const char* hcm_error_string(int err);

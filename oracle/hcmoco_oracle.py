@@ -169,6 +169,36 @@ def bank_nce(banks, idx, xs, T, use_depth=None, use_rgb=None):
     return losses, accs, grads, logits
 
 
+def bank_nce_chunked(banks, idx, xs, T, use_depth=None, use_rgb=None, chunk=4):
+    """``bank_nce`` (same definitions, same masked means) evaluated ``chunk`` samples at a time in float64, so
+    that BASELINE sizes (B=32, K up to 131072: 3 x 2.1 GB of gathered rows in one piece) stay small on the host.
+    Returns (losses[6], accs[6], grads[3]) in float64."""
+    B, D = xs[0].shape
+    per_l = torch.zeros(B, 6, dtype=torch.float64)
+    per_ok = torch.zeros(B, 6, dtype=torch.float64)
+    per_g = [torch.zeros(B, 6, D, dtype=torch.float64) for _ in range(3)]
+    for s in range(0, B, chunk):
+        e = min(B, s + chunk)
+        rows = [bk.index_select(0, idx[s:e].reshape(-1)).view(e - s, idx.shape[1], D).double() for bk in banks]
+        for p, (a, c) in enumerate(PAIRS):
+            l = torch.bmm(rows[c].to(xs[a].dtype), xs[a][s:e].unsqueeze(2)).squeeze(2).double() / T   # fp32 products like bank_logits
+            per_l[s:e, p] = torch.logsumexp(l, 1) - l[:, 0]
+            per_ok[s:e, p] = (l[:, 0] >= l.max(1).values).double()
+            per_g[a][s:e, p] = (torch.bmm(torch.softmax(l, 1).unsqueeze(1), rows[c]).squeeze(1) - rows[c][:, 0]) / T
+    sel, deg = bank_row_sets(B, use_depth, use_rgb)
+    losses, accs = torch.zeros(6, dtype=torch.float64), torch.zeros(6, dtype=torch.float64)
+    grads = [torch.zeros(B, D, dtype=torch.float64) for _ in range(3)]
+    for p, (a, c) in enumerate(PAIRS):
+        if deg[p]:
+            continue
+        R = sel[p]
+        cnt = int(R.sum())
+        losses[p] = per_l[R, p].sum() / cnt
+        accs[p] = 100.0 * per_ok[R, p].sum() / cnt
+        grads[a] += per_g[a][:, p] * R.double().unsqueeze(1) / cnt
+    return losses, accs, grads
+
+
 # --------------------------------------------------------------------------- #
 # row 3 -- momentum update of the bank        memory/mem_bank.py:15-28
 # --------------------------------------------------------------------------- #

@@ -42,14 +42,20 @@ class _Fmap(torch.autograd.Function):
 class OracleLossEngine(object):
     name = 'oracle'
 
+    @staticmethod
+    def draw_indices(contrast, index):
+        """idx [B, K+1] with idx[:,0] = index: the product's Philox draw restated on the host."""
+        mn = contrast.multinomial
+        B, K1 = index.shape[0], contrast.K + 1
+        idx = O.alias_draw_philox(mn.prob, mn.alias, B * K1, mn.seed, mn.offset).view(B, K1).clone()
+        idx[:, 0] = index
+        mn.offset += 1
+        return idx
+
     def bank(self, contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
              use_depth=None, use_rgb=None, idx=None):
         if idx is None:
-            mn = contrast.multinomial
-            B, K1 = f1.shape[0], contrast.K + 1
-            idx = O.alias_draw_philox(mn.prob, mn.alias, B * K1, mn.seed, mn.offset).view(B, K1).clone()
-            idx[:, 0] = index
-            mn.offset += 1
+            idx = self.draw_indices(contrast, index)
         banks = [b.clone() for b in contrast.banks()]
         total, losses, accs = _Bank.apply(f1, f2, f3, banks, idx, contrast.T, use_depth, use_rgb)
         with torch.no_grad():

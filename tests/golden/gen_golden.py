@@ -650,6 +650,16 @@ def gen_dataset():
     names = ['rgbd', 'index', 'norm_joints', 'joints3d', 'original_joints2d', 'joints_vis', 'true_depth', 'depth_mask', 'scale']
     for n, v in zip(names, out):
         arrays['ntu_out_' + n] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+    # the same frame when the image was NOT mirrored (need_flip False) under --random_flip: the reference tests
+    # resize_param[-1] (= original_w, always truthy) at dataset.py:589, so the normalised skeleton is mirrored anyway
+    resize_noflip = resize_param[:4] + (False,) + resize_param[5:]
+    D.NTURGBD3DSkeleton.__getitem__ = lambda self, index, return_resize_param=False: (rgbd.clone(), index, joints3d, resize_noflip, skel)
+    try:
+        out_nf = obj[5]
+    finally:
+        D.NTURGBD3DSkeleton.__getitem__ = orig
+    arrays['ntu_noflip_out_norm_joints'] = out_nf[2]
+    arrays['ntu_noflip_out_original_joints2d'] = out_nf[4]
 
     # --- NTU + COCO variant (:622-955): annotation records through the reference's own loader (the pycocotools API
     #     it calls is replaced by a minimal reader of the same json), box -> centre/scale, the two joint reductions,

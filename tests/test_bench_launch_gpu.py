@@ -1,0 +1,54 @@
+"""`python bench.py --gpus N` must start N ranks by itself: the reference launches one task per GPU
+from its scripts (scripts/SecondStage/train_ntumpiirgbd2s_hrnet_w18.sh:8-14, learning/base_trainer.py:38-47), and
+the driver's scaling run may use the plain command.  On the one-GPU box both ranks share cuda:0 over gloo (RCCL
+refuses two ranks per device); the control flow -- rendez-vous, packed all-gather, 9 gradient collectives per step,
+max-over-ranks timing, ONE JSON line from rank 0, printed last -- is the N>1 path's own."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env():
+    env = dict(os.environ, OMP_NUM_THREADS='4')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'HCM_FORCE_COLLECTIVES'):
+        env.pop(k, None)
+    return env
+
+
+def test_plain_python_bench_gpus_2_launches_two_ranks():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                          '--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--no_check'],
+                         capture_output=True, text=True, env=_clean_env(), timeout=1100)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith('{"metric"'), lines[-3:]                # the JSON line is the last thing on stdout
+    assert sum(l.startswith('{"metric"') for l in lines) == 1           # and there is exactly one
+    out = json.loads(lines[-1])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1
+    assert out['config']['global_batch'] == 64 and out['config']['batch_per_gpu'] == 32
+    assert out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
+    loss = out['config']['final_loss']
+    assert loss == loss and abs(loss) < 1e6
+    assert out['config']['grad_collectives_per_step'] == 9             # 4 chunks x 2 HRNets + the rest bucket
+    assert out['value'] > 0 and out['cpu_baseline'] is None
+
+
+def test_bench_under_torchrun_still_works():
+    """The driver's documented launch for N > 1 (torch.distributed.run sets RANK/WORLD_SIZE): no self-launch then."""
+    from conftest import free_port
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+                          os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '1',
+                          '--warmup', '1', '--no_cpu_baseline', '--no_check', '--size', '128', '--nce_k', '1024',
+                          '--n_data', '4096', '--batch_per_gpu', '8'],
+                         capture_output=True, text=True, env=_clean_env(), timeout=1100)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16

@@ -75,6 +75,21 @@ def test_ntu_tuple_matches_reference():
         else:
             assert float(v) == float(want), n
     assert int(out[5].sum()) not in (0, 16)            # the fixture has visible and invisible joints
+    # a frame that was NOT mirrored: the reference mirrors the normalised skeleton all the same under --random_flip
+    # (it tests resize_param[-1] = original_w, dataset.py:589); mirrored by default, switchable
+    noflip = resize_param[:4] + (False,) + resize_param[5:]
+    out_nf = N.ntu_tuple(g['ntu_rgbd_in'].clone(), 5, g['ntu_joints3d'], noflip, g['ntu_dloc'].numpy(),
+                         int(g['ntu_size']), random_flip=True)
+    assert torch.equal(out_nf[2], g['ntu_noflip_out_norm_joints'])
+    assert torch.equal(out_nf[4], g['ntu_noflip_out_original_joints2d'])
+    assert torch.equal(out_nf[2], out[2])
+    try:
+        N.REFERENCE_FLIP_QUIRK = False
+        intended = N.ntu_tuple(g['ntu_rgbd_in'].clone(), 5, g['ntu_joints3d'], noflip, g['ntu_dloc'].numpy(),
+                               int(g['ntu_size']), random_flip=True)
+        assert not torch.equal(intended[2], out[2])
+    finally:
+        N.REFERENCE_FLIP_QUIRK = True
 
 
 def test_warp_affine_identity_shift_and_border():

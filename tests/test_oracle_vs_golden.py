@@ -50,6 +50,23 @@ def test_alias_draw_philox_properties():
 REGIMES = ['none', 'depth_mix', 'depth_all0', 'both_mix', 'both_none']
 
 
+@pytest.mark.parametrize('regime', ['none', 'depth_mix', 'depth_all0', 'both_mix', 'both_none'])
+def test_bank_nce_chunked_is_pinned_too(golden, regime):
+    """The memory-bounded form the whole-step checker uses at BASELINE sizes (oracle/check_step.py) against the
+    reference's own losses / accuracies / gradients."""
+    g = golden('bank_nce')
+    banks = [g['bank0_%d' % i] for i in (1, 2, 3)]
+    xs = [g['x%d' % i] for i in (1, 2, 3)]
+    ud = g.get(regime + '_use_depth')
+    ur = g.get(regime + '_use_rgb')
+    losses, accs, grads = O.bank_nce_chunked(banks, g['idx'], xs, g['T'], use_depth=ud, use_rgb=ur, chunk=3)
+    close(losses, g[regime + '_losses'], rtol=1e-5, atol=1e-6)
+    close(accs, g[regime + '_accs'], rtol=0, atol=1e-4)
+    for i in range(3):
+        ref = g[regime + '_gx%d' % (i + 1)]
+        assert rel_l2(grads[i], ref) < 1e-5 or float(ref.abs().max()) == 0 and float(grads[i].abs().max()) == 0
+
+
 @pytest.mark.parametrize('regime', REGIMES)
 def test_bank_nce(golden, regime):
     g = golden('bank_nce')

@@ -179,6 +179,65 @@ def test_world_size_2_gloo_replicas_stay_identical():
         assert torch.equal(b0, b1)
 
 
+UNUSED_WORKER = r'''
+import os, sys, tempfile, torch
+sys.path.insert(0, %r)
+from hcmoco_amd.pycontrast import main_contrast
+from oracle.oracle_engine import OracleLossEngine
+rank = int(os.environ['RANK'])
+tmp = tempfile.mkdtemp()
+argv = ['--method', 'CMCRGBD2S', '--modal', 'RGBD2S', '--arch', 'HRNet', '--width', '18',
+        '--in_channel_list', '3,3', '--batch_size', '4', '--nce_k', '32', '--dist-backend', 'gloo', '--synthetic',
+        '--synthetic_n_data', '128', '--synthetic_size', '64', '--synthetic_steps', '2', '--epochs', '1',
+        '--linear_feat_map', '1', '--model_path', tmp, '--tb_path', tmp, '--seed', '5', '--print_freq', '100',
+        '--grad_sync', %r]
+torch.manual_seed(5)
+outs, trainer, model, contrast = main_contrast.main(argv, engine=OracleLossEngine())
+net = trainer.unwrap(model)
+names = [n for n, _ in net.named_parameters()]
+if rank == 0:      # local rank 0 writes the checkpoint (contrast_trainer.py:117-140)
+    ck = torch.load(os.path.join(trainer.args.model_folder, 'current.pth'), map_location='cpu')
+    with_state = set(names[i] for i in ck['optimizer']['state'])
+else:
+    with_state = set(names[:101])
+torch.save({'proj_grad_none': [p.grad is None for p in list(net.encoder1_linear.parameters()) + list(net.encoder2_linear.parameters())],
+            'proj_has_momentum': [n for n in with_state if 'encoder1_linear' in n or 'encoder2_linear' in n],
+            'n_state': len(with_state), 'proj': [p.detach().clone() for p in net.encoder1_linear.parameters()],
+            'head': net.head1[0].weight.detach().clone()},
+           os.path.join(%r, 'rank%%d.pt' %% rank))
+'''
+
+
+@pytest.mark.parametrize('mode', ['flat', 'overlap'])
+def test_globally_unused_parameters_keep_no_gradient_with_two_ranks(mode):
+    """Stage 1 with --linear_feat_map 1 never touches the two 1x1 projections.  With one GPU their ``.grad`` stays
+    None and SGD skips them; averaging zeros into them across ranks would apply weight decay and momentum, i.e. the
+    trained weights would depend on the GPU count (ADVICE r02, learning/grad_sync.py:_present).  Reference:
+    DistributedDataParallel leaves globally unused parameters without a gradient (learning/contrast_trainer.py:74)."""
+    out = tempfile.mkdtemp()
+    script = os.path.join(out, 'worker.py')
+    with open(script, 'w') as f:
+        f.write(UNUSED_WORKER % (ROOT, mode, out))
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(free_port()), script],
+                         capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS='2'), timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    r0, r1 = (torch.load(os.path.join(out, 'rank%d.pt' % r)) for r in (0, 1))
+    for r in (r0, r1):
+        assert r['proj_grad_none'] == [True] * 4 and r['proj_has_momentum'] == [] and r['n_state'] > 100
+    assert torch.equal(r0['head'], r1['head'])
+    # and they still hold their initial values (seed 5 -> build_model is the first consumer of the generator)
+    import argparse
+    from hcmoco_amd.pycontrast.networks.build_backbone import build_model
+    torch.manual_seed(5)
+    opt = argparse.Namespace(modal='RGBD2S', arch='HRNet', jigsaw=False, head='linear', feat_dim=128,
+                             in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
+                             skeleton_meta_name='mpii', IN_Pretrain=None, depth_Pretrain=None, mem='bank')
+    fresh, _ = build_model(opt)
+    for a, b in zip(r0['proj'], fresh.encoder1_linear.parameters()):
+        assert torch.equal(a, b.detach())
+
+
 def test_pretrain_handoff_stage1_to_stage2(capsys):
     """--pretrain strips the 7-char 'module.' prefix, loads matching keys, reports the rest and
     restores all three banks (main_contrast.py:52-67 of the reference)."""

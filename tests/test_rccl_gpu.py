@@ -56,7 +56,7 @@ def _run(grad_sync, steps=2, stage2=True, check_identity=False):
                 n = real(None)
                 torch.cuda.synchronize()
                 bad = [k for k, p in net.named_parameters()
-                       if (snap[k] is None and float(p.grad.abs().max()) != 0.0)
+                       if (snap[k] is None and p.grad is not None)
                        or (snap[k] is not None and not torch.equal(p.grad, snap[k]))]
                 info.setdefault('not_identity', []).extend(bad)
                 info.setdefault('none_grads', []).append(sum(v is None for v in snap.values()))
@@ -118,7 +118,7 @@ def baseline():
 def test_every_collective_is_the_identity_in_a_one_rank_group():
     """Exactness: with the helper threads joined first, the gradients before and after GradSync.reduce are
     bit-identical -- chunk views alias the encoders' buffers, the rest buckets are copied in, reduced and
-    re-bound without loss, parameters without a gradient receive zeros."""
+    re-bound without loss, parameters without a gradient on any rank keep ``.grad = None``."""
     got = _run('overlap', check_identity=True)
     info = got[3]
     assert info['not_identity'] == [], info['not_identity'][:10]
@@ -236,7 +236,7 @@ def test_hrnetpn_under_a_one_rank_rccl_group(tmp_path):
             n = real(None)
             torch.cuda.synchronize()
             bad.extend(k for k, p in model.named_parameters()
-                       if (snap[k] is None and float(p.grad.abs().max()) != 0.0)
+                       if (snap[k] is None and p.grad is not None)
                        or (snap[k] is not None and not torch.equal(p.grad, snap[k])))
             launched.append(n)
             return n

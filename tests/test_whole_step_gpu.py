@@ -1,0 +1,70 @@
+"""ONE whole training step per BASELINE.json configuration at the configuration's OWN size, checked against the
+oracle.  The step is the product's (``ContrastTrainer.train_step``: encoder programs, side streams,
+HIP loss kernels, SGD, bank update); a ``RecordingEngine`` keeps what the loss kernels were given and what they
+returned, and ``oracle/check_step.py`` re-evaluates all of it on the CPU: idx[:,0]==index bit-exact, six bank losses
+and accuracies, all B gradient rows per modality, the momentum update (touched rows to 1e-6, the others bit-identical),
+the nine feature-map meters and the gradients of the feature-map losses w.r.t. the HRNet branch maps, the 1x1
+projection weights and the SemGCN output (reference data flow: merge_all_res + full-resolution projection,
+networks/build_backbone.py:243-254, :290-300; losses learning/contrast_trainer.py:954-980).
+
+Tolerances (fp32): losses 1e-5 relative, bank gradients 1e-4 relative L2, feature-map meters 2e-4 relative (the
+projection sums 270 terms in another order than torch's convolution), feature-map gradients 5e-4 relative L2, bank
+update 1e-6 absolute.  bf16 (config 5): bank rows are compared in the rows' own rounding (update to 1 bf16 ulp), the
+bf16 feature-map contractions to 1e-2 on the meters and 2e-2 relative L2 on the gradients against the fp32 oracle."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (arch, width, batch, size, K, bank_dtype, fmap_dtype, skeleton)
+    'config2_stage2_w18_K16384': ('HRNet', 18, 32, 256, 16384, 'fp32', 'fp32', 'coco17'),
+    'config2_mpii16': ('HRNet', 18, 32, 256, 16384, 'fp32', 'fp32', 'mpii'),
+    'config3_per_gpu_half_K65536': ('HRNet', 18, 32, 256, 65536, 'fp32', 'fp32', 'coco17'),
+    'config4_hrnetpn_w32': ('HRNetPN', 32, 32, 256, 16384, 'fp32', 'fp32', 'coco17'),
+    'config5_bf16_K131072': ('HRNet', 18, 32, 256, 131072, 'bf16', 'bf16', 'coco17'),
+}
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_one_step_at_the_configs_own_size_against_the_oracle(name):
+    import bench
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    from hcmoco_amd.pycontrast.learning.engine import RecordingEngine
+    from oracle.check_step import check_records
+    arch, width, B, size, K, bank_dtype, fmap_dtype, skeleton = CONFIGS[name]
+    dev = torch.device('cuda:0')
+    args = bench.make_args(B, K, 131072, size, skeleton, 'nccl', tempfile.mkdtemp(), 2, arch=arch, width=width,
+                           bank_dtype=bank_dtype, fmap_dtype=fmap_dtype)
+    args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
+    eng = RecordingEngine(fmap_dtype)
+    tr = ContrastTrainer(args, engine=eng)
+    tr.device = dev
+    try:
+        model, contrast, opt, data = bench.build(args, tr, dev)
+        it = iter(data)
+        eng.armed = False
+        tr.train_step(next(it), model, contrast, opt, True)      # quiet-Find step (one stream, nothing deferred)
+        eng.armed = True
+        out = tr.train_step(next(it), model, contrast, opt, True)     # the DEFAULT runtime: this is the step checked
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out['loss']))
+        kinds = [r['kind'] for r in eng.records]
+        assert kinds == ['bank', 'fmap' if arch == 'HRNetPN' else 'fmap_sampled'], kinds
+        bank, fm = eng.records
+        assert bank['idx'].shape == (B, K + 1) and bank['x'][0].shape == (B, 128)
+        assert fm['sample_ind'].shape == (B, 400)
+        rep = check_records(eng.records)
+        print(name, rep)
+        # the step's loss is the sum of the two checked totals
+        assert abs(float(out['loss']) - float(bank['total']) - float(fm['total'])) <= 1e-4 * abs(float(out['loss']))
+    finally:
+        _lib.torch_glue().set_async_wgrad(False)
