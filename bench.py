@@ -382,12 +382,12 @@ def main():
                 ('sgc_fwd', 'SemGCN layer forward (sgc_mix + sgc_norm), per layer', 'latency', sgc_fwd_bytes),
                 ('sgc_bwd', 'SemGCN layer backward (stats + bwd + finish), per layer', 'latency', sgc_bwd_bytes)]
         secondary = []
-        for tag, name, bound, work in spec:
+        for tag, name, kind, work in spec:
             ms, n = secondary_raw[tag]
             if not n:
                 continue
             avg = ms / n
-            if bound == 'mfma':
+            if kind == 'mfma':
                 ach = work / (avg * 1e-3) / 1e12
                 secondary.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak,
                                   'unit': 'TFLOP/s', 'frac': round(ach / mfma_peak, 4), 'flops_per_launch': int(work),

@@ -24,6 +24,12 @@ class Strides4(C.Structure):
 
 _p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 
+
+class Branches(C.Structure):
+    """hcm_branches / hcm_branches_out: the four NCHW maps of one HRNet (include/hcmoco_hip.h)."""
+    _fields_ = [('map', C.c_void_p * 4), ('C', C.c_int * 4), ('H', C.c_int * 4), ('W', C.c_int * 4)]
+
+
 # name -> (restype, argtypes); mirrors include/hcmoco_hip.h one to one
 SIGNATURES = {
     # *_bf16 twins are added below the table (same argument lists, uint16 bank pointers)
@@ -95,6 +101,15 @@ SIGNATURES = {
     'hcm_conv3x3s2_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_rowmax_forward': (_i, [_p, C.c_longlong, _i, _p, _p, _p]),
     'hcm_rowmax_backward': (_i, [_p, _p, C.c_longlong, _i, _p, _p]),
+    'hcm_heads_forward': (_i, [Branches, Branches, _p] + [_i] * 5 + [_p] * 11 + [_i, _p, _p]),
+    'hcm_heads_backward': (_i, [_p] * 5 + [_i] * 5 + [_p] * 14),
+    'hcm_pixel_sample': (_i, [_p] + [_i] * 6 + [_p, _p, _i, _u64, _u64, _p, _p, _p, _p]),
+    'hcm_sample_branches_ld': (_i, [_i]),
+    'hcm_sample_branches': (_i, [Branches, Branches, _i, _p] + [_i] * 3 + [_p] * 8),
+    'hcm_branch_grad': (_i, [_p] * 4 + [_i] * 3 + [Branches, Branches, _p, _i, _p, _i] + [_p] * 5),
+    'hcm_section_total': (_i, [_p, _p, _p, _p]),
+    'hcm_alias_draw_checked': (_i, [_p, _p, _i64, _p, _i, _i, _u64, _u64, _p, _p, _p]),
+    'hcm_bank_update_checked': (_i, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p, _i, _i, _f, _p, _p]),
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
     'hcm_prof_read_tag': (_i, [_i, _p, _p]),
@@ -104,7 +119,7 @@ SIGNATURES['hcm_dense_soft_nce_coords_bf16'] = SIGNATURES['hcm_dense_soft_nce_co
 SIGNATURES['hcm_scl_bf16'] = SIGNATURES['hcm_scl']
 
 for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits_fwd', 'hcm_bank_logits_bwd',
-              'hcm_bank_update'):
+              'hcm_bank_update', 'hcm_bank_update_checked'):
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]
 
 _lib = None

@@ -80,4 +80,21 @@ __device__ __forceinline__ void scale4(float4& acc, float s) {
   acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s;
 }
 
+// Philox4x32-10 (Random123): the counter-based generator behind every on-device draw of this library
+// (negative rows: hcm_alias_draw; sampled pixels: hcm_pixel_sample).  Known-answer vectors: tests + oracle.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
 }  // namespace hcm

@@ -374,6 +374,11 @@ void join_workers() {
 }
 
 std::atomic<bool> g_async_wgrad{false};
+// set_deterministic(true) (or HCM_DETERMINISTIC=1 at load time): every convolution weight gradient the own kernels CAN
+// compute goes to them (csrc/wgrad.hip: fixed-order partial sums + fixed-order reduction), whatever its size -- MIOpen's
+// igemm_wrw...gkgs kernels accumulate with float atomics and are the one source of run-to-run noise in an HRNet step
+// (DESIGN 2).  Slower for the wide layers; meant for tests that compare runs bit for bit.
+std::atomic<bool> g_deterministic{[] { const char* e = getenv("HCM_DETERMINISTIC"); return e && e[0] != '0'; }()};
 std::atomic<bool> g_wgrad_stream{false};
 std::atomic<int> g_wgrad_batch{16};
 
@@ -435,12 +440,14 @@ int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no
   // the 3-channel stem convolution (3 -> 64, stride 2, 128x128 output) falls on the kernel's generic,
   // non-constant-folded instantiation: 279 us per call against MIOpen's ~60 us (r02 profile)
   static const int64_t minc = [] { const char* e = getenv("HCM_WGRAD_MINC"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
-  if (!on || (g.size(3) & 3) != 0 || w.size(1) < minc) return 0;
+  const bool det = g_deterministic.load(std::memory_order_relaxed);
+  if (!(on || det) || (g.size(3) & 3) != 0 || (!det && w.size(1) < minc)) return 0;
+  const int64_t mc = det ? (int64_t)1 << 30 : maxc, m1 = det ? (int64_t)1 << 30 : max1;
   const bool same = g.size(2) == x.size(2) && g.size(3) == x.size(3);
   const bool half = 2 * g.size(2) == x.size(2) && 2 * g.size(3) == x.size(3);
-  if (same && w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= maxc && w.size(1) <= maxc) return 3;
-  if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= max1 && w.size(1) <= max1) return 1;
-  if (half && w.size(2) == 3 && w.size(3) == 3 && w.size(1) <= maxc && w.size(0) <= 2 * maxc) return 2;   // stride 2
+  if (same && w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= mc && w.size(1) <= mc) return 3;
+  if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= m1 && w.size(1) <= m1) return 1;
+  if (half && w.size(2) == 3 && w.size(3) == 3 && w.size(1) <= mc && w.size(0) <= 2 * mc) return 2;   // stride 2
   return 0;
 }
 
@@ -488,6 +495,8 @@ void set_async_wgrad(bool on) {
   g_async_wgrad.store(on);
 }
 void wgrad_join() { join_workers(); }
+void set_deterministic(bool on) { g_deterministic.store(on); }
+bool get_deterministic() { return g_deterministic.load(); }
 void set_wgrad_stream(bool on, int64_t batch) { g_wgrad_stream.store(on); g_wgrad_batch.store(batch > 0 ? (int)batch : 16); }
 
 struct Conv2d : public torch::autograd::Function<Conv2d> {
@@ -1203,6 +1212,8 @@ TORCH_LIBRARY(hcmoco, m) {
   m.def("set_async_wgrad(bool on) -> ()", &set_async_wgrad);
   m.def("wgrad_join() -> ()", &wgrad_join);
   m.def("set_wgrad_stream(bool on, int batch) -> ()", &set_wgrad_stream);
+  m.def("set_deterministic(bool on) -> ()", &set_deterministic);
+  m.def("get_deterministic() -> bool", &get_deterministic);
   m.def("bn_act(Tensor x, Tensor? residual, Tensor weight, Tensor bias, Tensor? running_mean, "
         "Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &bn_act);
 }

@@ -78,9 +78,17 @@ def alias_build(probs):
     return prob, alias
 
 
-def alias_draw(prob, alias, y, B, K1, seed, offset):
-    """idx [B,K1] int64, idx[:,0]=y (mem_bank.py:176-177), Philox-keyed by (seed, offset)."""
+def alias_draw(prob, alias, y, B, K1, seed, offset, oob=None):
+    """idx [B,K1] int64, idx[:,0]=y (mem_bank.py:176-177), Philox-keyed by (seed, offset).  ``oob`` (int32[1] device
+    flag): y is clamped into [0, n) and the flag records that a clamp changed something."""
     idx = torch.empty(B, K1, dtype=torch.int64, device=prob.device)
+    if oob is not None:
+        check(_lib.lib().hcm_alias_draw_checked(
+            _dev(prob, torch.float32, 'alias_draw'), _dev(alias, torch.int64, 'alias_draw'), prob.numel(),
+            _opt(y, torch.int64, 'alias_draw'), B, K1, seed & (2 ** 64 - 1), offset & (2 ** 64 - 1),
+            _dev(idx, torch.int64, 'alias_draw'), _dev(oob, torch.int32, 'alias_draw'), _stream()),
+            'hcm_alias_draw_checked')
+        return idx
     check(_lib.lib().hcm_alias_draw(_dev(prob, torch.float32, 'alias_draw'), _dev(alias, torch.int64, 'alias_draw'),
                                     prob.numel(), _opt(y, torch.int64, 'alias_draw'), B, K1,
                                     seed & (2 ** 64 - 1), offset & (2 ** 64 - 1),
@@ -91,8 +99,8 @@ def alias_draw(prob, alias, y, B, K1, seed, offset):
 # --------------------------------------------------------------------------- #
 # rows 2+4: fused bank NCE
 # --------------------------------------------------------------------------- #
-def bank_nce_fused_raw(banks, idx, xs, T, use_depth=None, use_rgb=None):
-    """One launch sequence -> (losses[6], accs[6], [gx1,gx2,gx3]); gx = d sum(losses)/dx."""
+def bank_nce_fused_raw(banks, idx, xs, T, use_depth=None, use_rgb=None, stacked=False):
+    """One launch sequence -> (losses[6], accs[6], [gx1,gx2,gx3]); gx = d sum(losses)/dx (``stacked``: one [3,B,D] tensor)."""
     x1, x2, x3 = xs
     B, D = x1.shape
     K1 = idx.shape[1]
@@ -114,6 +122,8 @@ def bank_nce_fused_raw(banks, idx, xs, T, use_depth=None, use_rgb=None):
         C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 24),
         C.c_void_p(gx[0].data_ptr()), C.c_void_p(gx[1].data_ptr()), C.c_void_p(gx[2].data_ptr()),
         C.c_void_p(ws.data_ptr()), nbytes, _stream()), 'hcm_bank_nce_fused')
+    if stacked:
+        return out[:6], out[6:], gx
     return out[:6], out[6:], [gx[0], gx[1], gx[2]]
 
 
@@ -229,9 +239,31 @@ def bank_logits(xs, banks, idx, T):
 # --------------------------------------------------------------------------- #
 # row 3: momentum update (in place, no grad)
 # --------------------------------------------------------------------------- #
+def _strided_rows(t, ldx, name):
+    """Pointer of a [BW, D] fp32 block whose rows are ``ldx`` floats apart (a column slice of a wider matrix)."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError('hcmoco_amd.%s needs fp32 ROCm device tensors (no CPU fallback exists)' % name)
+    if t.dim() != 2 or t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) != ldx):
+        raise ValueError('%s: expected unit column stride and row stride %d' % (name, ldx))
+    p = C.c_void_p(t.data_ptr())
+    p._keepalive = t
+    return p
+
+
 @torch.no_grad()
-def bank_update(banks, all_xs, all_y, momentum):
+def bank_update(banks, all_xs, all_y, momentum, ldx=None, oob=None):
     BW, D = all_xs[0].shape
+    if oob is not None:
+        fn, bdt = _bank_entry('hcm_bank_update_checked', banks)
+        ldx = D if ldx is None else int(ldx)
+        check(fn(
+            _dev(banks[0], bdt, 'bank_update'), _dev(banks[1], bdt, 'bank_update'),
+            _dev(banks[2], bdt, 'bank_update'), banks[0].shape[0],
+            _strided_rows(all_xs[0].detach(), ldx, 'bank_update'), _strided_rows(all_xs[1].detach(), ldx, 'bank_update'),
+            _strided_rows(all_xs[2].detach(), ldx, 'bank_update'), ldx,
+            _dev(all_y.contiguous(), torch.int64, 'bank_update'), BW, D, float(momentum),
+            _dev(oob, torch.int32, 'bank_update'), _stream()), 'hcm_bank_update_checked')
+        return
     fn, bdt = _bank_entry('hcm_bank_update', banks)
     check(fn(
         _dev(banks[0], bdt, 'bank_update'), _dev(banks[1], bdt, 'bank_update'),
@@ -731,3 +763,281 @@ def conv3x3_wgrad(x, dy, ksize=3, stride=1):
                                     N, Cc, K, H, W, C.c_void_p(dw.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes,
                                     _stream()), name)
     return dw
+
+
+# --------------------------------------------------------------------------- #
+# The loss section of a second-stage step as ONE autograd node (csrc/section.hip):
+# heads -> [packed all-gather] -> negative draw -> bank NCE -> bank update -> pixel sampling -> sampled
+# merge_all_res + projection -> dense / joint / SCL losses, and in backward: projection, heads, the eight
+# branch gradients.  ~35 launches where the module-by-module form needed ~220.
+# --------------------------------------------------------------------------- #
+def _branches(maps, name):
+    """hcm_branches for the four NCHW maps of one HRNet (keeps the tensors alive through the struct)."""
+    if len(maps) != 4:
+        raise ValueError('%s: an HRNet returns four branch maps' % name)
+    br = _lib.Branches()
+    for i, t in enumerate(maps):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError('hcmoco_amd.%s needs fp32 ROCm device tensors (no CPU fallback exists)' % name)
+        if t.dim() != 4 or not t.is_contiguous():
+            raise ValueError('%s: branch maps must be NCHW-contiguous' % name)
+        br.map[i] = t.data_ptr()
+        br.C[i], br.H[i], br.W[i] = t.shape[1], t.shape[2], t.shape[3]
+    br._keepalive = list(maps)
+    return br
+
+
+def heads_forward(maps1, maps2, feat3, W1, b1, W2, b2, W3, b3, index=None):
+    """(pooled [2,B,Ctot], mean3 [B,D3], ypre [3,B,F], f [B,3F(+2)], fT [3,B,F]) -- build_backbone.py:265-288.
+    With ``index`` the rows of ``f`` are the packed rows of the feature/index all-gather."""
+    B = maps1[0].shape[0]
+    Ctot = sum(m.shape[1] for m in maps1)
+    J, D3 = feat3.shape[1], feat3.shape[2]
+    F = W1.shape[0]
+    dev = feat3.device
+    ldf = 3 * F + (2 if index is not None else 0)
+    pooled = torch.empty(2, B, Ctot, dtype=torch.float32, device=dev)
+    mean3 = torch.empty(B, D3, dtype=torch.float32, device=dev)
+    ypre = torch.empty(3, B, F, dtype=torch.float32, device=dev)
+    f = torch.empty(B, ldf, dtype=torch.float32, device=dev)
+    fT = torch.empty(3, B, F, dtype=torch.float32, device=dev)
+    d = lambda t: _dev(t, torch.float32, 'heads_forward')
+    check(_lib.lib().hcm_heads_forward(
+        _branches(maps1, 'heads_forward'), _branches(maps2, 'heads_forward'), d(feat3), B, J, Ctot, D3, F,
+        d(W1), d(b1), d(W2), d(b2), d(W3), d(b3), _opt(index, torch.int64, 'heads_forward'),
+        d(pooled), d(mean3), d(ypre), d(f), ldf, d(fT), _stream()), 'hcm_heads_forward')
+    return pooled, mean3, ypre, f, fT
+
+
+def heads_backward(gfT, scale, pooled, mean3, ypre, W1, W2, W3, gfeat3_joint, J):
+    """-> (dW1, db1, dW2, db2, dW3, db3, dpooled [2,B,Ctot], gfeat3 [B,J,D3]); ``scale``: 0-dim device tensor or None."""
+    _, B, F = gfT.shape
+    Ctot, D3 = pooled.shape[2], mean3.shape[1]
+    dev = gfT.device
+    dyws = torch.empty(3, B, F, dtype=torch.float32, device=dev)
+    dW1, dW2 = torch.empty_like(W1), torch.empty_like(W2)
+    dW3 = torch.empty_like(W3)
+    db = torch.empty(3, F, dtype=torch.float32, device=dev)
+    dpooled = torch.empty(2, B, Ctot, dtype=torch.float32, device=dev)
+    gfeat3 = torch.empty(B, J, D3, dtype=torch.float32, device=dev)
+    d = lambda t: _dev(t, torch.float32, 'heads_backward')
+    check(_lib.lib().hcm_heads_backward(
+        d(gfT), _opt(scale, torch.float32, 'heads_backward'), d(pooled), d(mean3), d(ypre), B, J, Ctot, D3, F,
+        d(W1), d(W2), d(W3), _opt(gfeat3_joint, torch.float32, 'heads_backward'), d(dyws), d(dW1),
+        C.c_void_p(db[0].data_ptr()), d(dW2), C.c_void_p(db[1].data_ptr()), d(dW3), C.c_void_p(db[2].data_ptr()),
+        d(dpooled), d(gfeat3), _stream()), 'hcm_heads_backward')
+    return dW1, db[0], dW2, db[1], dW3, db[2], dpooled, gfeat3
+
+
+def pixel_sample(depth_mask, h, w, S, use_depth, joints2d, seed, offset):
+    """(pix [B,S+J] int64, coord [B,S] int64, keep [B] int32): contrast_trainer.py:671-685 + :757-761 in one launch,
+    drawn by Philox(seed, offset) -- oracle: ``oracle.hcmoco_oracle.pixel_sample_philox``."""
+    B, H, W = depth_mask.shape
+    J = joints2d.shape[1]
+    dev = depth_mask.device
+    pix = torch.empty(B, S + J, dtype=torch.int64, device=dev)
+    coord = torch.empty(B, S, dtype=torch.int64, device=dev)
+    keep = torch.empty(B, dtype=torch.int32, device=dev)
+    if joints2d.dtype == torch.float64:      # see joint_pixels(): floor in the loader's dtype first
+        joints2d = torch.floor(joints2d / 4) * 4
+    check(_lib.lib().hcm_pixel_sample(
+        _dev(depth_mask.to(torch.float32).contiguous(), torch.float32, 'pixel_sample'), B, H, W, h, w, S,
+        _opt(_i32(use_depth), torch.int32, 'pixel_sample'),
+        _dev(joints2d.to(torch.float32).contiguous(), torch.float32, 'pixel_sample'), J,
+        seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), _dev(pix, torch.int64, 'pixel_sample'),
+        _dev(coord, torch.int64, 'pixel_sample'), _dev(keep, torch.int32, 'pixel_sample'), _stream()),
+        'hcm_pixel_sample')
+    return pix, coord, keep
+
+
+def sample_branches(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, zero_grows=True):
+    """(xs [2,B*R,ld], Wpad [2,F,ld], grows [2,B*R,F] zero-filled or None): merge_all_res at the pixels ``pix`` for
+    both modalities + the packed projections (build_backbone.py:243-254); rows = bmm(xs, Wpad^T)."""
+    B, R = pix.shape
+    Ctot = sum(m.shape[1] for m in maps1)
+    F = Wp1.shape[0]
+    ld = int(_lib.lib().hcm_sample_branches_ld(Ctot))
+    dev = pix.device
+    xs = torch.empty(2, B * R, ld, dtype=torch.float32, device=dev)
+    Wpad = torch.empty(2, F, ld, dtype=torch.float32, device=dev)
+    grows = torch.empty(2, B * R, F, dtype=torch.float32, device=dev) if zero_grows else None
+    d = lambda t: _dev(t, torch.float32, 'sample_branches')
+    check(_lib.lib().hcm_sample_branches(
+        _branches(maps1, 'sample_branches'), _branches(maps2, 'sample_branches'), B,
+        _dev(pix, torch.int64, 'sample_branches'), R, Ctot, F, d(Wp1.reshape(F, Ctot)), d(bp1),
+        d(Wp2.reshape(F, Ctot)), d(bp2), d(xs), d(Wpad), _opt(grows, torch.float32, 'sample_branches'), _stream()),
+        'hcm_sample_branches')
+    return xs, Wpad, grows
+
+
+def branch_grad(dxs, dpooled, scale, pix, shapes, dWpad=None, F=128, keep=None, S=0):
+    """The eight branch gradients (and, from ``dWpad``, the projections' weight/bias gradients) in one launch:
+    -> (gmaps1[4], gmaps2[4], dWp1, dbp1, dWp2, dbp2).  ``shapes``: the four branch map shapes [B,C,H,W]."""
+    B, R = pix.shape
+    dev = pix.device
+    Ctot = sum(s[1] for s in shapes)
+    g1 = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    g2 = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    dWp1 = dbp1 = dWp2 = dbp2 = None
+    if dWpad is not None:
+        dWp = torch.empty(2, F, Ctot, dtype=torch.float32, device=dev)
+        dbp = torch.empty(2, F, dtype=torch.float32, device=dev)
+        dWp1, dWp2, dbp1, dbp2 = dWp[0], dWp[1], dbp[0], dbp[1]
+    p = lambda t: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+    check(_lib.lib().hcm_branch_grad(
+        _opt(dxs, torch.float32, 'branch_grad'), _opt(dpooled, torch.float32, 'branch_grad'),
+        _opt(scale, torch.float32, 'branch_grad'), _dev(pix, torch.int64, 'branch_grad'), R, B, Ctot,
+        _branches(g1, 'branch_grad'), _branches(g2, 'branch_grad'), _opt(keep, torch.int32, 'branch_grad'), int(S),
+        _opt(dWpad, torch.float32, 'branch_grad'), F,
+        p(dWp1), p(dbp1), p(dWp2), p(dbp2), _stream()), 'hcm_branch_grad')
+    return g1, g2, dWp1, dbp1, dWp2, dbp2
+
+
+_ROW_INDEX = {}
+
+
+def _row_index(B, S, J, device):
+    """Constant gather indices of the row-matrix 'map' ([B,128,1,S+J] channels-last): dense rows 0..S-1, joints S.."""
+    key = (B, S, J, str(device))
+    v = _ROW_INDEX.get(key)
+    if v is None:
+        ar = torch.arange(S + J, device=device, dtype=torch.int64).unsqueeze(0).expand(B, S + J)
+        v = _ROW_INDEX[key] = (ar[:, :S].contiguous(), ar[:, S:].contiguous())
+    return v
+
+
+def fmap_losses_on_rows(rows, grows, feat3, S, coord, w, keep, joints_vis, ud, ur, temperature, gemm_dtype='fp32'):
+    """Rows 5-7 on the projected row matrix rows [2, B, S+J, 128] (modality major); the row gradients are accumulated
+    into the zero-filled ``grows`` (same layout).  -> (meters[9], gfeat3_joint [B,J,128]).  No autograd here: the
+    caller (``_Stage2Section``) owns the graph."""
+    _, B, R, Cc = rows.shape
+    J = R - S
+    dev = rows.device
+    L = _lib.lib()
+    st = Strides4(R * Cc, 1, R * Cc, Cc)
+    gd, gj = _row_index(B, S, J, dev)
+    out = torch.empty(9, dtype=torch.float32, device=dev)      # dense writes [0:4], joint [4:8], SCL [8]
+    p1, p2 = C.c_void_p(rows[0].data_ptr()), C.c_void_p(rows[1].data_ptr())
+    pg1, pg2 = C.c_void_p(grows[0].data_ptr()), C.c_void_p(grows[1].data_ptr())
+    nb = L.hcm_dense_soft_nce_workspace_bytes(B, S, Cc)
+    ws = _ws(nb, dev)
+    dense = L.hcm_dense_soft_nce_coords_bf16 if gemm_dtype == 'bf16' else L.hcm_dense_soft_nce_coords
+    check(dense(p1, p2, st, B, Cc, 1, R, _dev(gd, torch.int64, 'dense'), _dev(coord, torch.int64, 'dense'), int(w),
+                _dev(keep, torch.int32, 'dense'), S, float(temperature), C.c_void_p(out.data_ptr()), pg1, pg2,
+                C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_dense_soft_nce_coords')
+    feat3c = feat3.contiguous()
+    gfeat3 = torch.empty_like(feat3c)
+    nb = L.hcm_joint_nce_workspace_bytes(B, J, Cc)
+    ws = _ws(nb, dev)
+    check(L.hcm_joint_nce(p1, p2, st, B, Cc, 1, R, _dev(feat3c, torch.float32, 'joint'), _dev(gj, torch.int64, 'joint'),
+                          _dev(joints_vis, torch.int32, 'joint'), _opt(ud, torch.int32, 'joint'), J, float(temperature),
+                          C.c_void_p(out.data_ptr() + 16), pg1, pg2, C.c_void_p(gfeat3.data_ptr()),
+                          C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_joint_nce')
+    nb = L.hcm_scl_workspace_bytes(B, J, Cc)
+    ws = _ws(nb, dev)
+    scl = L.hcm_scl_bf16 if gemm_dtype == 'bf16' else L.hcm_scl
+    udv = ud if ud is not None else torch.ones(B, dtype=torch.int32, device=dev)
+    check(scl(p1, p2, st, B, Cc, 1, R, _dev(gj, torch.int64, 'scl'), _dev(udv, torch.int32, 'scl'),
+              _opt(ur, torch.int32, 'scl'), J, float(temperature), C.c_void_p(out.data_ptr() + 32), pg1, pg2,
+              C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_scl')
+    return out, gfeat3
+
+
+class _Stage2Section(torch.autograd.Function):
+    """forward(feat3, W1, b1, W2, b2, W3, b3, Wp1, bp1, Wp2, bp2, *maps1, *maps2, cfg) -> (total, bank_losses[6],
+    bank_accs[6], meters[9]); ``cfg``: plain-python description of the step (see ``stage2_section``)."""
+
+    @staticmethod
+    def forward(ctx, feat3, W1, b1, W2, b2, W3, b3, Wp1, bp1, Wp2, bp2, m10, m11, m12, m13, m20, m21, m22, m23, cfg):
+        maps1, maps2 = [m10, m11, m12, m13], [m20, m21, m22, m23]
+        mem, tape = cfg['contrast'], cfg.get('tape')
+        index = cfg['index'].contiguous()
+        B, J = feat3.shape[0], feat3.shape[1]
+        F = W1.shape[0]
+        feat3c = feat3.contiguous()
+        gather = cfg.get('gather')
+        # ---- heads (and the packed all-gather row when there are other ranks to tell)
+        pooled, mean3, ypre, f, fT = heads_forward(maps1, maps2, feat3c, W1, b1, W2, b2, W3, b3,
+                                                   index if gather is not None else None)
+        if gather is not None:
+            allp = gather(f)                                              # [B*W, 3F+2], rank-major
+            all_x = [allp[:, i * F:(i + 1) * F] for i in range(3)]
+            all_index = allp[:, 3 * F:].contiguous().view(torch.int64).view(-1)
+            ldx = allp.shape[1]
+        else:
+            all_x, all_index, ldx = [fT[0], fT[1], fT[2]], index, F
+        # ---- rows 1-4: negatives, fused bank NCE (gx = d sum(losses) / d fT), momentum update after the reads
+        ud, ur = _i32(cfg.get('use_depth')), _i32(cfg.get('use_rgb'))
+        idx = cfg.get('idx')
+        idx = mem.draw(index) if idx is None else mem._in_range(idx).contiguous()
+        if tape is not None:
+            tape.update(banks0=[b.detach().clone() for b in mem.banks()], idx=idx, f=f[:, :3 * F], fT=fT,
+                        all_x=[a.detach().clone() for a in all_x], all_index=all_index)
+        losses, accs, gxT = bank_nce_fused_raw(mem.banks(), idx, [fT[0], fT[1], fT[2]], mem.T, ud,
+                                               ur if cfg.get('bank_use_rgb') else None, stacked=True)
+        mem.update_strided(all_x, ldx, all_index)
+        meters = None
+        ctx.stage2 = bool(cfg.get('stage2', True))
+        if ctx.stage2:
+            # ---- sampled pixels (device Philox sampler unless the caller injects them)
+            h, w = maps1[0].shape[-2:]
+            S = int(cfg['num_samples'])
+            vis = _i32(cfg['joints_vis'])
+            if cfg.get('sample_ind') is not None:
+                pj = joint_pixels(cfg['joints2d'], h)
+                coord = cfg['sample_ind'].contiguous()
+                pix = torch.cat([coord, pj], dim=1).contiguous()
+                keep = _i32(cfg['keep'])
+            else:
+                pix, coord, keep = pixel_sample(cfg['depth_mask'], h, w, S, ud, cfg['joints2d'], *mem.next_pixel_key())
+            # ---- row 8 at the sampled pixels + the 1x1 projections as one batched GEMM (bias folded in)
+            xs, Wpad, grows = sample_branches(maps1, maps2, pix, Wp1, bp1, Wp2, bp2)
+            rows = torch.bmm(xs, Wpad.transpose(1, 2))                       # [2, B*R, F]
+            R = pix.shape[1]
+            meters, gj = fmap_losses_on_rows(rows.view(2, B, R, F), grows.view(2, B, R, F), feat3c, S, coord, w, keep,
+                                             vis, ud, ur, cfg['temperature'], cfg.get('gemm_dtype', 'fp32'))
+            if tape is not None:
+                tape.update(pix=pix, coord=coord, keep=keep, rows=rows, meters=meters)
+            ctx.save_for_backward(pooled, mean3, ypre, W1, W2, W3, gxT, gj, xs, Wpad, grows, pix, keep)
+            ctx.S = S
+        else:
+            ctx.save_for_backward(pooled, mean3, ypre, W1, W2, W3, gxT)
+        ctx.J = J
+        ctx.shapes = [tuple(m.shape) for m in maps1]
+        total = torch.empty((), dtype=torch.float32, device=losses.device)
+        check(_lib.lib().hcm_section_total(_dev(losses, torch.float32, 'section'), _opt(meters, torch.float32, 'section'),
+                                           C.c_void_p(total.data_ptr()), _stream()), 'hcm_section_total')
+        outs = (total, losses, accs, meters if meters is not None else total.new_zeros(9))
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        scale = g_total.contiguous().to(torch.float32)
+        if ctx.stage2:
+            pooled, mean3, ypre, W1, W2, W3, gxT, gj, xs, Wpad, grows, pix, keep = ctx.saved_tensors
+            F = W1.shape[0]
+            dxs = torch.bmm(grows, Wpad)                                     # [2, B*R, ld]
+            dWpad = torch.bmm(grows.transpose(1, 2), xs)                     # [2, F, ld]
+            dW1, db1, dW2, db2, dW3, db3, dpooled, gfeat3 = heads_backward(gxT, scale, pooled, mean3, ypre, W1, W2, W3,
+                                                                           gj, ctx.J)
+            g1, g2, dWp1, dbp1, dWp2, dbp2 = branch_grad(dxs, dpooled, scale, pix, ctx.shapes, dWpad, F, keep, ctx.S)
+            Ctot = dWp1.shape[1]
+            return (gfeat3, dW1, db1, dW2, db2, dW3, db3, dWp1.view(F, Ctot, 1, 1), dbp1, dWp2.view(F, Ctot, 1, 1), dbp2,
+                    g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3], None)
+        pooled, mean3, ypre, W1, W2, W3, gxT = ctx.saved_tensors
+        dW1, db1, dW2, db2, dW3, db3, dpooled, gfeat3 = heads_backward(gxT, scale, pooled, mean3, ypre, W1, W2, W3,
+                                                                       None, ctx.J)
+        # stage 1: the branch maps only feed the average pools
+        nopix = torch.empty(ctx.shapes[0][0], 0, dtype=torch.int64, device=gxT.device)
+        g1, g2, _, _, _, _ = branch_grad(None, dpooled, None, nopix, ctx.shapes)
+        return (gfeat3, dW1, db1, dW2, db2, dW3, db3, None, None, None, None,
+                g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3], None)
+
+
+def stage2_section(feat3, heads, projs, maps1, maps2, cfg):
+    """One autograd node for the whole loss section.  heads = (W1,b1,W2,b2,W3,b3) of the three Linear heads, projs =
+    (Wp1,bp1,Wp2,bp2) of the two 1x1 projections; cfg keys: contrast (CMCMem3), index, use_depth, use_rgb,
+    depth_mask, joints2d, joints_vis, num_samples, temperature, gemm_dtype, gather (callable or None), and the
+    parity-mode injections idx / sample_ind / keep; ``tape`` (dict) receives the intermediates."""
+    return _Stage2Section.apply(feat3, *heads, *projs, *maps1, *maps2, cfg)

@@ -59,6 +59,11 @@ class ContrastTrainer(BaseTrainer):
         if (hasattr(self.engine, 'fmap_sampled') and hasattr(model, 'defer_projection')
                 and getattr(args, 'sampled_projection', 1)):
             model.defer_projection = True
+            # ... and, when it can, the heads too: the whole serial section becomes one autograd node
+            if (getattr(self.engine, 'supports_section', None) is not None and hasattr(model, 'defer_heads')
+                    and self.device.type == 'cuda' and os.environ.get('HCM_FUSED_SECTION', '1') != '0'
+                    and getattr(args, 'grad_sync', 'auto') != 'ddp' and self.engine.supports_section(model)):
+                model.defer_heads = True
         if getattr(args, 'channels_last', False):
             model.to(memory_format=torch.channels_last)
         if isinstance(model_ema, torch.nn.Module):
@@ -188,6 +193,14 @@ class ContrastTrainer(BaseTrainer):
         index = packed[:, -2:].contiguous().view(torch.int32).view(-1).view(torch.int64)
         return f, index
 
+    @staticmethod
+    def _gather_rows(packed):
+        """[B, 3F+2] packed rows (written by the heads kernel) -> [B*W, 3F+2], rank-major: the one collective."""
+        out = torch.empty(dist.get_world_size() * packed.shape[0], packed.shape[1], dtype=packed.dtype,
+                          device=packed.device)
+        dist.all_gather_into_tensor(out, packed.contiguous())
+        return out
+
     def _packed_gather(self, f, index):
         """One collective per step; rank-major row order (it defines the duplicate-update winner)."""
         if not self._multi():
@@ -252,11 +265,22 @@ class ContrastTrainer(BaseTrainer):
             _feat1, _feat2, _feat3, f, aux = model(inputs, skeleton, return_fm=True)
         else:
             f = model(inputs, skeleton)
+        out = {}
+        if stage2 and f is None:
+            # the model ran with defer_heads: pooling, heads, all-gather, bank NCE + update, pixel sampling,
+            # sampled projection and the three feature-map losses are ONE autograd node (engine.section)
+            net = self.unwrap(model)
+            loss, losses, accs, meters = self.engine.section(
+                net, _feat1, _feat2, _feat3, index, contrast, True, depth_mask=self._to_dev(data[7]),
+                joints2d=self._to_dev(data[4]), joints_vis=self._to_dev(data[5]), use_depth=use_depth, use_rgb=use_rgb,
+                num_samples=args.pri3d_num_samples_per_image, temperature=args.temperature,
+                gather=self._gather_rows if self._multi() else None)
+            out['fmap'] = meters
+            return self._finish_step(loss, losses, accs, optimizer, out)
         all_f, all_index = self._packed_gather(f, index)
         f1, f2, f3 = torch.chunk(f, 3, dim=1)
         all_f1, all_f2, all_f3 = torch.chunk(all_f, 3, dim=1)
 
-        out = {}
         if stage2:      # stage 2 hands only use_depth to the bank CE (contrast_trainer.py:965-967)
             total, losses, accs = self.engine.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
                                                    use_depth=use_depth)
@@ -274,6 +298,9 @@ class ContrastTrainer(BaseTrainer):
             total, losses, accs = self.engine.bank(contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,
                                                    use_depth=use_depth, use_rgb=use_rgb)
             loss = total
+        return self._finish_step(loss, losses, accs, optimizer, out)
+
+    def _finish_step(self, loss, losses, accs, optimizer, out):
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
         join = self.async_wgrad.wgrad_join if self.async_wgrad is not None else None

@@ -77,6 +77,39 @@ class HipLossEngine(object):
         return hip_ops.fmap_losses_rows(rows1, rows2, feat3, sample_ind.shape[1], sample_ind, w, keep, joints_vis,
                                         ud, use_rgb, temperature, gemm_dtype=self.fmap_dtype)
 
+    # ---- rows 1-9 of a step as one autograd node ------------------------------
+    @staticmethod
+    def supports_section(net, stage2=True):
+        """The fused section covers the RGBD2S HRNet model with mean pooling and linear heads."""
+        return (type(net).__name__ == 'CMC3HRNetSGCNSingleHead' and net.pool_method == 'mean'
+                and (not stage2 or bool(net.linear_feat_map)) and net.head1[0].weight.shape[0] <= 256
+                and net.head1[0].weight.is_cuda)
+
+    def section(self, net, branches1, branches2, feat3, index, contrast, stage2, depth_mask=None, joints2d=None,
+                joints_vis=None, use_depth=None, use_rgb=None, num_samples=0, temperature=0.07, gather=None,
+                idx=None, sample_ind=None, keep=None, tape=None):
+        """Everything between the encoders' forward and backward as ONE autograd node (``hip_ops.stage2_section``,
+        csrc/section.hip): heads (build_backbone.py:265-288) -> [``gather``: the packed feature/index all-gather,
+        contrast_trainer.py:950-951] -> negative draw + fused bank NCE + momentum update (mem_bank.py:172-205) ->
+        pixel sampling (contrast_trainer.py:671-685) -> merge_all_res + projection at the sampled pixels
+        (build_backbone.py:243-254) -> dense / joint / SCL losses (:642-892), ~35 launches.  The model must have been
+        run with ``defer_heads`` (it returns the raw branch maps and no ``f``).
+        -> (total, bank_losses[6], bank_accs[6], meters[9])."""
+        heads = (net.head1[0].weight, net.head1[0].bias, net.head2[0].weight, net.head2[0].bias,
+                 net.head3[0].weight, net.head3[0].bias)
+        if stage2:
+            projs = (net.encoder1_linear.weight, net.encoder1_linear.bias, net.encoder2_linear.weight,
+                     net.encoder2_linear.bias)
+            h, w = branches1[0].shape[-2:]
+            assert h == w                               # contrast_trainer.py:751
+        else:
+            projs = (None, None, None, None)
+        cfg = dict(contrast=contrast, index=index, use_depth=use_depth, use_rgb=use_rgb, depth_mask=depth_mask,
+                   joints2d=joints2d, joints_vis=joints_vis, num_samples=num_samples, temperature=temperature,
+                   gemm_dtype=self.fmap_dtype, gather=gather, idx=idx, sample_ind=sample_ind, keep=keep, tape=tape,
+                   stage2=bool(stage2), bank_use_rgb=not stage2)
+        return hip_ops.stage2_section(feat3, heads, projs, list(branches1), list(branches2), cfg)
+
 
 class RecordingEngine(object):
     """Wrapper around a loss engine (the product's ``HipLossEngine`` unless told otherwise) that keeps CPU copies of everything one training step hands to the loss kernels and
@@ -184,3 +217,47 @@ class RecordingEngine(object):
         self._grads(rec, total, named)
         self.records.append(rec)
         return total, meters
+
+    def supports_section(self, net, stage2=True):
+        fn = getattr(self.inner, 'supports_section', None)
+        return bool(fn is not None and fn(net, stage2))
+
+    def section(self, net, branches1, branches2, feat3, index, contrast, stage2, depth_mask=None, joints2d=None,
+                joints_vis=None, use_depth=None, use_rgb=None, num_samples=0, temperature=0.07, gather=None,
+                idx=None, sample_ind=None, keep=None, tape=None):
+        kw = dict(depth_mask=depth_mask, joints2d=joints2d, joints_vis=joints_vis, use_depth=use_depth, use_rgb=use_rgb,
+                  num_samples=num_samples, temperature=temperature, gather=gather, idx=idx, sample_ind=sample_ind,
+                  keep=keep)
+        if not self.armed:
+            return self.inner.section(net, branches1, branches2, feat3, index, contrast, stage2, tape=tape, **kw)
+        c = self._cpu
+        tape = {} if tape is None else tape
+        heads = [net.head1[0], net.head2[0], net.head3[0]]
+        projs = [net.encoder1_linear, net.encoder2_linear] if stage2 else []
+        rec = {'kind': 'section', 'stage2': bool(stage2), 'T': contrast.T, 'm': contrast.m,
+               'branches1': c(list(branches1)), 'branches2': c(list(branches2)), 'feat3': c(feat3),
+               'heads': [(c(l.weight), c(l.bias)) for l in heads], 'projs': [(c(l.weight), c(l.bias)) for l in projs],
+               'index': c(index), 'depth_mask': c(depth_mask), 'joints2d': c(joints2d), 'joints_vis': c(joints_vis),
+               'use_depth': c(use_depth), 'use_rgb': c(use_rgb), 'num_samples': int(num_samples),
+               'temperature': float(temperature), 'fmap_dtype': self.fmap_dtype, 'grads': {}}
+        total, losses, accs, meters = self.inner.section(net, branches1, branches2, feat3, index, contrast, stage2,
+                                                         tape=tape, **kw)
+        rec.update(total=c(total), losses=c(losses), accs=c(accs), meters=c(meters), banks0=c(tape['banks0']),
+                   idx=c(tape['idx']), f=c(tape['f']), all_x=c(tape['all_x']), all_index=c(tape['all_index']))
+        if stage2:
+            S = int(num_samples)
+            rec.update(sample_ind=c(tape['coord']), keep=c(tape['keep']), pix=c(tape['pix']))
+        banks = contrast.banks()
+        ai = tape['all_index'].clamp(0, banks[0].shape[0] - 1)
+        touched = torch.zeros(banks[0].shape[0], dtype=torch.bool, device=banks[0].device)
+        touched[ai] = True
+        rec['after_rows'] = [c(b.index_select(0, ai)) for b in banks]
+        rec['untouched_rows_unchanged'] = [bool(torch.equal(b[~touched], b0[~touched]))
+                                           for b, b0 in zip(banks, tape['banks0'])]
+        named = [('b1_%d' % i, t) for i, t in enumerate(branches1)] + [('b2_%d' % i, t) for i, t in enumerate(branches2)]
+        named += [('feat3', feat3)]
+        named += [('head%d_%s' % (i + 1, n), getattr(l, a)) for i, l in enumerate(heads) for n, a in (('w', 'weight'), ('b', 'bias'))]
+        named += [('proj%d_%s' % (i + 1, n), getattr(l, a)) for i, l in enumerate(projs) for n, a in (('w', 'weight'), ('b', 'bias'))]
+        self._grads(rec, total, named)
+        self.records.append(rec)
+        return total, losses, accs, meters

@@ -38,6 +38,8 @@ class CMCMem3(BaseMem):
         for name in ('memory_1', 'memory_2', 'memory_3'):
             self.register_buffer(name, F.normalize(torch.randn(n_data, n_dim)).to(bank_dtype))
         self._oob = None             # device flag: some index had to be clamped (see _in_range)
+        self._oob_flag = None        # the same, set by the range-checked kernels (draw / update_strided)
+        self._pixel_draws = 0
 
     # nn.Module.cuda()/.to() move the buffers; the sampler tables follow
     def _apply(self, fn):
@@ -68,10 +70,13 @@ class CMCMem3(BaseMem):
         does, at ``print_freq`` and at the end of an epoch."""
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if self._oob is None and not multi:
+        if self._oob is None and self._oob_flag is None and not multi:
             return
         flag = self._oob if self._oob is not None else torch.zeros((), dtype=torch.bool, device=self.memory_1.device)
         self._oob = None
+        if self._oob_flag is not None:
+            flag = flag | (self._oob_flag[0] != 0)
+            self._oob_flag = None
         if multi:
             f = flag.to(torch.int32).reshape(1)
             dist.all_reduce(f, op=dist.ReduceOp.MAX)
@@ -79,6 +84,32 @@ class CMCMem3(BaseMem):
         if bool(flag):
             raise IndexError('CMCMem3: a bank row index was outside [0, %d) (dataset index / injected idx)%s'
                              % (self.n_data, ' on some rank' if multi else ''))
+
+    def _flag(self):
+        """Sticky int32 device flag the checked kernels OR a 1 into when they had to clamp a row index."""
+        if self._oob_flag is None or self._oob_flag.device != self.memory_1.device:
+            self._oob_flag = torch.zeros(1, dtype=torch.int32, device=self.memory_1.device)
+        return self._oob_flag
+
+    def draw(self, y):
+        """idx [B, K+1] with idx[:,0] = y clamped into the bank (mem_bank.py:176-177) -- one launch."""
+        mn = self.multinomial
+        idx = hip_ops.alias_draw(mn.prob, mn.alias, y.contiguous(), y.shape[0], self.K + 1, mn.seed, mn.offset,
+                                 oob=self._flag())
+        mn.offset += 1
+        return idx
+
+    def update_strided(self, all_xs, ldx, all_y):
+        """Momentum update from three [BW, D] column blocks with row stride ``ldx`` (slices of the gathered
+        feature matrix), indices range-checked inside the kernel."""
+        hip_ops.bank_update(self.banks(), all_xs, all_y, self.m, ldx=ldx, oob=self._flag())
+
+    def next_pixel_key(self):
+        """(seed, offset) of the next pixel draw: the sampler's Philox key, its own offset stream (high bit set,
+        so it never collides with the negative draws of the same step)."""
+        mn = self.multinomial
+        self._pixel_draws += 1
+        return mn.seed, (1 << 63) | self._pixel_draws
 
     def _indices(self, y, idx):
         if idx is not None:

@@ -48,6 +48,9 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # ``return_fm`` then hands back the raw branch maps and skips merge_all_res + the full 1x1
         # projections (aux entries are None).  Off by default = the reference data flow.
         self.defer_projection = False
+        # Set by a trainer whose loss engine also computes the pooling + heads inside its fused loss section
+        # (engine.section, csrc/section.hip): ``return_fm`` then returns ``f = None`` next to the raw branch maps.
+        self.defer_heads = False
         # The three encoders are independent until the heads.  HCM_TWO_STREAMS is a bit mask:
         #   1            SemGCN on a side HIP stream, issued first: its single-workgroup kernels
         #                (3.5 ms per step, one CU) run underneath the HRNets instead of in line;
@@ -121,6 +124,10 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         """mode 0/1: projected + L2-normalised features; 2: raw pooled features (:256-303)."""
         x1, x2 = torch.split(x, self.in_channel_list, dim=1)
         _feat1, _feat2, _feat3 = self._encode(x1, x2, s)
+        if (self.defer_heads and self.defer_projection and return_fm and self.linear_feat_map and mode in (0, 1)
+                and self.pool_method == 'mean'):
+            return _feat1, _feat2, _feat3, None, {'merge1': None, 'merge2': None, 'linear_merge1': None,
+                                                  'linear_merge2': None}
         avg1, avg2, avg3 = self._pool(_feat1), self._pool(_feat2), _feat3.mean(1)
         if mode in (0, 1):
             feat1, feat2, feat3 = self.head1(avg1), self.head2(avg2), self.head3(avg3)

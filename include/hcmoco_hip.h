@@ -109,6 +109,21 @@ int hcm_bank_update(float* bank1, float* bank2, float* bank3, int64_t n,
                     const float* all_x1, const float* all_x2, const float* all_x3,
                     const int64_t* all_y, int BW, int D, float momentum, hcm_stream_t stream);
 
+/* Range-checked forms used by the host mirror (memory/mem_bank.py): indices outside [0, n) are CLAMPED -- nothing
+ * outside the banks is read or written -- and *oob_flag (device int32, caller-zeroed, sticky) is OR-ed with 1 when a
+ * clamp changed a value (torch's index_select / index_copy_ would device-assert, memory/mem_bank.py:24-28, :179-184).
+ * hcm_bank_update_checked also takes the row stride `ldx` of all_x* (>= D): the three feature blocks may be column
+ * slices of one [BW, 3D (+2)] gathered matrix (learning/contrast_trainer.py:950-956). */
+int hcm_alias_draw_checked(const float* prob, const int64_t* alias, int64_t n, const int64_t* y, int B, int K1,
+                           uint64_t seed, uint64_t offset, int64_t* idx, int32_t* oob_flag, hcm_stream_t stream);
+int hcm_bank_update_checked(float* bank1, float* bank2, float* bank3, int64_t n, const float* all_x1,
+                            const float* all_x2, const float* all_x3, int64_t ldx, const int64_t* all_y, int BW,
+                            int D, float momentum, int32_t* oob_flag, hcm_stream_t stream);
+int hcm_bank_update_checked_bf16(uint16_t* bank1, uint16_t* bank2, uint16_t* bank3, int64_t n,
+                                 const float* all_x1, const float* all_x2, const float* all_x3, int64_t ldx,
+                                 const int64_t* all_y, int BW, int D, float momentum, int32_t* oob_flag,
+                                 hcm_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * MoCo queue (secondary) -- memory/mem_moco.py:15-49.
  * logits [B, K+1] = cat(q.k, q @ queue^T)/T ; enqueue rows (index + j) % K.
@@ -222,6 +237,79 @@ int hcm_sample_rows_grad(const float* grad_rows, int ldo, int col0, hcm_strides4
  * bmm(S^T, g) -- deterministic library GEMMs instead of atomics. */
 int hcm_sampling_matrix(const int64_t* pix, int nrows, int hi, int wi, int h0, int w0, float* S,
                         hcm_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * The serial section between the encoders' forward and backward as a few launches (SURVEY 8f-2, 8a rows 8-9;
+ * csrc/section.hip).  `hcm_branches` = the four NCHW-contiguous fp32 maps an HRNet returns
+ * (networks/official_hrnet/official_hrnet.py:411-454): map[i] is [B, C[i], H[i], W[i]], finest first.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  const float* map[4];
+  int C[4], H[4], W[4];
+} hcm_branches;
+typedef struct {
+  float* map[4];
+  int C[4], H[4], W[4];
+} hcm_branches_out;
+
+/* Heads (networks/build_backbone.py:265-288, networks/util.py:74-80): pooled[m] = cat_i mean_HW(enc_m.map[i])
+ * [2, B, Ctot]; mean3 = mean_j feat3[b, j, :] [B, D3] (feat3 [B, J, D3]); ypre[h] = W_h x_h + b_h [3, B, F]
+ * (W1, W2 [F, Ctot], W3 [F, D3], row-major like nn.Linear.weight); f[b, h*F + o] = ypre / max(|ypre|, 1e-12),
+ * row stride ldf >= 3F; fT [3, B, F] = the same values, one contiguous [B, F] matrix per head (what the bank
+ * entry points take).  index [B] int64 or NULL: when given, f[b, 3F], f[b, 3F+1] receive its bit pattern, so that
+ * f IS the packed row of the feature/index all-gather (learning/contrast_trainer.py:950-951).  F <= 256. */
+int hcm_heads_forward(hcm_branches enc1, hcm_branches enc2, const float* feat3, int B, int J, int Ctot, int D3,
+                      int F, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                      const float* b3, const int64_t* index, float* pooled, float* mean3, float* ypre, float* f,
+                      int ldf, float* fT, hcm_stream_t stream);
+/* Backward.  gfT [3, B, F] = d loss / d fT (the bank kernel's gx), multiplied by *scale (device scalar, NULL = 1).
+ * Outputs: dW1, dW2 [F, Ctot], dW3 [F, D3], db1..3 [F]; dpooled [2, B, Ctot]; gfeat3 [B, J, D3] =
+ * (*scale) * gfeat3_joint (the joint loss's own gradient w.r.t. feat3, NULL = 0) + head 3's share dX3[b] / J.
+ * dyws: [3, B, F] scratch.  Sums over the batch run in ascending order (deterministic). */
+int hcm_heads_backward(const float* gfT, const float* scale, const float* pooled, const float* mean3,
+                       const float* ypre, int B, int J, int Ctot, int D3, int F, const float* W1, const float* W2,
+                       const float* W3, const float* gfeat3_joint, float* dyws, float* dW1, float* db1, float* dW2,
+                       float* db2, float* dW3, float* db3, float* dpooled, float* gfeat3, hcm_stream_t stream);
+
+/* Pixel sampling of _compute_soft_pri3d_loss_accuracy (learning/contrast_trainer.py:671-685) and the joints'
+ * pixels (:757-761) in one launch.  depth_mask [B, H, W] fp32 (valid = value > 0; the datasets produce 0/1 masks,
+ * datasets/dataset.py:575, :600) is nearest-resized to h x w with torch's index rule; keep[b] = the resized mask is
+ * non-empty AND (use_depth == NULL or some use_depth != 0) (:663-665, :677-682); for kept images S pixels are drawn
+ * uniformly with replacement from the valid ones: element e = b*S + s uses Philox4x32-10(ctr = {e_lo, e_hi, off_lo,
+ * off_hi}, key = seed); k = (r0 * count) >> 32; pixel = the (k+1)-th valid pixel in raster order.  (torch.multinomial
+ * on the 0/1 weights draws from the same distribution with torch's own generator; parity tests inject indices.)
+ * Outputs: pix [B, S+J] int64 (S sampled pixels, then the J joint pixels clamp(floor(j/4), 0, h-1), joints2d [B, J, 2]
+ * fp32 (row, col)); coord [B, S] = the sampled pixels again (contiguous, for the soft target); keep [B] int32.
+ * Dropped images get pixel 0.  h == w, h*w*4 <= 150 KiB. */
+int hcm_pixel_sample(const float* depth_mask, int B, int H, int W, int h, int w, int S, const int32_t* use_depth,
+                     const float* joints2d, int J, uint64_t seed, uint64_t offset, int64_t* pix, int64_t* coord,
+                     int32_t* keep, hcm_stream_t stream);
+
+/* merge_all_res (networks/build_backbone.py:247-254) at the sampled pixels, both modalities in one launch:
+ * xs[m, b*R + r, :] = [enc_m.map[0][b, :, p] ; bilinear(map[1..3])[b, :, p] ; 1 ; 0...] for p = pix[b, r], row
+ * stride ld = hcm_sample_branches_ld(Ctot) (Ctot + the bias column, rounded up to 4).  Also packs the 1x1 projections
+ * (:243-245; Wp [F, Ctot], bp [F]) as Wpad [2, F, ld] = [W | b | 0], so that rows = xs Wpad^T is ONE batched GEMM
+ * including the bias, and zero-fills grows [2, B*R, F] (the loss kernels accumulate the row gradients into it;
+ * NULL = skip). */
+int hcm_sample_branches_ld(int Ctot);
+int hcm_sample_branches(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
+                        const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* Wpad,
+                        float* grows, hcm_stream_t stream);
+/* Backward of hcm_sample_branches + the average pooling of the heads, all eight branch gradients in one launch:
+ * g_m.map[i][b, c, q] = dpooled[m, b, coff_i + c] / (H_i W_i) + (*scale) * sum over the rows r of image b whose
+ * stencil holds q of weight * dxs[m, b*R + r, coff_i + c]   (dxs [2, B*R, ld] = grows Wpad; rows in ascending
+ * order, taps in stencil order: owner computes, deterministic, every element written exactly once -- the maps need
+ * no zero-fill).  dpooled NULL = 0.  keep [B] int32 / S (NULL / 0 = none): the first S rows of an image with
+ * keep[b] == 0 (the dense samples of a dropped image, all on pixel 0) carry an exactly-zero gradient and are skipped.
+ * Also unpacks dWpad [2, F, ld] (= grows^T xs) into dWp [F, Ctot], dbp [F] per
+ * modality, times *scale (dWpad NULL = skip). */
+int hcm_branch_grad(const float* dxs, const float* dpooled, const float* scale, const int64_t* pix, int R, int B,
+                    int Ctot, hcm_branches_out g1, hcm_branches_out g2, const int32_t* keep, int S, const float* dWpad,
+                    int F, float* dWp1, float* dbp1, float* dWp2, float* dbp2, hcm_stream_t stream);
+
+/* total[0] = sum(losses6) (+ meters9[0] + [1] + [4] + [5] + [8] when meters9 != NULL): the objective of
+ * learning/contrast_trainer.py:980 (:594 for stage 1) from the kernels' own outputs, in one tiny launch. */
+int hcm_section_total(const float* losses6, const float* meters9, float* total, hcm_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * SemGCN layer: SemGraphConv (networks/SGCN/sem_graph_conv.py:34-48) [+ BatchNorm1d +

@@ -144,6 +144,96 @@ def check_fmap_sampled(rec, tol):
     return rep
 
 
+def check_section(rec, tol):
+    """The fused loss section (engine.section, csrc/section.hip): rows 1-9 of SURVEY 8a in one record.  Oracle flow,
+    all on the CPU: pooling + heads (torch autograd over O.heads) -> f; bank NCE / update on f; merge_all_res + full
+    1x1 projection (torch autograd) -> oracle feature-map losses; the oracle's closed-form gradients w.r.t. f and the
+    two projected maps are pulled back by torch autograd to the eight branch maps, the SemGCN output, the three
+    heads and the two projections.  Everything the HIP section returned is compared: f, idx[:,0], the sampled pixels'
+    validity, 6 + 6 + 9 meters, the bank update and all 19 gradients."""
+    rep = {}
+
+    def leaf(t):
+        return t.float().clone().requires_grad_(True)
+
+    b1, b2 = [leaf(t) for t in rec['branches1']], [leaf(t) for t in rec['branches2']]
+    feat3 = leaf(rec['feat3'])
+    hw = [leaf(w) for w, _ in rec['heads']]
+    hb = [leaf(b) for _, b in rec['heads']]
+    f = O.heads(b1, b2, feat3, hw, hb)
+    F_ = f.shape[1] // 3
+    assert torch.allclose(rec['f'].float(), f.detach(), rtol=1e-5, atol=1e-6), ('heads f', float((rec['f'] - f.detach()).abs().max()))
+    rep['f_max_abs'] = float((rec['f'].float() - f.detach()).abs().max())
+    # ---- bank on the recorded f (the section's own features: errors do not compound)
+    fr = rec['f'].float()
+    bank = dict(rec)
+    bank.update(x=[fr[:, i * F_:(i + 1) * F_].contiguous() for i in range(3)],
+                use_rgb=None if rec['stage2'] else rec['use_rgb'], grads={})
+    bf16 = rec['banks0'][0].dtype == torch.bfloat16
+    banks = [b.float() for b in rec['banks0']]
+    idx = rec['idx']
+    assert torch.equal(idx[:, 0], rec['index'].clamp(0, banks[0].shape[0] - 1)), 'idx[:,0] != index'
+    lo, ao, go = O.bank_nce_chunked(banks, idx, bank['x'], rec['T'], rec['use_depth'], bank['use_rgb'])
+    l, a = rec['losses'].double(), rec['accs'].double()
+    assert torch.allclose(l, lo, rtol=tol['loss_rtol'], atol=tol['loss_atol']), ('bank losses', l, lo)
+    assert torch.allclose(a, ao, atol=1e-3), ('bank accs', a, ao)
+    rep['bank_loss_max_rel'] = float(((l - lo).abs() / lo.abs().clamp_min(1e-12)).max())
+    assert all(rec['untouched_rows_unchanged']), 'bank rows outside all_index changed'
+    upd = []
+    for i in range(3):
+        ref = O.bank_update(banks[i], rec['all_x'][i].float(), rec['all_index'], rec['m']).index_select(0, rec['all_index'])
+        err = (rec['after_rows'][i].float() - ref).abs()
+        if bf16:
+            assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all()), ('bank update (bf16)', i, float(err.max()))
+        else:
+            assert float(err.max()) <= tol['update_atol'], ('bank update', i, float(err.max()))
+        upd.append(float(err.max()))
+    rep['bank_update_max_abs'] = max(upd)
+    gf = torch.cat([g.float() for g in go], 1)
+    total = float(lo.sum())
+    if rec['stage2']:
+        # ---- sampled pixels must be valid draws: inside the resized mask of kept images
+        B = rec['index'].shape[0]
+        h, w = rec['branches1'][0].shape[-2:]
+        keep_ref, m = O.dense_keep(rec['depth_mask'], h, w)
+        ud = rec['use_depth']
+        if ud is not None:
+            keep_ref = keep_ref & bool(ud.sum() > 0)
+        assert torch.equal(rec['keep'].bool(), keep_ref), 'keep flags'
+        si = rec['sample_ind']
+        assert bool((m.gather(1, si)[keep_ref] > 0).all()), 'a sampled pixel lies outside the depth mask'
+        assert torch.equal(rec['pix'][:, si.shape[1]:], O.joint_pixels(rec['joints2d'], h)), 'joint pixels'
+
+        def project(branches, w, b):
+            size = branches[0].shape[-2:]
+            up = [branches[0]] + [F.interpolate(x, size=size, mode='bilinear', align_corners=False) for x in branches[1:]]
+            return F.conv2d(torch.cat(up, 1), w, b)
+
+        pw = [leaf(w_) for w_, _ in rec['projs']]
+        pb = [leaf(b_) for _, b_ in rec['projs']]
+        map1, map2 = project(b1, pw[0], pb[0]), project(b2, pw[1], pb[1])
+        frec = dict(rec, feat3=rec['feat3'])
+        want, g1, g2, g3 = _fmap_oracle(map1.detach(), map2.detach(), frec)
+        fm = dict(rec)
+        fm['total'] = rec['total'] - float(rec['losses'].sum())
+        _cmp_meters(fm, want, tol, rep)
+        torch.autograd.backward([f, map1, map2, feat3], [gf, g1, g2, g3])
+    else:
+        torch.autograd.backward([f], [gf])
+    ref = {'feat3': feat3.grad}
+    ref.update({'b1_%d' % i: t.grad for i, t in enumerate(b1)})
+    ref.update({'b2_%d' % i: t.grad for i, t in enumerate(b2)})
+    for i in range(3):
+        ref['head%d_w' % (i + 1)] = hw[i].grad
+        ref['head%d_b' % (i + 1)] = hb[i].grad
+    if rec['stage2']:
+        for i in range(2):
+            ref['proj%d_w' % (i + 1)] = pw[i].grad
+            ref['proj%d_b' % (i + 1)] = pb[i].grad
+    _cmp_grads(rec, ref, tol, rep)
+    return rep
+
+
 def check_records(records, tol=None):
     """-> report dict; raises AssertionError on the first disagreement."""
     report = {'calls': {}}
@@ -153,7 +243,7 @@ def check_records(records, tol=None):
             t.update(BF16_FMAP)
         if tol:
             t.update(tol)
-        fn = {'bank': check_bank, 'fmap': check_fmap, 'fmap_sampled': check_fmap_sampled}[rec['kind']]
+        fn = {'bank': check_bank, 'fmap': check_fmap, 'fmap_sampled': check_fmap_sampled, 'section': check_section}[rec['kind']]
         rep = fn(rec, t)
         report['calls'][rec['kind']] = report['calls'].get(rec['kind'], 0) + 1
         for k, v in rep.items():

@@ -285,6 +285,45 @@ def scatter_pixels(g, ind, shape):
     return out.view(B, C, h, w)
 
 
+def pixel_sample_philox(depth_mask, h, w, S, use_depth, seed, offset):
+    """Counter-based restatement of the pixel sampling of ``_compute_soft_pri3d_loss_accuracy``
+    (contrast_trainer.py:671-685): nearest-resize the mask, keep images whose resized mask is non-empty (and, :663-665,
+    only if some sample has depth), draw S pixels per kept image uniformly WITH replacement from the valid ones
+    (``torch.multinomial(mask, S, replacement=True)`` on a 0/1 mask).  Element e = b*S + s uses Philox counter
+    (e_lo, e_hi, offset_lo, offset_hi), key = seed; k = (r0 * count) >> 32; pixel = the (k+1)-th valid one in raster
+    order.  The reference consumes torch's generator instead; the distribution is the same and ``hcm_pixel_sample``
+    is bit-exact against this function.  -> (sample_ind [B,S] int64 (0 for dropped images), keep [B] bool)."""
+    B = depth_mask.shape[0]
+    m = nearest_resize_mask(depth_mask, h, w).reshape(B, h * w) > 0
+    cnt = m.long().cumsum(1)
+    total = cnt[:, -1]
+    any_depth = True if use_depth is None else bool(torch.as_tensor(use_depth).sum() > 0)
+    keep = (total > 0) & any_depth
+    N = B * S
+    i = np.arange(N, dtype=np.uint64)
+    ctr = np.stack([(i & _M32), (i >> np.uint64(32)),
+                    np.full(N, offset & 0xFFFFFFFF, np.uint64),
+                    np.full(N, (offset >> 32) & 0xFFFFFFFF, np.uint64)], axis=1).astype(np.uint32)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    r0 = torch.from_numpy(r[:, 0].astype(np.int64)).view(B, S)
+    k = (r0 * total.view(B, 1)) >> 32
+    ind = torch.searchsorted(cnt, k, right=True).clamp_max(h * w - 1)       # smallest q with cnt[q] > k
+    ind = torch.where(keep.view(B, 1), ind, torch.zeros_like(ind))
+    return ind, keep
+
+
+def heads(maps1, maps2, feat3, W, b):
+    """Rows 9: global average pool of the four branches + concat, Linear, L2-normalise for the two HRNets; mean over
+    the joints, Linear, L2-normalise for the SemGCN (networks/build_backbone.py:265-288, networks/util.py:74-80).
+    ``W``, ``b``: the three heads' weights / biases.  -> f [B, 3F] (differentiable torch graph)."""
+    x = [torch.cat([m.mean(dim=(2, 3)) for m in maps1], 1), torch.cat([m.mean(dim=(2, 3)) for m in maps2], 1),
+         feat3.mean(1)]
+    out = []
+    for xi, Wi, bi in zip(x, W, b):
+        out.append(F.normalize(F.linear(xi, Wi, bi), p=2, dim=1))        # Normalize(2), networks/util.py:74-80
+    return torch.cat(out, 1)
+
+
 # --------------------------------------------------------------------------- #
 # row 5 -- dense intra-sample soft InfoNCE     learning/contrast_trainer.py:642-723
 # --------------------------------------------------------------------------- #

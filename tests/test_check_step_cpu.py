@@ -85,3 +85,49 @@ def test_checker_command_line(tmp_path):
                          cwd=ROOT, timeout=600)
     rep = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
     assert rep['checked'] is False and 'bank losses' in rep['error']
+
+
+def test_oracle_heads_equal_the_model_heads():
+    """O.heads (what the whole-step checker derives f from) against the model's own pooling + Linear + Normalize
+    (networks/build_backbone.py:265-288; the model itself is pinned to the reference in tests/test_model_surface.py)."""
+    import argparse
+    from hcmoco_amd.pycontrast.networks.build_backbone import build_model
+    from oracle import hcmoco_oracle as O
+    torch.manual_seed(1)
+    opt = argparse.Namespace(modal='RGBD2S', arch='HRNet', jigsaw=False, head='linear', feat_dim=128,
+                             in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
+                             skeleton_meta_name='mpii', IN_Pretrain=None, depth_Pretrain=None, mem='bank')
+    model, _ = build_model(opt)
+    model.train()
+    x, s = torch.randn(2, 6, 64, 64), torch.rand(2, 16, 2) * 2 - 1
+    f1, f2, f3, f, _ = model(x, s, return_fm=True)
+    heads = [model.head1[0], model.head2[0], model.head3[0]]
+    ref = O.heads(f1, f2, f3, [l.weight for l in heads], [l.bias for l in heads])
+    assert torch.allclose(f, ref, rtol=1e-6, atol=1e-7)
+    # with the trainer's flags the model hands back the raw maps and no f
+    model.defer_projection = model.defer_heads = True
+    out = model(x, s, return_fm=True)
+    assert out[3] is None and out[4]['linear_merge1'] is None and len(out[0]) == 4
+
+
+def test_oracle_pixel_sampler_properties():
+    """O.pixel_sample_philox (bit-exact model of hcm_pixel_sample): valid pixels only, dropped images, the
+    use_depth early-out, determinism in (seed, offset), uniformity."""
+    from oracle import hcmoco_oracle as O
+    torch.manual_seed(0)
+    B, H, h, S = 4, 64, 16, 50
+    mask = (torch.rand(B, H, H) < 0.2).float()
+    mask[2] = 0
+    ind, keep = O.pixel_sample_philox(mask, h, h, S, None, 7, 1)
+    m = O.nearest_resize_mask(mask, h, h).reshape(B, -1)
+    assert keep.tolist() == [True, True, False, True] and ind.shape == (B, S)
+    assert bool((m.gather(1, ind)[keep] > 0).all()) and bool((ind[2] == 0).all())
+    ind2, _ = O.pixel_sample_philox(mask, h, h, S, None, 7, 1)
+    ind3, _ = O.pixel_sample_philox(mask, h, h, S, None, 7, 2)
+    assert torch.equal(ind, ind2) and not torch.equal(ind, ind3)
+    _, keep0 = O.pixel_sample_philox(mask, h, h, S, torch.zeros(B), 7, 1)
+    assert not bool(keep0.any())
+    big, _ = O.pixel_sample_philox(mask[:1], h, h, 100000, None, 3, 4)
+    valid = m[0] > 0
+    p = torch.bincount(big[0], minlength=h * h).double() / 100000
+    assert float(p[~valid].sum()) == 0 and float((p[valid] - 1.0 / int(valid.sum())).abs().max()) < 0.01

@@ -1,7 +1,8 @@
 """ONE whole training step per BASELINE.json configuration at the configuration's OWN size, checked against the
 oracle.  The step is the product's (``ContrastTrainer.train_step``: encoder programs, side streams,
 HIP loss kernels, SGD, bank update); a ``RecordingEngine`` keeps what the loss kernels were given and what they
-returned, and ``oracle/check_step.py`` re-evaluates all of it on the CPU: idx[:,0]==index bit-exact, six bank losses
+returned (for the HRNet models ONE record of the fused loss section, heads included), and ``oracle/check_step.py``
+re-evaluates all of it on the CPU: the head features f, idx[:,0]==index bit-exact, validity of the sampled pixels, six bank losses
 and accuracies, all B gradient rows per modality, the momentum update (touched rows to 1e-6, the others bit-identical),
 the nine feature-map meters and the gradients of the feature-map losses w.r.t. the HRNet branch maps, the 1x1
 projection weights and the SemGCN output (reference data flow: merge_all_res + full-resolution projection,
@@ -58,13 +59,19 @@ def test_one_step_at_the_configs_own_size_against_the_oracle(name):
         torch.cuda.synchronize()
         assert bool(torch.isfinite(out['loss']))
         kinds = [r['kind'] for r in eng.records]
-        assert kinds == ['bank', 'fmap' if arch == 'HRNetPN' else 'fmap_sampled'], kinds
-        bank, fm = eng.records
-        assert bank['idx'].shape == (B, K + 1) and bank['x'][0].shape == (B, 128)
+        if arch == 'HRNetPN':                # module path: heads inside the model, bank and feature-map calls apart
+            assert kinds == ['bank', 'fmap'], kinds
+            bank, fm = eng.records
+            assert bank['idx'].shape == (B, K + 1) and bank['x'][0].shape == (B, 128)
+            total = float(bank['total']) + float(fm['total'])
+        else:                                # the fused loss section: ONE record holds rows 1-9
+            assert kinds == ['section'], kinds
+            fm = eng.records[0]
+            assert fm['idx'].shape == (B, K + 1) and fm['f'].shape == (B, 384)
+            total = float(fm['total'])
         assert fm['sample_ind'].shape == (B, 400)
         rep = check_records(eng.records)
         print(name, rep)
-        # the step's loss is the sum of the two checked totals
-        assert abs(float(out['loss']) - float(bank['total']) - float(fm['total'])) <= 1e-4 * abs(float(out['loss']))
+        assert abs(float(out['loss']) - total) <= 1e-4 * abs(float(out['loss']))
     finally:
         _lib.torch_glue().set_async_wgrad(False)

@@ -47,10 +47,15 @@ def main():
     fwd = net.forward
     net.forward = lambda *a, **k: (lambda out: (mark('model_forward'), out)[1])(fwd(*a, **k))
     eng = trainer.engine
-    for nm in ('bank', 'fmap_sampled', 'fmap'):
+    for nm in ('bank', 'fmap_sampled', 'fmap', 'section'):
         if hasattr(eng, nm):
             f = getattr(eng, nm)
             setattr(eng, nm, (lambda f, nm: lambda *a, **k: (lambda out: (mark('loss_' + nm), out)[1])(f(*a, **k)))(f, nm))
+    # the fused loss section's backward (heads, projection, the eight branch gradients) ends where the encoders'
+    # reverse loops begin: model_forward -> loss_section -> section_backward is the serial section of SURVEY 8f-2
+    from hcmoco_amd import hip_ops
+    bwd0 = hip_ops._Stage2Section.backward
+    hip_ops._Stage2Section.backward = staticmethod(lambda ctx, *g: (lambda out: (mark('section_backward'), out)[1])(bwd0(ctx, *g)))
     if trainer.grad_sync is not None:
         red0 = trainer.grad_sync.reduce
         trainer.grad_sync.reduce = lambda join=None: (mark('backward_returned'), red0(join), mark('reduced'))[1]
