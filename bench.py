@@ -417,7 +417,8 @@ def main():
                                                      else (None if world > 1 else 0)),
                        'backend': a.backend if (world > 1 or forced) else None,
                        'final_loss': round(loss, 4)},
-            'roofline': {'kernel': 'bank_pass_kernel<2,fused> (gather + 6 logit sets + online softmax + d/dx)',
+            'roofline': {'kernel': ('bank_pass_kernel<bf16,fused,ring 4> (register ring' if a.bank_dtype == 'bf16' else
+                                    'bank_pass_glds_kernel<f32,2> (LDS-DMA ring') + '; gather + 6 logit sets + online softmax + d/dx)',
                          'bound': bound, 'bank_bytes': bank_bytes, 'bound_note': bound_note,
                          'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

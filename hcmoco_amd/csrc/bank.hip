@@ -960,8 +960,12 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
                                                          scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0); \
   } while (0)
     // variants 1-6: register ring of that depth; 12 / 13 / 14 / 16: LDS-DMA ring of 2 / 3 / 4 / 6 stages.
-    // Default (r03): the DMA form -- fp32 2 stages (48 KB of LDS per workgroup: three workgroups per CU), bf16 4.
-    switch (variant > 0 ? variant : (kBf16 ? 14 : 12)) {
+    // Defaults (r03 sweep, profiles/r03_bank_pass_sweep.json): fp32 the DMA form with 2 stages (48 KB of LDS per
+    // workgroup, three workgroups per CU): +1..3 % over the register ring of depth 3 wherever the banks are HBM-resident
+    // (1.6 GB: 5.73 vs 5.58 TB/s at K = 16384, 6.29 vs 6.19 at K = 65536), equal inside the training step; bf16 stays on
+    // the register ring of depth 4 (a bf16 stage is only 3 KB: the DMA form has half the bytes in flight per
+    // instruction and loses 7-10 %).
+    switch (variant > 0 ? variant : (kBf16 ? 4 : 12)) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;

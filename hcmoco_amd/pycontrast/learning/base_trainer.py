@@ -63,8 +63,15 @@ class BaseTrainer(object):
         args.node_rank = rank // ngpus_per_node
         args.local_rank = local
         args.local_center = args.node_rank * ngpus_per_node
-        # per-node groups exist for ShuffleBN only (MoCo path, :60-73); the bank path never uses them
+        # per-node groups exist for ShuffleBN only (MoCo path, :60-73): every rank creates every node's group (new_group
+        # is collective) and keeps its own; the bank path never uses them
         self.local_group = None
+        if getattr(args, 'mem', '') == 'moco' and world > 1:
+            for node in range(0, max(1, world // ngpus_per_node)):
+                ranks = list(range(node * ngpus_per_node, min(world, (node + 1) * ngpus_per_node)))
+                group = dist.new_group(ranks)
+                if rank in ranks:
+                    self.local_group = group
         if rank == 0:
             print('world size {}, backend {}, device {}'.format(world, backend, self.device))
 

@@ -318,9 +318,8 @@ class ContrastTrainer(BaseTrainer):
         model.train()
         t0 = time.time()
         if args.mem == 'moco':
-            raise NotImplementedError('the MoCo training loop needs the RGB/CMC ResNet models, which are '
-                                      'outside this build (SURVEY 0-1); the queue module itself is in memory/mem_moco.py')
-        if args.mem == 'bank':
+            outs = self._train_moco(epoch, train_loader, model, model_ema, contrast, criterion, optimizer)
+        elif args.mem == 'bank':
             outs = self._train_mem_skeleton3d(epoch, train_loader, model, contrast, criterion, optimizer)
         elif args.mem == 'bank+jointspri3d':
             outs = self._train_bank_joints_pri3d_cmc3(epoch, train_loader, model, contrast, None, None, optimizer)
@@ -380,6 +379,108 @@ class ContrastTrainer(BaseTrainer):
         """stage 2 (contrast_trainer.py:894-1039): (loss, acc12, jig_loss=0, jig_acc=0)."""
         loss_m, acc_m, _ = self._run_epoch(epoch, train_loader, model, contrast, optimizer, stage2=True)
         return loss_m.avg, acc_m[0].avg, 0.0, 0.0
+
+    # ------------------------------------------------------------------ MoCo (secondary row of SURVEY 8a)
+    @staticmethod
+    def _ce_accuracy(logits, target):
+        """nn.CrossEntropyLoss + top-1 accuracy in percent per logit set: the plain branch of
+        _compute_loss_accuracy (contrast_trainer.py:212-222, :249-251; learning/util.py:24-38)."""
+        losses = [torch.nn.functional.cross_entropy(l, target) for l in logits]
+        accs = [(l.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0]) for l in logits]
+        return losses, accs
+
+    def _shuffle_bn(self, x, model_ema, shuffle_ids=None):
+        """Shuffle-BN forward of the momentum encoder (contrast_trainer.py:167-210): the key crops of one node are
+        gathered, permuted with a permutation rank 0 broadcasts, every GPU encodes a shuffled slice (so the key
+        encoder's batch statistics do not leak which keys belong to this GPU's queries), the keys are gathered from
+        everybody and un-shuffled.  -> (k for the local batch, all_k in rank-major order).  One collective per gather
+        (``all_gather_into_tensor``); with a single process the shuffle is a permutation of the local batch.
+        ``shuffle_ids`` injects the permutation (parity tests); otherwise ``torch.randperm`` on the host generator,
+        as in the reference."""
+        args = self.args
+        bsz = x.size(0)
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        nlocal = dist.get_world_size(self.local_group) if multi and self.local_group is not None else \
+            (dist.get_world_size() if multi else 1)
+        if multi:
+            node_x = torch.empty((nlocal * bsz,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(node_x, x.contiguous(), group=self.local_group)
+        else:
+            node_x = x
+        if shuffle_ids is None:
+            shuffle_ids = torch.randperm(bsz * nlocal)
+        shuffle_ids = shuffle_ids.to(x.device)
+        if multi:                                       # rank 0's permutation for everybody (:184-187)
+            dist.broadcast(shuffle_ids, 0)
+        reverse_ids = torch.argsort(shuffle_ids)
+        local = getattr(args, 'local_rank', 0) if multi else 0
+        this_ids = shuffle_ids[local * bsz:(local + 1) * bsz]
+        with torch.no_grad():
+            k = model_ema(node_x[this_ids], mode=1)
+        if multi:
+            all_k = torch.empty((dist.get_world_size() * bsz,) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
+            dist.all_gather_into_tensor(all_k, k.contiguous())
+            node = getattr(args, 'node_rank', 0)
+            node_k = all_k[node * nlocal * bsz:(node + 1) * nlocal * bsz]
+        else:
+            all_k = node_k = k
+        k = node_k[reverse_ids[local * bsz:(local + 1) * bsz]]
+        return k, all_k
+
+    def _train_moco(self, epoch, train_loader, model, model_ema, contrast, criterion, optimizer):
+        """MoCo-style epoch (contrast_trainer.py:255-389) for the RGB and CMC modalities without jigsaw: query encoder
+        on crop 1, shuffle-BN momentum encoder on crop 2, ``contrast`` = RGBMoCo / CMCMoCo (memory/mem_moco.py: logits
+        against the ring queue on the HIP kernels, then the enqueue), cross entropy, SGD step, momentum update of the
+        key encoder.  Returns (loss, acc, jig_loss, jig_acc) like the reference."""
+        args = self.args
+        if getattr(args, 'jigsaw', False):
+            raise NotImplementedError('the jigsaw branch of the MoCo loop needs the JigsawHead models (out of scope)')
+        model.train()
+        model_ema.eval()
+        for mod in model_ema.modules():                 # BN of the key encoder stays in training mode (:266-270)
+            if 'BatchNorm' in mod.__class__.__name__:
+                mod.train()
+        loss_m, acc_m, bt = AverageMeter(), AverageMeter(), AverageMeter()
+        end = time.time()
+        nb = len(train_loader)
+        inject = getattr(self, 'inject_shuffle_ids', None)       # parity tests: the reference's recorded permutations
+        for idx, data in enumerate(train_loader):
+            inputs = self._to_dev(data[0]).float()
+            bsz = inputs.size(0)
+            self.warmup_learning_rate(epoch, idx, nb, optimizer)
+            x1, x2 = torch.split(inputs, [3, 3], dim=1)
+            k, all_k = self._shuffle_bn(x2, model_ema, None if inject is None else inject[idx])
+            q = model(x1)
+            if args.modal == 'CMC':
+                q1, q2 = torch.chunk(q, 2, dim=1)
+                k1, k2 = torch.chunk(k, 2, dim=1)
+                all_k1, all_k2 = torch.chunk(all_k, 2, dim=1)
+                output = contrast(q1.contiguous(), k1.contiguous(), q2.contiguous(), k2.contiguous(),
+                                  all_k1=all_k1.contiguous(), all_k2=all_k2.contiguous())
+                losses, accs = self._ce_accuracy(output[:-1], output[-1])
+                loss = losses[0] + losses[1]
+                update_loss, update_acc = 0.5 * (losses[0] + losses[1]), 0.5 * (accs[0] + accs[1])
+            else:
+                output = contrast(q, k, all_k=all_k)
+                losses, accs = self._ce_accuracy(output[:-1], output[-1])
+                loss = update_loss = losses[0]
+                update_acc = accs[0]
+            self.last_moco = {'logits': [l.detach() for l in output[:-1]], 'losses': [l.detach() for l in losses],
+                              'accs': accs}
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            loss_m.update(update_loss.detach(), bsz)
+            acc_m.update(update_acc, bsz)
+            self.momentum_update(self.unwrap(model), model_ema, args.alpha)
+            bt.update(time.time() - end)
+            end = time.time()
+            if args.local_rank == 0 and (idx + 1) % args.print_freq == 0:
+                print('Train: [{0}][{1}/{2}]\tBT {3:.3f} ({4:.3f})\tl_I {5:.3f} ({6:.3f})\ta_I {7:.3f} ({8:.3f})'
+                      .format(epoch, idx + 1, nb, bt.val, bt.avg, float(loss_m.val), float(loss_m.avg),
+                              float(acc_m.val), float(acc_m.avg)))
+                sys.stdout.flush()
+        return float(loss_m.avg), float(acc_m.avg), 0.0, 0.0
 
     @staticmethod
     def momentum_update(model, model_ema, m):

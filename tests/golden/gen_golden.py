@@ -529,6 +529,96 @@ def gen_trace():
 
 
 # --------------------------------------------------------------------------- #
+# 9b. 3-step trace of the reference's MoCo loop (learning/contrast_trainer.py:255-389 _train_moco, :167-210
+#     _shuffle_bn, :1041-1045 momentum_update) with the reference CMCMoCo (memory/mem_moco.py:91-142), torch SGD and
+#     the stand-in CMC encoder pair of tests/golden/standin.py.  World size 1: the shuffle is a permutation of the
+#     local batch.  K = 20 with B = 6: the ring pointer wraps inside the trace.
+# --------------------------------------------------------------------------- #
+def gen_trace_moco():
+    import importlib.util
+    import torch.distributed as dist
+    import torch.nn as nn
+    from memory.mem_moco import CMCMoCo
+    from learning.contrast_trainer import ContrastTrainer
+    spec = importlib.util.spec_from_file_location('standin', os.path.join(OUT, 'standin.py'))
+    standin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(standin)
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29872', rank=0, world_size=1)
+    B, K, H, D, steps = 6, 20, 16, 32, 4
+    T, alpha, lr = 0.2, 0.9, 0.05
+    torch.manual_seed(931)
+    model = standin.StandInMoCoEncoder(D=D)
+    model_ema = standin.StandInMoCoEncoder(D=D)
+    mem = CMCMoCo(D, K, T)
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    batches = standin.make_moco_batches(steps, B, H, seed=77)
+    tr = ContrastTrainer.__new__(ContrastTrainer)
+    tr.args = argparse.Namespace(gpu=None, amp=False, local_rank=0, node_rank=0, ngpus_per_node=1, print_freq=10 ** 6,
+                                 warm=False, jigsaw=False, modal='CMC', alpha=alpha, beta=0.5)
+    tr.local_group = dist.new_group([0])
+    ContrastTrainer.momentum_update(model, model_ema, 0)            # main_contrast.py / wrap_up: ema <- model
+
+    class Wrapped(nn.Module):                                       # the loop updates `model.module` (DDP)
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+    wrapped = Wrapped(model)
+    arrays = dict(B=B, K=K, H=H, D=D, T=T, alpha=alpha, lr=lr, momentum=0.9, weight_decay=1e-4, steps=steps,
+                  queue0_1=mem.memory_1.clone(), queue0_2=mem.memory_2.clone())
+    for k, v in model.state_dict().items():
+        arrays['w0_' + k] = v.clone()
+    for k, v in model_ema.state_dict().items():
+        arrays['e0_' + k] = v.clone()
+    for t, b in enumerate(batches):
+        arrays['s%d_data0' % t], arrays['s%d_data1' % t] = b[0], b[1]
+    rec = {'perm': [], 'ce': [], 'logits': [], 'after': []}
+    orig_perm = torch.randperm
+
+    def perm(*a, **k):
+        out = orig_perm(*a, **k)
+        rec['perm'].append(out.clone())
+        return out
+    fn = tr._compute_loss_accuracy
+
+    def ce(*a, **k):
+        out = fn(*a, **k)
+        rec['logits'].append([l.detach().clone() for l in k['logits']])
+        rec['ce'].append(([f32(v) for v in out[0]], [f32(v) for v in out[1]]))
+        return out
+    tr._compute_loss_accuracy = ce
+    orig_mu = ContrastTrainer.momentum_update
+
+    def mu(m, e, a):                                                # called last in an iteration (:372)
+        orig_mu(m, e, a)
+        rec['after'].append(({k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in e.state_dict().items()},
+                             mem.memory_1.clone(), mem.memory_2.clone(), mem.index))
+    tr.momentum_update = mu
+    torch.randperm = perm
+    try:
+        outs = tr._train_moco(1, batches, wrapped, model_ema, mem, nn.CrossEntropyLoss(), opt)
+    finally:
+        torch.randperm = orig_perm
+    assert len(rec['after']) == steps and len(rec['perm']) == steps
+    arrays['epoch_outs'] = np.array([float(o) for o in outs], np.float64)
+    for t in range(steps):
+        arrays['s%d_shuffle_ids' % t] = rec['perm'][t]
+        arrays['s%d_logits1' % t], arrays['s%d_logits2' % t] = rec['logits'][t][0], rec['logits'][t][1]
+        arrays['s%d_losses' % t] = np.array(rec['ce'][t][0], np.float32)
+        arrays['s%d_accs' % t] = np.array(rec['ce'][t][1], np.float32)
+        sd, se, q1, q2, index = rec['after'][t]
+        arrays['s%d_queue_1' % t], arrays['s%d_queue_2' % t], arrays['s%d_index' % t] = q1, q2, index
+        for k, v in sd.items():
+            arrays['s%d_w_%s' % (t, k)] = v
+        for k, v in se.items():
+            arrays['s%d_e_%s' % (t, k)] = v
+    npz('trace_moco', **arrays)
+
+
+# --------------------------------------------------------------------------- #
 # 10. dataset tuple producers (datasets/dataset.py:306-617, datasets/mpii_utils.py:14-65): the numpy / torch
 #     arithmetic AROUND the image decoding.  cv2 / torchvision / json_tricks / pycocotools are not in the image:
 #     process-local stub modules let `datasets.dataset` import; the functions driven here never touch them, except
@@ -771,7 +861,8 @@ if __name__ == '__main__':
     only = set(sys.argv[1:])
     sys.argv = sys.argv[:1]
     gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
-                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options, trace=gen_trace, dataset=gen_dataset)
+                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options, trace=gen_trace,
+                trace_moco=gen_trace_moco, dataset=gen_dataset)
     for name, fn in gens.items():
         if not only or name in only:
             fn()

@@ -56,3 +56,29 @@ def make_batches(steps, B, n, H, J, seed):
                     use_depth, mask, torch.ones(B), torch.zeros(B, H, H, dtype=torch.long),
                     torch.zeros(B, dtype=torch.long), use_rgb])
     return out
+
+
+class StandInMoCoEncoder(nn.Module):
+    """Tiny stand-in with the forward contract of the reference's CMC single-head model
+    (networks/build_backbone.py:72-120: ``model(x, mode)`` -> [B, 2 D], an L and an ab half): 1x1 conv + BatchNorm +
+    ReLU + pool + linear + L2 per half.  The BatchNorm is what makes the MoCo loop's shuffled key batch matter.
+    Written for this repo (NOT reference code); drives the reference's ``_train_moco`` in gen_golden.py."""
+
+    def __init__(self, C=16, D=32):
+        super().__init__()
+        self.conv_l, self.conv_ab = nn.Conv2d(1, C, 1), nn.Conv2d(2, C, 1)
+        self.bn_l, self.bn_ab = nn.BatchNorm2d(C), nn.BatchNorm2d(C)
+        self.head_l, self.head_ab = nn.Linear(C, D), nn.Linear(C, D)
+
+    def forward(self, x, x_jig=None, mode=0):
+        fl = F.relu(self.bn_l(self.conv_l(x[:, :1]))).mean((2, 3))
+        fab = F.relu(self.bn_ab(self.conv_ab(x[:, 1:3]))).mean((2, 3))
+        if mode in (0, 1):
+            return torch.cat([F.normalize(self.head_l(fl)), F.normalize(self.head_ab(fab))], dim=1)
+        return torch.cat([fl, fab], dim=1)
+
+
+def make_moco_batches(steps, B, H, seed):
+    """(two 3-channel crops stacked on the channel axis [B, 6, H, H], index) per step, like the CMC loader."""
+    g = torch.Generator().manual_seed(seed)
+    return [[torch.randn(B, 6, H, H, generator=g), torch.arange(B) + t * B] for t in range(steps)]

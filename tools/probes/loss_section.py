@@ -9,7 +9,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?')))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'bank_pass_kernel' in r[2]]
+marks = [i for i, r in enumerate(rows) if 'bank_pass_' in r[2]]
 m = marks[-2]
 # walk back to the last encoder-forward kernel (bn_apply / conv / winograd) before the marker, forward to the first bn_bwd
 enc_fwd = ('bn_apply_kernel', 'bn_small_fwd', 'conv3x3_mfma', 'miopenSp3AsmConv', 'bn_stats_kernel', 'upsample_bilinear_kernel')

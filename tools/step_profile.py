@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 trace, out = sys.argv[1], sys.argv[2]
-marker = sys.argv[3] if len(sys.argv) > 3 else 'bank_pass_kernel'
+marker = sys.argv[3] if len(sys.argv) > 3 else 'bank_pass_'
 rows = []
 with open(trace) as f:
     for r in csv.DictReader(f):

@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 trace = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else 'bank_pass_kernel'
+marker = sys.argv[2] if len(sys.argv) > 2 else 'bank_pass_'
 rows = []
 with open(trace) as f:
     for r in csv.DictReader(f):
