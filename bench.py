@@ -45,10 +45,10 @@ MFMA_BF16_PEAK_TFS = 2500.0    # dense bf16 MFMA peak
 
 
 def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, sampled=1, arch='HRNet', width=18,
-              bank_dtype='fp32', fmap_dtype='fp32'):
+              bank_dtype='fp32', fmap_dtype='fp32', encoder_dtype='fp32'):
     from hcmoco_amd.pycontrast.options.train_options import TrainOptions
     argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', arch, '--width', str(width),
-            '--bank_dtype', bank_dtype, '--fmap_dtype', fmap_dtype,
+            '--bank_dtype', bank_dtype, '--fmap_dtype', fmap_dtype, '--encoder_dtype', encoder_dtype,
             '--in_channel_list', '3,3', '--linear_feat_map', '1', '--modality_missing', '1',
             '--pri3d_num_samples_per_image', '400', '--temperature', '0.07', '--nce_k', str(nce_k),
             '--nce_m', '0.5', '--batch_size', str(batch_global), '--skeleton_meta_name', skeleton,
@@ -235,6 +235,9 @@ def main():
                     help='bf16 = BASELINE config 5 bank storage; not the headline config')
     ap.add_argument('--fmap_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
                     help='bf16 = BASELINE config 5 feature-map GEMMs; not the headline config')
+    ap.add_argument('--encoder_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
+                    help='bf16 = BASELINE config 5 mixed precision (bf16 encoder convolutions under autocast, fp32 '
+                         'batch-norm statistics / master weights / loss section); not the headline config')
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--backend', type=str, default='nccl',
@@ -277,7 +280,7 @@ def main():
     B = a.batch_per_gpu
     args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, a.backend, tempfile.mkdtemp(),
                      a.steps + a.warmup + 2, sampled=a.sampled_projection, arch=a.arch, width=a.width,
-                     bank_dtype=a.bank_dtype, fmap_dtype=a.fmap_dtype)
+                     bank_dtype=a.bank_dtype, fmap_dtype=a.fmap_dtype, encoder_dtype=a.encoder_dtype)
     args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
     args.channels_last = bool(a.channels_last)
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
@@ -403,13 +406,13 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1e3 * dt / a.steps, 3), 'ms_per_step_hipevent': round(ev_ms / a.steps, 3),
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if a.encoder_dtype == 'fp32' else 'bf16 (encoders) / f32', 'data': 'synthetic',
             'config': {'workload': 'second-stage HCMoCo step (bank NCE + dense + joint + SCL losses, fwd+bwd+SGD+bank '
                                    'update), %s + SemGCN, %dx%d RGB+depth+%s keypoints'
                                    % ('HRNet-w%d x2' % a.width if a.arch == 'HRNet' else
                                       'HRNet-w%d (RGB) + PointNet++ MSG (depth cloud, 4096 pts)' % a.width,
                                       a.size, a.size, a.skeleton),
-                       'bank_dtype': a.bank_dtype, 'fmap_dtype': a.fmap_dtype,
+                       'bank_dtype': a.bank_dtype, 'fmap_dtype': a.fmap_dtype, 'encoder_dtype': a.encoder_dtype,
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
                        'channels_last': bool(a.channels_last), 'sampled_projection': bool(a.sampled_projection),

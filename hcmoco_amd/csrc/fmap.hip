@@ -9,9 +9,9 @@
 //                        (v_mfma_f32_16x16x4_f32): a 256-thread workgroup owns 64 query rows (one
 //                        16-row strip per wave) and walks the key set in 16-row tiles staged once
 //                        per workgroup in LDS.  STATS pass: online row softmax + soft-target sums.
-//                        GRAD pass: re-forms the tile, builds the logit gradient in registers,
-//                        transposes it through LDS and feeds a second MFMA chain (G x K) -- the
-//                        S x S matrices never exist in memory.
+//                        GRAD pass: re-forms the tile TRANSPOSED (operands of the first MFMA chain swapped),
+//                        so the logit gradient built in registers already has the A-operand layout of the
+//                        second MFMA chain (G x K) -- no LDS transpose; the S x S matrices never exist in memory.
 //   joint_nce_kernel     one workgroup per image (J<=32 joints, launch/latency bound): VALU.
 //   scatter_rows_kernel  deterministic owner-computes scatter-add of the sampled-pixel gradients
 //                        into the map gradient (duplicates summed in index order, no atomics).
@@ -137,11 +137,17 @@ struct StripArgs {
   float* pdq;           // [nkc][N][128]
 };
 
-// LDS row stride of the key tile: 148 = 20 mod 32.  GEMM 1 reads a float4 per lane with lane = key ROW (np): eight
-// consecutive rows must start in eight different bank quads (np*20 mod 32 = 0,20,8,28,16,4,24,12); with the earlier
-// 144 (16 mod 32, ideal for GEMM 2's b32 reads of four rows) those reads were 4-way conflicts and the LDS pipe,
-// shared by the CU's waves, took longer per tile than the 32 MFMAs.  GEMM 2's reads become 3 lanes per bank instead of 2.
-constexpr int kKS = 148;
+// LDS image of a key tile (16 rows x 32 float4 slots): row stride 128 floats, NO padding, slot s of row r stored at
+// slot s ^ r.  Found by exhaustive search over strides and row-dependent rotations / XORs against the part's real lane
+// groups (MI355X_MICROARCH.md, LDS): with this image all three accesses are conflict-free --
+//   GEMM 1   ds_read_b128, lane (np, g) reads slot 4j + g of row np (four non-contiguous 16-lane groups, bank =
+//            float4 slot mod 16).  A padded linear image cannot do that: the 8 + 8 lanes of a group need slots
+//            {np st} and {np st + 1} disjoint, impossible for a shift of a proper subset of Z_16 -- r02's stride 148
+//            left 96 conflict cycles per tile here (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 1.5 in the stats pass);
+//   GEMM 2   ds_read_b32, lane (np, g) reads float 16nt + np of row 4g + ks (32-lane halves, bank = float mod 32);
+//   commit   ds_write_b128, thread e writes slot e & 31 of row e >> 5 (8 contiguous lanes, bank = slot mod 8).
+constexpr int kKS = 128;
+__device__ __forceinline__ int ksw(int row, int slot) { return (row * 32 + (slot ^ row)) * 4; }   // float index
 
 // BF16 (BASELINE config 5, "bf16 feature-map GEMMs"): both contractions run on the bf16 matrix cores with
 // fp32 accumulation -- the similarity P = Q K^T as 4 x v_mfma_f32_16x16x32_bf16 per tile (32 fp32 MFMAs
@@ -160,7 +166,6 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   // in the instruction stream, independent accumulators, conflict-free LDS strides each changed nothing).  The pass is
   // bounded by (MFMA + VALU) instruction time: fewer VALU instructions per element is the only lever left in fp32.
   __shared__ __attribute__((aligned(16))) float sKb[3][16 * kKS];
-  __shared__ float sG[4][16][17];
   __shared__ int sMetaCb[3][16];
   __shared__ float sStatCb[3][16][3];
 
@@ -208,12 +213,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  // rows owned in the C layout: row0 + 4g + reg
+  // rows owned in the C layout: row0 + 4g + reg (stats pass: P = Q K^T) or row0 + np for every reg (grad pass: the
+  // TRANSPOSED similarity K Q^T is formed there, see GEMM 1)
   int mrow[4];
   float lse_r[4], al_r[4], be_r[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int r = row0 + 4 * g + q;
+    const int r = GRAD ? row0 + np : row0 + 4 * g + q;
     mrow[q] = (r < S) ? pol.pack(metaQ[r]) : 0;
     if (GRAD) {
       lse_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 0] : 0.f;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int e = threadIdx.x + h * kWG;
-      *reinterpret_cast<float4*>(&sKb[buf][(e >> 5) * kKS + (e & 31) * 4]) = kreg[h];
+      *reinterpret_cast<float4*>(&sKb[buf][ksw(e >> 5, e & 31)]) = kreg[h];
     }
     if (threadIdx.x < 16) {
       sMetaCb[buf][threadIdx.x] = mreg;
@@ -280,19 +286,27 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
     if constexpr (BF16) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 lo = *reinterpret_cast<const float4*>(&sK[np * kKS + 32 * j + 8 * g]);
-        const float4 hi = *reinterpret_cast<const float4*>(&sK[np * kKS + 32 * j + 8 * g + 4]);
+        const float4 lo = *reinterpret_cast<const float4*>(&sK[ksw(np, 8 * j + 2 * g)]);
+        const float4 hi = *reinterpret_cast<const float4*>(&sK[ksw(np, 8 * j + 2 * g + 1)]);
         const v8f kv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        ap[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], __builtin_convertvector(kv, v8bf), ap[j], 0, 0, 0);
+        if (GRAD) ap[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_convertvector(kv, v8bf), qh[j], ap[j], 0, 0, 0);
+        else ap[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], __builtin_convertvector(kv, v8bf), ap[j], 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float4 kb = *reinterpret_cast<const float4*>(&sK[np * kKS + 16 * j + 4 * g]);
-        ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, ap[0], 0, 0, 0);
-        ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, ap[1], 0, 0, 0);
-        ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, ap[2], 0, 0, 0);
-        ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, ap[3], 0, 0, 0);
+        const float4 kb = *reinterpret_cast<const float4*>(&sK[ksw(np, 4 * j + g)]);
+        if (GRAD) {      // A <-> B: the accumulator holds P^T, i.e. lane (np, g) reg q = P[row0 + np][c0 + 4g + q]
+          ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.x, qf[j].x, ap[0], 0, 0, 0);
+          ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.y, qf[j].y, ap[1], 0, 0, 0);
+          ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.z, qf[j].z, ap[2], 0, 0, 0);
+          ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qf[j].w, ap[3], 0, 0, 0);
+        } else {
+          ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, ap[0], 0, 0, 0);
+          ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, ap[1], 0, 0, 0);
+          ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, ap[2], 0, 0, 0);
+          ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, ap[3], 0, 0, 0);
+        }
       }
     }
   };
@@ -347,38 +361,43 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         bestc[q] = better ? c : bestc[q];
       }
     } else {
-      const float lse_c = sStatC[np][0], al_c = sStatC[np][1], be_c = sStatC[np][2];
+      // Grad pass: GEMM 1 ran with its operands swapped, so this lane owns QUERY ROW row0 + np and its four
+      // accumulator registers are the keys c0 + 4g + q -- exactly the A-operand layout of GEMM 2 when the key index of
+      // its reduction is ordered (4 x k-slot + step).  The logit gradient goes from the element-wise code straight into
+      // the second MFMA chain; r02 wrote it to LDS in C layout and read it back transposed (4-way bank conflicts on the
+      // writes: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 2.4 in this pass).
+      const int r = row0 + np;
+      float ga[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int r = row0 + 4 * g + q;
-        const float okf = (cvalid && r < S) ? gs * a.inv_tau : 0.f;
+        const int kq = 4 * g + q, cq = c0 + kq;
+        const float okf = (cq < S && r < S) ? gs * a.inv_tau : 0.f;
         const float P = fminf(acc[q] * a.inv_tau, 2.f * a.inv_tau);      // (clamp: padded rows must not make inf * 0)
-        const float wgt = pol.weight(mrow[q], mc, r, c);
-        float G = al_r[q] * __expf(P - lse_r[q]) - be_r[q] * wgt + al_c * __expf(P - lse_c) - be_c * wgt;
-        G *= okf;
-        sG[wave][4 * g + q][np] = G;
+        const float wgt = pol.weight(mrow[q], sMetaC[kq], r, cq);
+        const float lse_c = sStatC[kq][0], al_c = sStatC[kq][1], be_c = sStatC[kq][2];
+        const float G = al_r[q] * __expf(P - lse_r[q]) - be_r[q] * wgt + al_c * __expf(P - lse_c) - be_c * wgt;
+        ga[q] = G * okf;
       }
-      __builtin_amdgcn_wave_barrier();  // sG[wave] is written and read by this wave only; LDS operations of a wave execute in order
-      // GEMM 2: dQ[16 x 128] += G[16 x 16] . Ktile[16 x 128]   (4 k-steps x 8 channel tiles)
+      // GEMM 2: dQ[16 x 128] += G[16 x 16] . Ktile[16 x 128]   (4 k-steps x 8 channel tiles); key of (step, slot g) = 4g + step
       if constexpr (BF16) {
         // A = G[np][4g + i], B = Ktile[4g + i][16nt + np], i < 4: one 16-key contraction per channel tile
-        const v4f gv = {sG[wave][np][4 * g], sG[wave][np][4 * g + 1], sG[wave][np][4 * g + 2], sG[wave][np][4 * g + 3]};
-        const v4s ga = __builtin_bit_cast(v4s, __builtin_convertvector(gv, v4bf));
+        const v4f gv = {ga[0], ga[1], ga[2], ga[3]};
+        const v4s gb = __builtin_bit_cast(v4s, __builtin_convertvector(gv, v4bf));
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
-          const v4f kv = {sK[(4 * g) * kKS + 16 * nt + np], sK[(4 * g + 1) * kKS + 16 * nt + np],
-                          sK[(4 * g + 2) * kKS + 16 * nt + np], sK[(4 * g + 3) * kKS + 16 * nt + np]};
-          dq[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ga, __builtin_bit_cast(v4s, __builtin_convertvector(kv, v4bf)),
+          const int sl = 4 * nt + (np >> 2), el = np & 3;
+          const v4f kv = {sK[ksw(4 * g, sl) + el], sK[ksw(4 * g + 1, sl) + el], sK[ksw(4 * g + 2, sl) + el],
+                          sK[ksw(4 * g + 3, sl) + el]};
+          dq[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb, __builtin_bit_cast(v4s, __builtin_convertvector(kv, v4bf)),
                                                              dq[nt], 0, 0, 0);
         }
       } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const float av = sG[wave][np][4 * ks + g];
 #pragma unroll
           for (int nt = 0; nt < 8; ++nt) {
-            const float bv = sK[(4 * ks + g) * kKS + 16 * nt + np];
-            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dq[nt], 0, 0, 0);
+            const float bv = sK[ksw(4 * g + ks, 4 * nt + (np >> 2)) + (np & 3)];
+            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], bv, dq[nt], 0, 0, 0);
           }
         }
       }

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(kWG) void sample_branches_kernel(
 // pixel-0 hub of the dropped images is quadratic there).
 // blocks with blockIdx.y == B unpack the projection's weight gradient from the padded GEMM output.
 // ------------------------------------------------------------------------------------------
-constexpr int kCB = 36;          // channels per workgroup (LDS rows: R x 36 floats = 60 KB at R = 417)
+constexpr int kCB = 36;          // channels per workgroup
+constexpr int kRB = 128;         // gradient rows staged in LDS at a time (128 x 36 floats = 18 KB)
 struct GradPlan {
   int first[5];                  // first workgroup (blockIdx.x) of branch i; first[4] = total
   int ntile[4];                  // pixel tiles of branch i (workgroups per channel block)
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(kWG) void branch_grad_kernel(
   int* list = ldsraw + 8 * R;
   int* ckey = ldsraw + 9 * R + 4;
   unsigned char* ctgt = reinterpret_cast<unsigned char*>(ldsraw + ((13 * R + 8 + 3) & ~3));
-  float* rows = reinterpret_cast<float*>(ldsraw + ((13 * R + 8 + 3) & ~3) + ((R + 3) & ~3) + 4);
+  float* rows = reinterpret_cast<float*>(ldsraw + ((13 * R + 8 + 3) & ~3) + ((R + 3) & ~3) + 4);   // [kRB][kCB]
   // ---- (1) stencils + ordered compaction of the rows that reach this tile
   if (tid == 0) { nlist = 0; ncon = 0; }
   cnt[tid] = 0;
@@ -490,14 +491,6 @@ __global__ __launch_bounds__(kWG) void branch_grad_kernel(
     __syncthreads();
   }
   const int n = nlist;
-  // ---- (2) stage the listed rows' gradients for this channel block (coalesced over the channels)
-  if (n > 0) {
-    const float* src = dxs + ((int64_t)m * B * R + (int64_t)b * R) * ld + coff + c0;
-    for (int e = tid; e < n * kCB; e += kWG) {
-      const int li = e / kCB, k = e - li * kCB;
-      rows[e] = k < nc ? src[(int64_t)list[li] * ld + k] : 0.f;
-    }
-  }
   // ---- (3) in-tile contributions (row li, tap t) compacted in (li, t) order; per-pixel counts
   for (int lb = 0; lb < n; lb += kWG) {
     const int li = lb + tid;
@@ -575,23 +568,38 @@ __global__ __launch_bounds__(kWG) void branch_grad_kernel(
       if (ctgt[e] == (unsigned char)tid) ent[pos++] = ckey[e];
   }
   __syncthreads();
-  // ---- (5) owner-computes accumulation
+  // ---- (5) owner-computes accumulation, the listed rows staged kRB at a time (a pixel's list is sorted by row, so a
+  // batch is a contiguous piece of it): 18 KB of LDS for the rows instead of R x 36 floats, four workgroups per CU
   const int px_ = tid % PT, sub = tid / PT;
   const int q = q0 + px_;
   const bool live = q < hw;
   float acc[kCB];
 #pragma unroll
   for (int k = 0; k < kCB; ++k) acc[k] = 0.f;
-  if (live) {
-    const int lo = cnt[px_], up = lo + (px_ == tid ? mycnt : (px_ + 1 < kWG ? cnt[px_ + 1] - lo : nco - lo));
-    for (int a = lo; a < up; ++a) {
-      const int key = ent[a];
+  int cur_ = live ? cnt[px_] : 0;
+  const int up = live ? (px_ + 1 < kWG ? cnt[px_ + 1] : nco) : 0;
+  const float* src = dxs + ((int64_t)m * B * R + (int64_t)b * R) * ld + coff + c0;
+  for (int lb = 0; lb < n; lb += kRB) {
+    const int nb = min(kRB, n - lb);
+    if (lb > 0) __syncthreads();                     // the previous batch has been consumed
+    // coalesced over the channels; independent loads, several in flight per thread
+#pragma unroll 6
+    for (int e = tid; e < nb * kCB; e += kWG) {
+      const int li = e / kCB, k = e - li * kCB;
+      rows[e] = k < nc ? src[(int64_t)list[lb + li] * ld + k] : 0.f;
+    }
+    __syncthreads();
+    const int lim = (lb + nb) * 4;                   // keys of this batch: li * 4 + t < lim
+    while (cur_ < up) {
+      const int key = ent[cur_];
+      if (key >= lim) break;
       const int li = key >> 2;
       const float wq = tw[4 * list[li] + (key & 3)];
-      const float* row = rows + li * kCB + sub;
+      const float* row = rows + (li - lb) * kCB + sub;
 #pragma unroll
       for (int k = 0; k < kCB; ++k)
         if (sub + k * nsub < kCB) acc[k] = fmaf(wq, row[k * nsub], acc[k]);
+      ++cur_;
     }
   }
   if (!live) return;
@@ -724,7 +732,7 @@ int hcm_branch_grad(const float* dxs, const float* dpooled, const float* scale, 
     v += plan.ntile[i] * ((g1.C[i] + kCB - 1) / kCB);
   }
   plan.first[4] = v;
-  const size_t lds = ((size_t)R * (14 + kCB) + 32) * sizeof(int);
+  const size_t lds = ((size_t)R * 14 + (size_t)kRB * kCB + 32) * sizeof(int);
   if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(branch_grad_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -278,10 +278,17 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g)
   if (!pick_tiles(g.mt, g.ntw, wn_max)) return false;
   int wn = (g.nt + g.ntw - 1) / g.ntw;
   if (wn > wn_max) wn = wn_max;
+  // fewer waves across N (= fewer input channels per workgroup) until one unit row of X and dY fits LDS: the 256 -> 64
+  // 1x1 convolutions of layer1 on 64-wide maps staged 194 channels per workgroup (167 KB) and fell back to MIOpen's
+  // atomic kernels -- the last six layers of an HRNet pair that were not run-to-run reproducible (r03)
+  for (;; --wn) {
+    g.cmax = (wn * g.ntw * 16 + taps - 1) / taps + 2;
+    if (g.cmax > C) g.cmax = C;
+    const size_t min_bytes = ((size_t)g.cmax * (st + 2) * (st * W + 8) + (size_t)(K + 1) * (W + 4)) * 4;
+    if (min_bytes <= 150 * 1024 || wn == 1) break;
+  }
   g.wn = wn;
   g.ngroups = (g.nt + wn * g.ntw - 1) / (wn * g.ntw);
-  g.cmax = (wn * g.ntw * 16 + taps - 1) / taps + 2;
-  if (g.cmax > C) g.cmax = C;
   // rows per unit: X tile + dY tile within ~48 KB of LDS
   int rb = H;
   for (;;) {

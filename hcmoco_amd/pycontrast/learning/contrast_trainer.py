@@ -68,8 +68,13 @@ class ContrastTrainer(BaseTrainer):
             model.to(memory_format=torch.channels_last)
         if isinstance(model_ema, torch.nn.Module):
             model_ema.to(self.device)
-        if args.amp:
-            raise NotImplementedError('apex amp (fp16) is not part of this build; the hot path is fp32')
+        # mixed precision (BASELINE config 5; the reference's hook is apex amp, contrast_trainer.py:65-72): the HRNets
+        # run under bf16 autocast, everything else -- batch-norm statistics, master weights, SGD, the loss section --
+        # stays fp32.  The model owns the switch (networks/build_backbone.py:_encode).
+        if getattr(args, 'encoder_dtype', 'fp32') == 'bf16' or getattr(args, 'amp', False):
+            if not hasattr(model, 'encoder_dtype'):
+                raise NotImplementedError('--encoder_dtype bf16 / --amp needs a model with an encoder_dtype switch')
+            model.encoder_dtype = torch.bfloat16
         multi = self._multi()
         sync = getattr(args, 'grad_sync', 'auto')
         if sync == 'auto':           # ROCm: own bucketed reduction (see below); CPU: DistributedDataParallel

@@ -61,6 +61,16 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # Backward follows automatically: autograd replays every node on its forward stream.
         self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '3'))
         self._side_streams = {}
+        # torch.bfloat16: the two HRNets run under bf16 autocast (module path: stock MIOpen bf16 convolutions, batch
+        # norm with fp32 statistics and parameters); their maps come back as fp32.  Set by the trainer from
+        # --encoder_dtype / --amp.
+        self.encoder_dtype = torch.float32
+
+    def _run_hrnet(self, enc, x):
+        if self.encoder_dtype == torch.float32 or not x.is_cuda:
+            return enc(x)
+        with torch.autocast('cuda', dtype=self.encoder_dtype):
+            return [m.float() for m in enc(x.to(self.encoder_dtype))]
 
     def _side(self, idx, device):
         st = self._side_streams.get((idx, device))
@@ -72,7 +82,8 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         """(feat1 maps, feat2 maps, feat3) with the stream placement described in __init__."""
         mode = self.two_streams if x1.is_cuda else 0
         if not mode:
-            return self.encoder1(x1), self.encoder2(x2), self.encoder3(s)
+            return self._run_hrnet(self.encoder1, x1), self._run_hrnet(self.encoder2, x2), self.encoder3(s)
+        mixed = self.encoder_dtype != torch.float32
         main = torch.cuda.current_stream(x1.device)
         joined = []
 
@@ -91,16 +102,16 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
             handle = []
 
             def start():
-                h = self.encoder2.forward_async(x2) if hasattr(self.encoder2, 'forward_async') else None
+                h = self.encoder2.forward_async(x2) if (hasattr(self.encoder2, 'forward_async') and not mixed) else None
                 handle.append(h)
-                return [] if h is not None else self.encoder2(x2)
+                return [] if h is not None else self._run_hrnet(self.encoder2, x2)
 
             feat2 = on_side(1, start)
-            feat1 = self.encoder1(x1)
+            feat1 = self._run_hrnet(self.encoder1, x1)
             if handle[0] is not None:
                 feat2.extend(self.encoder2.forward_wait(handle[0]))
         else:
-            feat1, feat2 = self.encoder1(x1), self.encoder2(x2)
+            feat1, feat2 = self._run_hrnet(self.encoder1, x1), self._run_hrnet(self.encoder2, x2)
         if feat3 is None:
             feat3 = self.encoder3(s)
         for side, out in joined:             # consumed on the main stream from here on

@@ -115,6 +115,11 @@ BASE_FLAGS = [
                                   'arithmetic) or bf16 MFMA with fp32 accumulation (BASELINE config 5)')),
     (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
                              help='storage type of the memory banks (bf16: BASELINE config 5)')),
+    (('--encoder_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
+                                help='arithmetic of the HRNet encoders: fp32 (the reference) or bf16 mixed precision -- '
+                                     'bf16 convolutions under torch.autocast, fp32 batch-norm statistics, fp32 master '
+                                     'weights and optimizer, fp32 loss section (BASELINE config 5).  --amp (the '
+                                     'reference\'s apex fp16 switch, train_options.py:16-19) selects it too')),
 ]
 
 

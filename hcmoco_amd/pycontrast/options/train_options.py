@@ -27,6 +27,9 @@ class TrainOptions(BaseOptions):
                                          'aug', opt.aug, opt.head, opt.nce_t, opt.tag))
         if opt.amp:
             name += '_amp_' + opt.opt_level
+            # the reference's apex amp is fp16 (learning/contrast_trainer.py:65-72); this build's mixed precision is
+            # bf16 autocast of the encoders: same flag, no loss scaling needed
+            opt.encoder_dtype = 'bf16'
         if opt.cosine:
             name += '_cosine'
 

@@ -545,7 +545,7 @@ def gen_trace_moco():
     spec.loader.exec_module(standin)
     if not dist.is_initialized():
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29872', rank=0, world_size=1)
-    B, K, H, D, steps = 6, 20, 16, 32, 4
+    B, K, H, D, steps = 6, 20, 16, 64, 4   # D: the queue kernels take 64 or 128
     T, alpha, lr = 0.2, 0.9, 0.05
     torch.manual_seed(931)
     model = standin.StandInMoCoEncoder(D=D)

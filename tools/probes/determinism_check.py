@@ -13,7 +13,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench                                                             # noqa: E402
 
 
-def run(plain, steps=3, size=128, batch=8):
+SIZE = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+
+
+def run(plain, steps=3, size=SIZE, batch=BATCH):
     from hcmoco_amd import _lib
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     from hcmoco_amd.pycontrast.networks import hrnet
@@ -62,7 +66,7 @@ def diff(a, b, tag):
 if __name__ == '__main__':
     from hcmoco_amd import _lib
     glue = _lib.torch_glue()
-    for det in (True, False):
+    for det in ((True,) if os.environ.get('DET_ONLY') else (True, False)):
         glue.set_deterministic(det)
         print('=== deterministic weight gradients: %s' % det, flush=True)
         a = run(False)
