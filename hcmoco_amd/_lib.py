@@ -76,6 +76,9 @@ SIGNATURES = {
     'hcm_three_nn_contract': (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_three_interpolate_contract': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    'hcm_scatter_sort_workspace_bytes': (_sz, [_i, _i, _i]),
+    'hcm_scatter_sort': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    'hcm_scatter_add_sorted': (_i, [_p] * 5 + [_i] * 6 + [_p, _p]),
     'hcm_sgc_workspace_floats': (C.c_size_t, [_i] * 4),
     'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 6),
     'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 7),

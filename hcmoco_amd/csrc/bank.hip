@@ -45,7 +45,10 @@ __host__ __device__ inline int rows_per_wg(int B, int K1) {
   static const int forced = getenv("HCM_BANK_ROWS") ? atoi(getenv("HCM_BANK_ROWS")) : 0;
   if (forced > 0) return forced;
 #endif
-  int R = 256;
+  // 512 rows = 32 iterations per stream: the prologue (first gathered rows: a full HBM round trip) and the merge are
+  // amortised over twice the work of r02's 256 -- the lever the r03 sweep found: in the training step 0.1244-0.1266 ms
+  // against 0.1279-0.1297 ms (0.80-0.81 of the 8 TB/s peak against 0.78-0.79), 5.92 against 5.58 TB/s with 1.6 GB of banks
+  int R = 512;
   while ((long long)B * ((K1 + R - 1) / R) > 8192 && R < (1 << 20)) R <<= 1;
   return R;
 }
@@ -960,12 +963,12 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
                                                          scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0); \
   } while (0)
     // variants 1-6: register ring of that depth; 12 / 13 / 14 / 16: LDS-DMA ring of 2 / 3 / 4 / 6 stages.
-    // Defaults (r03 sweep, profiles/r03_bank_pass_sweep.json): fp32 the DMA form with 2 stages (48 KB of LDS per
-    // workgroup, three workgroups per CU): +1..3 % over the register ring of depth 3 wherever the banks are HBM-resident
-    // (1.6 GB: 5.73 vs 5.58 TB/s at K = 16384, 6.29 vs 6.19 at K = 65536), equal inside the training step; bf16 stays on
-    // the register ring of depth 4 (a bf16 stage is only 3 KB: the DMA form has half the bytes in flight per
-    // instruction and loses 7-10 %).
-    switch (variant > 0 ? variant : (kBf16 ? 4 : 12)) {
+    // Defaults (r03 sweep, profiles/r03_bank_pass_sweep.json): the register ring -- depth 3 for fp32, 4 for bf16 -- with
+    // 512 rows per workgroup.  The DMA form was built to lift the HBM-resident case and does, at equal geometry (1.6 GB of
+    // banks, 256 rows: 5.73 vs 5.58 TB/s; K = 65536: 6.29 vs 6.19), but the longer streams help the register ring more
+    // (5.92 TB/s at K = 16384 / 1.6 GB, 0.80-0.81 of peak inside the training step) and the DMA form not at all; a bf16
+    // stage is only 3 KB and the DMA form loses 7-10 % there.  It stays selectable for the large-K / large-bank regime.
+    switch (variant > 0 ? variant : (kBf16 ? 4 : 3)) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;

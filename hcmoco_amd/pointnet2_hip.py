@@ -116,6 +116,43 @@ def scatter_add_lds(grad_out, idx, coef, m, div=1):
     return out
 
 
+def scatter_sort(idx, m):
+    """Sort the contributions of an index tensor idx [B, ...] (values in [0, m)) by (b, target, q): the structure
+    ``scatter_add_sorted`` consumes; built once per index tensor and shared by every backward that uses it."""
+    B = idx.shape[0]
+    idx2 = idx.reshape(B, -1).contiguous()
+    Q = idx2.shape[1]
+    dev = idx.device
+    nbytes = int(_lib.lib().hcm_scatter_sort_workspace_bytes(B, Q, m))
+    if nbytes == 0:
+        raise ValueError('scatter_sort: unsupported size B=%d Q=%d m=%d' % (B, Q, m))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    order = torch.empty(B * Q, dtype=torch.int32, device=dev)
+    skey = torch.empty(B * Q, dtype=torch.int32, device=dev)
+    seg = torch.empty(B * m + 1, dtype=torch.int32, device=dev)
+    check(_lib.lib().hcm_scatter_sort(_i(idx2, 'scatter_sort'), B, Q, m, _i(order, 'scatter_sort'), _i(skey, 'scatter_sort'),
+                                      _i(seg, 'scatter_sort'), C.c_void_p(ws.data_ptr()), nbytes, _stream()),
+          'hcm_scatter_sort')
+    return order, skey, seg, Q
+
+
+def scatter_add_sorted(grad_out, idx, coef, m, div=1):
+    """grad_points[b,c,j] = sum_{q: idx[b,q]==j} coef[b,q] * grad_out[b,c,q//div] -> [B, C, m], deterministic (sorted
+    contributions, fixed-shape segmented sums, no float atomics).  The sorted structure is cached on the index tensor."""
+    B, Cc, qsrc = grad_out.shape
+    cached = getattr(idx, '_hcm_sorted', None)
+    if cached is None or cached[0] != (idx._version, m):
+        cached = ((idx._version, m), scatter_sort(idx, m))
+        idx._hcm_sorted = cached
+    order, skey, seg, Q = cached[1]
+    out = torch.empty(B, Cc, m, dtype=torch.float32, device=grad_out.device)
+    cf = C.c_void_p(0) if coef is None else _f(coef.reshape(B, -1).contiguous(), 'scatter_add_sorted')
+    check(_lib.lib().hcm_scatter_add_sorted(_f(grad_out, 'scatter_add_sorted'), cf, _i(order, 'scatter_add_sorted'),
+                                            _i(skey, 'scatter_add_sorted'), _i(seg, 'scatter_add_sorted'), B, Cc, qsrc, Q, m,
+                                            div, _f(out, 'scatter_add_sorted'), _stream()), 'hcm_scatter_add_sorted')
+    return out
+
+
 class _BallMax(torch.autograd.Function):
     """max over the last axis with ATen max_pool2d's tie rule (first index); hcm_rowmax_*."""
 

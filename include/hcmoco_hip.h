@@ -471,6 +471,22 @@ int hcm_three_interpolate_contract(int b, int c, int m, int n, const float* poin
 int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx, int B, int C,
                         int Qsrc, int Q, int m, int div, float* grad_points, hcm_stream_t stream);
 
+/* Deterministic form of the same backward (csrc/scatter.hip; r03): no float atomics, sums in a fixed order, and a
+ * target that receives most of the contributions (an empty-mask image: all pixels interpolate from points 0, 1, 2) is
+ * shared by all waves of its workgroup.
+ *   hcm_scatter_sort: once per index tensor idx [B, Q] (values in [0, m)): order [B*Q] int32 = the contribution
+ *   numbers q sorted by (b, idx[b, q], q) (stable radix sort of the key b*m + idx), sorted_key [B*Q] = that key in
+ *   sorted order, seg [B*m + 1] = first sorted position of every (b, target).  workspace:
+ *   hcm_scatter_sort_workspace_bytes(B, Q, m) bytes (0 = unsupported size: B*Q and B*m must be < 2^31).
+ *   hcm_scatter_add_sorted: grad_points [B, C, m] (overwritten, needs no zero-fill) from grad_out [B, C, Qsrc],
+ *   coef [B, Q] or NULL (= 1) and the three arrays above; contribution q reads grad_out[b, c, q / div]. */
+size_t hcm_scatter_sort_workspace_bytes(int B, int Q, int m);
+int hcm_scatter_sort(const int* idx, int B, int Q, int m, int* order, int* sorted_key, int* seg, void* workspace,
+                     size_t workspace_bytes, hcm_stream_t stream);
+int hcm_scatter_add_sorted(const float* grad_out, const float* coef, const int* order, const int* sorted_key,
+                           const int* seg, int B, int C, int Qsrc, int Q, int m, int div, float* grad_points,
+                           hcm_stream_t stream);
+
 /* Max over the ball (F.max_pool2d(y, [1, nsample]) in PointnetSAModuleMSG.forward,
  * networks/pointnet2/pointnet2_modules.py:60-63): x [rows, ns] fp32 contiguous (rows = B*C*npoint) ->
  * y [rows], arg [rows] (first index of the maximum, ATen's tie rule); backward writes

@@ -227,6 +227,76 @@ def test_lds_scatter_backward_matches_the_scatter_add_oracle(B, C, Q, m, div):
         assert float(out[:, :, 5].abs().max()) == 0               # untouched targets are written as zeros
 
 
+@pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1), (2, 9, 600, 40, 1),
+                                         (2, 19, 3 * 5000, 257, 3), (1, 4, 4000, 3, 1), (2, 70, 4096 * 4, 4096, 1),
+                                         (2, 3, 4096, 4096, 1), (2, 128, 3 * 16384, 4096, 3), (3, 515, 64 * 32, 256, 1)])
+def test_sorted_scatter_backward_matches_the_oracle_and_is_bit_reproducible(B, C, Q, m, div):
+    """hcm_scatter_sort + hcm_scatter_add_sorted (csrc/scatter.hip; reference semantics: src/group_points_gpu.cu:8-25,
+    src/interpolate_gpu.cu:120-142 without the atomics) == oracle scatter-add, including empty targets, a hub target
+    holding a quarter of all contributions, an image whose contributions ALL go to three targets (the empty-mask case of
+    pts2depth), repeated indices, m = 4096 (eight target tiles); and two runs are bit-identical."""
+    torch.manual_seed(Q + m)
+    idx = torch.randint(0, m, (B, Q), dtype=torch.int32)
+    idx[:, : Q // 4] = idx[:, :1]                                  # a hot target
+    if m > 8:
+        idx[idx == 5] = 6                                          # an empty target
+    idx[B - 1] = torch.arange(Q, dtype=torch.int32) % min(3, m)    # everything on (at most) three targets
+    g = torch.randn(B, C, Q // div)
+    if div == 3:
+        coef = torch.rand(B, Q // 3, 3)
+        ref = P.three_interpolate_grad(g, idx.view(B, Q // 3, 3), coef, m)
+    else:
+        coef = None
+        ref = P.group_points_grad(g.view(B, C, Q, 1), idx.view(B, Q, 1), m)
+    gi, ii = g.to(d()), idx.to(d())
+    ci = None if coef is None else coef.to(d())
+    out = mod().scatter_add_sorted(gi, ii, ci, m, div)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=2e-4 * max(1.0, (Q / m) ** 0.5))
+    if m > 8:
+        assert float(out[: B - 1, :, 5].abs().max()) == 0          # untouched targets are written as zeros
+    assert hasattr(ii, '_hcm_sorted')                              # the sorted structure is cached on the index tensor
+    order, skey, seg, _ = ii._hcm_sorted[1]
+    sk = skey.cpu().long()
+    assert bool((sk[1:] >= sk[:-1]).all())                         # sorted by (b, target) ...
+    o = order.cpu().long()
+    same = sk[1:] == sk[:-1]
+    assert bool((o[1:][same] > o[:-1][same]).all())                # ... and stable: q ascends inside a target
+    assert int(seg[-1]) == B * Q and int(seg[0]) == 0
+    again = mod().scatter_add_sorted(gi, ii, ci, m, div)
+    fresh = mod().scatter_add_sorted(gi, ii.clone(), ci, m, div)   # rebuilt structure
+    assert torch.equal(out, again) and torch.equal(out, fresh)
+
+
+def test_autograd_functions_use_the_sorted_backward_by_default():
+    """three_interpolate / grouping_operation / gather_operation backward (pointnet2_utils.py:108-197) through the
+    deterministic path: equal to the LDS-atomic path of r02 within fp32 summation noise, bit-identical run to run."""
+    from hcmoco_amd.pycontrast.networks.pointnet2 import pointnet2_utils as U
+    torch.manual_seed(1)
+    B, C, n, mm = 2, 32, 2048, 256
+    feats = torch.randn(B, C, mm, device=d())
+    unknown, known = torch.rand(B, n, 3, device=d()), torch.rand(B, mm, 3, device=d())
+    dist, idx = U.three_nn(unknown, known)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(2, keepdim=True)
+    gy = torch.randn(B, C, n, device=d())
+    grads = {}
+    for mode in ('sorted', 'sorted', 'lds'):
+        U.SCATTER_BACKWARD = mode
+        f = feats.clone().requires_grad_()
+        U.three_interpolate(f, idx, w).backward(gy)
+        grads.setdefault(mode, []).append(f.grad.clone())
+    U.SCATTER_BACKWARD = 'sorted'
+    assert torch.equal(grads['sorted'][0], grads['sorted'][1])
+    assert torch.allclose(grads['sorted'][0], grads['lds'][0], rtol=1e-4, atol=1e-4)
+    gidx = torch.randint(0, mm, (B, 64, 16), dtype=torch.int32, device=d())
+    f = feats.clone().requires_grad_()
+    U.grouping_operation(f, gidx).square().sum().backward()
+    ref = torch.zeros_like(feats)
+    grouped = feats[torch.arange(B)[:, None, None, None], torch.arange(C)[None, :, None, None], gidx[:, None].long()]
+    ref.scatter_add_(2, gidx.long().view(B, 1, -1).expand(B, C, -1), (2 * grouped).reshape(B, C, -1))
+    assert torch.allclose(f.grad, ref, rtol=1e-4, atol=1e-4)
+
+
 def test_lds_scatter_refuses_targets_that_do_not_fit_lds():
     from hcmoco_amd import _lib
     with pytest.raises(_lib.HipError):
