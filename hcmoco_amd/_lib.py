@@ -76,9 +76,9 @@ SIGNATURES = {
     'hcm_three_nn_contract': (_i, [_i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_three_interpolate_contract': (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     'hcm_scatter_add_lds': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    'hcm_scatter_sort_workspace_bytes': (_sz, [_i, _i, _i]),
-    'hcm_scatter_sort': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
-    'hcm_scatter_add_sorted': (_i, [_p] * 5 + [_i] * 6 + [_p, _p]),
+    'hcm_scatter_plan_elems': (_sz, [_i] * 4),
+    'hcm_scatter_plan': (_i, [_p, _p] + [_i] * 4 + [_p] * 3),
+    'hcm_scatter_add_planned': (_i, [_p] * 3 + [_i] * 5 + [_p, _p]),
     'hcm_sgc_workspace_floats': (C.c_size_t, [_i] * 4),
     'hcm_sgc_forward': (_i, [_p] * 12 + [_i] * 7 + [_f, _f] + [_p] * 6),
     'hcm_sgc_backward': (_i, [_p] * 12 + [_i] * 7 + [_p] * 7),
@@ -90,7 +90,7 @@ SIGNATURES = {
     'hcm_conv_wgrad_partial': (_i, [_i, _p, _p] + [_i] * 5 + [_p, C.c_size_t, _p, _p]),
     'hcm_wgrad_reduce_batch': (_i, [_p, _i, _p]),
     'hcm_conv3x3_stats_slots': (_i, [_i] * 2),
-    'hcm_conv3x3_forward_stats': (_i, [_p] * 3 + [_i] * 5 + [_p, _p]),
+    'hcm_conv3x3_forward_stats': (_i, [_p] * 3 + [_i] * 5 + [_p] * 3),
     'hcm_bn_act_forward_pre': (_i, [_p] * 6 + [_f, _f] + [_i] * 4 + [_p] * 3 + [_i, _p]),
     'hcm_conv3x3_supported': (_i, [_i] * 4),
     'hcm_conv3x3_forward': (_i, [_p] * 3 + [_i] * 5 + [_p]),

@@ -94,9 +94,10 @@ __global__ __launch_bounds__(kBT) void bn_stats_kernel(const float* __restrict__
   }
 }
 
-// PRE: the statistics pass was done by the PRODUCER of x (conv.hip's epilogue): `part` holds `nslots` partial PLAIN
-// sums (sum x, sum x^2; shift 0) per channel, [2*slot][C]; they are added in a fixed order (thread t: slots t,
-// t + 256, ...; then the block tree).
+// PRE: the statistics pass was done by the PRODUCER of x (conv.hip's epilogue): `part` holds `nslots` partial sums
+// (sum (x - k), sum (x - k)^2) per channel, [2*slot][C], and the shift k[C] the producer used in row 2*nslots (the
+// running mean as it stood BEFORE this kernel updates it, or zeros); they are added in a fixed order (thread t:
+// slots t, t + 256, ...; then the block tree).
 template <bool RELU, bool RES, bool PRE>
 __global__ __launch_bounds__(kBT) void bn_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kBT) void bn_apply_kernel(
   } else {
     merge_partials(part, g, c, p1, p2);
   }
-  const float k = PRE ? 0.f : x[(size_t)c * g.HW];
+  const float k = PRE ? part[(size_t)(2 * nslots) * g.C + c] : x[(size_t)c * g.HW];
   const float invM = 1.f / (float)g.M;
   const float m1 = p1 * invM;
   const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);

@@ -33,13 +33,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // matrix work spent on zeros.  A wave owns one map row; its 64 lanes are (pixel, channel pair) for the leftover
 // channels and do them as plain FMAs -- x from the same LDS tile (lane = pixel: conflict-free), the two weights
 // of the pair from a small LDS table (broadcast read) -- in the shadow of the MFMAs, which run 32 cycles each.
-// STATS (forward only): the epilogue also leaves this workgroup's per-channel sums of y and y^2 in
+// STATS (forward only): the epilogue also leaves this workgroup's per-channel sums of (y - k) and (y - k)^2 in
 // stat_part[2*blockIdx.x + {0,1}][K] -- the statistics pass of the BatchNorm that follows every one of these
-// convolutions (hcm_bn_act_forward_pre), taken from the accumulators instead of re-reading y.
+// convolutions (hcm_bn_act_forward_pre), taken from the accumulators instead of re-reading y.  k[c] = stat_shift[c]
+// (the BatchNorm's running mean: close to the batch mean, so the variance is not a difference of two large sums) or 0;
+// workgroup 0 leaves the k it used in row 2*gridDim.x, where the BatchNorm kernel reads it back (it updates the
+// running mean itself, so it must not read k from there).
 template <int CG, int MT, int WT, int RB, int LO, bool FLIP, bool STATS>
 __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                 float* __restrict__ y, int C, int K, int H,
-                                                                float* __restrict__ stat_part) {
+                                                                float* __restrict__ stat_part,
+                                                                const float* __restrict__ stat_shift) {
   constexpr int LW = WT + 8;                       // [3 unused][left halo][WT][right halo][3 unused]
   constexpr int LH = RB + 2;
   constexpr int PLANE = LH * LW;
@@ -206,14 +210,19 @@ __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s1 = 0.f, s2 = 0.f;
+        const int oc = 16 * m + 4 * kq + r;
+        const float k = (stat_shift && oc < n_out) ? stat_shift[oc] : 0.f;
 #pragma unroll
-        for (int p = 0; p < P; ++p) { const float v = acc[m][p][r]; s1 += v; s2 = fmaf(v, v, s2); }
+        for (int p = 0; p < P; ++p) { const float v = acc[m][p][r] - k; s1 += v; s2 = fmaf(v, v, s2); }
         s1 = hcm::row16_sum(s1);                      // the 16 pixels of a tile sit in one DPP row (same kq)
         s2 = hcm::row16_sum(s2);
         if (np == 0) { mine[16 * m + 4 * kq + r] = s1; mine[NC + 16 * m + 4 * kq + r] = s2; }
       }
     if (LO) {
-      float a0 = lo0, a1 = lo1, b0 = lo0 * lo0, b1 = lo1 * lo1;
+      const int oc = 16 * MT + 2 * pair;
+      float a0 = lo0 - ((stat_shift && oc < n_out) ? stat_shift[oc] : 0.f);
+      float a1 = lo1 - ((stat_shift && oc + 1 < n_out) ? stat_shift[oc + 1] : 0.f);
+      float b0 = a0 * a0, b1 = a1 * a1;
       // lanes of one channel pair: all 64 (WT = 64) or one 32-lane half (WT = 32)
       a0 = hcm::row16_sum(a0); a1 = hcm::row16_sum(a1); b0 = hcm::row16_sum(b0); b1 = hcm::row16_sum(b1);
       a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
@@ -235,11 +244,14 @@ __global__ __launch_bounds__(64 * RB) void conv3x3_mfma_kernel(const float* __re
         stat_part[(size_t)(2 * blockIdx.x + which) * n_out + c] = v;
       }
     }
+    if (blockIdx.x == 0)
+      for (int c = tid; c < n_out; c += kThreads) stat_part[(size_t)2 * gridDim.x * n_out + c] = stat_shift ? stat_shift[c] : 0.f;
   }
 }
 
 template <int CG, int MT, int WT, int RB, int LO>
-int launch(const float* x, const float* w, float* y, int N, int C, int K, int H, bool flip, hipStream_t st, float* stat_part = nullptr) {
+int launch(const float* x, const float* w, float* y, int N, int C, int K, int H, bool flip, hipStream_t st, float* stat_part = nullptr,
+           const float* stat_shift = nullptr) {
   constexpr size_t lds = ((size_t)4 * CG * (RB + 2) * (WT + 8) + (size_t)9 * CG * MT * 64 + (size_t)4 * CG * 9 * LO +
                           (size_t)RB * 2 * (16 * MT + LO)) * sizeof(float);
   const dim3 grid(N * (H / RB));
@@ -247,7 +259,7 @@ int launch(const float* x, const float* w, float* y, int N, int C, int K, int H,
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, true><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, stat_part);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, true><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, stat_part, stat_shift);
     HCM_CHECK_LAUNCH();
     return 0;
   }
@@ -255,12 +267,12 @@ int launch(const float* x, const float* w, float* y, int N, int C, int K, int H,
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, nullptr);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, true, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, nullptr, nullptr);
   } else {
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, nullptr);
+    conv3x3_mfma_kernel<CG, MT, WT, RB, LO, false, false><<<grid, 64 * RB, lds, st>>>(x, w, y, C, K, H, nullptr, nullptr);
   }
   HCM_CHECK_LAUNCH();
   return 0;
@@ -268,16 +280,16 @@ int launch(const float* x, const float* w, float* y, int N, int C, int K, int H,
 
 // shapes with a kernel instance: C == K (BasicBlock), 64- or 32-wide maps
 int dispatch(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, bool flip, hipStream_t st,
-             float* stat_part = nullptr) {
+             float* stat_part = nullptr, const float* stat_shift = nullptr) {
   if (N <= 0 || C != K || !x || !w || !y || H % 4 != 0) return (int)hipErrorInvalidValue;
   static const bool hybrid = !(getenv("HCM_CONV_HYBRID") && getenv("HCM_CONV_HYBRID")[0] == '0');
   // 4-row bands (4 waves): 8-row bands with 8 waves halve the workgroup count and the weight re-reads, but the
   // kernel gets slower (36ch: 14.6 -> 19.5 us) and so does the step (654 -> 642 samples/s)
-  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st, stat_part);
-  if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part);
+  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
+  if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
   // (a padded 32-channel instance for HRNet-w32's first branch was measured: 436 vs 441 samples/s with MIOpen -- not kept)
-  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st, stat_part);
-  if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part);
+  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
+  if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
   return (int)hipErrorInvalidValue;
 }
 
@@ -298,10 +310,10 @@ int hcm_conv3x3_forward(const float* x, const float* w, float* y, int N, int C, 
 
 int hcm_conv3x3_stats_slots(int N, int H) { return (N > 0 && H > 0 && H % 4 == 0) ? N * (H / 4) : 0; }
 
-int hcm_conv3x3_forward_stats(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, float* partial_sums,
-                              hcm_stream_t stream) {
+int hcm_conv3x3_forward_stats(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, const float* shift,
+                              float* partial_sums, hcm_stream_t stream) {
   if (!partial_sums) return (int)hipErrorInvalidValue;
-  return dispatch(x, w, y, N, C, K, H, W, false, (hipStream_t)stream, partial_sums);
+  return dispatch(x, w, y, N, C, K, H, W, false, (hipStream_t)stream, partial_sums, shift);
 }
 
 int hcm_conv3x3_backward_data(const float* dy, const float* w, float* dx, int N, int C, int K, int H, int W,

@@ -1053,9 +1053,10 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
           const int N = (int)xin.size(0), Cc = (int)xin.size(1), Kc = (int)w.size(0), H = (int)xin.size(2), W = (int)xin.size(3);
           const int slots = hcm_conv3x3_stats_slots(N, H);
           z = at::empty({N, Kc, H, W}, xin.options());
-          Tensor part = at::empty({2 * (int64_t)slots * Kc}, xin.options());
+          // sums about the running mean (shifted: no cancellation when |mean| >> std); the kernel leaves the shift in the last row
+          Tensor part = at::empty({(2 * (int64_t)slots + 1) * Kc}, xin.options());
           check_rc(hcm_conv3x3_forward_stats(xin.data_ptr<float>(), w.data_ptr<float>(), z.data_ptr<float>(), N, Cc, Kc, H, W,
-                                             part.data_ptr<float>(), current_stream(xin)),
+                                             fptr(buffers[2 * L]), part.data_ptr<float>(), current_stream(xin)),
                    "hcm_conv3x3_forward_stats");
           const Tensor res = b >= 0 ? T.val[b] : Tensor();
           o.y = at::empty_like(z);

@@ -116,40 +116,45 @@ def scatter_add_lds(grad_out, idx, coef, m, div=1):
     return out
 
 
-def scatter_sort(idx, m):
-    """Sort the contributions of an index tensor idx [B, ...] (values in [0, m)) by (b, target, q): the structure
-    ``scatter_add_sorted`` consumes; built once per index tensor and shared by every backward that uses it."""
+def scatter_plan(idx, coef, m, div=1):
+    """The streaming order, collision ranks and heavy-target flags of an index tensor idx [B, ...] (values in [0, m)) and
+    its weights: what ``scatter_add_planned`` consumes; built once per (idx, coef) and shared by every backward."""
     B = idx.shape[0]
     idx2 = idx.reshape(B, -1).contiguous()
     Q = idx2.shape[1]
-    dev = idx.device
-    nbytes = int(_lib.lib().hcm_scatter_sort_workspace_bytes(B, Q, m))
-    if nbytes == 0:
-        raise ValueError('scatter_sort: unsupported size B=%d Q=%d m=%d' % (B, Q, m))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    order = torch.empty(B * Q, dtype=torch.int32, device=dev)
-    skey = torch.empty(B * Q, dtype=torch.int32, device=dev)
-    seg = torch.empty(B * m + 1, dtype=torch.int32, device=dev)
-    check(_lib.lib().hcm_scatter_sort(_i(idx2, 'scatter_sort'), B, Q, m, _i(order, 'scatter_sort'), _i(skey, 'scatter_sort'),
-                                      _i(seg, 'scatter_sort'), C.c_void_p(ws.data_ptr()), nbytes, _stream()),
-          'hcm_scatter_sort')
-    return order, skey, seg, Q
+    if Q % div:
+        raise ValueError('scatter_plan: %d contributions are not a multiple of div=%d' % (Q, div))
+    qsrc = Q // div
+    n = int(_lib.lib().hcm_scatter_plan_elems(B, qsrc, div, m))
+    if n == 0:
+        raise ValueError('scatter_plan: unsupported shape B=%d Qsrc=%d div=%d m=%d' % (B, qsrc, div, m))
+    plan = torch.empty(n, dtype=torch.int32, device=idx.device)
+    pcoef = None if coef is None else torch.empty(n, dtype=torch.float32, device=idx.device)
+    cf = C.c_void_p(0) if coef is None else _f(coef.reshape(B, -1).contiguous(), 'scatter_plan')
+    check(_lib.lib().hcm_scatter_plan(_i(idx2, 'scatter_plan'), cf, B, qsrc, div, m, _i(plan, 'scatter_plan'),
+                                      C.c_void_p(0) if pcoef is None else _f(pcoef, 'scatter_plan'), _stream()),
+          'hcm_scatter_plan')
+    return plan, pcoef, qsrc
 
 
-def scatter_add_sorted(grad_out, idx, coef, m, div=1):
-    """grad_points[b,c,j] = sum_{q: idx[b,q]==j} coef[b,q] * grad_out[b,c,q//div] -> [B, C, m], deterministic (sorted
-    contributions, fixed-shape segmented sums, no float atomics).  The sorted structure is cached on the index tensor."""
+def scatter_add_planned(grad_out, idx, coef, m, div=1):
+    """grad_points[b,c,j] = sum_{q: idx[b,q]==j} coef[b,q] * grad_out[b,c,q//div] -> [B, C, m], deterministic (source
+    order, per-wave channel ownership, ranked LDS read-add-write rounds, no atomics).  The plan is cached on the index
+    tensor, keyed by the weights it was built with."""
     B, Cc, qsrc = grad_out.shape
-    cached = getattr(idx, '_hcm_sorted', None)
-    if cached is None or cached[0] != (idx._version, m):
-        cached = ((idx._version, m), scatter_sort(idx, m))
-        idx._hcm_sorted = cached
-    order, skey, seg, Q = cached[1]
+    key = (idx._version, m, div, None if coef is None else (coef.data_ptr(), coef._version))
+    cached = getattr(idx, '_hcm_plan', None)
+    if cached is None or cached[0] != key:
+        cached = (key, scatter_plan(idx, coef, m, div))
+        idx._hcm_plan = cached
+    plan, pcoef, q = cached[1]
+    if q != qsrc:
+        raise ValueError('scatter_add_planned: grad_out has %d sources, the index tensor %d' % (qsrc, q))
     out = torch.empty(B, Cc, m, dtype=torch.float32, device=grad_out.device)
-    cf = C.c_void_p(0) if coef is None else _f(coef.reshape(B, -1).contiguous(), 'scatter_add_sorted')
-    check(_lib.lib().hcm_scatter_add_sorted(_f(grad_out, 'scatter_add_sorted'), cf, _i(order, 'scatter_add_sorted'),
-                                            _i(skey, 'scatter_add_sorted'), _i(seg, 'scatter_add_sorted'), B, Cc, qsrc, Q, m,
-                                            div, _f(out, 'scatter_add_sorted'), _stream()), 'hcm_scatter_add_sorted')
+    check(_lib.lib().hcm_scatter_add_planned(_f(grad_out, 'scatter_add_planned'), _i(plan, 'scatter_add_planned'),
+                                             C.c_void_p(0) if pcoef is None else _f(pcoef, 'scatter_add_planned'), B, Cc,
+                                             qsrc, m, div, _f(out, 'scatter_add_planned'), _stream()),
+          'hcm_scatter_add_planned')
     return out
 
 

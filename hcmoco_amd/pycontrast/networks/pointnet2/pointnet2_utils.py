@@ -15,9 +15,9 @@ import os
 
 from .... import pointnet2_hip as pointnet2
 
-# backward of the gather-type ops: 'sorted' (deterministic segmented sums, csrc/scatter.hip), 'lds' (r02: LDS float
+# backward of the gather-type ops: 'planned' (deterministic ranked LDS rounds, csrc/scatter.hip), 'lds' (r02: LDS float
 # atomics) or 'atomic' (the reference's global atomics, *_grad_wrapper)
-SCATTER_BACKWARD = os.environ.get('HCM_PN2_BACKWARD', 'sorted')
+SCATTER_BACKWARD = os.environ.get('HCM_PN2_BACKWARD', 'planned')
 
 
 def _scatter_backward(grad_out, idx, coef, m, div, legacy):
@@ -27,8 +27,8 @@ def _scatter_backward(grad_out, idx, coef, m, div, legacy):
     (tools/bench_pointnet2.py).  A module with only the nine reference functions (the pybind
     original, or the CPU oracle shim used by tests), or a target axis too long for LDS, takes the
     ``*_grad_wrapper`` route."""
-    fn = getattr(pointnet2, 'scatter_add_sorted', None)      # r03: sorted contributions, deterministic, hub-proof
-    if fn is not None and SCATTER_BACKWARD == 'sorted':
+    fn = getattr(pointnet2, 'scatter_add_planned', None)     # r03: deterministic, no atomics, hub-proof
+    if fn is not None and SCATTER_BACKWARD == 'planned' and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0):
         return fn(grad_out.contiguous(), idx, coef, m, div)
     fn = getattr(pointnet2, 'scatter_add_lds', None)
     if fn is not None and SCATTER_BACKWARD != 'atomic' and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0):

@@ -361,8 +361,9 @@ int hcm_bn_act_forward(const float* x, const float* residual, const float* gamma
 int hcm_bn_act_backward(const float* dy, const float* dy2, const float* x, const float* y, const float* gamma,
                         const float* stats, int relu, int N, int C, int HW, float* dz, float* dx,
                         float* gstats, hcm_stream_t stream);
-/* hcm_bn_act_forward whose statistics pass was done by the producer of x: partial_sums [2 * nslots][C] = per-slot
- * plain sums of x and x^2 (hcm_conv3x3_forward_stats), added in a fixed order.  Mid-size and large maps only
+/* hcm_bn_act_forward whose statistics pass was done by the producer of x: partial_sums [2 * nslots + 1][C] = per-slot
+ * sums of (x - k) and (x - k)^2 and, in the last row, the shift k[C] they were taken about
+ * (hcm_conv3x3_forward_stats), added in a fixed order; mean = k + S1/M, var = S2/M - (S1/M)^2.  Mid-size and large maps only
  * (N*HW per channel > 8192): hipErrorInvalidValue otherwise.  stats as for hcm_bn_act_forward. */
 int hcm_bn_act_forward_pre(const float* x, const float* residual, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, int relu,
@@ -471,21 +472,22 @@ int hcm_three_interpolate_contract(int b, int c, int m, int n, const float* poin
 int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx, int B, int C,
                         int Qsrc, int Q, int m, int div, float* grad_points, hcm_stream_t stream);
 
-/* Deterministic form of the same backward (csrc/scatter.hip; r03): no float atomics, sums in a fixed order, and a
- * target that receives most of the contributions (an empty-mask image: all pixels interpolate from points 0, 1, 2) is
- * shared by all waves of its workgroup.
- *   hcm_scatter_sort: once per index tensor idx [B, Q] (values in [0, m)): order [B*Q] int32 = the contribution
- *   numbers q sorted by (b, idx[b, q], q) (stable radix sort of the key b*m + idx), sorted_key [B*Q] = that key in
- *   sorted order, seg [B*m + 1] = first sorted position of every (b, target).  workspace:
- *   hcm_scatter_sort_workspace_bytes(B, Q, m) bytes (0 = unsupported size: B*Q and B*m must be < 2^31).
- *   hcm_scatter_add_sorted: grad_points [B, C, m] (overwritten, needs no zero-fill) from grad_out [B, C, Qsrc],
- *   coef [B, Q] or NULL (= 1) and the three arrays above; contribution q reads grad_out[b, c, q / div]. */
-size_t hcm_scatter_sort_workspace_bytes(int B, int Q, int m);
-int hcm_scatter_sort(const int* idx, int B, int Q, int m, int* order, int* sorted_key, int* seg, void* workspace,
-                     size_t workspace_bytes, hcm_stream_t stream);
-int hcm_scatter_add_sorted(const float* grad_out, const float* coef, const int* order, const int* sorted_key,
-                           const int* seg, int B, int C, int Qsrc, int Q, int m, int div, float* grad_points,
-                           hcm_stream_t stream);
+/* Deterministic form of the same backward (csrc/scatter.hip; r03): no atomics of any kind, every sum in an order fixed
+ * by idx alone (bit-reproducible), and contributions that pile onto one target (an empty-mask image: all pixels
+ * interpolate from points 0, 1, 2) are summed across the wave instead of serialised.
+ *   hcm_scatter_plan: once per index tensor idx [B, Qsrc * div] (values in [0, m), m <= 65535; div = 1 or 3) and its
+ *   weights coef [B, Qsrc * div] (NULL = 1): plan / plan_coef [hcm_scatter_plan_elems(B, Qsrc, div, m)] (int32 /
+ *   float; 0 elements = unsupported shape) receive target | collision rank | heavy flag and the weights in the order
+ *   the kernel streams them: [b][step of 256 sources][t < div][lane][4 sources of the lane].  plan_coef NULL iff coef
+ *   NULL.
+ *   hcm_scatter_add_planned: grad_points [B, C, m] (overwritten, needs no zero-fill) from grad_out [B, C, Qsrc] and the
+ *   plan; contribution q = src * div + t reads grad_out[b, c, src].  hipErrorInvalidConfiguration when m floats do not
+ *   fit LDS (then use the atomic kernels). */
+size_t hcm_scatter_plan_elems(int B, int Qsrc, int div, int m);
+int hcm_scatter_plan(const int* idx, const float* coef, int B, int Qsrc, int div, int m, int* plan, float* plan_coef,
+                     hcm_stream_t stream);
+int hcm_scatter_add_planned(const float* grad_out, const int* plan, const float* plan_coef, int B, int C, int Qsrc, int m,
+                            int div, float* grad_points, hcm_stream_t stream);
 
 /* Max over the ball (F.max_pool2d(y, [1, nsample]) in PointnetSAModuleMSG.forward,
  * networks/pointnet2/pointnet2_modules.py:60-63): x [rows, ns] fp32 contiguous (rows = B*C*npoint) ->
@@ -540,11 +542,13 @@ int hcm_conv3x3_forward(const float* x, const float* w, float* y, int N, int C, 
 int hcm_conv3x3_backward_data(const float* dy, const float* w, float* dx, int N, int C, int K, int H, int W,
                               hcm_stream_t stream);
 /* The forward with the statistics pass of the BatchNorm that follows it folded into its epilogue: partial_sums
- * [2 * hcm_conv3x3_stats_slots(N, H)][K] receives, per workgroup (slot), the sums of y and of y^2 over the slot's
- * pixels for every output channel (plain sums, no shift); hcm_bn_act_forward_pre consumes them. */
+ * [2 * hcm_conv3x3_stats_slots(N, H) + 1][K] receives, per workgroup (slot), the sums of (y - shift) and of
+ * (y - shift)^2 over the slot's pixels for every output channel, and in its last row the shift itself.  shift [K]:
+ * any estimate of the channel means (the BatchNorm's running mean), which keeps the variance from being a difference
+ * of two large sums when |mean| >> std; NULL = 0.  hcm_bn_act_forward_pre consumes the buffer. */
 int hcm_conv3x3_stats_slots(int N, int H);
-int hcm_conv3x3_forward_stats(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, float* partial_sums,
-                              hcm_stream_t stream);
+int hcm_conv3x3_forward_stats(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, const float* shift,
+                              float* partial_sums, hcm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -72,11 +72,12 @@ def test_conv3x3_forward_stats_and_the_batch_norm_that_consumes_them(N, Cc, H, W
     slots = int(L.hcm_conv3x3_stats_slots(N, H))
     assert slots == N * H // 4
     y = torch.empty_like(y0)
-    part = torch.full((2 * slots, Cc), float('nan'), device=dev)
-    check(L.hcm_conv3x3_forward_stats(p(x), p(w), p(y), N, Cc, Cc, H, W, p(part), st), 'forward_stats')
+    part = torch.full((2 * slots + 1, Cc), float('nan'), device=dev)
+    check(L.hcm_conv3x3_forward_stats(p(x), p(w), p(y), N, Cc, Cc, H, W, None, p(part), st), 'forward_stats')
     assert torch.equal(y, y0)
-    s1 = part[0::2].double().sum(0)
-    s2 = part[1::2].double().sum(0)
+    assert torch.equal(part[-1], torch.zeros(Cc, device=dev))          # the shift that was used: none
+    s1 = part[:-1][0::2].double().sum(0)
+    s2 = part[:-1][1::2].double().sum(0)
     yd = y.double()
     r1, r2 = yd.sum((0, 2, 3)), yd.square().sum((0, 2, 3))
     assert (s1 - r1).abs().max().item() <= 1e-5 * r2.sqrt().max().item() * (N * H * W) ** 0.5
@@ -86,17 +87,68 @@ def test_conv3x3_forward_stats_and_the_batch_norm_that_consumes_them(N, Cc, H, W
     gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), torch.randn(Cc, generator=g).to(dev)
     res = torch.randn(N, Cc, H, W, generator=g).to(dev)
     outs = []
-    for pre in (False, True):
+    for pre in (False, True, 'shifted'):
         rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
         out = torch.empty_like(y)
         stats = torch.empty(int(L.hcm_bn_act_stats_floats(N, Cc, H * W)), device=dev)
-        if pre:
+        if pre == 'shifted':
+            shift = (y.mean((0, 2, 3)) * 0.9 + 0.05).contiguous()
+            part2 = torch.full((2 * slots + 1, Cc), float('nan'), device=dev)
+            check(L.hcm_conv3x3_forward_stats(p(x), p(w), p(y), N, Cc, Cc, H, W, p(shift), p(part2), st), 'forward_stats')
+            assert torch.equal(y, y0) and torch.equal(part2[-1], shift)
+            check(L.hcm_bn_act_forward_pre(p(y), p(res), p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 1, N, Cc, H * W, p(out),
+                                           p(stats), p(part2), slots, st), 'bn_pre')
+        elif pre:
             check(L.hcm_bn_act_forward_pre(p(y), p(res), p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 1, N, Cc, H * W, p(out),
                                            p(stats), p(part), slots, st), 'bn_pre')
         else:
             check(L.hcm_bn_act_forward(p(y), p(res), p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 1, N, Cc, H * W, p(out),
                                        p(stats), st), 'bn')
         outs.append((out, stats[:2 * Cc].clone(), rm, rv))
-    for a, b in zip(outs[0], outs[1]):
-        scale = a.abs().max().item()
-        assert (a - b).abs().max().item() <= 2e-5 * scale
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            scale = a.abs().max().item()
+            assert (a - b).abs().max().item() <= 2e-5 * scale
+
+
+def test_batch_norm_statistics_from_the_conv_epilogue_survive_a_large_mean():
+    """|mean| >> std (E[y^2] - E[y]^2 from unshifted fp32 sums cancels): a centre-tap filter on inputs
+    100 + 0.01 noise gives y ~ 90 +- 0.0025 per channel.  With the sums taken about a running mean within 0.05 of the
+    batch mean, hcm_bn_act_forward_pre's mean / invstd agree with float64 statistics of y to 1e-3; the two-pass
+    hcm_bn_act_forward (shifted by the first element) is the yardstick."""
+    from hcmoco_amd import _lib
+    from hcmoco_amd.hip_ops import check
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    N, Cc, H, W = 32, 18, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = (100 + 0.01 * torch.randn(N, Cc, H, W, generator=g)).to(dev)
+    w = torch.zeros(Cc, Cc, 3, 3)
+    w[:, :, 1, 1] = torch.rand(Cc, Cc, generator=g) * 0.1
+    w = w.to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    slots = int(L.hcm_conv3x3_stats_slots(N, H))
+    y = torch.empty(N, Cc, H, W, device=dev)
+    gamma, beta = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    got = {}
+    for name, shift in (('plain', None), ('shifted', 'near')):
+        part = torch.empty(2 * slots + 1, Cc, device=dev)
+        if shift is not None:
+            check(L.hcm_conv3x3_forward(p(x), p(w), p(y), N, Cc, Cc, H, W, st), 'conv')
+            shift = (y.mean((0, 2, 3)) + 0.05).contiguous()
+        check(L.hcm_conv3x3_forward_stats(p(x), p(w), p(y), N, Cc, Cc, H, W, p(shift), p(part), st), 'forward_stats')
+        rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+        out = torch.empty_like(y)
+        stats = torch.empty(int(L.hcm_bn_act_stats_floats(N, Cc, H * W)), device=dev)
+        check(L.hcm_bn_act_forward_pre(p(y), None, p(gamma), p(beta), p(rm), p(rv), 0.1, 1e-5, 0, N, Cc, H * W, p(out), p(stats),
+                                       p(part), slots, st), 'bn_pre')
+        got[name] = stats[:2 * Cc].clone()
+    yd = y.double()
+    mean = yd.mean((0, 2, 3))
+    invstd = 1.0 / (yd.var((0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    assert float(mean.abs().min()) > 30 and float(invstd.min()) > 100          # the regime this test is about
+    sh = got['shifted'].double()
+    assert float(((sh[:Cc] - mean) / mean).abs().max()) < 1e-6
+    assert float((sh[Cc:] / invstd - 1).abs().max()) < 1e-3
+    print('plain sums: invstd off by up to %.3g (relative)' % float((got['plain'].double()[Cc:] / invstd - 1).abs().max()))

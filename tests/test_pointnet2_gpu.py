@@ -205,39 +205,20 @@ def test_bad_arguments_raise_instead_of_exit():
 
 
 @pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1), (2, 9, 600, 40, 1),
-                                         (2, 19, 3 * 5000, 257, 3), (1, 4, 4000, 3, 1), (2, 70, 4096 * 4, 4096, 1)])
-def test_lds_scatter_backward_matches_the_scatter_add_oracle(B, C, Q, m, div):
-    """hcm_scatter_add_lds == oracle scatter-add (group / three_interpolate forms), including empty
-    buckets, hub buckets (m=3: a thousand references each), repeated indices and m = 4096."""
-    torch.manual_seed(Q + m)
-    idx = torch.randint(0, m, (B, Q), dtype=torch.int32)
-    idx[:, : Q // 4] = idx[:, :1]                                  # a hot bucket
-    if m > 8:
-        idx[idx == 5] = 6                                          # an empty bucket
-    g = torch.randn(B, C, Q // div)
-    if div == 3:
-        coef = torch.rand(B, Q // 3, 3)
-        ref = P.three_interpolate_grad(g, idx.view(B, Q // 3, 3), coef, m)
-    else:
-        coef = None
-        ref = P.group_points_grad(g.view(B, C, Q, 1), idx.view(B, Q, 1), m)
-    out = mod().scatter_add_lds(g.to(d()), idx.to(d()), None if coef is None else coef.to(d()), m, div)
-    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=2e-4)
-    if m > 8:
-        assert float(out[:, :, 5].abs().max()) == 0               # untouched targets are written as zeros
-
-
-@pytest.mark.parametrize('B,C,Q,m,div', [(2, 5, 37, 11, 1), (3, 37, 3 * 300, 64, 3), (2, 130, 128 * 16, 500, 1), (2, 9, 600, 40, 1),
                                          (2, 19, 3 * 5000, 257, 3), (1, 4, 4000, 3, 1), (2, 70, 4096 * 4, 4096, 1),
-                                         (2, 3, 4096, 4096, 1), (2, 128, 3 * 16384, 4096, 3), (3, 515, 64 * 32, 256, 1)])
-def test_sorted_scatter_backward_matches_the_oracle_and_is_bit_reproducible(B, C, Q, m, div):
-    """hcm_scatter_sort + hcm_scatter_add_sorted (csrc/scatter.hip; reference semantics: src/group_points_gpu.cu:8-25,
+                                         (2, 3, 4096, 4096, 1), (2, 128, 3 * 16384, 4096, 3), (3, 515, 64 * 32, 256, 1),
+                                         (2, 40, 3 * 1023, 700, 3), (2, 33, 1021, 1024, 1)])
+def test_planned_scatter_backward_matches_the_oracle_and_is_bit_reproducible(B, C, Q, m, div):
+    """hcm_scatter_plan + hcm_scatter_add_planned (csrc/scatter.hip; reference semantics: src/group_points_gpu.cu:8-25,
     src/interpolate_gpu.cu:120-142 without the atomics) == oracle scatter-add, including empty targets, a hub target
-    holding a quarter of all contributions, an image whose contributions ALL go to three targets (the empty-mask case of
-    pts2depth), repeated indices, m = 4096 (eight target tiles); and two runs are bit-identical."""
+    holding a quarter of all contributions (heavy path), runs of 2-4 equal neighbours (ranked rounds), an image whose
+    contributions ALL go to three targets (the empty-mask case of pts2depth), source counts that are not multiples of
+    4 or 256, every channels-per-wave instance; and two runs are bit-identical."""
     torch.manual_seed(Q + m)
     idx = torch.randint(0, m, (B, Q), dtype=torch.int32)
     idx[:, : Q // 4] = idx[:, :1]                                  # a hot target
+    run = torch.arange(Q // 2, Q // 2 + Q // 8)
+    idx[0, run] = idx[0, run - run % (3 * div)]                    # short runs of equal targets among neighbouring sources
     if m > 8:
         idx[idx == 5] = 6                                          # an empty target
     idx[B - 1] = torch.arange(Q, dtype=torch.int32) % min(3, m)    # everything on (at most) three targets
@@ -250,24 +231,34 @@ def test_sorted_scatter_backward_matches_the_oracle_and_is_bit_reproducible(B, C
         ref = P.group_points_grad(g.view(B, C, Q, 1), idx.view(B, Q, 1), m)
     gi, ii = g.to(d()), idx.to(d())
     ci = None if coef is None else coef.to(d())
-    out = mod().scatter_add_sorted(gi, ii, ci, m, div)
+    out = mod().scatter_add_planned(gi, ii, ci, m, div)
     assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=2e-4 * max(1.0, (Q / m) ** 0.5))
     if m > 8:
         assert float(out[: B - 1, :, 5].abs().max()) == 0          # untouched targets are written as zeros
-    assert hasattr(ii, '_hcm_sorted')                              # the sorted structure is cached on the index tensor
-    order, skey, seg, _ = ii._hcm_sorted[1]
-    sk = skey.cpu().long()
-    assert bool((sk[1:] >= sk[:-1]).all())                         # sorted by (b, target) ...
-    o = order.cpu().long()
-    same = sk[1:] == sk[:-1]
-    assert bool((o[1:][same] > o[:-1][same]).all())                # ... and stable: q ascends inside a target
-    assert int(seg[-1]) == B * Q and int(seg[0]) == 0
-    again = mod().scatter_add_sorted(gi, ii, ci, m, div)
-    fresh = mod().scatter_add_sorted(gi, ii.clone(), ci, m, div)   # rebuilt structure
+    assert hasattr(ii, '_hcm_plan')                                # the plan is cached on the index tensor
+    plan = ii._hcm_plan[1][0].cpu()
+    steps = (Q // div + 255) // 256
+    assert plan.numel() == B * steps * div * 256
+    pl = plan.view(B, steps, div, 64, 4)
+    # plan[b, s, t, lane, i] describes contribution (256 s + 4 lane + i) * div + t
+    src = (256 * torch.arange(steps).view(-1, 1, 1, 1) + 4 * torch.arange(64).view(1, 1, -1, 1) + torch.arange(4).view(1, 1, 1, -1))
+    q = src * div + torch.arange(div).view(1, -1, 1, 1)
+    valid = (src < Q // div).expand(steps, div, 64, 4)
+    for b in range(B):
+        assert bool((pl[b][~valid] == -1).all())
+        assert torch.equal(pl[b][valid] & 0xFFFF, idx[b][q[valid]])
+    heavy = ((pl >> 18) & 1).bool() & (pl >= 0)
+    if B > 1 and Q // div >= 512:                                  # the three-target image goes the heavy way, a random one mostly by rounds
+        assert float(heavy[B - 1][valid].float().mean()) > 0.9 and float(heavy[0][valid].float().mean()) < 0.6
+    again = mod().scatter_add_planned(gi, ii, ci, m, div)
+    fresh = mod().scatter_add_planned(gi, ii.clone(), ci, m, div)  # rebuilt plan
     assert torch.equal(out, again) and torch.equal(out, fresh)
+    if ci is not None:                                             # other weights on the same index tensor: plan rebuilt
+        c2 = ci * 2
+        assert torch.allclose(mod().scatter_add_planned(gi, ii, c2, m, div), out * 2, rtol=1e-6, atol=1e-6)
 
 
-def test_autograd_functions_use_the_sorted_backward_by_default():
+def test_autograd_functions_use_the_planned_backward_by_default():
     """three_interpolate / grouping_operation / gather_operation backward (pointnet2_utils.py:108-197) through the
     deterministic path: equal to the LDS-atomic path of r02 within fp32 summation noise, bit-identical run to run."""
     from hcmoco_amd.pycontrast.networks.pointnet2 import pointnet2_utils as U
@@ -280,14 +271,14 @@ def test_autograd_functions_use_the_sorted_backward_by_default():
     w = w / w.sum(2, keepdim=True)
     gy = torch.randn(B, C, n, device=d())
     grads = {}
-    for mode in ('sorted', 'sorted', 'lds'):
+    for mode in ('planned', 'planned', 'lds'):
         U.SCATTER_BACKWARD = mode
         f = feats.clone().requires_grad_()
         U.three_interpolate(f, idx, w).backward(gy)
         grads.setdefault(mode, []).append(f.grad.clone())
-    U.SCATTER_BACKWARD = 'sorted'
-    assert torch.equal(grads['sorted'][0], grads['sorted'][1])
-    assert torch.allclose(grads['sorted'][0], grads['lds'][0], rtol=1e-4, atol=1e-4)
+    U.SCATTER_BACKWARD = 'planned'
+    assert torch.equal(grads['planned'][0], grads['planned'][1])
+    assert torch.allclose(grads['planned'][0], grads['lds'][0], rtol=1e-4, atol=1e-4)
     gidx = torch.randint(0, mm, (B, 64, 16), dtype=torch.int32, device=d())
     f = feats.clone().requires_grad_()
     U.grouping_operation(f, gidx).square().sum().backward()

@@ -66,9 +66,9 @@ for n, m, radii, nsamples, cin in levels:
         timeit('group_points_grad c=%d  [LDS float atomics, r02]' % cin,
                lambda: pn.scatter_add_lds(out.view(B, cin, m * ns), bidx.view(B, -1), None, n, 1), work=by, unit='GB/s')
         bflat = bidx.view(B, -1)
-        timeit('   contribution sort (once per index tensor)', lambda: pn.scatter_sort(bflat, n))
-        total += timeit('group_points_grad c=%d  [sorted, deterministic]' % cin,
-                        lambda: pn.scatter_add_sorted(out.view(B, cin, m * ns), bflat, None, n, 1), work=by, unit='GB/s')
+        timeit('   scatter plan (once per index tensor)', lambda: pn.scatter_plan(bflat, None, n, 1))
+        total += timeit('group_points_grad c=%d  [planned, deterministic]' % cin,
+                        lambda: pn.scatter_add_planned(out.view(B, cin, m * ns), bflat, None, n, 1), work=by, unit='GB/s')
     xyz = new_xyz
 
 for n, m, c in [(256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (4096, 4096, 256), (65536, 4096, 128)]:
@@ -89,9 +89,9 @@ for n, m, c in [(256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (4096, 409
     timeit('three_interpolate_grad c=%d  [LDS float atomics, r02]' % c,
            lambda: pn.scatter_add_lds(out, idx.view(B, -1), w, m, 3), work=by, unit='GB/s')
     iflat = idx.view(B, -1)
-    timeit('   contribution sort (once per index tensor)', lambda: pn.scatter_sort(iflat, m))
-    total += timeit('three_interpolate_grad c=%d  [sorted, deterministic]' % c,
-                    lambda: pn.scatter_add_sorted(out, iflat, w, m, 3), work=by, unit='GB/s')
+    timeit('   scatter plan (once per index tensor)', lambda: pn.scatter_plan(iflat, w, m, 3))
+    total += timeit('three_interpolate_grad c=%d  [planned, deterministic]' % c,
+                    lambda: pn.scatter_add_planned(out, iflat, w, m, 3), work=by, unit='GB/s')
     if n == 65536:
         # the empty-mask case of pts2depth (build_backbone.py:427-445): a quarter of the images send every pixel to points 0, 1, 2
         hub = idx.clone()
@@ -99,6 +99,6 @@ for n, m, c in [(256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (4096, 409
         hflat = hub.view(B, -1)
         timeit('three_interpolate_grad c=%d, 25%% empty-mask images  [LDS float atomics, r02]' % c,
                lambda: pn.scatter_add_lds(out, hflat, w, m, 3), work=by, unit='GB/s')
-        timeit('three_interpolate_grad c=%d, 25%% empty-mask images  [sorted, deterministic]' % c,
-               lambda: pn.scatter_add_sorted(out, hflat, w, m, 3), work=by, unit='GB/s')
+        timeit('three_interpolate_grad c=%d, 25%% empty-mask images  [planned, deterministic]' % c,
+               lambda: pn.scatter_add_planned(out, hflat, w, m, 3), work=by, unit='GB/s')
 print('sum of one call each: %.2f ms' % total)
