@@ -12,7 +12,7 @@
 //                      the kernel below, so each gets its RANK among them (order: t, then lane).  Targets with more than
 //                      4 contributions in a domain are flagged HEAVY (an empty-mask image sends every pixel of pts2depth
 //                      to points 0, 1, 2; background pixels of a row share their nearest silhouette points).
-//                      plan[b][step][t][lane][i] = target | rank << 16 | heavy << 18 (-1: past the end), the weights
+//                      plan[b][step][t][lane][i] = target | (rank, or 4 = heavy) << 16 (-1: past the end), the weights
 //                      re-laid the same way.
 //   hcm_scatter_add_planned   workgroup = (b, block of CBL channels): the accumulators acc[CBL][m] of ALL targets live in
 //                      LDS; wave w OWNS channels w*CPW .. w*CPW+CPW-1 -- no other wave touches their rows, so there is
@@ -34,10 +34,9 @@ using namespace hcm;
 
 constexpr int kSPL = 4;                 // sources per lane and step
 constexpr int kStep = 64 * kSPL;        // sources per step
-constexpr int kMaxAcc = 36 * 1024;      // accumulators per workgroup (144 KB of LDS)
+constexpr int kMaxAcc = 37 * 1024;      // accumulators (+ 64 spare slots per row) per workgroup: 148 KB of LDS
 constexpr int kLight = 4;               // up to this many contributions per target and domain go by rounds
 
-__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 // one wave per (b, step)
 template <int DIV>
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const int* __restrict__ idx, 
 #pragma unroll
     for (int t = 0; t < DIV; ++t) {
       const bool heavy = gs[t] > kLight;
-      const int p = valid ? (tgt[t] | (heavy ? (1 << 18) : (rank[t] << 16))) : -1;
+      const int p = valid ? (tgt[t] | ((heavy ? 4 : rank[t]) << 16)) : -1;
       const int64_t at = ((((int64_t)b * steps + s) * DIV + t) * 64 + lane) * kSPL + i;
       plan[at] = p;
       if (wq != nullptr) wq[at] = w[t];
@@ -88,47 +87,54 @@ __global__ __launch_bounds__(256) void plan_kernel(const int* __restrict__ idx, 
   }
 }
 
-__device__ __forceinline__ int comp(const int4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+// component select without branches or register moves of the ring: masks are -1 for the wanted component, 0 otherwise
+__device__ __forceinline__ int pick(const int4& v, int m0, int m1, int m2, int m3) {
+  return (v.x & m0) | (v.y & m1) | (v.z & m2) | (v.w & m3);
+}
+__device__ __forceinline__ float pick(const float4& v, int m0, int m1, int m2, int m3) {
+  return __int_as_float((__float_as_int(v.x) & m0) | (__float_as_int(v.y) & m1) | (__float_as_int(v.z) & m2) |
+                        (__float_as_int(v.w) & m3));
+}
 
-// One domain: DIV slots (p, w, val[CPW]) per lane.
+// One domain: DIV slots (p, w) and the CPW channel values of one source per lane.  accw: this wave's rows, row stride ms =
+// m + 64: the last 64 floats of a row are per-lane spare slots, so a lane that sits a round out reads and writes its own
+// spare instead of being masked off -- no exec juggling, no branches inside a round.
 template <int DIV, int CPW>
-__device__ __forceinline__ void domain(float* __restrict__ accw, int m, int lane, const int (&p)[DIV], const float (&w)[DIV],
-                                       const float (&val)[CPW]) {
-  bool valid[DIV], light[DIV];
-  int tgt[DIV], rank[DIV];
-  bool any_heavy = false;
+__device__ __forceinline__ void domain(float* __restrict__ accw, int m, int ms, int lane, const int (&p)[DIV],
+                                       const float (&w)[DIV], const float (&val)[CPW]) {
+  int tgt[DIV], cls[DIV];                                  // cls: 0..3 rank of a light contribution, 4 heavy, 7 past the end
+  bool heavy = false;
 #pragma unroll
   for (int t = 0; t < DIV; ++t) {
-    valid[t] = p[t] >= 0;
     tgt[t] = p[t] & 0xFFFF;
-    rank[t] = (p[t] >> 16) & 3;
-    light[t] = valid[t] && !(p[t] & (1 << 18));
-    any_heavy |= valid[t] && !light[t];
+    cls[t] = (p[t] >> 16) & 7;
+    heavy |= cls[t] == 4;
   }
 #pragma unroll
   for (int r = 0; r < kLight; ++r) {
-    bool mine[DIV], some = false;
+    if (r > 0) {
+      bool some = false;
 #pragma unroll
-    for (int t = 0; t < DIV; ++t) { mine[t] = light[t] && rank[t] == r; some |= mine[t]; }
-    if (r > 0 && !__any(some)) break;                      // ranks are dense: nobody at r => nobody above
-    float cur[DIV][CPW];
+      for (int t = 0; t < DIV; ++t) some |= cls[t] == r;
+      if (!__any(some)) break;                             // ranks are dense: nobody at r => nobody above
+    }
+    int off[DIV];
+    float cur[DIV][CPW];                                   // (product rounded, then added: the reference's grad * weight -> atomicAdd)
+#pragma unroll
+    for (int t = 0; t < DIV; ++t) {
+      off[t] = cls[t] == r ? tgt[t] : m + lane;
+#pragma unroll
+      for (int k = 0; k < CPW; ++k) cur[t][k] = accw[k * ms + off[t]];
+    }
 #pragma unroll
     for (int t = 0; t < DIV; ++t)
-      if (mine[t]) {
 #pragma unroll
-        for (int k = 0; k < CPW; ++k) cur[t][k] = accw[(size_t)k * m + tgt[t]];
-      }
-#pragma unroll
-    for (int t = 0; t < DIV; ++t)
-      if (mine[t]) {
-#pragma unroll
-        for (int k = 0; k < CPW; ++k) accw[(size_t)k * m + tgt[t]] = cur[t][k] + w[t] * val[k];
-      }
+      for (int k = 0; k < CPW; ++k) accw[k * ms + off[t]] = __fadd_rn(cur[t][k], __fmul_rn(w[t], val[k]));
   }
-  if (__any(any_heavy)) {
+  if (__any(heavy)) {
     unsigned long long hm[DIV];
 #pragma unroll
-    for (int t = 0; t < DIV; ++t) hm[t] = __ballot(valid[t] && !light[t]);
+    for (int t = 0; t < DIV; ++t) hm[t] = __ballot(cls[t] == 4);
 #pragma unroll
     for (int t = 0; t < DIV; ++t)
       while (hm[t]) {
@@ -139,129 +145,142 @@ __device__ __forceinline__ void domain(float* __restrict__ accw, int m, int lane
         for (int k = 0; k < CPW; ++k) x[k] = 0.f;
 #pragma unroll
         for (int t2 = 0; t2 < DIV; ++t2) {
-          const bool in = valid[t2] && tgt[t2] == T;
+          const bool in = cls[t2] == 4 && tgt[t2] == T;
 #pragma unroll
-          for (int k = 0; k < CPW; ++k) x[k] += in ? w[t2] * val[k] : 0.f;
+          for (int k = 0; k < CPW; ++k) x[k] = __fadd_rn(x[k], in ? __fmul_rn(w[t2], val[k]) : 0.f);
           hm[t2] &= ~__ballot(in);
         }
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
           const float sum = wave_sum(x[k]);
-          if (lane == L) accw[(size_t)k * m + T] += sum;
+          if (lane == L) accw[k * ms + T] += sum;
         }
       }
   }
 }
 
-// grid (channel blocks, B); 64 * ceil(CBL / CPW) threads; dynamic LDS acc[CBL][m]
-template <int DIV, int CPW, bool WEIGHTED, int D>
-__global__ __launch_bounds__(1024) void scatter_planned_kernel(const float* __restrict__ grad_out, const int* __restrict__ plan,
+template <int DIV, int CPW, bool WEIGHTED>
+struct Stage {
+  float4 v[CPW];
+  int4 P[DIV];
+  float4 W[WEIGHTED ? DIV : 1];
+};
+
+// grid (channel blocks, B); 64 * ceil(CBL / CPW) threads (<= MAXT); dynamic LDS acc[CBL][m + 64]
+template <int DIV, int CPW, bool WEIGHTED, bool VEC, int D, int MAXT>
+__global__ __launch_bounds__(MAXT) void scatter_planned_kernel(const float* __restrict__ grad_out, const int* __restrict__ plan,
                                                                 const float* __restrict__ wq, int C, int Qsrc, int m, int steps,
                                                                 int CBL, float* __restrict__ grad_points) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];      // [CBL][m]
+  extern __shared__ __attribute__((aligned(16))) float acc[];      // [CBL][ms]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, c0 = blockIdx.x * CBL;
   const int nc = min(CBL, C - c0);
-  for (int e = tid; e < CBL * m; e += blockDim.x) acc[e] = 0.f;
+  const int ms = m + 64;
+  for (int e = tid; e < CBL * ms; e += blockDim.x) acc[e] = 0.f;
   __syncthreads();
   const int wch = wave * CPW;
   if (wch < nc) {
-    const bool vec = (Qsrc & 3) == 0;
     const float* rows[CPW];
 #pragma unroll
     for (int k = 0; k < CPW; ++k)                                 // channels past the block's end: a copy into a spare row
       rows[k] = grad_out + ((int64_t)b * C + c0 + min(wch + k, nc - 1)) * Qsrc;
-    float* accw = acc + (size_t)wch * m;
+    float* accw = acc + (size_t)wch * ms;
     const int4* pl = reinterpret_cast<const int4*>(plan) + (int64_t)b * steps * (DIV * 64) + lane;
     const float4* wl = WEIGHTED ? reinterpret_cast<const float4*>(wq) + (int64_t)b * steps * (DIV * 64) + lane : nullptr;
-    float4 ring[D][CPW];
-    int4 Pb[2][DIV];
-    float4 Wb[2][DIV];
-    auto load_rows = [&](float4 (&dst)[CPW], int s) {
+    Stage<DIV, CPW, WEIGHTED> ring[D];
+    auto load = [&](Stage<DIV, CPW, WEIGHTED>& st, int s) {
       const int src = kStep * s + kSPL * lane;
 #pragma unroll
+      for (int t = 0; t < DIV; ++t) {
+        st.P[t] = pl[((int64_t)s * DIV + t) * 64];
+        if (WEIGHTED) st.W[t] = wl[((int64_t)s * DIV + t) * 64];
+      }
+      // past the end: re-read valid floats (no zero-fill, no branch -- the plan sends those lanes to their spare slot)
+#pragma unroll
       for (int k = 0; k < CPW; ++k) {
-        if (vec) {
-          dst[k] = src < Qsrc ? *reinterpret_cast<const float4*>(rows[k] + src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (VEC) {
+          st.v[k] = *reinterpret_cast<const float4*>(rows[k] + min(src, Qsrc - 4));
         } else {
-          dst[k].x = src < Qsrc ? rows[k][src] : 0.f;
-          dst[k].y = src + 1 < Qsrc ? rows[k][src + 1] : 0.f;
-          dst[k].z = src + 2 < Qsrc ? rows[k][src + 2] : 0.f;
-          dst[k].w = src + 3 < Qsrc ? rows[k][src + 3] : 0.f;
+          st.v[k].x = rows[k][min(src, Qsrc - 1)];
+          st.v[k].y = rows[k][min(src + 1, Qsrc - 1)];
+          st.v[k].z = rows[k][min(src + 2, Qsrc - 1)];
+          st.v[k].w = rows[k][min(src + 3, Qsrc - 1)];
         }
       }
     };
-    auto load_plan = [&](int4 (&P)[DIV], float4 (&W)[DIV], int s) {
+    // every load below is unconditional (past the end: the last step again), so that the number of loads in flight
+    // behind the one a step needs is the same on every path and the compiler's s_waitcnt vmcnt(N) stays exact
 #pragma unroll
-      for (int t = 0; t < DIV; ++t) {
-        P[t] = pl[((int64_t)s * DIV + t) * 64];
-        if (WEIGHTED) W[t] = wl[((int64_t)s * DIV + t) * 64];
-      }
-    };
-    load_plan(Pb[0], Wb[0], 0);
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < steps) load_rows(ring[d], d);
-    static_assert(D % 2 == 0, "the plan double buffer alternates with the unrolled step");
+    for (int d = 0; d < D; ++d) {
+      load(ring[d], min(d, steps - 1));
+      __builtin_amdgcn_sched_barrier(0);                          // oldest stage first, as in the steady state
+    }
     for (int s0 = 0; s0 < steps; s0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int s = s0 + d;
         if (s < steps) {
-          if (s + 1 < steps) load_plan(Pb[(d + 1) & 1], Wb[(d + 1) & 1], s + 1);
-          float4 cur[CPW];
-#pragma unroll
-          for (int k = 0; k < CPW; ++k) cur[k] = ring[d][k];
-          if (s + D < steps) load_rows(ring[d], s + D);
-#pragma unroll
-          for (int i = 0; i < kSPL; ++i) {
+#pragma unroll 1
+          for (int i = 0; i < kSPL; ++i) {          // rolled (the body is large); component i by wave-uniform bit masks
+            const int m0 = -(i == 0), m1 = -(i == 1), m2 = -(i == 2), m3 = -(i == 3);
             float val[CPW], w[DIV];
             int p[DIV];
 #pragma unroll
-            for (int k = 0; k < CPW; ++k) val[k] = comp(cur[k], i);
+            for (int k = 0; k < CPW; ++k) val[k] = pick(ring[d].v[k], m0, m1, m2, m3);
 #pragma unroll
             for (int t = 0; t < DIV; ++t) {
-              p[t] = comp(Pb[d & 1][t], i);
-              w[t] = WEIGHTED ? comp(Wb[d & 1][t], i) : 1.f;
+              p[t] = pick(ring[d].P[t], m0, m1, m2, m3);
+              w[t] = WEIGHTED ? pick(ring[d].W[t], m0, m1, m2, m3) : 1.f;
             }
-            domain<DIV, CPW>(accw, m, lane, p, w, val);
+            domain<DIV, CPW>(accw, m, ms, lane, p, w, val);
           }
         }
+        load(ring[d], min(s + D, steps - 1));
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
   __syncthreads();
   float* out = grad_points + ((int64_t)b * C + c0) * m;
-  for (int e = tid; e < nc * m; e += blockDim.x) out[e] = acc[e];
+  for (int e = tid; e < nc * m; e += blockDim.x) {
+    const int ch = e / m, j = e - ch * m;
+    out[e] = acc[ch * ms + j];
+  }
 }
 
 template <int DIV, bool WEIGHTED>
 int launch_planned(const float* grad_out, const int* plan, const float* wq, int B, int C, int Qsrc, int m, float* grad_points,
                    hipStream_t st) {
-  int CBL = kMaxAcc / m;
+  const int ms = m + 64;
+  int CBL = kMaxAcc / ms;
   if (CBL < 1) return (int)hipErrorInvalidConfiguration;           // the target axis does not fit LDS: atomic kernels
-  if (CBL > (DIV == 3 ? 32 : 64)) CBL = DIV == 3 ? 32 : 64;   // (DIV 3 with 4 channels per wave does not fit 128 VGPRs)
+  constexpr int kCap = DIV == 3 ? 32 : 64;                         // (DIV 3 with 4 channels per wave does not fit 128 VGPRs)
+  if (CBL > kCap) CBL = kCap;
   if (CBL > C) CBL = C;
   // keep the device busy: at least ~2 workgroups per CU when the channels allow it
   while (CBL > 1 && (long long)B * ((C + CBL - 1) / CBL) < 512) CBL = (CBL + 1) / 2;
-  const int cpw = CBL > 32 ? 4 : (CBL > 16 ? 2 : 1);
+  const int cpw = CBL > 32 ? 4 : (CBL > 8 ? 2 : 1);
   const int waves = (CBL + cpw - 1) / cpw;
   const int steps = (Qsrc + kStep - 1) / kStep;
-  const size_t ldsb = (size_t)CBL * m * sizeof(float);
+  const size_t ldsb = (size_t)CBL * ms * sizeof(float);
   const dim3 grid((C + CBL - 1) / CBL, B);
-#define HCM_PLANNED(CPW, D)                                                                                              \
-  do {                                                                                                                   \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_planned_kernel<DIV, CPW, WEIGHTED, D>),      \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                           \
-    if (e != hipSuccess) return (int)e;                                                                                  \
-    scatter_planned_kernel<DIV, CPW, WEIGHTED, D><<<grid, 64 * waves, ldsb, st>>>(grad_out, plan, wq, C, Qsrc, m, steps, \
-                                                                                 CBL, grad_points);                      \
+#define HCM_PLANNED1(CPW, D, MAXT, VEC)                                                                                           \
+  do {                                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_planned_kernel<DIV, CPW, WEIGHTED, VEC, D, MAXT>),    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                               \
+    if (e != hipSuccess) return (int)e;                                                                                      \
+    scatter_planned_kernel<DIV, CPW, WEIGHTED, VEC, D, MAXT><<<grid, 64 * waves, ldsb, st>>>(grad_out, plan, wq, C, Qsrc, m,      \
+                                                                                       steps, CBL, grad_points);             \
   } while (0)
-  if (cpw == 1) HCM_PLANNED(1, 6);
-  else if (cpw == 2) HCM_PLANNED(2, 4);
-  else if (DIV == 1) HCM_PLANNED(4, 2);
+#define HCM_PLANNED(CPW, D, MAXT) do { if ((Qsrc & 3) == 0) HCM_PLANNED1(CPW, D, MAXT, true); else HCM_PLANNED1(CPW, D, MAXT, false); } while (0)
+  // <= 8 waves of one channel each: 256 VGPRs, six steps (data + plan + weights) in flight; more waves:
+  // 128 VGPRs, two steps
+  if (cpw == 1) HCM_PLANNED(1, 6, 512);
+  else if (cpw == 2) HCM_PLANNED(2, 2, 1024);
+  else if constexpr (DIV == 1) HCM_PLANNED(4, 2, 1024);
   else return (int)hipErrorInvalidConfiguration;
 #undef HCM_PLANNED
+#undef HCM_PLANNED1
   HCM_CHECK_LAUNCH();
   return 0;
 }
