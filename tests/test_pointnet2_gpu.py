@@ -237,19 +237,30 @@ def test_planned_scatter_backward_matches_the_oracle_and_is_bit_reproducible(B, 
         assert float(out[: B - 1, :, 5].abs().max()) == 0          # untouched targets are written as zeros
     assert hasattr(ii, '_hcm_plan')                                # the plan is cached on the index tensor
     plan = ii._hcm_plan[1][0].cpu()
-    steps = (Q // div + 255) // 256
+    region = (((Q // div + 63) // 64) + 3) // 4 * 4                # lane l owns sources [l * region, (l + 1) * region)
+    steps = region // 4
     assert plan.numel() == B * steps * div * 256
     pl = plan.view(B, steps, div, 64, 4)
-    # plan[b, s, t, lane, i] describes contribution (256 s + 4 lane + i) * div + t
-    src = (256 * torch.arange(steps).view(-1, 1, 1, 1) + 4 * torch.arange(64).view(1, 1, -1, 1) + torch.arange(4).view(1, 1, 1, -1))
+    # plan[b, s, t, lane, i] describes contribution (lane * region + 4 s + i) * div + t
+    src = (4 * torch.arange(steps).view(-1, 1, 1, 1) + region * torch.arange(64).view(1, 1, -1, 1) + torch.arange(4).view(1, 1, 1, -1))
     q = src * div + torch.arange(div).view(1, -1, 1, 1)
     valid = (src < Q // div).expand(steps, div, 64, 4)
+    cls = (pl >> 16) & 7                                          # 0-3 rank of a flush, 4 heavy flush, 5 run goes on, 7 past the end
     for b in range(B):
         assert bool((pl[b][~valid] == -1).all())
-        assert torch.equal(pl[b][valid] & 0xFFFF, idx[b][q[valid]])
-    heavy = ((pl >> 18) & 1).bool() & (pl >= 0)
-    if B > 1 and Q // div >= 512:                                  # the three-target image goes the heavy way, a random one mostly by rounds
-        assert float(heavy[B - 1][valid].float().mean()) > 0.9 and float(heavy[0][valid].float().mean()) < 0.6
+        want = idx[b][q.clamp(max=Q - 1)].sort(dim=1).values       # the slots of one source are ordered by target
+        assert torch.equal((pl[b] & 0xFFFF)[valid], want[valid])
+        # a run goes on exactly where the lane's next source (same slot) names the same target
+        nxt = torch.full_like(want, -1)
+        flat, nflat = want.permute(2, 0, 3, 1).reshape(64, steps * 4, div), nxt.permute(2, 0, 3, 1).reshape(64, steps * 4, div)
+        nflat[:, :-1] = flat[:, 1:]
+        vflat = valid.permute(2, 0, 3, 1).reshape(64, steps * 4, div)
+        nflat[:, :-1][~vflat[:, 1:]] = -1
+        goes_on = (nflat == flat) & vflat
+        assert torch.equal((cls[b] == 5).permute(2, 0, 3, 1).reshape(64, steps * 4, div), goes_on)
+    if B > 1 and Q // div >= 512:            # the three-target image flushes everything the heavy way, a random one mostly by rounds
+        fl = (cls <= 4) & valid
+        assert float((cls[B - 1][fl[B - 1]] == 4).float().mean()) > 0.9 and float((cls[0][fl[0]] == 4).float().mean()) < 0.6
     again = mod().scatter_add_planned(gi, ii, ci, m, div)
     fresh = mod().scatter_add_planned(gi, ii.clone(), ci, m, div)  # rebuilt plan
     assert torch.equal(out, again) and torch.equal(out, fresh)
