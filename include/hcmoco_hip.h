@@ -477,9 +477,12 @@ int hcm_scatter_add_lds(const float* grad_out, const float* coef, const int* idx
  * interpolate from points 0, 1, 2) are summed across the wave instead of serialised.
  *   hcm_scatter_plan: once per index tensor idx [B, Qsrc * div] (values in [0, m), m <= 65535; div = 1 or 3) and its
  *   weights coef [B, Qsrc * div] (NULL = 1): plan / plan_coef [hcm_scatter_plan_elems(B, Qsrc, div, m)] (int32 /
- *   float; 0 elements = unsupported shape) receive target | collision rank | heavy flag and the weights in the order
- *   the kernel streams them: [b][step of 256 sources][t < div][lane][4 sources of the lane].  plan_coef NULL iff coef
- *   NULL.
+ *   float; 0 elements = unsupported shape) receive, in the order the kernel streams them ([b][step][slot < div][lane]
+ *   [4 sources]; lane l owns sources [l R, (l+1) R), R = ceil(Qsrc / 64) rounded up to 4; the div pairs of a source
+ *   ordered by target): target | class << 16 | any-flush << 20 -- class 5 = the lane's next source names the same
+ *   target in this slot (the run is summed in registers), 0-3 = the run ends here and this is the k-th flush to that
+ *   target among the 64 lanes, 4 = more than four such flushes (summed across the wave) -- and the weights.
+ *   plan_coef NULL iff coef NULL.
  *   hcm_scatter_add_planned: grad_points [B, C, m] (overwritten, needs no zero-fill) from grad_out [B, C, Qsrc] and the
  *   plan; contribution q = src * div + t reads grad_out[b, c, src].  hipErrorInvalidConfiguration when m floats do not
  *   fit LDS (then use the atomic kernels). */
