@@ -14,7 +14,7 @@ for flags in "--width 32" "--arch HRNetPN" "--arch HRNetPN --width 32" "--bank_d
   python bench.py --steps 20 --warmup 5 --no_cpu_baseline $flags 2>/dev/null | grep "^{" | tail -1 >> $OUT/${TAG}_secondary_configs.log
 done
 HCM_DETERMINISTIC=1 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | grep "^{" | tail -1 > $OUT/${TAG}_deterministic_mode_bench_line.json
-python bench.py --gpus 2 --steps 10 --warmup 3 --no_cpu_baseline 2>/dev/null | grep "^{" | tail -1 > $OUT/${TAG}_two_ranks_one_gpu_gloo_bench_line.json || true
+python bench.py --gpus 2 --backend gloo --steps 10 --warmup 3 --no_cpu_baseline --no_check 2>/dev/null | grep "^{" | tail -1 > $OUT/${TAG}_two_ranks_one_gpu_gloo_bench_line.json || true
 (python tools/bench_pointnet2.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_pointnet2_ops_config4.txt
 (python tools/probes/phase_times.py 2>&1 | tail -12) > $OUT/${TAG}_phase_times.txt || true
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/fp
