@@ -156,7 +156,7 @@ template <class T, int NV, int MODE, int NPF = 1, int MINW = 1>
 __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
     const T* __restrict__ b1, const T* __restrict__ b2, const T* __restrict__ b3,
     const int64_t* __restrict__ idx, const float* __restrict__ x1, const float* __restrict__ x2,
-    const float* __restrict__ x3, const float* __restrict__ glogits, int B, int K1, int R, int stagger,
+    const float* __restrict__ x3, const float* __restrict__ glogits, int B, int K1, int R,
     float scale, float* __restrict__ part_m, float* __restrict__ part_s,
     float* __restrict__ part_acc, float* __restrict__ l0_out, float* __restrict__ logits_out) {
   constexpr int D = 64 * NV;
@@ -164,11 +164,9 @@ __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = lane & 15, g = lane >> 4;
   const int s = wave * 4 + g;
-  // stagger: chunks 2j, 2j+1 split their 2R rows R+stagger : R-stagger instead of R : R, so that the workgroups sharing a
-  // CU do not run out of rows (and refill their pipelines) at the same moment
-  const int kbeg = (chunk >> 1) * 2 * R + ((chunk & 1) ? R + stagger : 0);
-  const int kend = min(K1, (chunk & 1) ? (chunk >> 1) * 2 * R + 2 * R : kbeg + R + stagger);
-  const int niter = max(0, kend - kbeg + kStreams - 1) / kStreams;
+  const int kbeg = chunk * R;
+  const int kend = min(K1, kbeg + R);
+  const int niter = (kend - kbeg + kStreams - 1) / kStreams;
   const int64_t* __restrict__ idxb = idx + (int64_t)b * K1;
 
   float4 xq[3][NV];
@@ -947,12 +945,10 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
   hcm::ProfSpan span(HCM_PROF_BANK_PASS, st);  // brackets the dominant kernel only
   if (D == 128) {
     static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
-    static const int stag_env = getenv("HCM_BANK_STAGGER") ? atoi(getenv("HCM_BANK_STAGGER")) : 0;
-    const int stag = (stag_env > 0 && stag_env < R && stag_env % kStreams == 0) ? stag_env : 0;
 #define HCM_LAUNCH_PASS(NPF, MINW)                                                                   \
   bank_pass_kernel<T, 2, kFused, NPF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
-                                                                  nullptr, B, K1, R, stag, scale2,       \
-                                                                  ws.part_m, ws.part_s, ws.part_acc, ws.l0, nullptr)
+                                                                  nullptr, B, K1, R, scale2, ws.part_m, \
+                                                                  ws.part_s, ws.part_acc, ws.l0, nullptr)
     // prefetch depth (row triples in flight per stream).  Measured (tools/tune_bank.py and the
     // in-bench hipEvents): fp32 3 > 2 > 1 (0.129 / 0.137 / 0.159 ms on the same box), bf16 best at 4;
     // depth 4+ for fp32 drops to one wave per SIMD and loses.  HCM_BANK_VARIANT overrides for tuning.
@@ -993,7 +989,7 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
   } else {
     if constexpr (!kBf16) {
       bank_pass_kernel<T, 1, kFused><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
-                                                           nullptr, B, K1, R, 0, scale2, ws.part_m,
+                                                           nullptr, B, K1, R, scale2, ws.part_m,
                                                            ws.part_s, ws.part_acc, ws.l0, nullptr);
       span.stop();
       HCM_CHECK_LAUNCH();
@@ -1022,12 +1018,12 @@ int logits_fwd_impl(const T* bank1, const T* bank2, const T* bank3, const int64_
   hipStream_t st = (hipStream_t)stream;
   if (D == 128) {
     bank_pass_kernel<T, 2, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
-                                                             nullptr, B, K1, R, 0, invT, nullptr,
+                                                             nullptr, B, K1, R, invT, nullptr,
                                                              nullptr, nullptr, nullptr, logits);
   } else {
     if constexpr (!kBf16)
       bank_pass_kernel<T, 1, kLogitsFwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3,
-                                                               nullptr, B, K1, R, 0, invT, nullptr,
+                                                               nullptr, B, K1, R, invT, nullptr,
                                                                nullptr, nullptr, nullptr, logits);
   }
   HCM_CHECK_LAUNCH();
@@ -1050,7 +1046,7 @@ int logits_bwd_impl(const T* bank1, const T* bank2, const T* bank3, const int64_
   hipStream_t st = (hipStream_t)stream;
   if (D == 128) {
     bank_pass_kernel<T, 2, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr,
-                                                             nullptr, nullptr, grad_logits, B, K1, R, 0,
+                                                             nullptr, nullptr, grad_logits, B, K1, R,
                                                              invT, nullptr, nullptr, ws.part_acc,
                                                              nullptr, nullptr);
     HCM_CHECK_LAUNCH();
@@ -1059,7 +1055,7 @@ int logits_bwd_impl(const T* bank1, const T* bank2, const T* bank3, const int64_
     if constexpr (!kBf16) {
       bank_pass_kernel<T, 1, kLogitsBwd><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, nullptr,
                                                                nullptr, nullptr, grad_logits, B, K1,
-                                                               R, 0, invT, nullptr, nullptr, ws.part_acc,
+                                                               R, invT, nullptr, nullptr, ws.part_acc,
                                                                nullptr, nullptr);
       HCM_CHECK_LAUNCH();
       bank_logits_bwd_finish_kernel<64><<<B, kWG, 0, st>>>(nch, ws.part_acc, gx1, gx2, gx3);
