@@ -359,6 +359,12 @@ def main():
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
     dt = float(tdt.item())
     loss = float(last['loss'].item())
+    if dist.is_initialized():
+        # every rank leaves the process group HERE, together: what follows (stand-alone kernel timings, the oracle check
+        # of the recorded step, the CPU baseline) is rank 0's own work and takes a minute; the other ranks must not sit in
+        # a communicator teardown -- or trip its watchdog -- while it runs
+        dist.barrier()
+        dist.destroy_process_group()
     if not (loss == loss):
         raise SystemExit('non-finite loss in the timed region')
 
@@ -477,8 +483,6 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a.nce_k, a.n_data, a.size, a.skeleton, B)
         else:
             out['cpu_baseline'] = None
-    if dist.is_initialized():
-        dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which is block-
         # buffered on a pipe and would otherwise come out at process exit, after python's own (flushed) print
