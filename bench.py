@@ -270,6 +270,8 @@ def main():
         os.environ['MASTER_PORT'] = str(free_port())       # only reached with world == 1 (forced collectives)
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.device('cuda', torch.cuda.current_device())
+    from hcmoco_amd.pycontrast.learning.affinity import pin_to_gpu_node
+    pinned = pin_to_gpu_node(dev.index)           # the cores of the GPU's own socket (HCM_PIN_NUMA=0: leave it to the OS)
     forced = world == 1 and os.environ.get('HCM_FORCE_COLLECTIVES', '0') != '0'
     if world > 1 or forced:      # forced: a 1-rank group that still runs every collective (cost of the N>1 path)
         dist.init_process_group(a.backend, rank=rank, world_size=world, device_id=dev)   # nccl = RCCL over xGMI
@@ -463,6 +465,7 @@ def main():
                        'grad_collectives_per_step': (trainer.grad_sync.launched if trainer.grad_sync is not None
                                                      else (None if world > 1 else 0)),
                        'backend': a.backend if (world > 1 or forced) else None,
+                       'cpu_affinity': None if pinned is None else {'numa_node': pinned[0], 'cpus': len(pinned[1])},
                        'final_loss': round(loss, 4)},
             'roofline': {'kernel': ('bank_pass_kernel<bf16,fused,ring 4>' if a.bank_dtype == 'bf16' else
                                     'bank_pass_kernel<f32,fused,ring 3>') + ' (gather + 6 logit sets + online softmax + d/dx)',

@@ -44,6 +44,8 @@ class BaseTrainer(object):
         if use_gpu:
             torch.cuda.set_device(local % torch.cuda.device_count())
             self.device = torch.device('cuda', torch.cuda.current_device())
+            from .affinity import pin_to_gpu_node                       # the reference relies on SLURM's --cpu-bind
+            pin_to_gpu_node(self.device.index)
             torch.backends.cudnn.benchmark = True                       # MIOpen find mode (:28)
         else:
             backend = 'gloo'

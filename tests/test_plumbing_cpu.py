@@ -299,3 +299,14 @@ def test_flat_param_sgd_without_encoder_programs_is_a_transparent_wrapper():
         assert torch.equal(sa['state'][k]['momentum_buffer'], sb['state'][k]['momentum_buffer'])
     a.load_state_dict(sb)
     assert a.inner.param_groups[0]['lr'] == 0.05
+
+
+def test_cpu_affinity_helper_parses_sysfs_lists_and_is_a_no_op_without_a_gpu():
+    """learning/affinity.py: the cpulist grammar of sysfs, and no change (None) where no GPU / sysfs entry exists."""
+    import os
+    from hcmoco_amd.pycontrast.learning import affinity
+    assert affinity._parse_cpulist('64-127,192-255\n') == list(range(64, 128)) + list(range(192, 256))
+    assert affinity._parse_cpulist('3') == [3] and affinity._parse_cpulist('') == []
+    before = os.sched_getaffinity(0)
+    assert affinity.pin_to_gpu_node(0) is None and affinity.pin_to_gpu_node(0, mode='0') is None
+    assert os.sched_getaffinity(0) == before
