@@ -13,6 +13,9 @@ B = int(os.environ.get('B', 32))
 torch.manual_seed(0)
 
 
+VEC_PEAK_TFS = 157.3          # fp32 vector / matrix peak of the MI355X (guide); a distance evaluation = 3 sub + 3 mul-add + compare ~ 9 flop
+
+
 def timeit(name, fn, reps=5, work=None, unit=''):
     fn()
     torch.cuda.synchronize()
@@ -24,6 +27,8 @@ def timeit(name, fn, reps=5, work=None, unit=''):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     extra = '' if work is None else '  %.1f %s' % (work / ms / 1e6, unit)
+    if work is not None and 'evals/s' in unit:          # rows 12 / 13 / 16 against the fp32 vector peak
+        extra += '  (%.3f of the fp32 vector peak at 9 flop per evaluation)' % (work * 9 / (ms * 1e-3) / (VEC_PEAK_TFS * 1e12))
     print('%-58s %9.3f ms%s' % (name, ms, extra), flush=True)
     return ms
 
