@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
 //                 unsigned integers);
 //   low  32 bits: 0xFFFFFFFF - ((bitrev(tid) << 21) | j)  -> among equal distances the smaller
 //                 bit-reversed thread id wins; j (< 2^21) says which of the thread's points it was.
-// A serial round then costs 4 DPP steps + 2 cross-row shuffles + one LDS exchange and ONE barrier
+// A serial round then costs 4 DPP steps + 8 v_readlane + one LDS exchange and ONE barrier
 // (the per-wave results are double-buffered and every wave finishes the reduction redundantly).
 __device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) {
   return a > b ? a : b;
@@ -331,12 +331,11 @@ __device__ __forceinline__ unsigned long long row16_umax64(unsigned long long v)
   v = umax64(v, dpp_mov64<0x140>(v));
   return v;
 }
-__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int off) {
-  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64);
-  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
   return ((unsigned long long)hi << 32) | lo;
 }
-
 // Every point k has the unique key (distance, ~(bitrev(k % bs) << 21 | k / bs)); the global maximum
 // of that key IS the reference winner whatever physical thread evaluated the point, so the physical
 // workgroup size P is a pure performance choice (fewer waves = cheaper barrier, more points each).
@@ -405,8 +404,9 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
       }
     }
     c = row16_umax64(c);
-    c = umax64(c, shfl_xor64(c, 16));
-    c = umax64(c, shfl_xor64(c, 32));
+    // every lane of a DPP row holds its row's maximum: the four rows meet in scalar registers (v_readlane + s_max),
+    // not through the LDS crossbar (r02: two 64-bit ds_bpermute exchanges, ~10 % of a round)
+    c = umax64(umax64(readlane64(c, 0), readlane64(c, 16)), umax64(readlane64(c, 32), readlane64(c, 48)));
     const int par = r & 1;
     if ((tid & 63) == 0) red[par][wave] = c;
     __syncthreads();
@@ -464,6 +464,49 @@ __global__ __launch_bounds__(256) void rowmax_fwd_kernel(const float* __restrict
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
   if (r < rows && l == 0) { y[r] = best; arg[r] = bi; }
+}
+
+// nsample = 16 / 32 (every level of Pointnet2MSG): a row is 4 / 8 lanes of one float4 each; the lane's own four
+// candidates in order, then quad_perm / row_half_mirror DPP exchanges of (value, index) -- no LDS crossbar.  The
+// generic kernel above spends ten ds_bpermute per 256 bytes of input on its butterfly: 0.40 ms for a 268 MB ball
+// tensor (0.67 TB/s).
+template <int CTRL>
+__device__ __forceinline__ void rowmax_merge(float& best, int& bi) {
+  const float ov = hcm::dpp_mov<CTRL>(best);
+  const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xF, 0xF, true);
+  if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+}
+template <int NS>
+__global__ __launch_bounds__(256) void rowmax_fwd_vec_kernel(const float4* __restrict__ x, long long rows,
+                                                             float* __restrict__ y, int* __restrict__ arg) {
+  constexpr int LQ = NS / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long r = t / LQ;
+  const int l = (int)(t & (LQ - 1));
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (r < rows) {
+    const float4 v = x[t];
+    best = v.x; bi = 4 * l;                                 // the first candidate is taken as it is (like the scan above)
+    if (v.y > best) { best = v.y; bi = 4 * l + 1; }
+    if (v.z > best) { best = v.z; bi = 4 * l + 2; }
+    if (v.w > best) { best = v.w; bi = 4 * l + 3; }
+  }
+  rowmax_merge<0xB1>(best, bi);                             // quad_perm [1,0,3,2]
+  rowmax_merge<0x4E>(best, bi);                             // quad_perm [2,3,0,1]
+  if (LQ == 8) rowmax_merge<0x141>(best, bi);               // row_half_mirror: lane i <-> 7 - i of each 8
+  if (r < rows && l == 0) { y[r] = best; arg[r] = bi; }
+}
+
+// four consecutive elements of dx per thread (nsample % 4 == 0): one float4 store
+__global__ __launch_bounds__(256) void rowmax_bwd_vec_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
+                                                             long long total4, int ns, float4* __restrict__ dx) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const long long e = 4 * i, r = e / ns;
+  const int j = (int)(e - r * ns) , a = arg[r] - j;
+  const float d = dy[r];
+  dx[i] = make_float4(a == 0 ? d : 0.f, a == 1 ? d : 0.f, a == 2 ? d : 0.f, a == 3 ? d : 0.f);
 }
 
 __global__ __launch_bounds__(256) void rowmax_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
@@ -636,6 +679,14 @@ int hcm_rowmax_forward(const float* x, long long rows, int ns, float* y, int* ar
   if (rows < 0 || ns <= 0 || !x || !y || !arg) return (int)hipErrorInvalidValue;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if ((ns == 16 || ns == 32) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const long long threads = rows * (ns / 4);
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (ns == 16) rowmax_fwd_vec_kernel<16><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(x), rows, y, arg);
+    else rowmax_fwd_vec_kernel<32><<<grid, 256, 0, st>>>(reinterpret_cast<const float4*>(x), rows, y, arg);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   int lpr = 1;
   while (lpr < 64 && lpr * 2 <= ns) lpr *= 2;                    // largest power of two <= min(ns, 64)
   const long long threads = rows * lpr;
@@ -657,6 +708,12 @@ int hcm_rowmax_backward(const float* dy, const int* arg, long long rows, int ns,
   if (rows < 0 || ns <= 0 || !dy || !arg || !dx) return (int)hipErrorInvalidValue;
   if (rows == 0) return 0;
   const long long total = rows * ns;
+  if (ns % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
+    rowmax_bwd_vec_kernel<<<(unsigned)((total / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        dy, arg, total / 4, ns, reinterpret_cast<float4*>(dx));
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   rowmax_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, arg, total, ns, dx);
   HCM_CHECK_LAUNCH();
   return 0;

@@ -107,3 +107,15 @@ for n, m, c in [(256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (4096, 409
         timeit('three_interpolate_grad c=%d, 25%% empty-mask images  [planned, deterministic]' % c,
                lambda: pn.scatter_add_planned(out, hflat, w, m, 3), work=by, unit='GB/s')
 print('sum of one call each: %.2f ms' % total)
+total = 0.0
+# max over the ball (pointnet2_modules.py:60-63) at the four set-abstraction levels: [B, C_out, npoint, nsample]
+for npoint, outs in [(4096, (32, 64)), (1024, (128, 128)), (256, (256, 256)), (64, (512, 512))]:
+    for cout, ns in zip(outs, (16, 32)):
+        x = torch.randn(B, cout, npoint, ns, device=d, requires_grad=True)
+        y = pn.ball_max(x)
+        gy = torch.randn_like(y)
+        by = x.numel() * 4
+        total += timeit('ball max forward  [%d, %d, %d, %d]' % (B, cout, npoint, ns), lambda: pn.ball_max(x), work=by, unit='GB/s')
+        total += timeit('ball max backward [%d, %d, %d, %d]' % (B, cout, npoint, ns),
+                        lambda: torch.autograd.grad(y, x, gy, retain_graph=True), work=by, unit='GB/s')
+print('ball max, sum of one call each: %.2f ms' % total)
