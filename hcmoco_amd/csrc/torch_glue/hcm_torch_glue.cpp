@@ -446,7 +446,14 @@ int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no
   const bool same = g.size(2) == x.size(2) && g.size(3) == x.size(3);
   const bool half = 2 * g.size(2) == x.size(2) && 2 * g.size(3) == x.size(3);
   if (same && w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= mc && w.size(1) <= mc) return 3;
-  if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= m1 && w.size(1) <= m1) return 1;
+  if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= m1 && w.size(1) <= m1) {
+    // wide 1x1 layers on maps far larger than an HRNet branch -- the shared MLPs of PointNet++ on [B, C, npoint, nsample]
+    // ball tensors (64 / 128 channels, 16 K - 131 K positions per image) -- run one or two map rows per unit here
+    // (0.8-1.5 ms, 2 TB/s); MIOpen's implicit GEMM is faster on them: HRNetPN 468 -> 480 samples/s (r03)
+    static const int64_t maxpix = [] { const char* e = getenv("HCM_WGRAD_MAX1X1_PIXELS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    if (!det && std::max(w.size(0), w.size(1)) > maxc && g.size(2) * g.size(3) > maxpix) return 0;
+    return 1;
+  }
   if (half && w.size(2) == 3 && w.size(3) == 3 && w.size(1) <= mc && w.size(0) <= 2 * mc) return 2;   // stride 2
   return 0;
 }

@@ -39,7 +39,9 @@ def test_wgrad_rejects_unsupported():
 
 SHAPES_1X1 = [(32, 36, 18, 32, 32), (8, 72, 18, 16, 16), (4, 144, 36, 8, 8), (8, 64, 256, 16, 16), (3, 5, 7, 12, 20),
               (2, 18, 144, 8, 8),
-              (4, 256, 64, 64, 64)]      # layer1's 256 -> 64 on the 64-wide map: used to exceed LDS and fall back to MIOpen
+              (4, 256, 64, 64, 64),      # layer1's 256 -> 64 on the 64-wide map: used to exceed LDS and fall back to MIOpen
+              # the shared MLPs of PointNet++ on ball tensors [B, C, npoint, nsample]: constant-folded (W, rows) = (32, 2), (16, 2), (32, 1)
+              (2, 32, 64, 300, 32), (2, 99, 64, 130, 16), (2, 64, 128, 67, 16), (2, 99, 64, 50, 32), (2, 64, 128, 33, 32)]
 
 
 @pytest.mark.parametrize('shape', SHAPES_1X1)
