@@ -62,9 +62,16 @@ class ContrastTrainer(BaseTrainer):
             # ... and, when it can, the heads too: the whole serial section becomes one autograd node
             if (getattr(self.engine, 'supports_section', None) is not None and hasattr(model, 'defer_heads')
                     and self.device.type == 'cuda' and os.environ.get('HCM_FUSED_SECTION', '1') != '0'
-                    and getattr(args, 'grad_sync', 'auto') != 'ddp' and self.engine.supports_section(model)):
+                    and getattr(args, 'grad_sync', 'auto') != 'ddp' and not getattr(args, 'channels_last', False)
+                    and self.engine.supports_section(model)):      # (the section kernels read NCHW branch maps)
                 model.defer_heads = True
         if getattr(args, 'channels_last', False):
+            # an r01 experiment for the stock-ATen encoders (HCMOCO_CHANNELS_LAST=1): the encoder runtime's kernels and
+            # the loss section read NCHW
+            from ..networks import hrnet as _hrnet
+            if self.device.type == 'cuda' and (_hrnet.CONV_GLUE or _hrnet.ENCODER_PROGRAM or _hrnet.FUSED_BN):
+                raise ValueError('channels_last needs the stock ATen encoders: HCM_CONV_GLUE=0 HCM_ENCODER_PROGRAM=0 '
+                                 'HCM_FUSED_BN=0 (the encoder runtime and the loss section are NCHW)')
             model.to(memory_format=torch.channels_last)
         if isinstance(model_ema, torch.nn.Module):
             model_ema.to(self.device)

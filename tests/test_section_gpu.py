@@ -338,3 +338,17 @@ def test_section_draws_its_own_negatives_and_pixels_and_counts_launches():
     assert not torch.equal(outs[0]['coord'], outs[1]['coord'])
     assert bool(torch.isfinite(total))
     model.defer_projection = model.defer_heads = False
+
+
+def test_channels_last_is_refused_with_the_encoder_runtime():
+    """--channels_last / HCMOCO_CHANNELS_LAST=1 was an r01 experiment for stock ATen encoders; the encoder runtime and the
+    section kernels are NCHW, so the trainer says so instead of failing inside the first convolution."""
+    import tempfile
+    import bench
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    args = bench.make_args(4, 512, 1024, 64, 'coco17', 'nccl', tempfile.mkdtemp(), 2)
+    args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, True
+    tr = ContrastTrainer(args)
+    tr.device = dev()
+    with pytest.raises(ValueError, match='channels_last needs the stock ATen encoders'):
+        bench.build(args, tr, dev())
