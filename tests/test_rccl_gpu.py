@@ -4,6 +4,8 @@ bank ``broadcast``s, the model broadcast, and the chunked in-place ``all_reduce`
 flat gradient buffers that learning/grad_sync.py launches while the reverse loops are still being
 issued.  With one rank every collective is the identity, so two training steps must reproduce the
 run that has no process group at all.  (Reference: learning/contrast_trainer.py:74, 81-91, 160-165.)
+Default mode: compared statistically where whole steps are involved; the bit-exact form of the same comparison
+(deterministic mode, bench shape) is tests/test_exact_gpu.py.
 """
 import os
 import sys

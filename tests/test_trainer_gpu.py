@@ -1,6 +1,9 @@
 """ContrastTrainer on the GPU: the default runtime (encoder programs, three streams, deferred backward on
 helper threads, quiet first step) against the plain one (module-by-module, one stream, everything issued
-inline by autograd) from the same seed: same losses, same first parameter update (by direction), same banks after two SGD steps."""
+inline by autograd) from the same seed: same losses, same first parameter update (by direction), same banks after two SGD steps.
+These are the DEFAULT-mode comparisons (MIOpen's atomic weight-gradient kernels make a whole step non-reproducible there,
+so they are statistical); their exact counterparts -- bit-identical runs in deterministic mode at the bench shape -- are
+tests/test_exact_gpu.py."""
 import os
 import sys
 import tempfile
