@@ -959,23 +959,37 @@ class _Stage2Section(torch.autograd.Function):
         # ---- heads (and the packed all-gather row when there are other ranks to tell)
         pooled, mean3, ypre, f, fT = heads_forward(maps1, maps2, feat3c, W1, b1, W2, b2, W3, b3,
                                                    index if gather is not None else None)
+        pending = None
         if gather is not None:
-            allp = gather(f)                                              # [B*W, 3F+2], rank-major
+            # the one collective of the forward pass: started here, waited for where its result is first needed -- the
+            # bank update, which only has to come after the NCE pass has read the rows.  Nothing in between depends on
+            # the other ranks, so a rank that arrives late costs the others nothing until then.
+            allp, pending = gather(f)                                     # [B*W, 3F+2], rank-major
+            if pending is not None and (tape is not None or os.environ.get('HCM_SYNC_GATHER', '0') != '0'):
+                pending.wait()
+                pending = None
             all_x = [allp[:, i * F:(i + 1) * F] for i in range(3)]
-            all_index = allp[:, 3 * F:].contiguous().view(torch.int64).view(-1)
+            all_index_of = lambda: allp[:, 3 * F:].contiguous().view(torch.int64).view(-1)
             ldx = allp.shape[1]
         else:
-            all_x, all_index, ldx = [fT[0], fT[1], fT[2]], index, F
+            all_x, ldx = [fT[0], fT[1], fT[2]], F
+            all_index_of = lambda: index
         # ---- rows 1-4: negatives, fused bank NCE (gx = d sum(losses) / d fT), momentum update after the reads
         ud, ur = _i32(cfg.get('use_depth')), _i32(cfg.get('use_rgb'))
         idx = cfg.get('idx')
         idx = mem.draw(index) if idx is None else mem._in_range(idx).contiguous()
         if tape is not None:
             tape.update(banks0=[b.detach().clone() for b in mem.banks()], idx=idx, f=f[:, :3 * F], fT=fT,
-                        all_x=[a.detach().clone() for a in all_x], all_index=all_index)
+                        all_x=[a.detach().clone() for a in all_x], all_index=all_index_of())
         losses, accs, gxT = bank_nce_fused_raw(mem.banks(), idx, [fT[0], fT[1], fT[2]], mem.T, ud,
                                                ur if cfg.get('bank_use_rgb') else None, stacked=True)
-        mem.update_strided(all_x, ldx, all_index)
+
+        def update_banks():
+            if pending is not None:
+                pending.wait()
+            mem.update_strided(all_x, ldx, all_index_of())
+        if pending is None:
+            update_banks()
         meters = None
         ctx.stage2 = bool(cfg.get('stage2', True))
         if ctx.stage2:
@@ -1002,6 +1016,8 @@ class _Stage2Section(torch.autograd.Function):
             ctx.S = S
         else:
             ctx.save_for_backward(pooled, mean3, ypre, W1, W2, W3, gxT)
+        if pending is not None:
+            update_banks()
         ctx.J = J
         ctx.shapes = [tuple(m.shape) for m in maps1]
         total = torch.empty((), dtype=torch.float32, device=losses.device)

@@ -207,11 +207,12 @@ class ContrastTrainer(BaseTrainer):
 
     @staticmethod
     def _gather_rows(packed):
-        """[B, 3F+2] packed rows (written by the heads kernel) -> [B*W, 3F+2], rank-major: the one collective."""
+        """[B, 3F+2] packed rows (written by the heads kernel) -> ([B*W, 3F+2] rank-major, work handle): the one
+        collective of the forward pass, asynchronous -- the caller waits where it first reads the result."""
         out = torch.empty(dist.get_world_size() * packed.shape[0], packed.shape[1], dtype=packed.dtype,
                           device=packed.device)
-        dist.all_gather_into_tensor(out, packed.contiguous())
-        return out
+        work = dist.all_gather_into_tensor(out, packed.contiguous(), async_op=True)
+        return out, work
 
     def _packed_gather(self, f, index):
         """One collective per step; rank-major row order (it defines the duplicate-update winner)."""
