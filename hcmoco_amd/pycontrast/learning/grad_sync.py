@@ -32,6 +32,7 @@ Not synchronised, unlike DDP's default ``broadcast_buffers=True``: BatchNorm run
 per-replica.  They never enter a training-mode forward, and rank 0 writes the checkpoint from its
 own buffers in both implementations, so checkpoints agree with the reference's.
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -80,14 +81,31 @@ class GradSync(object):
         self._flat = {}
         self._presence = {}          # bucket key -> (local pattern, agreed pattern): see _present
         self._comm = None
+        # several chunks in one RCCL launch (nccl only: gloo's coalescing manager has no all-reduce fast path)
+        self.coalesce = self.avg and os.environ.get('HCM_GRAD_COALESCE', '1') != '0'
         self.launched = 0            # collectives launched by the last reduce() (tests / bench read it)
 
     # ------------------------------------------------------------------ helpers
     def _launch(self, t):
         self.launched += 1
         if self.avg:
-            return t, dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
-        return t, dist.all_reduce(t, async_op=True)
+            return [t], dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
+        return [t], dist.all_reduce(t, async_op=True)
+
+    def _launch_group(self, pieces):
+        """The k-th chunks of all encoders as ONE RCCL launch (ncclGroupStart ... ncclGroupEnd through torch's
+        coalescing manager): the two encoders walk their reverse loops at the same pace, so their k-th chunks are ready
+        together, and a collective costs ~0.15 ms of launch and stream hand-over whatever its size."""
+        if len(pieces) == 1 or not self.coalesce:
+            return [self._launch(t) for t in pieces]
+        self.launched += 1
+        with dist._coalescing_manager(device=pieces[0].device, async_ops=True) as cm:
+            for t in pieces:
+                if self.avg:
+                    dist.all_reduce(t, op=dist.ReduceOp.AVG)
+                else:
+                    dist.all_reduce(t)
+        return [(list(pieces), cm)]
 
     def _present(self, key, group):
         """Which parameters of ``group`` received a gradient on SOME rank.  A parameter that no rank used (stage 1
@@ -145,12 +163,9 @@ class GradSync(object):
                     live.append((enc, n))
             # chunk-major: chunk k of every encoder before chunk k+1 of any (= completion order)
             for k in range(max([n for _, n in live] or [0])):
-                for enc, n in live:
-                    if k >= n:
-                        continue
-                    with torch.cuda.stream(self._comm):
-                        piece = self.glue.grad_chunk_wait(enc.grad_tag, k)
-                        works.append(self._launch(piece))
+                with torch.cuda.stream(self._comm):
+                    pieces = [self.glue.grad_chunk_wait(enc.grad_tag, k) for enc, n in live if k < n]
+                    works.extend(self._launch_group(pieces))
             for enc, _ in live:
                 handled.update(id(p) for p in enc.last_program.params)
         if join is not None:
@@ -166,8 +181,9 @@ class GradSync(object):
                 flat = self._bucket(key, g)
                 if flat is not None:
                     works.append(self._launch(flat))
-        for t, w in works:
+        for ts, w in works:
             w.wait()                 # RCCL: orders the current stream behind the collective, no host block
             if not self.avg:
-                t.div_(self.world)
+                for t in ts:
+                    t.div_(self.world)
         return self.launched

@@ -7,7 +7,7 @@ on three streams, helper-thread backward, fused loss section, SGD -- is a pure f
   * two runs of the default runtime from the same seed: every parameter, every bank row, every loss bit-identical
     after three steps;
   * the same under a 1-rank nccl group with every collective of the N > 1 path forced on (RCCL all-gather, 9 in-place
-    all-reduces per step, broadcasts): bit-identical to the run without a process group -- the comparison r02 could
+    all-reduces per step in 5 launches, broadcasts): bit-identical to the run without a process group -- the comparison r02 could
     only make statistically (cosine >= 0.9);
   * the default runtime against plain autograd (module-by-module, one stream): both are reproducible but sum in
     different orders (batch-norm statistics from the convolution epilogue, gradient pairs added inside the
@@ -94,10 +94,10 @@ def test_default_runtime_is_bit_reproducible(default_run):
 
 def test_one_rank_rccl_group_is_bit_identical_to_no_group(default_run):
     """Every collective of the N > 1 path on RCCL (packed all-gather written by the heads kernel, 4 + 4 + 1 in-place
-    all-reduces launched while the reverse loops still run, the broadcasts) is the identity with one rank: the run
+    all-reduces (as 4 coalesced pairs + 1) launched while the reverse loops still run, the broadcasts) is the identity with one rank: the run
     must reproduce the run without a process group BIT FOR BIT."""
     got = _run('rccl1')
-    assert got[4] == 9, got[4]
+    assert got[4] == 5, got[4]          # 4 coalesced chunk pairs + the rest bucket
     _assert_identical(default_run, got)
 
 

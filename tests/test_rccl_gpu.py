@@ -125,18 +125,20 @@ def test_every_collective_is_the_identity_in_a_one_rank_group():
     info = got[3]
     assert info['not_identity'] == [], info['not_identity'][:10]
     assert info['storages'] == [1, 1] and info['storage_numel'] == info['numel'], info
-    assert info['launched'] == [2 * CHUNKS + 1] * len(info['launched']), info    # 4 chunks x 2 HRNets + the rest
+    # 4 chunk PAIRS (the k-th chunks of the two HRNets go out as one RCCL launch) + the rest bucket
+    assert info['launched'] == [CHUNKS + 1] * len(info['launched']), info
 
 
 def test_overlapped_rccl_allreduce_one_rank_group(baseline):
     """The real schedule: all-reduces launched while the reverse loops are still being issued."""
     got = _run('overlap')
     info = got[3]
-    # per step: CHUNKS in-place all-reduces per HRNet + one per remaining top-level module group; the
-    # first step (quiet Find, everything inline) takes the same route
+    # per step: CHUNKS in-place all-reduces per HRNet, the two encoders' k-th chunks coalesced into one launch, + one for
+    # the remaining parameters; the first step (quiet Find, everything inline) takes the same route
     assert info['storages'] == [1, 1], info                    # one flat buffer per encoder ...
     assert info['storage_numel'] == info['numel'], info        # ... and it is dense (nothing but gradients)
-    assert info['launched'] == [2 * CHUNKS + 1] * len(info['launched']), info    # 4 chunks x 2 HRNets + the rest
+    # 4 chunk PAIRS (the k-th chunks of the two HRNets go out as one RCCL launch) + the rest bucket
+    assert info['launched'] == [CHUNKS + 1] * len(info['launched']), info
     _same(got, baseline)
 
 
@@ -204,7 +206,7 @@ def test_two_ranks_on_one_gpu_stay_bit_identical(mode, tmp_path):
     assert not torch.equal(r0['index'], r1['index'])                       # the ranks did train on different samples
     assert r0['loss'] == r0['loss'] and r0['loss'] != r1['loss']
     if mode == 'overlap':
-        assert r0['launched'] == [2 * 4 + 1] * 3, r0['launched']
+        assert r0['launched'] == [2 * 4 + 1] * 3, r0['launched']         # gloo: no coalescing, 4 chunks x 2 HRNets + the rest
     else:
         assert r0['launched'] == [1, 1, 1]
 
