@@ -56,10 +56,12 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         #                (3.5 ms per step, one CU) run underneath the HRNets instead of in line;
         #   2            encoder2 on a second side stream (small HRNet kernels overlap; when it runs as a
         #                compiled program its forward is issued by that stream's C++ helper thread);
-        #                default 3 = 1|2.  (Issuing encoder2 from a PYTHON helper thread was measured
-        #                slower -- the GIL -- and is gone.)
+        #                (Issuing encoder2 from a PYTHON helper thread was measured slower -- the GIL -- and is gone.)
+        # Default 2 since r03: the SemGCN layers are batch-parallel kernels now (0.6 ms per step, r02) and run on the
+        # caller's stream right behind encoder1, underneath encoder2's tail; a stream of their own is one more active
+        # stream for four hardware queues to share (697-699 -> 699-702 samples/s, alternating runs on one box).
         # Backward follows automatically: autograd replays every node on its forward stream.
-        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '3'))
+        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '2'))
         self._side_streams = {}
         # torch.bfloat16: the two HRNets run under bf16 autocast (module path: stock MIOpen bf16 convolutions, batch
         # norm with fp32 statistics and parameters); their maps come back as fp32.  Set by the trainer from
@@ -242,16 +244,21 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             # the point-cloud branch (back-projection, PointNet++) and the SemGCN on side HIP streams,
             # the HRNet on the caller's: same placement rule as CMC3HRNetSGCNSingleHead._encode
             main = torch.cuda.current_stream(x.device)
-            side_pn, side_g = self._side(1, x.device), self._side(0, x.device)
+            side_pn = self._side(1, x.device)
+            side_g = self._side(0, x.device) if self.two_streams & 1 else None
             side_pn.wait_stream(main)
-            side_g.wait_stream(main)
-            with torch.cuda.stream(side_g):
-                _feat3 = self.encoder3(s)
+            if side_g is not None:
+                side_g.wait_stream(main)
+                with torch.cuda.stream(side_g):
+                    _feat3 = self.encoder3(s)
             with torch.cuda.stream(side_pn):
                 sample_pn, full_pn, _feat2 = cloud_branch()
             _feat1 = self.encoder1(x1)
+            if side_g is None:
+                _feat3 = self.encoder3(s)          # behind the HRNet on the caller's stream (see CMC3HRNetSGCNSingleHead)
             main.wait_stream(side_pn)
-            main.wait_stream(side_g)
+            if side_g is not None:
+                main.wait_stream(side_g)
             for t in (sample_pn, full_pn, _feat2, _feat3):
                 t.record_stream(main)
         else:
