@@ -12,12 +12,13 @@ rows.sort()
 marks = [i for i, r in enumerate(rows) if 'bank_pass_' in r[2]]
 m = marks[-2]
 # walk back to the last encoder-forward kernel (bn_apply / conv / winograd) before the marker, forward to the first bn_bwd
-enc_fwd = ('bn_apply_kernel', 'bn_small_fwd', 'conv3x3_mfma', 'miopenSp3AsmConv', 'bn_stats_kernel', 'upsample_bilinear_kernel')
+enc_fwd = ('bn_apply_kernel', 'bn_small_fwd', 'conv3x3_mfma', 'miopenSp3AsmConv', 'bn_stats_kernel', 'upsample_bilinear_kernel',
+           'sgc_mix_kernel', 'sgc_norm_kernel')        # (the SemGCN is the third encoder; since r03 it runs on the caller's stream)
 lo = m
 while lo > 0 and not any(k in rows[lo][2] for k in enc_fwd):
     lo -= 1
 hi = m
-while hi < len(rows) and 'bn_bwd' not in rows[hi][2] and 'bn_small_bwd' not in rows[hi][2]:
+while hi < len(rows) and 'bn_bwd' not in rows[hi][2] and 'bn_small_bwd' not in rows[hi][2] and 'sgc_bwd' not in rows[hi][2]:
     hi += 1
 t0 = rows[lo][1]
 print('loss section: %d launches, %.3f ms from the end of the last encoder forward kernel to the first encoder backward kernel'
