@@ -192,6 +192,7 @@ def self_launch(n):
     import subprocess
     env = dict(os.environ)
     env.setdefault('OMP_NUM_THREADS', '8')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs between the ranks' processes here
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
@@ -256,6 +257,8 @@ def main():
         raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the HIP runtime comes up (first device call)
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'

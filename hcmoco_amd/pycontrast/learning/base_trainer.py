@@ -38,6 +38,8 @@ class BaseTrainer(object):
             rank, world, local = 0, 1, 0
         env.setdefault('MASTER_ADDR', '127.0.0.1')
         env.setdefault('MASTER_PORT', '23456')
+        if world > 1:
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC between the ranks' processes (RCCL)
 
         backend = args.dist_backend
         use_gpu = torch.cuda.is_available() and backend != 'gloo'
