@@ -352,3 +352,26 @@ def test_channels_last_is_refused_with_the_encoder_runtime():
     tr.device = dev()
     with pytest.raises(ValueError, match='channels_last needs the stock ATen encoders'):
         bench.build(args, tr, dev())
+
+
+def test_ranks_bind_to_the_cores_of_their_gpus_numa_node():
+    """learning/affinity.py on the real box: the GPU's PCI address resolves to a NUMA node and a cpu list in sysfs; binding
+    leaves the process on a non-empty subset of that list (restored afterwards), HCM_PIN_NUMA=0 leaves it alone."""
+    import os
+    from hcmoco_amd.pycontrast.learning import affinity
+    info = affinity.gpu_node(0)
+    if info is None:
+        pytest.skip('no NUMA information for this device in sysfs')
+    node, cpus = info
+    assert node >= 0 and len(cpus) > 0
+    before = os.sched_getaffinity(0)
+    try:
+        assert affinity.pin_to_gpu_node(0, mode='0') is None and os.sched_getaffinity(0) == before
+        got = affinity.pin_to_gpu_node(0, mode='node')
+        assert got is not None and got[0] == node
+        now = os.sched_getaffinity(0)
+        assert now and now <= set(cpus) and now <= before
+        share = affinity.pin_to_gpu_node(0, mode='share')          # one visible GPU: the whole node again
+        assert share is not None and set(share[1]) <= set(cpus)
+    finally:
+        os.sched_setaffinity(0, before)
