@@ -442,7 +442,9 @@ __global__ __launch_bounds__(kWG) void branch_grad_kernel(
   const int cblk = wg / ntile, tile = wg - cblk * ntile;
   const int c0 = cblk * kCB, nc = min(kCB, C - c0);
   const int PT = hw < kWG ? hw : kWG;               // pixels per tile
-  const int nsub = kWG / PT;                        // channel subgroups sharing a pixel
+  const int nsub = kWG / PT;                        // channel subgroups sharing a pixel; when PT does not divide the
+                                                    // workgroup (10 x 10 maps of a 320 x 320 crop) the last
+                                                    // kWG - nsub * PT threads have no (pixel, subgroup) and idle in (5)
   const int q0 = tile * PT;
   // LDS carve (ints): stencil pixels [4R] (later: the per-pixel entry lists), stencil weights [4R], row list [R],
   // contribution keys [4R], contribution targets [4R bytes, 16-byte aligned], rows [R][kCB]
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(kWG) void branch_grad_kernel(
   // batch is a contiguous piece of it): 18 KB of LDS for the rows instead of R x 36 floats, four workgroups per CU
   const int px_ = tid % PT, sub = tid / PT;
   const int q = q0 + px_;
-  const bool live = q < hw;
+  const bool live = q < hw && sub < nsub;
   float acc[kCB];
 #pragma unroll
   for (int k = 0; k < kCB; ++k) acc[k] = 0.f;
@@ -726,7 +728,6 @@ int hcm_branch_grad(const float* dxs, const float* dpooled, const float* scale, 
   for (int i = 0; i < 4; ++i) {
     if (g1.C[i] != g2.C[i] || g1.H[i] != g2.H[i] || g1.W[i] != g2.W[i]) return (int)hipErrorInvalidValue;
     const int hw = g1.H[i] * g1.W[i];
-    if (hw < kWG && (kWG % hw) != 0) return (int)hipErrorInvalidValue;      // small maps: a power-of-two pixel count
     plan.ntile[i] = (hw + kWG - 1) / kWG;
     plan.first[i] = v;
     v += plan.ntile[i] * ((g1.C[i] + kCB - 1) / kCB);

@@ -79,7 +79,10 @@ class GradSync(object):
                 groups.append(stray)
             self.groups = [g for g in groups if g]
         self._flat = {}
-        self._presence = {}          # bucket key -> (local pattern, agreed pattern): see _present
+        self._presence = {}          # bucket key -> agreed pattern (union over the ranks): see _present
+        self._changed = False        # this rank saw a gradient outside an agreed pattern during this reduce()
+        self._flag_host = self._flag_event = None
+        self.agreements = 0          # presence all-reduces issued so far (tests read it)
         self._comm = None
         # several chunks in one RCCL launch (nccl only: gloo's coalescing manager has no all-reduce fast path)
         self.coalesce = self.avg and os.environ.get('HCM_GRAD_COALESCE', '1') != '0'
@@ -111,16 +114,39 @@ class GradSync(object):
         """Which parameters of ``group`` received a gradient on SOME rank.  A parameter that no rank used (stage 1
         with ``--linear_feat_map 1``: the two 1x1 projections) must keep ``.grad = None`` -- SGD then skips it, as it
         does with one GPU and as DistributedDataParallel does for globally unused parameters; averaging zeros into it
-        would hand it weight decay and momentum that the single-GPU run never applies.  The pattern is
-        a property of the graph, identical on every rank and from step to step, so it is agreed on ONCE per local
-        pattern (a MAX all-reduce of the presence flags + one host read, first step only) and cached."""
+        would hand it weight decay and momentum that the single-GPU run never applies.
+
+        Every collective here is entered by ALL ranks or by none (the r03 version re-agreed whenever the
+        LOCAL pattern changed, i.e. one rank alone could issue the MAX all-reduce while its peers were already in the
+        bucket average).  The agreed pattern is the union over the ranks and is decided (a) at the first step, when
+        every rank's cache is empty, and (b) again when the ``changed`` flag that every step's last bucket carries
+        came back non-zero -- a reduced value, hence the same decision on every rank.  In between, a rank whose local
+        pattern shrinks contributes zeros (no collective needed), and a rank that suddenly has a gradient OUTSIDE the
+        union raises the flag: that one gradient is dropped on that step (``.grad = None``, so no replica applies a
+        local-only update) and the union grows on the next."""
         local = tuple(p.grad is not None for p in group)
         cached = self._presence.get(key)
-        if cached is None or cached[0] != local:
+        if cached is None:
             flags = torch.tensor([1.0 if v else 0.0 for v in local], dtype=torch.float32, device=group[0].device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX)
-            cached = self._presence[key] = (local, tuple(bool(v) for v in (flags > 0).tolist()))
-        return cached[1]
+            self.agreements += 1
+            cached = self._presence[key] = tuple(bool(v) for v in (flags > 0).tolist())
+        for p, mine, ok in zip(group, local, cached):
+            if mine and not ok:
+                self._changed = True
+                p.grad = None
+        return cached
+
+    def _poll_changed(self):
+        """The ``changed`` flag of the PREVIOUS step (reduced with that step's last bucket, copied to the host without
+        blocking): non-zero on every rank or on none.  Non-zero -> forget the agreed patterns, so that this step's
+        ``_present`` calls re-agree, on every rank alike."""
+        if self._flag_event is not None:
+            self._flag_event.synchronize()
+            self._flag_event = None
+        if self._flag_host is not None and float(self._flag_host[0]) > 0:
+            self._presence.clear()
+        self._flag_host = None
 
     def _bucket(self, key, group):
         """Copy the group's gradients into its persistent flat buffer and re-bind ``.grad`` to views of it; returns
@@ -134,12 +160,13 @@ class GradSync(object):
         key = (key, present)
         n = sum(p.numel() for p in group)
         flat = self._flat.get(key)
-        if flat is None or flat.numel() != n or flat.device != group[0].device:
-            flat = self._flat[key] = torch.zeros(n, dtype=group[0].dtype, device=group[0].device)
-        views = [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in group]), group)]
+        if flat is None or flat.numel() != n + 1 or flat.device != group[0].device:
+            # one slot more than the gradients: the step's ``changed`` flag rides in the last bucket (see _present)
+            flat = self._flat[key] = torch.zeros(n + 1, dtype=group[0].dtype, device=group[0].device)
+        views = [v.view_as(p) for v, p in zip(flat[:n].split([p.numel() for p in group]), group)]
         have = [(v, p.grad) for v, p in zip(views, group) if p.grad is not None]
         if len(have) != len(group):
-            flat.zero_()
+            flat[:n].zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for p, v in zip(group, views):
@@ -151,6 +178,8 @@ class GradSync(object):
         """Call right after ``loss.backward()``.  ``join``: callable that blocks until every deferred
         gradient is in its stream and orders the current stream behind them (``wgrad_join``)."""
         self.launched = 0
+        self._poll_changed()
+        self._changed = False
         works, handled = [], set()
         if self.encoders:
             dev = self.params[0].device
@@ -181,14 +210,32 @@ class GradSync(object):
             groups = {'rest': [p for p in self.params if id(p) not in handled]}
         else:
             groups = dict(enumerate(self.groups))
+        flats = []
         for key, g in groups.items():
             if g:
                 flat = self._bucket(key, g)
                 if flat is not None:
-                    works.append(self._launch(flat))
+                    flats.append(flat)
+        if not flats:            # nothing has a gradient anywhere: the flag still has to travel
+            flat = self._flat.get('flag')
+            if flat is None:
+                flat = self._flat['flag'] = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
+            flats.append(flat)
+        carrier = flats[-1]
+        carrier[-1:].fill_(1.0 if self._changed else 0.0)     # MAX-like under AVG / SUM: non-zero iff some rank raised it
+        for flat in flats:
+            works.append(self._launch(flat))
         for ts, w in works:
             w.wait()                 # RCCL: orders the current stream behind the collective, no host block
             if not self.avg:
                 for t in ts:
                     t.div_(self.world)
+        # the reduced flag goes to the host without a sync; it is read at the top of the next reduce()
+        if carrier.is_cuda:
+            self._flag_host = torch.empty(1, dtype=carrier.dtype, pin_memory=True)
+            self._flag_host.copy_(carrier[-1:], non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
+        else:
+            self._flag_host = carrier[-1:].clone()
         return self.launched

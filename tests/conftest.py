@@ -22,6 +22,23 @@ def pytest_configure(config):
         pointnet2_oracle.build()
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _scratch_dir():
+    """Every ``tempfile.mkdtemp()`` of the suite (model / tensorboard folders: a stage-2 checkpoint is 150-450 MB) lands
+    under ONE directory that is removed when the session ends; the tests used to leave them in /tmp, which filled the
+    build container's disk over three rounds."""
+    import shutil
+    import tempfile
+    base = tempfile.mkdtemp(prefix='hcmoco_tests_')
+    old = tempfile.tempdir
+    tempfile.tempdir = base
+    try:
+        yield base
+    finally:
+        tempfile.tempdir = old
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def load_golden(name):
     import torch
     z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)

@@ -238,6 +238,65 @@ def test_globally_unused_parameters_keep_no_gradient_with_two_ranks(mode):
         assert torch.equal(a, b.detach())
 
 
+ASYM_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from hcmoco_amd.pycontrast.learning.grad_sync import GradSync
+dist.init_process_group('gloo')
+rank = dist.get_rank()
+torch.manual_seed(0)
+net = torch.nn.ModuleDict({'a': torch.nn.Linear(4, 3), 'b': torch.nn.Linear(4, 3), 'c': torch.nn.Linear(4, 3)})
+params = list(net.parameters())
+gs = GradSync(net, params, mode=%r)
+x = torch.ones(2, 4) * (rank + 1)
+# step: which branches each rank runs.  'c' is used by nobody at first, then by rank 1 ALONE (step 2), then by both;
+# 'b' is dropped by rank 0 alone in step 1 (a shrinking local pattern: zeros, no collective)
+plan = [({'a', 'b'}, {'a', 'b'}), ({'a'}, {'a', 'b'}), ({'a', 'b'}, {'a', 'b', 'c'}), ({'a', 'b', 'c'}, {'a', 'b', 'c'}),
+        ({'a', 'b', 'c'}, {'a', 'b', 'c'})]
+log = []
+for step, use in enumerate(plan):
+    for p in params:
+        p.grad = None
+    sum(net[k](x).sum() for k in sorted(use[rank])).backward()
+    gs.reduce()
+    log.append({'agreements': gs.agreements, 'launched': gs.launched,
+                'grads': [None if p.grad is None else p.grad.clone() for p in params]})
+torch.save(log, os.path.join(%r, 'rank%%d.pt' %% rank))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('mode', ['flat', 'overlap'])
+def test_a_rank_whose_gradient_pattern_changes_alone_never_issues_a_collective_alone(mode):
+    """ADVICE r03 (learning/grad_sync.py:_present): the presence all-reduce used to be gated on the LOCAL pattern, so
+    a rank whose pattern changed alone entered a MAX all-reduce while its peer was in the bucket average (hang or
+    silent corruption).  Now: the union is agreed at step 0 (every rank), a shrinking local pattern contributes zeros,
+    a gradient outside the union is dropped for that step on the rank that has it, raises a flag that rides in the
+    step's last bucket, and every rank re-agrees at the next step.  Two gloo ranks finish, count the same collectives,
+    and hold identical gradients after every step.  Reference: DistributedDataParallel, contrast_trainer.py:74."""
+    out = tempfile.mkdtemp()
+    script = os.path.join(out, 'worker.py')
+    with open(script, 'w') as f:
+        f.write(ASYM_WORKER % (ROOT, mode, out))
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(free_port()), script],
+                         capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS='2'), timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    r0, r1 = (torch.load(os.path.join(out, 'rank%d.pt' % r)) for r in (0, 1))
+    for a, b in zip(r0, r1):
+        assert a['agreements'] == b['agreements'] and a['launched'] == b['launched']
+        for ga, gb in zip(a['grads'], b['grads']):
+            assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb))
+    # params: a.w a.b b.w b.b c.w c.b ; x = 1 on rank 0, 2 on rank 1 -> d/dW = sum over the batch of x
+    g = lambda step, i: r0[step]['grads'][i]
+    assert g(0, 4) is None and torch.allclose(g(0, 0), torch.full((3, 4), 3.0))          # (2*1 + 2*2) / 2
+    assert torch.allclose(g(1, 2), torch.full((3, 4), 2.0))                               # rank 0 sent zeros for b
+    assert g(2, 4) is None                                  # rank 1's lone gradient for c: dropped, flag raised
+    assert torch.allclose(g(3, 4), torch.full((3, 4), 3.0))  # union re-agreed by both ranks
+    n = [r['agreements'] for r in r0]
+    assert n[0] == n[1] == n[2] and n[3] > n[2] and n[4] == n[3]
+
+
 def test_pretrain_handoff_stage1_to_stage2(capsys):
     """--pretrain strips the 7-char 'module.' prefix, loads matching keys, reports the rest and
     restores all three banks (main_contrast.py:52-67 of the reference)."""

@@ -128,7 +128,12 @@ def _project_full(maps, W, b):
     return F.conv2d(torch.cat(up, 1), W, b)
 
 
-@pytest.mark.parametrize('B,width,size,R', [(3, 18, 16, 37), (2, 32, 8, 20), (32, 18, 64, 417)])
+@pytest.mark.parametrize('B,width,size,R', [(3, 18, 16, 37), (2, 32, 8, 20), (32, 18, 64, 417),
+                                            # finest maps of 224 / 288 / 320 / 384 crops: the coarsest branch has 49 / 81 /
+                                            # 100 / 144 pixels (no divisor of the 256-thread workgroup), the 320 crop's third
+                                            # one 400 (a partial second tile); datasets/dataset.py:475 trains at 320
+                                            (2, 18, 56, 60), (2, 18, 72, 417), (3, 18, 80, 416), (2, 32, 80, 417),
+                                            (2, 18, 96, 100), (1, 18, 40, 33), (1, 18, 24, 9)])
 def test_sampled_merge_projection_and_its_backward_against_torch(B, width, size, R):
     """merge_all_res + 1x1 conv (build_backbone.py:243-254) restricted to sampled pixels == gathering the full
     projected map; backward (branch_grad) == torch autograd of that flow plus the average-pool gradient."""
@@ -229,15 +234,15 @@ def _build(width=18, B=4, size=64, K=256, n=1024, J=17):
     return model, mem, data.pool[0]
 
 
-@pytest.mark.parametrize('stage2', [True, False])
-def test_fused_section_equals_the_module_path(stage2):
+@pytest.mark.parametrize('stage2,size', [(True, 64), (False, 64), (True, 160), (False, 160), (True, 224)])
+def test_fused_section_equals_the_module_path(stage2, size):
     """One autograd node (heads + bank + sampling + projection + three losses) against the module-by-module path it
     replaces (the model's own pooling / Linear / Normalize modules in torch, engine.bank, engine.fmap_sampled) on the
     SAME branch maps, negatives and pixels (the encoders run once: MIOpen may pick another algorithm on a second
     run, which moves the maps by 1e-6): f and losses to 1e-5, every gradient to 1e-4 relative L2; and the node is
     bit-identical run to run."""
     from hcmoco_amd.pycontrast.learning.engine import HipLossEngine
-    model, mem, batch = _build()
+    model, mem, batch = _build(size=size)           # 160 / 224 crops: coarsest maps of 25 / 49 pixels (5^2, 7^2)
     x, index, skel, j2d, vis, ud, mask = batch[0], batch[1], batch[2], batch[4], batch[5], batch[6], batch[7]
     eng = HipLossEngine()
     S, temp = 50, 0.07

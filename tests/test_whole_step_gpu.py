@@ -31,6 +31,13 @@ CONFIGS = {
     'config3_per_gpu_half_K65536': ('HRNet', 18, 32, 256, 65536, 'fp32', 'fp32', 'coco17'),
     'config4_hrnetpn_w32': ('HRNetPN', 32, 32, 256, 16384, 'fp32', 'fp32', 'coco17'),
     'config5_bf16_K131072': ('HRNet', 18, 32, 256, 131072, 'bf16', 'bf16', 'coco17'),
+    # the reference's recipe of record (scripts/SecondStage/train_ntumpiirgbd2s_hrnet_w18.sh:8-46: global batch 224 on
+    # 4 GPUs = 56 per GPU, K = 16384, MPII 16 joints; datasets/dataset.py:475 size=320): HRNet maps 80^2 40^2 20^2 10^2
+    'recipe_320_b56_mpii16': ('HRNet', 18, 56, 320, 16384, 'fp32', 'fp32', 'mpii'),
+    # HRNetPN at 320^2: pts2depth interpolates n = 102 400 pixels from 4096 points (build_backbone.py:448-455)
+    'recipe_320_hrnetpn_w32': ('HRNetPN', 32, 32, 320, 16384, 'fp32', 'fp32', 'coco17'),
+    # first stage (scripts/FirstStage/train_ntumpiirgbd2s_hrnet_w18.sh) at the same crop and per-GPU batch
+    'recipe_320_b56_stage1': ('HRNet', 18, 56, 320, 16384, 'fp32', 'fp32', 'mpii', 1),
 }
 
 
@@ -41,7 +48,8 @@ def test_one_step_at_the_configs_own_size_against_the_oracle(name):
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
     from hcmoco_amd.pycontrast.learning.engine import RecordingEngine
     from oracle.check_step import check_records
-    arch, width, B, size, K, bank_dtype, fmap_dtype, skeleton = CONFIGS[name]
+    arch, width, B, size, K, bank_dtype, fmap_dtype, skeleton = CONFIGS[name][:8]
+    stage2 = len(CONFIGS[name]) == 8
     dev = torch.device('cuda:0')
     args = bench.make_args(B, K, 131072, size, skeleton, 'nccl', tempfile.mkdtemp(), 2, arch=arch, width=width,
                            bank_dtype=bank_dtype, fmap_dtype=fmap_dtype)
@@ -53,12 +61,20 @@ def test_one_step_at_the_configs_own_size_against_the_oracle(name):
         model, contrast, opt, data = bench.build(args, tr, dev)
         it = iter(data)
         eng.armed = False
-        tr.train_step(next(it), model, contrast, opt, True)      # quiet-Find step (one stream, nothing deferred)
+        tr.train_step(next(it), model, contrast, opt, stage2)    # quiet-Find step (one stream, nothing deferred)
         eng.armed = True
-        out = tr.train_step(next(it), model, contrast, opt, True)     # the DEFAULT runtime: this is the step checked
+        out = tr.train_step(next(it), model, contrast, opt, stage2)   # the DEFAULT runtime: this is the step checked
         torch.cuda.synchronize()
         assert bool(torch.isfinite(out['loss']))
         kinds = [r['kind'] for r in eng.records]
+        if not stage2:                       # stage 1 (contrast_trainer.py:532-640): heads in the model, bank NCE only
+            assert kinds == ['bank'], kinds
+            bank = eng.records[0]
+            assert bank['idx'].shape == (B, K + 1) and bank['x'][0].shape == (B, 128)
+            rep = check_records(eng.records)
+            print(name, rep)
+            assert abs(float(out['loss']) - float(bank['total'])) <= 1e-4 * abs(float(out['loss']))
+            return
         if arch == 'HRNetPN':                # module path: heads inside the model, bank and feature-map calls apart
             assert kinds == ['bank', 'fmap'], kinds
             bank, fm = eng.records
