@@ -317,6 +317,17 @@ def main():
             recorder.records = []
     for _ in range(a.warmup):
         trainer.train_step(next(it), model, contrast, opt, stage2=True)
+    ranks_seen = None
+    if dist.is_initialized():
+        # the first multi-GPU run must be able to say WHY it scales as it does: exposed communication per step from HIP
+        # events around the two places where the trainer's stream waits for a collective, and the number of ranks that
+        # actually answered a sum
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        if trainer.grad_sync is not None:
+            trainer.grad_sync.wait_events = []
+        hip_ops.GATHER_WAIT_EVENTS = []
     hip_ops.prof_enable(True)
     if world > 1:
         dist.barrier()
@@ -333,6 +344,21 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
+    comm = None
+    if dist.is_initialized():
+        ar = trainer.grad_sync.wait_events if trainer.grad_sync is not None else []
+        ag = hip_ops.GATHER_WAIT_EVENTS or []
+        mean_ms = lambda evs: round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs), 4) if evs else None
+        comm = {'allreduce_exposed_ms': mean_ms(ar), 'allgather_wait_ms': mean_ms(ag),
+                'launches': trainer.grad_sync.launched if trainer.grad_sync is not None else 0,
+                'ranks_seen': ranks_seen, 'world_size': world, 'backend': dist.get_backend(),
+                'steps_measured': len(ar), 'rank': rank,
+                'note': 'HIP events on the trainer stream around work.wait() of the gradient all-reduces (after backward '
+                        'returned) and around the wait for the packed feature/index all-gather in front of the bank '
+                        'update: the time the stream stands still for communication that compute did not cover'}
+        if trainer.grad_sync is not None:
+            trainer.grad_sync.wait_events = None
+        hip_ops.GATHER_WAIT_EVENTS = None
     kern_ms, kern_n = hip_ops.prof_read()
     secondary_raw = {tag: hip_ops.prof_read(tag) for tag in ('dense_stats', 'dense_grad', 'scl_stats', 'scl_grad',
                                                                'sgc_fwd', 'sgc_bwd')}
@@ -480,6 +506,7 @@ def main():
                          'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
         }
         out['roofline_secondary'] = secondary
+        out['comm'] = comm
         if records_path is not None:
             out['check'] = check_step(records_path)
             out['checked'] = bool(out['check'].get('checked'))

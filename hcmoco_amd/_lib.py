@@ -111,6 +111,11 @@ SIGNATURES = {
     'hcm_sample_branches': (_i, [Branches, Branches, _i, _p] + [_i] * 3 + [_p] * 8),
     'hcm_branch_grad': (_i, [_p] * 4 + [_i] * 3 + [Branches, Branches, _p, _i, _p, _i] + [_p] * 5),
     'hcm_section_total': (_i, [_p, _p, _p, _p]),
+    'hcm_project_rows': (_i, [Branches, Branches, _i, _p] + [_i] * 3 + [_p] * 8),
+    'hcm_project_rows_dw_workspace_bytes': (_sz, [_i, _i]),
+    'hcm_project_rows_dw': (_i, [_p] * 3 + [_i] * 4 + [_p] * 5 + [_sz, _p]),
+    'hcm_project_rows_backward_workspace_bytes': (_sz, [_i, _i, _i, Branches]),
+    'hcm_project_rows_backward': (_i, [_p] * 7 + [_i] * 4 + [Branches, Branches, _p, _i] + [_p] * 5 + [_sz, _p]),
     'hcm_alias_draw_checked': (_i, [_p, _p, _i64, _p, _i, _i, _u64, _u64, _p, _p, _p]),
     'hcm_bank_update_checked': (_i, [_p, _p, _p, _i64, _p, _p, _p, _i64, _p, _i, _i, _f, _p, _p]),
     'hcm_prof_enable': (_i, [_i]),
@@ -126,7 +131,7 @@ for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]
 
 _lib = None
-ABI_VERSION = 2       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
+ABI_VERSION = 3       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
 
 
 def build(verbose=False):

@@ -99,6 +99,48 @@ __global__ __launch_bounds__(kT) void three_interp_kernel(int c, int m, int n,
   for (int ch = c0; ch < c1; ++ch, p += m, o += n) *o = dot3<FMA>(w0, p[i0], w1, p[i1], w2, p[i2]);
 }
 
+// three_interpolate with the source rows in LDS (r04).  The kernel above gathers three 4-byte words per output element
+// from rows that live in L2: at c = 128, n = 65 536, m = 4096 (pts2depth, build_backbone.py:448-455) and c = 256,
+// n = m = 4096 it runs at 2.4-2.7 TB/s of useful bytes.  Here a workgroup keeps a block of CBL channels of ALL m source
+// points in LDS, point-major ([m][CBL]: one ds_read_b128 fetches four channels of a point), and streams its share of the
+// n positions: idx / weight are read once per position and channel block, every output row is written coalesced.
+// Same expression per element (dot3<FMA>), so the results are bit-identical to the gather kernel's.
+constexpr int kTIThreads = 1024;
+template <bool FMA>
+__global__ __launch_bounds__(kTIThreads) void three_interp_lds_kernel(int c, int m, int n, int cbl, int npos,
+                                                                      const float* __restrict__ points,
+                                                                      const int* __restrict__ idx,
+                                                                      const float* __restrict__ weight,
+                                                                      float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float src[];     // [m][cbl], cbl % 4 == 0
+  const int b = blockIdx.z, c0 = blockIdx.y * cbl, nc = min(cbl, c - c0);
+  const int p0 = blockIdx.x * npos, p1 = min(n, p0 + npos);
+  const float* pb = points + ((int64_t)b * c + c0) * m;
+  // fill: consecutive threads read consecutive points of one channel (coalesced); channels past the end stay zero
+  for (int e = threadIdx.x; e < cbl * m; e += kTIThreads) {
+    const int k = e / m, j = e - k * m;
+    src[j * cbl + k] = k < nc ? pb[(int64_t)k * m + j] : 0.f;
+  }
+  __syncthreads();
+  float* ob = out + ((int64_t)b * c + c0) * n;
+  for (int pos = p0 + threadIdx.x; pos < p1; pos += kTIThreads) {
+    const int64_t t3 = ((int64_t)b * n + pos) * 3;
+    const int i0 = idx[t3], i1 = idx[t3 + 1], i2 = idx[t3 + 2];
+    const float w0 = weight[t3], w1 = weight[t3 + 1], w2 = weight[t3 + 2];
+    const float4* r0 = reinterpret_cast<const float4*>(src + i0 * cbl);
+    const float4* r1 = reinterpret_cast<const float4*>(src + i1 * cbl);
+    const float4* r2 = reinterpret_cast<const float4*>(src + i2 * cbl);
+    for (int k4 = 0; 4 * k4 < nc; ++k4) {
+      const float4 a = r0[k4], bq = r1[k4], d = r2[k4];
+      float* o = ob + (int64_t)(4 * k4) * n + pos;
+      o[0] = dot3<FMA>(w0, a.x, w1, bq.x, w2, d.x);
+      if (4 * k4 + 1 < nc) o[n] = dot3<FMA>(w0, a.y, w1, bq.y, w2, d.y);
+      if (4 * k4 + 2 < nc) o[2 * (int64_t)n] = dot3<FMA>(w0, a.z, w1, bq.z, w2, d.z);
+      if (4 * k4 + 3 < nc) o[3 * (int64_t)n] = dot3<FMA>(w0, a.w, w1, bq.w, w2, d.w);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kT) void three_interp_grad_kernel(int c, int n, int m,
                                                                const float* __restrict__ grad_out,
                                                                const int* __restrict__ idx,
@@ -218,6 +260,78 @@ __global__ __launch_bounds__(kT) void ball_query_kernel(int n, int m, float radi
 }
 
 // ------------------------------------------------------------------------------------------
+// ball query, the scan split across the lanes of a wave (r04; the open item of DESIGN 4.3c).  The kernel above gives every
+// centre one thread that walks the cloud serially: with m = 1024 centres per cloud there is half a wave per SIMD and
+// each lane pays ~100 ns per scanned point (0.385 ms for 32 x 1024 centres -- as long as 32 x 4096).  Here a WAVE owns
+// a centre at a time: lane l evaluates point base + l, the ballot of the hits is the hit set in index order, and lane l
+// knows its rank among them from a prefix popcount -- "the first nsample points in index order" (ball_query_gpu.cu:31-43)
+// without any serial dependence, bit-exact.  The cloud sits in LDS once per workgroup (n x 16 bytes), a wave walks kCPW
+// centres, two at a time against the same ds_read_b128 of the points.
+// ------------------------------------------------------------------------------------------
+constexpr int kBQWaves = 16;       // waves per workgroup: they share one LDS copy of the cloud, and 2 x 16 waves per CU are
+                                   // what hides the ds_read -> compare -> ballot -> scalar bookkeeping chain of a step
+constexpr int kBQCentres = 8;      // centres per wave
+
+// one 64-point step of one centre: the hits of this step, in index order, go to slots cnt, cnt + 1, ...
+__device__ __forceinline__ void bq_record(unsigned long long mask, int base, int lane, unsigned long long below,
+                                          int nsample, int& cnt, int& first, int* __restrict__ out) {
+  if (mask != 0ull && cnt < nsample) {
+    if (cnt == 0) first = base + __builtin_ctzll(mask);
+    const int slot = cnt + __popcll(mask & below);
+    if (((mask >> lane) & 1ull) && slot < nsample) out[slot] = base + lane;
+    cnt += __popcll(mask);
+  }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(kBQWaves * 64) void ball_query_wave_kernel(int n, int m, float radius2, int nsample,
+                                                                       const float* __restrict__ new_xyz,
+                                                                       const float* __restrict__ xyz,
+                                                                       int* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float4 cloud4[];   // [n rounded up to 128]
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* cloud = xyz + (int64_t)b * n * 3;
+  const int npad = (n + 127) & ~127;
+  for (int e = tid; e < npad; e += kBQWaves * 64) {
+    float4 p = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);    // padding: never inside a ball
+    if (e < n) p = make_float4(cloud[3 * e], cloud[3 * e + 1], cloud[3 * e + 2], 0.f);
+    cloud4[e] = p;
+  }
+  __syncthreads();
+  const int c0 = (blockIdx.x * kBQWaves + wave) * kBQCentres;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int cc = 0; cc < kBQCentres; cc += 2) {
+    const int pa = c0 + cc, pb = pa + 1;
+    if (pa >= m) break;
+    const bool hasb = pb < m;
+    const float* ca = new_xyz + ((int64_t)b * m + pa) * 3;
+    const float* cb = new_xyz + ((int64_t)b * m + (hasb ? pb : pa)) * 3;
+    const float ax = ca[0], ay = ca[1], az = ca[2], bx = cb[0], by = cb[1], bz = cb[2];
+    int* outa = idx + ((int64_t)b * m + pa) * nsample;
+    int* outb = idx + ((int64_t)b * m + pb) * nsample;
+    int cnta = 0, cntb = hasb ? 0 : nsample, firsta = 0, firstb = 0;
+    // two steps (128 points) x two centres per trip: four independent distance / ballot chains, then the bookkeeping
+    // in index order
+    for (int base = 0; base < npad && (cnta < nsample || cntb < nsample); base += 128) {
+      const float4 p = cloud4[base + lane], q = cloud4[base + 64 + lane];
+      const unsigned long long ma0 = __ballot(sqdist<FMA>(ax, ay, az, p.x, p.y, p.z) < radius2);
+      const unsigned long long mb0 = __ballot(sqdist<FMA>(bx, by, bz, p.x, p.y, p.z) < radius2);
+      const unsigned long long ma1 = __ballot(sqdist<FMA>(ax, ay, az, q.x, q.y, q.z) < radius2);
+      const unsigned long long mb1 = __ballot(sqdist<FMA>(bx, by, bz, q.x, q.y, q.z) < radius2);
+      bq_record(ma0, base, lane, below, nsample, cnta, firsta, outa);
+      bq_record(ma1, base + 64, lane, below, nsample, cnta, firsta, outa);
+      bq_record(mb0, base, lane, below, nsample, cntb, firstb, outb);
+      bq_record(mb1, base + 64, lane, below, nsample, cntb, firstb, outb);
+    }
+    // the first hit fills the unused slots; a centre without any hit keeps the caller's zeros (ball_query_gpu.cu:36-40)
+    if (cnta > 0)
+      for (int l = cnta + lane; l < nsample; l += 64) outa[l] = firsta;
+    if (hasb && cntb > 0)
+      for (int l = cntb + lane; l < nsample; l += 64) outb[l] = firstb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // three_nn (interpolate_gpu.cu:9-52): three smallest squared distances, strict '<', first wins.
 // ------------------------------------------------------------------------------------------
 // Each thread owns TWO unknown points (halves the LDS traffic per distance) and the known cloud is
@@ -294,6 +408,87 @@ __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
     const int64_t o = ((int64_t)b * n + pt1) * 3;
     dist2[o] = t1.b1; dist2[o + 1] = t1.b2; dist2[o + 2] = t1.b3;
     idx[o] = t1.i1; idx[o + 1] = t1.i2; idx[o + 2] = t1.i3;
+  }
+}
+
+// three_nn with the scan of one unknown split across the 16 lanes of a DPP row (r04; the open item of DESIGN 4.3c).
+// The kernel above walks all m known points per thread: at the feature-propagation levels of Pointnet2MSG there are only
+// 32 x {256, 1024, 4096} unknowns -- 64 to 1024 waves on 1024 SIMDs -- and a thread pays ~100 ns per scanned point.
+// Here lane j of a row takes known points j, j + 16, ... (ascending, so the strict '<' of interpolate_gpu.cu:41-47 keeps
+// the first of equal distances inside a lane) for kNU unknowns at once, and the 16 partial top-3 lists are merged by a
+// DPP butterfly under the order (distance, index) -- exactly the order the reference's sequential insertion realises:
+// among equal distances the smaller index ranks first.  Unset slots are (+inf, 0) in every lane and compare equal.
+struct Top3L : Top3 {
+  __device__ __forceinline__ static bool lt(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
+  __device__ __forceinline__ void push_lex(float d, int k) {
+    if (lt(d, k, b3, i3)) {
+      if (lt(d, k, b1, i1)) {
+        b3 = b2; i3 = i2;
+        b2 = b1; i2 = i1;
+        b1 = d; i1 = k;
+      } else if (lt(d, k, b2, i2)) {
+        b3 = b2; i3 = i2;
+        b2 = d; i2 = k;
+      } else {
+        b3 = d; i3 = k;
+      }
+    }
+  }
+  template <int CTRL>
+  __device__ __forceinline__ void merge_dpp() {
+    const float o1 = hcm::dpp_mov<CTRL>(b1), o2 = hcm::dpp_mov<CTRL>(b2), o3 = hcm::dpp_mov<CTRL>(b3);
+    const int j1 = __builtin_amdgcn_update_dpp(0, i1, CTRL, 0xF, 0xF, true);
+    const int j2 = __builtin_amdgcn_update_dpp(0, i2, CTRL, 0xF, 0xF, true);
+    const int j3 = __builtin_amdgcn_update_dpp(0, i3, CTRL, 0xF, 0xF, true);
+    push_lex(o1, j1);
+    push_lex(o2, j2);
+    push_lex(o3, j3);
+  }
+};
+constexpr int kNU = 4;      // unknowns per 16-lane row
+
+template <bool FMA>
+__global__ __launch_bounds__(kT) void three_nn_split_kernel(int n, int m, const float* __restrict__ unknown,
+                                                            const float* __restrict__ known,
+                                                            float* __restrict__ dist2, int* __restrict__ idx) {
+  __shared__ float4 tile[kTile];
+  const int b = blockIdx.y, l16 = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const int u0 = (blockIdx.x * (kT / 16) + row) * kNU;
+  float ux[kNU], uy[kNU], uz[kNU];
+  Top3L t[kNU];
+#pragma unroll
+  for (int q = 0; q < kNU; ++q) {
+    const int u = min(u0 + q, n - 1);
+    const float* p = unknown + ((int64_t)b * n + u) * 3;
+    ux[q] = p[0]; uy[q] = p[1]; uz[q] = p[2];
+    t[q].init();
+  }
+  const float* cloud = known + (int64_t)b * m * 3;
+  for (int base = 0; base < m; base += kTile) {
+    const int len = min(kTile, m - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len; e += kT) {
+      const float* c = cloud + (int64_t)(base + e) * 3;
+      tile[e] = make_float4(c[0], c[1], c[2], 0.f);
+    }
+    __syncthreads();
+    for (int k = l16; k < len; k += 16) {
+      const float4 p = tile[k];
+#pragma unroll
+      for (int q = 0; q < kNU; ++q) t[q].push(sqdist<FMA>(ux[q], uy[q], uz[q], p.x, p.y, p.z), base + k);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kNU; ++q) {
+    t[q].template merge_dpp<0xB1>();       // quad_perm [1,0,3,2]
+    t[q].template merge_dpp<0x4E>();       // quad_perm [2,3,0,1]
+    t[q].template merge_dpp<0x141>();      // row_half_mirror
+    t[q].template merge_dpp<0x140>();      // row_mirror
+    if (l16 == 0 && u0 + q < n) {
+      const int64_t o = ((int64_t)b * n + u0 + q) * 3;
+      dist2[o] = t[q].b1; dist2[o + 1] = t[q].b2; dist2[o + 2] = t[q].b3;
+      idx[o] = t[q].i1; idx[o + 1] = t[q].i2; idx[o + 2] = t[q].i3;
+    }
   }
 }
 
@@ -559,6 +754,31 @@ int hcm_three_interpolate_contract(int b, int c, int m, int n, const float* poin
                                    const float* weight, float* out, int contract, hcm_stream_t stream) {
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || c <= 0 || n <= 0) return b < 0 || c < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
+  // source rows in LDS when a useful block of channels of all m points fits (m <= 8960 points at 4 channels) and there
+  // is enough work per workgroup to pay for the fill; HCM_THREE_INTERP=1 forces the gather kernel
+  static const int ti_variant = getenv("HCM_THREE_INTERP") ? atoi(getenv("HCM_THREE_INTERP")) : 0;
+  int cbl = m > 0 ? (int)((140 * 1024) / ((size_t)m * sizeof(float))) & ~3 : 0;
+  if (cbl > 32) cbl = 32;
+  if (cbl > ((c + 3) & ~3)) cbl = (c + 3) & ~3;
+  if (ti_variant != 1 && cbl >= 4 && n >= 2048) {
+    const int nblk = (c + cbl - 1) / cbl;
+    // positions per workgroup: all of them unless that leaves the GPU short of workgroups (fill cost ~ m positions)
+    int nsplit = 1;
+    while ((long long)b * nblk * nsplit < 512 && n / (nsplit * 2) >= 4 * m && n / (nsplit * 2) >= 4096) nsplit *= 2;
+    const int npos = (n + nsplit - 1) / nsplit;
+    const size_t lds = (size_t)cbl * m * sizeof(float);
+    const void* fn = contract == HCM_CONTRACT_FMA ? reinterpret_cast<const void*>(three_interp_lds_kernel<true>)
+                                                  : reinterpret_cast<const void*>(three_interp_lds_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(nsplit, nblk, b);
+    if (contract == HCM_CONTRACT_FMA)
+      three_interp_lds_kernel<true><<<grid, kTIThreads, lds, (hipStream_t)stream>>>(c, m, n, cbl, npos, points, idx, weight, out);
+    else
+      three_interp_lds_kernel<false><<<grid, kTIThreads, lds, (hipStream_t)stream>>>(c, m, n, cbl, npos, points, idx, weight, out);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   if (contract == HCM_CONTRACT_FMA)
     three_interp_kernel<true><<<grid3(n, c, b), kT, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
   else
@@ -581,6 +801,24 @@ int hcm_ball_query_contract(int b, int n, int m, float radius, int nsample, cons
                             const float* xyz, int* idx, int contract, hcm_stream_t stream) {
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || m <= 0 || nsample <= 0) return b < 0 || m < 0 || nsample < 0 ? (int)hipErrorInvalidValue : 0;
+  // the cloud fits LDS (every level of Pointnet2MSG: n <= 4096 points = 64 KB): one WAVE per centre, lanes over the points
+  static const int bq_variant = getenv("HCM_BALL_QUERY") ? atoi(getenv("HCM_BALL_QUERY")) : 0;      // 1 = thread per centre
+  const size_t cloud_lds = (size_t)((n + 127) & ~127) * sizeof(float4);
+  if (bq_variant != 1 && n > 0 && cloud_lds <= 72 * 1024) {          // two workgroups per CU
+    const void* fw = contract == HCM_CONTRACT_FMA ? reinterpret_cast<const void*>(ball_query_wave_kernel<true>)
+                                                  : reinterpret_cast<const void*>(ball_query_wave_kernel<false>);
+    hipError_t e2 = hipFuncSetAttribute(fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cloud_lds);
+    if (e2 != hipSuccess) return (int)e2;
+    dim3 gridw((m + kBQWaves * kBQCentres - 1) / (kBQWaves * kBQCentres), b);
+    if (contract == HCM_CONTRACT_FMA)
+      ball_query_wave_kernel<true><<<gridw, kBQWaves * 64, cloud_lds, (hipStream_t)stream>>>(n, m, radius * radius, nsample,
+                                                                                         new_xyz, xyz, idx);
+    else
+      ball_query_wave_kernel<false><<<gridw, kBQWaves * 64, cloud_lds, (hipStream_t)stream>>>(n, m, radius * radius, nsample,
+                                                                                          new_xyz, xyz, idx);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   // one thread per centre: shrink the workgroup when there are too few centres to fill 256 CUs
   int threads = kT;
   while (threads > 64 && (long long)b * ((m + threads - 1) / threads) < 1024) threads >>= 1;
@@ -607,6 +845,18 @@ int hcm_three_nn_contract(int b, int n, int m, const float* unknown, const float
                           int* idx, int contract, hcm_stream_t stream) {
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || n <= 0) return b < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
+  // few unknowns (the feature-propagation levels: b x n <= 2^17 ... 2^19): split each scan across 16 lanes; many
+  // (pts2depth: 2 M unknowns) -> a thread per two unknowns keeps every SIMD busy.  HCM_THREE_NN = 1 / 2 forces one of them.
+  static const int nn_variant = getenv("HCM_THREE_NN") ? atoi(getenv("HCM_THREE_NN")) : 0;
+  if (nn_variant == 2 || (nn_variant != 1 && (long long)b * n <= (1ll << 19) && m >= 16)) {
+    dim3 gs((n + (kT / 16) * kNU - 1) / ((kT / 16) * kNU), b);
+    if (contract == HCM_CONTRACT_FMA)
+      three_nn_split_kernel<true><<<gs, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+    else
+      three_nn_split_kernel<false><<<gs, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid((n + 2 * kT - 1) / (2 * kT), b);
   if (contract == HCM_CONTRACT_FMA)
     three_nn_kernel<true><<<grid, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);

@@ -1,0 +1,721 @@
+// Row 8 of SURVEY.md 8a -- merge_all_res + the 1x1 projection (networks/build_backbone.py:243-254, :290-300) -- at the
+// sampled pixels, on the fp32 matrix cores (r04; r03 staged a [2, B R, 272] matrix for three rocBLAS GEMMs):
+//
+//   project_rows_kernel   forward.  A workgroup owns a run of rows of one (modality, image).  It stages the two
+//                         coarsest branch maps of that image in LDS (coalesced 16-byte loads; at 256 x 256 they are 84 %
+//                         of the 1026 stencil taps of a row), gathers / bilinearly samples 32 rows at a time into an
+//                         LDS tile [32][Ctot | 1 | 0], and multiplies the tile by the [W | b] panel with
+//                         v_mfma_f32_16x16x4_f32: each of the 8 waves owns 16 of the 128 output channels and holds its
+//                         B fragments in registers for the whole launch.  Writes rows [2, B R, 128], zero-fills grows,
+//                         and stores the sampled tile xs [2, B R, ld] once (the weight gradient reads it back).
+//   proj_dw_partial_kernel, proj_dw_reduce_kernel
+//                         d[W | b] = grows^T xs, split over row chunks (MFMA), then summed chunk by chunk in a fixed order
+//                         (deterministic; no atomics), scaled, unpacked into dWp [F, Ctot] and dbp [F].
+//
+//   stencil_plan_kernel   backward, once per step: for every (image, branch) the (row, tap) stencil entries sorted by
+//                         target pixel (bitonic sort of 32-bit keys pixel * E + entry in LDS) + per-pixel offsets: a CSR
+//                         transpose of the sampling operator, shared by both modalities and all channels.
+//   branch_grad_t_kernel  backward of sampling + projection + average pooling, owner computes, in the TRANSPOSED order:
+//                         dX_i = W_i^T (S_i^T grows) instead of S_i^T (grows W): a workgroup owns 64 pixels of one
+//                         branch map; its waves walk the pixels' entry lists and accumulate T[pixel][128] = sum of
+//                         weight * grows[row] (512-byte coalesced row reads) into LDS, then multiply by the branch's
+//                         slice of W on the matrix cores ([C_i x 128] x [128 x 64]) and store the map tile once, pooling
+//                         gradient included.  No dxs matrix, no per-workgroup list building (r03: 70 % of the wave
+//                         cycles of branch_grad_kernel were barrier / LDS waits of its list construction), linear in the
+//                         length of a pixel's list (r03 was quadratic for a pixel sampled hundreds of times).
+// Everything is fp32; an fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md), sums run in a fixed order.
+#include "hcm_common.h"
+#include "../../include/hcmoco_hip.h"
+#include "section_common.h"
+
+namespace {
+
+using namespace hcm;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kPW = 512;     // forward workgroup: 8 waves, wave w owns output channels [16 w, 16 w + 16)
+constexpr int kSR = 32;      // rows per LDS tile: two 16-row MFMA tiles = two independent accumulator chains per wave
+constexpr int kF = 128;      // projected channels (the loss kernels' C)
+
+// one channel of one row from a branch: a plain gather (finest branch) or the 4-tap bilinear stencil
+struct RowTaps {
+  int o00, o01, o10, o11;
+  float hy, ly, hx, lx;
+};
+__device__ __forceinline__ float tap4(const float* __restrict__ xc, const RowTaps& t) {
+  return t.hy * (t.hx * xc[t.o00] + t.lx * xc[t.o01]) + t.ly * (t.hx * xc[t.o10] + t.lx * xc[t.o11]);
+}
+
+// KS = k-steps of 4 channels: 4 KS >= Ctot + 1 (the bias column).  LDS: [kSR][4 KS + 2] tile, then the staged maps.
+// The tile's row stride 4 KS + 2 makes the A-fragment read (lane (i, g) -> row i, column 4 s + g) conflict-free:
+// (stride * i + g) mod 32 takes 32 different values for i < 16, g < 2.
+template <int KS>
+__global__ __launch_bounds__(kPW) void project_rows_kernel(
+    Maps8 e, int B, const int64_t* __restrict__ pix, int R, int Ctot, const float* __restrict__ Wp1,
+    const float* __restrict__ bp1, const float* __restrict__ Wp2, const float* __restrict__ bp2,
+    float* __restrict__ xs, int ld, float* __restrict__ rows, float* __restrict__ grows, int per, int off2, int off3) {
+  constexpr int XS = 4 * KS + 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ __attribute__((aligned(16))) int s_to[kSR][3][4];      // the tile's stencils: tap offsets ...
+  __shared__ __attribute__((aligned(16))) float s_tw[kSR][3][4];    // ... and (hy, ly, hx, lx)
+  __shared__ int s_pix[kSR];
+  float* lx = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.z, b = blockIdx.y;
+  const int r_begin = blockIdx.x * per, r_end = min(R, r_begin + per);
+  if (r_begin >= r_end) return;
+  const int n = lane & 15, g = lane >> 4;
+  // ---- stage the coarse maps of this image: plane stride odd, so that the channel lanes of a tap hit different banks
+  const int h0 = e.H[0], w0 = e.W[0];
+#pragma unroll
+  for (int i = 2; i < 4; ++i) {
+    const int off = i == 2 ? off2 : off3;
+    if (off < 0) continue;
+    const int C = e.C[i], hw = e.H[i] * e.W[i], P = hw | 1;
+    const float* src = (m ? e.p[4 + i] : e.p[i]) + (int64_t)b * C * hw;
+    float* dst = lds + off;
+    if ((hw & 3) == 0) {
+      const int n4 = (C * hw) >> 2;
+      for (int base = tid; base < n4; base += 8 * kPW) {          // eight 16-byte loads in flight per thread
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(src)[min(base + u * kPW, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                   // (a clamped index rewrites the last quad with itself)
+          {
+            const int e0 = min(base + u * kPW, n4 - 1) << 2, c = e0 / hw, q = e0 - c * hw;
+            float* d = dst + c * P + q;
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+          }
+        }
+      }
+    } else {
+      for (int e0 = tid; e0 < C * hw; e0 += kPW) {
+        const int c = e0 / hw, q = e0 - c * hw;
+        dst[c * P + q] = src[e0];
+      }
+    }
+  }
+  // ---- the wave's B fragments: [W | b | 0]^T, column 16 wave + n, rows 4 s + g
+  float breg[KS];
+  {
+    const float* Wp = (m ? Wp2 : Wp1) + (int64_t)(16 * wave + n) * Ctot;
+    const float bias = (m ? bp2 : bp1)[16 * wave + n];
+    // unconditional loads (clamped index), selected afterwards: a guarded load is a branch plus a full s_waitcnt each
+#pragma unroll
+    for (int s = 0; s < KS; ++s) breg[s] = Wp[min(4 * s + g, Ctot - 1)];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + g;
+      breg[s] = k < Ctot ? breg[s] : (k == Ctot ? bias : 0.f);
+    }
+  }
+  const int64_t row0 = ((int64_t)m * B + b) * R;
+  for (int r0 = r_begin; r0 < r_end; r0 += kSR) {
+    __syncthreads();        // the staged maps are in place / the previous tile has been multiplied
+    // ---- the tile's stencils: one thread per (row, coarse branch)
+    if (tid < kSR * 3) {
+      const int lr = tid / 3, br = 1 + tid - 3 * lr, r = min(r0 + lr, r_end - 1);
+      const int p = (int)pix[(int64_t)b * R + r];
+      const int py = p / w0, px = p - py * w0;
+      const int hi = sel4(e.H, br), wi = sel4(e.W, br);
+      const Taps t = bilinear_taps(py, px, hi, wi, (float)hi / (float)h0, (float)wi / (float)w0);
+      int* o = &s_to[lr][br - 1][0];
+      float* w = &s_tw[lr][br - 1][0];
+      o[0] = t.y0 * wi + t.x0; o[1] = t.y0 * wi + t.x1; o[2] = t.y1 * wi + t.x0; o[3] = t.y1 * wi + t.x1;
+      w[0] = t.hy; w[1] = t.ly; w[2] = t.hx; w[3] = t.lx;
+      if (br == 1) s_pix[lr] = p;
+    }
+    __syncthreads();
+    // ---- gather: every (row, channel) of the tile is one independent element; consecutive threads take consecutive
+    // channels of a row (coalesced xs stores), several elements per thread so that their loads are in flight together.
+    // Rows past the end repeat the last row's pixels; they are computed and never stored.
+    {
+      int coff = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int C = e.C[i], hw = e.H[i] * e.W[i];
+        const int off = i == 2 ? off2 : (i == 3 ? off3 : -1);
+        const float* xg = (m ? e.p[4 + i] : e.p[i]) + (int64_t)b * C * hw;
+        const float* xl = lds + (off >= 0 ? off : 0);
+        const int P = hw | 1, total = kSR * C;
+        // branch-free: a thread past the end repeats the last element (same value to the same addresses), so that the
+        // loads of several trips can be requested together
+#pragma unroll 4
+        for (int e0 = tid; e0 < total + kPW - 1 - (total + kPW - 1) % kPW; e0 += kPW) {
+          const int ec = min(e0, total - 1);
+          const int lr = ec / C, c = ec - lr * C;
+          float v;
+          if (i == 0) {
+            v = xg[(int64_t)c * hw + s_pix[lr]];
+          } else {
+            const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i - 1][0]);
+            const float4 w = *reinterpret_cast<const float4*>(&s_tw[lr][i - 1][0]);
+            RowTaps q;
+            q.o00 = o.x; q.o01 = o.y; q.o10 = o.z; q.o11 = o.w;
+            q.hy = w.x; q.ly = w.y; q.hx = w.z; q.lx = w.w;
+            if (off >= 0) v = tap4(xl + c * P, q);           // block-uniform
+            else v = tap4(xg + (int64_t)c * hw, q);
+          }
+          lx[lr * XS + coff + c] = v;
+          if (xs != nullptr) xs[(row0 + min(r0 + lr, r_end - 1)) * ld + coff + c] = v;
+        }
+        coff += C;
+      }
+      const int npad = 4 * KS - Ctot;                          // the bias column, then padding
+      for (int e0 = tid; e0 < kSR * npad; e0 += kPW) {
+        const int lr = e0 / npad, k = Ctot + e0 - lr * npad;
+        const float v = k == Ctot ? 1.f : 0.f;
+        lx[lr * XS + k] = v;
+        if (xs != nullptr && k < ld) xs[(row0 + min(r0 + lr, r_end - 1)) * ld + k] = v;
+      }
+    }
+    __syncthreads();
+    // ---- multiply: two 16-row tiles, one accumulator chain each (an fp32 MFMA depends on its predecessor for 40 cycles
+    // and issues every 32: two chains keep the pipe full with the second wave of the SIMD as further cover)
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* a0 = lx + n * XS + g;
+    const float* a1 = a0 + 16 * XS;
+    const bool two = r0 + 16 < r_end;                           // block-uniform (the second tile is multiplied regardless)
+    // The A fragments of the next kCH k-steps are requested from LDS before the MFMAs of the current kCH issue (left to
+    // itself the compiler reads each fragment right in front of its MFMA: LDS latency + the 40-cycle accumulator
+    // dependency per k-step instead of 32 cycles of issue)
+    constexpr int kCH = KS > 121 ? 4 : 16, kNC = (KS + kCH - 1) / kCH;      // (w48: 181 B fragments leave room for 8)
+    float fa[2][kCH], fb[2][kCH];
+#pragma unroll
+    for (int u = 0; u < kCH; ++u) { fa[0][u] = a0[4 * u]; fb[0][u] = a1[4 * u]; }
+#pragma unroll
+    for (int c = 0; c < kNC; ++c) {
+      if (c + 1 < kNC) {
+#pragma unroll
+        for (int u = 0; u < kCH; ++u)
+          if ((c + 1) * kCH + u < KS) { fa[(c + 1) & 1][u] = a0[4 * ((c + 1) * kCH + u)]; fb[(c + 1) & 1][u] = a1[4 * ((c + 1) * kCH + u)]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kCH; ++u)
+        if (c * kCH + u < KS) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c & 1][u], breg[c * kCH + u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[c & 1][u], breg[c * kCH + u], acc1, 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // D: lane (g, n) holds rows 4 g + j, column n
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ra = r0 + 4 * g + j, rb = ra + 16;
+      if (ra < r_end) {
+        const int64_t o = (row0 + ra) * kF + 16 * wave + n;
+        rows[o] = acc0[j];
+        if (grows != nullptr) grows[o] = 0.f;
+      }
+      if (two && rb < r_end) {
+        const int64_t o = (row0 + rb) * kF + 16 * wave + n;
+        rows[o] = acc1[j];
+        if (grows != nullptr) grows[o] = 0.f;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// d[W | b] partials: grid (chunks, column groups, 2).  A workgroup (8 waves) reduces `rpc` rows of one modality into a
+// [128][<= 16 kNT] block: wave w owns output channels [16 w, 16 w + 16) (A = grows^T, straight from global memory: lane
+// (i, g) reads grows[row 4 s + g][16 w + i], 64 contiguous bytes per g) times up to kNT 16-column tiles of xs.
+// ------------------------------------------------------------------------------------------
+constexpr int kNT = 17;      // column tiles per workgroup: 272 = the HRNet-w18 row (270 channels + bias + pad)
+constexpr int kDW = 256;     // 4 waves: wave w owns output channels [32 w, 32 w + 32) = two 16-row tiles x kNT column tiles
+constexpr int kRing = 3;     // k-steps of fragments in flight per wave (one wave per SIMD: the ring is the latency cover)
+__global__ __launch_bounds__(kDW, 1) void proj_dw_partial_kernel(const float* __restrict__ grows,
+                                                                 const float* __restrict__ xs, int M, int ld, int rpc,
+                                                                 float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int chunk = blockIdx.x, cg = blockIdx.y, m = blockIdx.z, nchunk = gridDim.x;
+  const int col0 = cg * kNT * 16;
+  const int nt = min(kNT, (ld - col0 + 15) / 16);
+  const int r_begin = chunk * rpc, r_end = min(M, r_begin + rpc);
+  const float* A = grows + (int64_t)m * M * kF + 32 * wave + n;
+  const float* Bm = xs + (int64_t)m * M * ld + col0 + n;
+  v4f acc[2][kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) { acc[0][t] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[1][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  // Every load is unconditional (a row past the end is clamped and its A values zeroed, a column past ld is clamped and
+  // its product never stored): a guarded load is a branch and a full s_waitcnt in the middle of the stream.
+  int cofs[kNT];
+#pragma unroll
+  for (int t = 0; t < kNT; ++t) cofs[t] = min(col0 + 16 * t + n, ld - 1) - col0 - n;
+  float ra[kRing][2], rb[kRing][kNT];
+  auto load = [&](int r, float (&a)[2], float (&bv)[kNT]) {
+    const int rg = min(r + g, M - 1);
+    const bool ok = r + g < r_end;
+    const float a0 = A[(int64_t)rg * kF], a1 = A[(int64_t)rg * kF + 16];
+    a[0] = ok ? a0 : 0.f;
+    a[1] = ok ? a1 : 0.f;
+    const float* brow = Bm + (int64_t)rg * ld;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) bv[t] = brow[cofs[t]];
+  };
+#pragma unroll
+  for (int j = 0; j < kRing; ++j) load(r_begin + 4 * j, ra[j], rb[j]);
+  for (int r = r_begin; r < r_end; r += 4 * kRing) {
+#pragma unroll
+    for (int j = 0; j < kRing; ++j) {
+      if (r + 4 * j < r_end) {                        // block-uniform
+        float a0 = ra[j][0], a1 = ra[j][1], bv[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) bv[t] = rb[j][t];
+        load(r + 4 * (j + kRing), ra[j], rb[j]);      // the slot is free again: request k-step r + 4 (j + kRing)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv[t], acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv[t], acc[1][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // part [2][nchunk][128][ld]; D: lane (g, n) holds output channels 32 wave + 16 h + 4 g + j, column 16 t + n
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float* out = part + (((int64_t)m * nchunk + chunk) * kF + 32 * wave + 16 * h + 4 * g) * ld + col0 + n;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+      if (t < nt && col0 + 16 * t + n < ld) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(int64_t)j * ld + 16 * t] = acc[h][t][j];
+      }
+    }
+  }
+}
+
+// one thread per (modality, output channel, column): chunks summed in ascending order
+__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ part, int nchunk, int ld, int Ctot,
+                                                             const float* __restrict__ scale, float* __restrict__ dWp1,
+                                                             float* __restrict__ dbp1, float* __restrict__ dWp2,
+                                                             float* __restrict__ dbp2) {
+  const int e = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+  if (e >= kF * ld) return;
+  const int o = e / ld, k = e - o * ld;
+  if (k > Ctot) return;
+  const float* p = part + (int64_t)m * nchunk * kF * ld + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < nchunk; c += 4) {          // four loads in flight; the association is fixed by the chunk count alone
+    s0 += p[(int64_t)c * kF * ld];
+    s1 += p[(int64_t)(c + 1) * kF * ld];
+    s2 += p[(int64_t)(c + 2) * kF * ld];
+    s3 += p[(int64_t)(c + 3) * kF * ld];
+  }
+  for (; c < nchunk; ++c) s0 += p[(int64_t)c * kF * ld];
+  const float v = (scale != nullptr ? scale[0] : 1.f) * ((s0 + s1) + (s2 + s3));
+  float* dW = m ? dWp2 : dWp1;
+  float* db = m ? dbp2 : dbp1;
+  if (k < Ctot) dW[(int64_t)o * Ctot + k] = v;
+  else db[o] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stencil plan.  grid (4 branches, B), 256 threads, dynamic LDS = N2 keys.  Entry e of image b, branch i: branch 0 has one
+// entry per row (e = r: the gather), branches 1-3 four (e = 4 r + tap, tap order y0x0, y0x1, y1x0, y1x1 = the order the
+// forward adds them).  key = pixel * E + e: ascending keys = pixels in raster order, inside a pixel ascending (row, tap) --
+// the summation order of the gradient.  The first S rows of a dropped image (keep[b] == 0) are left out: their gradient is
+// exactly zero and they all sit on pixel 0.
+// ------------------------------------------------------------------------------------------
+constexpr int kRowBits = 14;  // plan entry .x = row | pixel << 14: R < 16384, H W < 2^17
+struct PlanGeom {
+  int H[4], W[4];
+  int ent_off[4], off_off[4];      // per-image offsets of branch i inside ent (entries) / off (ints)
+  int ent_per_image, off_per_image;
+};
+
+constexpr int kPT = 1024;     // plan workgroup
+__global__ __launch_bounds__(kPT) void stencil_plan_kernel(const int64_t* __restrict__ pix, int R, PlanGeom gm,
+                                                           const int32_t* __restrict__ keep, int S, int N2max,
+                                                           int2* __restrict__ ent, int* __restrict__ off) {
+  extern __shared__ uint32_t keys[];
+  const int tid = threadIdx.x, i = blockIdx.x, b = blockIdx.y;
+  const int hi = sel4(gm.H, i), wi = sel4(gm.W, i), hw = hi * wi;
+  const int h0 = gm.H[0], w0 = gm.W[0];
+  const int taps = i == 0 ? 1 : 4, E = taps * R;
+  int N2 = 128;                                     // a wave sorts runs of 128 keys on its own
+  while (N2 < E) N2 <<= 1;
+  (void)N2max;
+  const bool dropped = keep != nullptr && keep[b] == 0;
+  const float sy = (float)hi / (float)h0, sx = (float)wi / (float)w0;
+  for (int e = tid; e < N2; e += kPT) {
+    uint32_t key = 0xffffffffu;
+    if (e < E) {
+      const int r = e / taps, t = e - r * taps;
+      if (!(dropped && r < S)) {
+        const int p = (int)pix[(int64_t)b * R + r];
+        int q = p;
+        if (i > 0) {
+          const int py = p / w0, px = p - py * w0;
+          const Taps tp = bilinear_taps(py, px, hi, wi, sy, sx);
+          q = ((t & 2) ? tp.y1 : tp.y0) * wi + ((t & 1) ? tp.x1 : tp.x0);
+        }
+        key = (uint32_t)q * (uint32_t)E + (uint32_t)e;
+      }
+    }
+    keys[e] = key;
+  }
+  __syncthreads();
+  // Bitonic network.  Thread t handles pair t of each 2 kPT-key slab.  A compare-exchange distance j < 64 keeps both
+  // keys inside the 128-key run of the thread's own wave (pair index t -> keys with the same t / 64), and LDS requests of
+  // one wave complete in order: those stages need no workgroup barrier, only the stages with j >= 64 do.
+  for (int k = 2; k <= N2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (N2 >> 1); t += kPT) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi2 = lo | j;
+        const uint32_t a = keys[lo], c = keys[hi2];
+        const bool up = (lo & k) == 0;
+        if ((a > c) == up) { keys[lo] = c; keys[hi2] = a; }
+      }
+      if (j >= 64) __syncthreads();
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (k >= 128) __syncthreads();                  // the next phase starts at distance k: other waves' runs
+  }
+  __syncthreads();
+  int2* eo = ent + (int64_t)b * gm.ent_per_image + sel4(gm.ent_off, i);
+  int* oo = off + (int64_t)b * gm.off_per_image + sel4(gm.off_off, i);
+  for (int j = tid; j < E; j += kPT) {
+    const uint32_t key = keys[j];
+    if (key == 0xffffffffu) continue;
+    const int e = (int)(key % (uint32_t)E), r = e / taps, t = e - r * taps;
+    float w = 1.f;
+    if (i > 0) {
+      const int p = (int)pix[(int64_t)b * R + r];
+      const int py = p / w0, px = p - py * w0;
+      const Taps tp = bilinear_taps(py, px, hi, wi, sy, sx);
+      w = ((t & 2) ? tp.ly : tp.hy) * ((t & 1) ? tp.lx : tp.hx);
+    }
+    eo[j] = make_int2(r | ((int)(key / (uint32_t)E) << kRowBits), __builtin_bit_cast(int, w));
+  }
+  // off[q] = number of entries with pixel < q (lower bound of q * E), q = 0 .. hw
+  for (int q = tid; q <= hw; q += kPT) {
+    const uint64_t want = (uint64_t)q * (uint64_t)E;
+    int lo = 0, hi2 = E;                         // first j with keys[j] >= want (padding keys are the largest)
+    while (lo < hi2) {
+      const int mid = (lo + hi2) >> 1;
+      if ((uint64_t)keys[mid] < want) lo = mid + 1; else hi2 = mid;
+    }
+    oo[q] = lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Branch gradients, transposed order.  grid (tiles of all four branches, B, 2), 512 threads.
+// ------------------------------------------------------------------------------------------
+constexpr int kTP = 64;       // pixels per sub-tile (a workgroup walks `span` of them)
+constexpr int kTS = 130;      // LDS row stride of T: the B-fragment read (lane (g, n) -> T[n][4 s + g]) is conflict-free
+struct TilePlan {
+  int first[5];               // first workgroup (blockIdx.x) of branch i; first[4] = total
+  int span[4];                // 64-pixel sub-tiles per workgroup of branch i
+};
+
+constexpr int kGW = 256;      // 4 waves; <= 128 VGPRs -> four workgroups (16 waves) per CU
+__global__ __launch_bounds__(kGW, 4) void branch_grad_t_kernel(
+    const float* __restrict__ grows, const float* __restrict__ Wp1, const float* __restrict__ Wp2,
+    const float* __restrict__ dpooled, const float* __restrict__ scale, const int2* __restrict__ ent,
+    const int* __restrict__ off, int R, int B, int Ctot, Maps8Out g, TilePlan tp, PlanGeom gm) {
+  __shared__ __attribute__((aligned(16))) float T[kTP * kTS];
+  __shared__ int soff[kTP + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, m = blockIdx.z;
+  int i = 0;
+  while (i < 3 && (int)blockIdx.x >= tp.first[i + 1]) ++i;
+  const int wg = blockIdx.x - tp.first[i], span = sel4(tp.span, i);
+  const int C = sel4(g.C, i), hw = sel4(g.H, i) * sel4(g.W, i);
+  int coff = 0;
+  for (int k = 0; k < i; ++k) coff += sel4(g.C, k);
+  const int* offb = off + (int64_t)b * gm.off_per_image + sel4(gm.off_off, i);
+  const int2* entb = ent + (int64_t)b * gm.ent_per_image + sel4(gm.ent_off, i);
+  const float* gb = grows + ((int64_t)m * B + b) * R * kF + 2 * lane;
+  const int n = lane & 15, gq = lane >> 4;
+  const float sc = scale != nullptr ? scale[0] : 1.f;
+  const float inv = 1.f / (float)hw;
+  const float* Wp = (m ? Wp2 : Wp1) + coff;
+  const int nmt = (C + 15) >> 4;
+  float* out = sel8(g.p, m * 4 + i) + (int64_t)b * C * hw;
+  const float* dp = dpooled != nullptr ? dpooled + ((int64_t)m * B + b) * Ctot + coff : nullptr;
+  constexpr int kPPW = kTP / (kGW / 64);            // pixels per wave: a contiguous run, i.e. a contiguous run of entries
+  for (int sub = 0; sub < span; ++sub) {
+    const int q0 = (wg * span + sub) * kTP;
+    if (q0 >= hw) break;
+    if (sub > 0) __syncthreads();                   // the previous sub-tile's products have been formed
+    if (tid <= kTP) soff[tid] = offb[min(q0 + tid, hw)];
+    __syncthreads();
+    const bool any = soff[kTP] > soff[0];           // block-uniform
+    if (!any) {
+      // nothing sampled here: the pooling gradient alone, 16-byte stores
+      if ((hw & 3) == 0) {
+        for (int e0 = tid; e0 < C * (kTP / 4); e0 += kGW) {
+          const int c = e0 / (kTP / 4), q = q0 + 4 * (e0 - c * (kTP / 4));
+          if (q < hw) {
+            const float pool = dp != nullptr ? dp[c] * inv : 0.f;
+            *reinterpret_cast<float4*>(out + (int64_t)c * hw + q) = make_float4(pool, pool, pool, pool);
+          }
+        }
+      } else {
+        for (int e0 = tid; e0 < C * kTP; e0 += kGW) {
+          const int c = e0 / kTP, q = q0 + e0 - c * kTP;
+          if (q < hw) out[(int64_t)c * hw + q] = dp != nullptr ? dp[c] * inv : 0.f;
+        }
+      }
+      continue;
+    }
+    // ---- T[pixel][f] = sum over the pixel's entries of weight * grows[row][f], entries in (row, tap) order.  A wave owns
+    // kPPW consecutive pixels = ONE run of the sorted entry list: eight entries (lanes 0-7) and their eight 512-byte rows
+    // are requested together, the adds follow in entry order, a pixel's sum is stored when the next pixel begins.
+    {
+#pragma unroll
+      for (int k = 0; k < kPPW; ++k) *reinterpret_cast<float2*>(&T[(wave * kPPW + k) * kTS + 2 * lane]) = make_float2(0.f, 0.f);
+      int j = soff[wave * kPPW];
+      const int jend = soff[wave * kPPW + kPPW];
+      int cur = -1;
+      float2 acc = make_float2(0.f, 0.f);
+      while (j < jend) {
+        const int n8 = min(8, jend - j);
+        const int2 en = lane < n8 ? entb[j + lane] : make_int2(0, 0);
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                 // unconditional: a lane past the run reads row 0 and is not added
+          const int r = __builtin_amdgcn_readlane(en.x, u) & ((1 << kRowBits) - 1);
+          v[u] = *reinterpret_cast<const float2*>(gb + (int64_t)r * kF);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < n8) {
+            const int px = (__builtin_amdgcn_readlane(en.x, u) >> kRowBits) - q0;
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(en.y, u));
+            if (px != cur) {
+              if (cur >= 0) *reinterpret_cast<float2*>(&T[cur * kTS + 2 * lane]) = acc;
+              acc = make_float2(0.f, 0.f);
+              cur = px;
+            }
+            acc.x = fmaf(w, v[u].x, acc.x);
+            acc.y = fmaf(w, v[u].y, acc.y);
+          }
+        }
+        j += 8;
+      }
+      if (cur >= 0) *reinterpret_cast<float2*>(&T[cur * kTS + 2 * lane]) = acc;
+    }
+    __syncthreads();
+    // ---- dX[c][q] = sum_f W[f][coff + c] T[q][f]: a task = one 16-channel tile x two 16-pixel tiles (two accumulator
+    // chains sharing the A fragments, which come straight from W in global memory: 64-byte runs per lane group)
+    for (int task = wave; task < nmt * (kTP / 32); task += kGW / 64) {
+      const int mt = task / (kTP / 32), np = task - mt * (kTP / 32);
+      if (q0 + 32 * np >= hw) continue;
+      const bool z0 = soff[32 * np + 16] > soff[32 * np], z1 = soff[32 * np + 32] > soff[32 * np + 16];
+      v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      if (z0 || z1) {
+        float a[32];
+        const int c = 16 * mt + n, cc = min(c, C - 1);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) a[s] = Wp[(int64_t)(4 * s + gq) * Ctot + cc];
+        if (c >= C) {
+#pragma unroll
+          for (int s = 0; s < 32; ++s) a[s] = 0.f;
+        }
+        const float* t0 = T + (32 * np + n) * kTS + gq;
+        const float* t1 = t0 + 16 * kTS;
+        // B fragments from LDS, eight k-steps requested ahead of the MFMAs that use them
+        float tb0[2][8], tb1[2][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { tb0[0][u] = t0[4 * u]; tb1[0][u] = t1[4 * u]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < 3) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { tb0[(c + 1) & 1][u] = t0[4 * (8 * c + 8 + u)]; tb1[(c + 1) & 1][u] = t1[4 * (8 * c + 8 + u)]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * c + u], tb0[c & 1][u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * c + u], tb1[c & 1][u], acc1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // D: lane (gq, n) holds channels 16 mt + 4 gq + j, pixel 16 (2 np [+ 1]) + n
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 16 * mt + 4 * gq + j;
+        if (c >= C) continue;
+        const float pool = dp != nullptr ? dp[c] * inv : 0.f;
+        const int qa = q0 + 32 * np + n, qb = qa + 16;
+        if (qa < hw) out[(int64_t)c * hw + qa] = fmaf(sc, acc0[j], pool);
+        if (qb < hw) out[(int64_t)c * hw + qb] = fmaf(sc, acc1[j], pool);
+      }
+    }
+  }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+int dw_chunks(int B) {
+  (void)B;
+  return 128;                     // x 2 modalities = one workgroup per CU of an MI355X
+}
+
+template <int KS>
+int launch_project(const Maps8& e, int B, const int64_t* pix, int R, int Ctot, const float* Wp1, const float* bp1,
+                   const float* Wp2, const float* bp2, float* xs, int ld, float* rows, float* grows, hipStream_t s) {
+  constexpr int XS = 4 * KS + 2;
+  // LDS budget: the tile, then branch 3, then branch 2 if they fit in 160 KiB
+  const int cap = (160 * 1024 - 4096) / 4;            // 3.2 KB of static LDS: the stencil table
+  int used = kSR * XS, off2 = -1, off3 = -1;
+  const int n3 = e.C[3] * ((e.H[3] * e.W[3]) | 1), n2 = e.C[2] * ((e.H[2] * e.W[2]) | 1);
+  if (used + n3 <= cap) { off3 = used; used += n3; }
+  if (used + n2 <= cap) { off2 = used; used += n2; }
+  if (kSR * XS > cap) return (int)hipErrorInvalidValue;
+  // rows per workgroup: fewest (rounds over the CUs) x (tiles per workgroup + the staging prologue)
+  const int cus = num_cus();
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ns = 1; ns <= 32 && ns <= R; ++ns) {
+    const int per = (R + ns - 1) / ns, tiles = (per + kSR - 1) / kSR;
+    const int rounds = (2 * B * ns + cus - 1) / cus;
+    const double cost = rounds * (tiles + 1.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
+  }
+  const int per = (R + best - 1) / best;
+  const size_t bytes = (size_t)used * sizeof(float);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(project_rows_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (err != hipSuccess) return (int)err;
+  project_rows_kernel<KS><<<dim3(best, B, 2), kPW, bytes, s>>>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows,
+                                                             per, off2, off3);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
+                     const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
+                     float* grows, hcm_stream_t stream) {
+  if (B <= 0 || R <= 0 || F != kF || pix == nullptr || rows == nullptr || !branches_ok(enc1, Ctot) ||
+      !branches_ok(enc2, Ctot))
+    return (int)hipErrorInvalidValue;
+  for (int i = 0; i < 4; ++i)
+    if (enc1.C[i] != enc2.C[i] || enc1.H[i] != enc2.H[i] || enc1.W[i] != enc2.W[i]) return (int)hipErrorInvalidValue;
+  const int ld = hcm_sample_branches_ld(Ctot);
+  const Maps8 e = pack8(enc1, enc2);
+  hipStream_t s = (hipStream_t)stream;
+  // HRNet-w18 / w32 / w48: 270 / 480 / 720 channels + the bias column
+  if (Ctot + 1 <= 4 * 68) return launch_project<68>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  if (Ctot + 1 <= 4 * 121) return launch_project<121>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  if (Ctot + 1 <= 4 * 181) return launch_project<181>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  return (int)hipErrorInvalidValue;
+}
+
+size_t hcm_project_rows_dw_workspace_bytes(int B, int Ctot) {
+  return (size_t)2 * dw_chunks(B) * kF * hcm_sample_branches_ld(Ctot) * sizeof(float);
+}
+
+int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale, int B, int R, int Ctot, int F,
+                        float* dWp1, float* dbp1, float* dWp2, float* dbp2, void* workspace, size_t workspace_bytes,
+                        hcm_stream_t stream) {
+  if (B <= 0 || R <= 0 || Ctot <= 0 || F != kF || !grows || !xs || !dWp1 || !dbp1 || !dWp2 || !dbp2 || !workspace ||
+      workspace_bytes < hcm_project_rows_dw_workspace_bytes(B, Ctot))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const int ld = hcm_sample_branches_ld(Ctot), M = B * R;
+  const int nchunk = dw_chunks(B);
+  int rpc = (M + nchunk - 1) / nchunk;
+  rpc = (rpc + 3) & ~3;
+  const int ncg = (ld + kNT * 16 - 1) / (kNT * 16);
+  float* part = static_cast<float*>(workspace);
+  proj_dw_partial_kernel<<<dim3(nchunk, ncg, 2), kDW, 0, s>>>(grows, xs, M, ld, rpc, part);
+  HCM_CHECK_LAUNCH();
+  proj_dw_reduce_kernel<<<dim3((kF * ld + 255) / 256, 2), 256, 0, s>>>(part, nchunk, ld, Ctot, scale, dWp1, dbp1, dWp2, dbp2);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+
+static int plan_geom(const hcm_branches_out& g1, int R, PlanGeom* gm) {
+  int eo = 0, oo = 0;
+  for (int i = 0; i < 4; ++i) {
+    gm->H[i] = g1.H[i]; gm->W[i] = g1.W[i];
+    gm->ent_off[i] = eo; gm->off_off[i] = oo;
+    eo += (i == 0 ? 1 : 4) * R;
+    oo += g1.H[i] * g1.W[i] + 1;
+  }
+  gm->ent_per_image = eo;
+  gm->off_per_image = (oo + 3) & ~3;
+  return 0;
+}
+
+size_t hcm_project_rows_backward_workspace_bytes(int B, int R, int Ctot, hcm_branches_out g1) {
+  PlanGeom gm;
+  plan_geom(g1, R, &gm);
+  const size_t dw = hcm_project_rows_dw_workspace_bytes(B, Ctot);
+  return dw + (size_t)B * gm.ent_per_image * sizeof(int2) + (size_t)B * gm.off_per_image * sizeof(int) + 256;
+}
+
+int hcm_project_rows_backward(const float* grows, const float* xs, const float* Wp1, const float* Wp2,
+                              const float* dpooled, const float* scale, const int64_t* pix, int R, int B, int Ctot,
+                              int F, hcm_branches_out g1, hcm_branches_out g2, const int32_t* keep, int S, float* dWp1,
+                              float* dbp1, float* dWp2, float* dbp2, void* workspace, size_t workspace_bytes,
+                              hcm_stream_t stream) {
+  if (B <= 0 || R <= 0 || F != kF || !grows || !xs || !Wp1 || !Wp2 || !pix || !workspace || !branches_ok(g1, Ctot) ||
+      !branches_ok(g2, Ctot) || workspace_bytes < hcm_project_rows_backward_workspace_bytes(B, R, Ctot, g1))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  PlanGeom gm;
+  plan_geom(g1, R, &gm);
+  TilePlan tp;
+  int v = 0, n2 = 2;
+  for (int i = 0; i < 4; ++i) {
+    if (g1.C[i] != g2.C[i] || g1.H[i] != g2.H[i] || g1.W[i] != g2.W[i]) return (int)hipErrorInvalidValue;
+    // keys are pixel * E + entry in 32 bits
+    if ((uint64_t)g1.H[i] * g1.W[i] * 4ull * (uint64_t)R >= 0xffffffffull) return (int)hipErrorInvalidValue;
+    if (g1.H[i] * g1.W[i] >= (1 << 17) || R >= (1 << kRowBits)) return (int)hipErrorInvalidValue;
+    const int nt = (g1.H[i] * g1.W[i] + kTP - 1) / kTP;
+    tp.span[i] = (nt + 127) / 128;                   // one 64-pixel sub-tile per workgroup up to 128 x 64 = 8192 pixels
+    tp.first[i] = v;
+    v += (nt + tp.span[i] - 1) / tp.span[i];
+  }
+  tp.first[4] = v;
+  n2 = 128;
+  while (n2 < 4 * R) n2 <<= 1;
+  if ((size_t)n2 * 4 > 150 * 1024) return (int)hipErrorInvalidValue;            // R <= 9600 rows per image
+  char* base = static_cast<char*>(workspace);
+  const size_t dwb = hcm_project_rows_dw_workspace_bytes(B, Ctot);
+  int2* ent = reinterpret_cast<int2*>(base + ((dwb + 15) & ~(size_t)15));
+  int* off = reinterpret_cast<int*>(ent + (size_t)B * gm.ent_per_image);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(stencil_plan_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4);
+  if (err != hipSuccess) return (int)err;
+  stencil_plan_kernel<<<dim3(4, B), kPT, (size_t)n2 * 4, s>>>(pix, R, gm, keep, S, n2, ent, off);
+  HCM_CHECK_LAUNCH();
+  if (dWp1 != nullptr) {
+    const int rc = hcm_project_rows_dw(grows, xs, scale, B, R, Ctot, F, dWp1, dbp1, dWp2, dbp2, workspace, dwb, stream);
+    if (rc != 0) return rc;
+  }
+  branch_grad_t_kernel<<<dim3(v, B, 2), kGW, 0, s>>>(grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot,
+                                                     pack8(g1, g2), tp, gm);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

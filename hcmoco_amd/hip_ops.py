@@ -893,7 +893,56 @@ def branch_grad(dxs, dpooled, scale, pix, shapes, dWpad=None, F=128, keep=None, 
     return g1, g2, dWp1, dbp1, dWp2, dbp2
 
 
+def project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, save=True, zero_grows=True):
+    """(rows [2,B*R,128], xs [2,B*R,ld] or None, grows [2,B*R,128] zero-filled or None): merge_all_res + the 1x1
+    projections (build_backbone.py:243-254, :290-300) at the pixels ``pix`` for both modalities in ONE launch on the fp32
+    matrix cores (csrc/rowproj.hip).  ``save``: keep the sampled rows ``xs`` for the weight gradient."""
+    B, R = pix.shape
+    Ctot = sum(m.shape[1] for m in maps1)
+    F = Wp1.shape[0]
+    ld = int(_lib.lib().hcm_sample_branches_ld(Ctot))
+    dev = pix.device
+    rows = torch.empty(2, B * R, F, dtype=torch.float32, device=dev)
+    xs = torch.empty(2, B * R, ld, dtype=torch.float32, device=dev) if save else None
+    grows = torch.empty(2, B * R, F, dtype=torch.float32, device=dev) if zero_grows else None
+    d = lambda t: _dev(t, torch.float32, 'project_rows')
+    check(_lib.lib().hcm_project_rows(
+        _branches(maps1, 'project_rows'), _branches(maps2, 'project_rows'), B, _dev(pix, torch.int64, 'project_rows'), R,
+        Ctot, F, d(Wp1.reshape(F, Ctot)), d(bp1), d(Wp2.reshape(F, Ctot)), d(bp2), _opt(xs, torch.float32, 'project_rows'),
+        d(rows), _opt(grows, torch.float32, 'project_rows'), _stream()), 'hcm_project_rows')
+    return rows, xs, grows
+
+
+def project_rows_backward(grows, xs, Wp1, Wp2, dpooled, scale, pix, shapes, keep=None, S=0, weight_grads=True):
+    """Backward of ``project_rows`` + the heads' average pooling -> (gmaps1[4], gmaps2[4], dWp1, dbp1, dWp2, dbp2):
+    stencil plan, weight-gradient partials + reduction, transposed-order branch tiles (csrc/rowproj.hip)."""
+    B, R = pix.shape
+    dev = pix.device
+    Ctot = sum(s[1] for s in shapes)
+    F = grows.shape[-1]
+    g1 = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    g2 = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    dWp1 = dbp1 = dWp2 = dbp2 = None
+    if weight_grads:
+        dWp = torch.empty(2, F, Ctot, dtype=torch.float32, device=dev)
+        dbp = torch.empty(2, F, dtype=torch.float32, device=dev)
+        dWp1, dWp2, dbp1, dbp2 = dWp[0], dWp[1], dbp[0], dbp[1]
+    b1, b2 = _branches(g1, 'project_rows_backward'), _branches(g2, 'project_rows_backward')
+    L = _lib.lib()
+    nb = L.hcm_project_rows_backward_workspace_bytes(B, R, Ctot, b1)
+    ws = _ws(nb, dev)
+    p = lambda t: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+    d = lambda t: _dev(t, torch.float32, 'project_rows_backward')
+    check(L.hcm_project_rows_backward(
+        d(grows), d(xs), d(Wp1.reshape(F, Ctot)), d(Wp2.reshape(F, Ctot)), _opt(dpooled, torch.float32, 'project_rows_backward'),
+        _opt(scale, torch.float32, 'project_rows_backward'), _dev(pix, torch.int64, 'project_rows_backward'), R, B, Ctot, F,
+        b1, b2, _opt(keep, torch.int32, 'project_rows_backward'), int(S), p(dWp1), p(dbp1), p(dWp2), p(dbp2),
+        C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_project_rows_backward')
+    return g1, g2, dWp1, dbp1, dWp2, dbp2
+
+
 _ROW_INDEX = {}
+GATHER_WAIT_EVENTS = None       # bench.py sets a list: HIP event pairs around the wait for the feature/index all-gather
 
 
 def _row_index(B, S, J, device):
@@ -986,7 +1035,14 @@ class _Stage2Section(torch.autograd.Function):
 
         def update_banks():
             if pending is not None:
-                pending.wait()
+                if GATHER_WAIT_EVENTS is not None:      # bench.py: how long the stream stands still for the all-gather
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                    pending.wait()
+                    ev[1].record()
+                    GATHER_WAIT_EVENTS.append(ev)
+                else:
+                    pending.wait()
             mem.update_strided(all_x, ldx, all_index_of())
         if pending is None:
             update_banks()
@@ -1004,15 +1060,14 @@ class _Stage2Section(torch.autograd.Function):
                 keep = _i32(cfg['keep'])
             else:
                 pix, coord, keep = pixel_sample(cfg['depth_mask'], h, w, S, ud, cfg['joints2d'], *mem.next_pixel_key())
-            # ---- row 8 at the sampled pixels + the 1x1 projections as one batched GEMM (bias folded in)
-            xs, Wpad, grows = sample_branches(maps1, maps2, pix, Wp1, bp1, Wp2, bp2)
-            rows = torch.bmm(xs, Wpad.transpose(1, 2))                       # [2, B*R, F]
+            # ---- row 8 at the sampled pixels: merge + 1x1 projections (bias folded in) in one MFMA launch
+            rows, xs, grows = project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2)          # [2, B*R, F]
             R = pix.shape[1]
             meters, gj = fmap_losses_on_rows(rows.view(2, B, R, F), grows.view(2, B, R, F), feat3c, S, coord, w, keep,
                                              vis, ud, ur, cfg['temperature'], cfg.get('gemm_dtype', 'fp32'))
             if tape is not None:
                 tape.update(pix=pix, coord=coord, keep=keep, rows=rows, meters=meters)
-            ctx.save_for_backward(pooled, mean3, ypre, W1, W2, W3, gxT, gj, xs, Wpad, grows, pix, keep)
+            ctx.save_for_backward(pooled, mean3, ypre, W1, W2, W3, gxT, gj, xs, Wp1, Wp2, grows, pix, keep)
             ctx.S = S
         else:
             ctx.save_for_backward(pooled, mean3, ypre, W1, W2, W3, gxT)
@@ -1031,13 +1086,12 @@ class _Stage2Section(torch.autograd.Function):
     def backward(ctx, g_total, *_unused):
         scale = g_total.contiguous().to(torch.float32)
         if ctx.stage2:
-            pooled, mean3, ypre, W1, W2, W3, gxT, gj, xs, Wpad, grows, pix, keep = ctx.saved_tensors
+            pooled, mean3, ypre, W1, W2, W3, gxT, gj, xs, Wp1, Wp2, grows, pix, keep = ctx.saved_tensors
             F = W1.shape[0]
-            dxs = torch.bmm(grows, Wpad)                                     # [2, B*R, ld]
-            dWpad = torch.bmm(grows.transpose(1, 2), xs)                     # [2, F, ld]
             dW1, db1, dW2, db2, dW3, db3, dpooled, gfeat3 = heads_backward(gxT, scale, pooled, mean3, ypre, W1, W2, W3,
                                                                            gj, ctx.J)
-            g1, g2, dWp1, dbp1, dWp2, dbp2 = branch_grad(dxs, dpooled, scale, pix, ctx.shapes, dWpad, F, keep, ctx.S)
+            g1, g2, dWp1, dbp1, dWp2, dbp2 = project_rows_backward(grows, xs, Wp1, Wp2, dpooled, scale, pix, ctx.shapes,
+                                                                   keep, ctx.S)
             Ctot = dWp1.shape[1]
             return (gfeat3, dW1, db1, dW2, db2, dW3, db3, dWp1.view(F, Ctot, 1, 1), dbp1, dWp2.view(F, Ctot, 1, 1), dbp2,
                     g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3], None)

@@ -83,6 +83,9 @@ class GradSync(object):
         self._changed = False        # this rank saw a gradient outside an agreed pattern during this reduce()
         self._flag_host = self._flag_event = None
         self.agreements = 0          # presence all-reduces issued so far (tests read it)
+        # bench.py sets this to a list: every reduce() then appends a HIP event pair around the waits below -- the time the
+        # trainer's stream stands still for collectives that backward did not cover (exposed communication)
+        self.wait_events = None
         self._comm = None
         # several chunks in one RCCL launch (nccl only: gloo's coalescing manager has no all-reduce fast path)
         self.coalesce = self.avg and os.environ.get('HCM_GRAD_COALESCE', '1') != '0'
@@ -225,11 +228,18 @@ class GradSync(object):
         carrier[-1:].fill_(1.0 if self._changed else 0.0)     # MAX-like under AVG / SUM: non-zero iff some rank raised it
         for flat in flats:
             works.append(self._launch(flat))
+        timed = self.wait_events is not None and carrier.is_cuda
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for ts, w in works:
             w.wait()                 # RCCL: orders the current stream behind the collective, no host block
             if not self.avg:
                 for t in ts:
                     t.div_(self.world)
+        if timed:
+            ev[1].record()
+            self.wait_events.append(ev)
         # the reduced flag goes to the host without a sync; it is read at the top of the next reduce()
         if carrier.is_cuda:
             self._flag_host = torch.empty(1, dtype=carrier.dtype, pin_memory=True)

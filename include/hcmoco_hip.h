@@ -26,8 +26,9 @@ extern "C" {
 typedef void* hcm_stream_t; /* hipStream_t */
 
 /* 2 (round 3): hcm_sgc_forward/backward take a workspace, the PointNet++ index/distance ops default to the
- * FMA arithmetic contract, new loss-section entry points.  A library and a caller must agree on this number. */
-#define HCM_ABI_VERSION 2
+ * FMA arithmetic contract, new loss-section entry points.  3 (round 4): hcm_project_rows* added (row 8 on the matrix
+ * cores); nothing removed.  A library and a caller must agree on this number. */
+#define HCM_ABI_VERSION 3
 int hcm_abi_version(void);
 /* hipGetErrorString() for a value returned by any entry point. */
 const char* hcm_error_string(int err);
@@ -306,6 +307,37 @@ int hcm_sample_branches(hcm_branches enc1, hcm_branches enc2, int B, const int64
 int hcm_branch_grad(const float* dxs, const float* dpooled, const float* scale, const int64_t* pix, int R, int B,
                     int Ctot, hcm_branches_out g1, hcm_branches_out g2, const int32_t* keep, int S, const float* dWpad,
                     int F, float* dWp1, float* dbp1, float* dWp2, float* dbp2, hcm_stream_t stream);
+
+/* Row 8 on the matrix cores (r04, csrc/rowproj.hip; replaces hcm_sample_branches + three library GEMMs + hcm_branch_grad
+ * in the trainer's path).  Forward: rows[m, b*R + r, :] = [W_m | b_m] applied to the merged, sampled row
+ * (merge_all_res + encoder{1,2}_linear at pixel pix[b, r]; networks/build_backbone.py:243-254, :290-300), fp32 MFMA,
+ * F == 128.  xs [2, B*R, ld] (ld = hcm_sample_branches_ld(Ctot)) receives the sampled rows [x | 1 | 0] for the weight
+ * gradient (NULL = inference, nothing saved); grows [2, B*R, F] is zero-filled (NULL = skip).  Ctot + 1 <= 724
+ * (HRNet-w48: 720 channels). */
+int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
+                     const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
+                     float* grows, hcm_stream_t stream);
+/* d[W | b] = (*scale) * grows^T xs per modality -> dWp [F, Ctot], dbp [F]: MFMA partials over 128 row chunks, summed in
+ * chunk order (deterministic).  workspace: hcm_project_rows_dw_workspace_bytes(B, Ctot). */
+size_t hcm_project_rows_dw_workspace_bytes(int B, int Ctot);
+int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale, int B, int R, int Ctot, int F,
+                        float* dWp1, float* dbp1, float* dWp2, float* dbp2, void* workspace, size_t workspace_bytes,
+                        hcm_stream_t stream);
+/* Backward of hcm_project_rows + the average pooling of the heads: the weight / bias gradients (above; dWp1 == NULL
+ * skips them) and all eight branch gradients,
+ *   g_m.map[i][b, c, q] = dpooled[m, b, coff_i + c] / (H_i W_i)
+ *                         + (*scale) * sum_f W_m[f, coff_i + c] * ( sum over the stencil entries (r, tap) of image b that
+ *                           land on pixel q of weight(r, tap) * grows[m, b*R + r, f] ),
+ * entries in ascending (row, tap) order, f ascending: owner computes, no atomics, every element written exactly once.
+ * keep / S as in hcm_branch_grad.  Three launches: the stencil plan (entries sorted by pixel, shared by both modalities),
+ * the weight-gradient partials + reduction, the branch tiles.  workspace:
+ * hcm_project_rows_backward_workspace_bytes(B, R, Ctot, g1).  H_i W_i * 4R < 2^32, R <= 9600. */
+size_t hcm_project_rows_backward_workspace_bytes(int B, int R, int Ctot, hcm_branches_out g1);
+int hcm_project_rows_backward(const float* grows, const float* xs, const float* Wp1, const float* Wp2,
+                              const float* dpooled, const float* scale, const int64_t* pix, int R, int B, int Ctot,
+                              int F, hcm_branches_out g1, hcm_branches_out g2, const int32_t* keep, int S, float* dWp1,
+                              float* dbp1, float* dWp2, float* dbp2, void* workspace, size_t workspace_bytes,
+                              hcm_stream_t stream);
 
 /* total[0] = sum(losses6) (+ meters9[0] + [1] + [4] + [5] + [8] when meters9 != NULL): the objective of
  * learning/contrast_trainer.py:980 (:594 for stage 1) from the kernels' own outputs, in one tiny launch. */

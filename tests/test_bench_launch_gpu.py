@@ -38,6 +38,12 @@ def test_plain_python_bench_gpus_2_launches_two_ranks():
     assert loss == loss and abs(loss) < 1e6
     assert out['config']['grad_collectives_per_step'] == 9             # 4 chunks x 2 HRNets + the rest bucket
     assert out['value'] > 0 and out['cpu_baseline'] is None
+    # the N > 1 line says where communication was exposed: HIP events around the two stream waits
+    comm = out['comm']
+    assert comm['ranks_seen'] == 2 and comm['world_size'] == 2 and comm['backend'] == 'gloo'
+    assert comm['launches'] == 9 and comm['steps_measured'] == 2
+    assert comm['allreduce_exposed_ms'] is not None and comm['allreduce_exposed_ms'] >= 0
+    assert comm['allgather_wait_ms'] is not None and comm['allgather_wait_ms'] >= 0
 
 
 def test_bench_under_torchrun_still_works():

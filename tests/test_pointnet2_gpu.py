@@ -64,7 +64,12 @@ def test_fps_known_answer_tie_break():
 
 
 @pytest.mark.parametrize('N,M,r,ns', [(10, 4, 0.3, 3), (300, 300, 0.2, 16), (4096, 1024, 0.125, 32),
-                                      (2500, 777, 0.05, 16), (1024, 256, 1.0, 32)])
+                                      (2500, 777, 0.05, 16), (1024, 256, 1.0, 32),
+                                      # r04, one wave per centre: more slots than lanes, an odd number of centres (the
+                                      # kernel takes them two at a time), a cloud that is not a multiple of 64, every
+                                      # point inside the ball, and a cloud too large for LDS (thread-per-centre kernel)
+                                      (1000, 77, 0.5, 100), (65, 9, 10.0, 70), (4096, 4096, 0.025, 16),
+                                      (9500, 300, 0.1, 16)])
 def test_ball_query_bit_exact(N, M, r, ns, contract):
     xyz = cloud(2, N, N + M)
     new_xyz = xyz[:, torch.randperm(N)[:M]].contiguous()
@@ -76,7 +81,11 @@ def test_ball_query_bit_exact(N, M, r, ns, contract):
     assert idx[:, 0].abs().sum() == 0
 
 
-@pytest.mark.parametrize('n,m', [(7, 2), (256, 64), (4096, 1024), (3000, 4096)])
+@pytest.mark.parametrize('n,m', [(7, 2), (256, 64), (4096, 1024), (3000, 4096),
+                                 # r04, scan split over 16 lanes: fewer known points than lanes (m < 16 keeps the
+                                 # thread-per-unknown kernel), m not a multiple of 16, more than one LDS tile, and
+                                 # 2 x 300 000 unknowns (> 2^19: thread-per-unknown kernel)
+                                 (100, 15), (100, 17), (1030, 1100), (5, 3000), (300000, 50)])
 def test_three_nn_bit_exact(n, m, contract):
     unknown, known = cloud(2, n, n), cloud(2, m, m + 1)
     rd, ri = P.three_nn(unknown, known)
@@ -85,6 +94,23 @@ def test_three_nn_bit_exact(n, m, contract):
     mod().three_nn_wrapper(2, n, m, unknown.to(d()), known.to(d()), dist2, idx)
     assert torch.equal(idx.cpu(), ri)
     assert torch.equal(dist2.cpu(), rd)
+
+
+@pytest.mark.parametrize('B,C,m,n', [(2, 5, 700, 2500), (2, 130, 4096, 4096), (1, 33, 9000, 3000), (2, 64, 64, 5000),
+                                     (1, 7, 2048, 70000)])
+def test_three_interpolate_with_the_source_rows_in_lds(B, C, m, n, contract):
+    """interpolate_gpu.cu:77-97 through the r04 LDS kernel (n >= 2048 and a block of >= 4 channels of all m points fits
+    LDS; (33, 9000, 3000) does not and takes the gather kernel): channel counts that are not multiples of 4 or of the
+    block, a split position axis, bit-exact against the oracle in both arithmetic contracts."""
+    torch.manual_seed(C + n)
+    feats = torch.randn(B, C, m)
+    ii = torch.randint(0, m, (B, n, 3), dtype=torch.int32)
+    ii[:, :50] = ii[:, :1]                          # runs of equal indices
+    w = torch.rand(B, n, 3)
+    w = w / w.sum(-1, keepdim=True)
+    out = torch.full((B, C, n), float('nan'), device=d())
+    mod().three_interpolate_wrapper(B, C, m, n, feats.to(d()), ii.to(d()), w.to(d()), out)
+    assert torch.equal(out.cpu(), P.three_interpolate(feats, ii, w))
 
 
 def test_group_gather_interpolate_and_grads(contract):

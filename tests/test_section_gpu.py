@@ -188,6 +188,119 @@ def test_sampled_merge_projection_and_its_backward_against_torch(B, width, size,
         assert torch.equal(a, b_) and bool(torch.isfinite(a).all())
 
 
+@pytest.mark.parametrize('B,width,size,R', [(3, 18, 16, 37), (2, 32, 8, 20), (32, 18, 64, 417), (2, 18, 56, 60),
+                                            (2, 18, 72, 417), (3, 18, 80, 416), (2, 32, 80, 417), (2, 48, 32, 50),
+                                            (2, 18, 96, 100), (1, 18, 40, 33), (1, 18, 24, 9), (56, 18, 80, 416)])
+def test_row8_on_the_matrix_cores_against_torch(B, width, size, R):
+    """csrc/rowproj.hip (r04): hcm_project_rows == gathering the full-resolution merge_all_res + 1x1 conv map
+    (build_backbone.py:243-254, :290-300); hcm_project_rows_backward == torch autograd of that flow plus the
+    average-pool gradient, for the branch maps, the projection weights and biases.  fp32 MFMA vs float64: 1e-5 on the
+    rows, 1e-4 relative L2 on every gradient.  Sizes: powers of two, the maps of 224 / 288 / 320 / 384 crops, all three
+    HRNet widths, the recipe's B = 56 at 320.  Bit-repeatable; every output element written."""
+    torch.manual_seed(width + R)
+    d = dev()
+    m1, m2 = make_maps(B, width, size, 3), make_maps(B, width, size, 4)
+    Ctot, Fd = 15 * width, 128
+    Wp = [torch.randn(Fd, Ctot, 1, 1) * 0.05 for _ in range(2)]
+    bp = [torch.randn(Fd) * 0.1 for _ in range(2)]
+    pix = torch.randint(0, size * size, (B, R))
+    pix[:, 1] = pix[:, 0]                           # duplicates
+    pix[0, 2] = 0
+    pix[0, 3] = size * size - 1                     # corners (clamped stencils)
+    S = R // 2
+    keep = torch.ones(B, dtype=torch.int32)
+    if B > 1:
+        keep[1] = 0
+        pix[1, :S] = 0                              # a dropped image: its dense samples sit on pixel 0, gradient zero
+    g = lambda t: t.to(d)
+    gm1, gm2 = [g(t) for t in m1], [g(t) for t in m2]
+    rows, xs, grows = ops().project_rows(gm1, gm2, g(pix), g(Wp[0]), g(bp[0]), g(Wp[1]), g(bp[1]))
+    assert float(grows.abs().max()) == 0 and rows.shape == (2, B * R, Fd)
+    rows_only, none_xs, _ = ops().project_rows(gm1, gm2, g(pix), g(Wp[0]), g(bp[0]), g(Wp[1]), g(bp[1]), save=False)
+    assert none_xs is None and torch.equal(rows_only, rows)
+    big = B * size * size * Ctot > 40e6              # float64 autograd of the full maps on the CPU: keep it bounded
+    dd = (lambda t: t.double().requires_grad_(True)) if not big else (lambda t: t.float().requires_grad_(True))
+    md = [[dd(t) for t in m1], [dd(t) for t in m2]]
+    Wd, bd = [dd(t) for t in Wp], [dd(t) for t in bp]
+    full = [_project_full(md[k], Wd[k], bd[k]) for k in range(2)]
+    sel = []
+    for k in range(2):
+        ref = full[k].flatten(2).gather(2, pix[:, None, :].expand(B, Fd, R)).transpose(1, 2)      # [B, R, F]
+        sel.append(ref)
+        assert torch.allclose(rows[k].view(B, R, Fd).cpu().to(ref.dtype), ref.detach(), rtol=1e-5 if not big else 1e-4,
+                              atol=1e-5 if not big else 1e-4)
+    # the saved rows: [x | 1 | 0]
+    assert torch.equal(xs[:, :, Ctot], torch.ones_like(xs[:, :, Ctot])) and float(xs[:, :, Ctot + 1:].abs().max()) == 0
+    # backward
+    gr = torch.randn(2, B, R, Fd)
+    gr[:, keep == 0, :S] = 0                        # what the loss kernels leave for a dropped image
+    dpooled = torch.randn(2, B, Ctot)
+    scale = torch.tensor(1.7)
+    shapes = [tuple(t.shape) for t in m1]
+    args = (g(gr).view(2, B * R, Fd), xs, g(Wp[0]), g(Wp[1]), g(dpooled), g(scale), g(pix), shapes, g(keep), S)
+    g1, g2, dWp1, dbp1, dWp2, dbp2 = ops().project_rows_backward(*args)
+    loss = 0
+    for k in range(2):
+        loss = loss + 1.7 * (sel[k] * gr[k].to(sel[k].dtype)).sum()
+        off = 0
+        for t in md[k]:
+            C = t.shape[1]
+            loss = loss + (t.mean((2, 3)) * dpooled[k][:, off:off + C].to(t.dtype)).sum()
+            off += C
+    loss.backward()
+    tol = 1e-4 if not big else 1e-3
+    for k, gm in enumerate((g1, g2)):
+        for i in range(4):
+            assert rel_l2(gm[i], md[k][i].grad) < tol, (k, i, rel_l2(gm[i], md[k][i].grad))
+    for got, ref in ((dWp1, Wd[0].grad), (dWp2, Wd[1].grad), (dbp1, bd[0].grad), (dbp2, bd[1].grad)):
+        assert rel_l2(got.reshape(ref.shape), ref) < tol, rel_l2(got.reshape(ref.shape), ref)
+    # the same gradients without the keep hint (the dropped image's rows are listed and contribute exact zeros)
+    h1, h2 = ops().project_rows_backward(*args[:8], None, 0)[:2]
+    for a, b_ in zip(g1 + g2, h1 + h2):
+        assert rel_l2(a, b_) < 1e-6
+    # deterministic, and every element is written (poisoned output buffers would show)
+    again = ops().project_rows_backward(*args)
+    for a, b_ in zip(g1 + g2 + [dWp1, dbp1, dWp2, dbp2], again[0] + again[1] + list(again[2:])):
+        assert torch.equal(a, b_) and bool(torch.isfinite(a).all())
+    # and the r03 path (staging matrix + library GEMMs + owner-computes scan) agrees
+    xs0, Wpad, _ = ops().sample_branches(gm1, gm2, g(pix), g(Wp[0]), g(bp[0]), g(Wp[1]), g(bp[1]))
+    assert torch.allclose(xs0, xs, rtol=1e-6, atol=1e-6)      # same taps; the two kernels contract the four products differently
+    old = ops().branch_grad(torch.bmm(g(gr).view(2, B * R, Fd), Wpad), g(dpooled), g(scale), g(pix), shapes,
+                            torch.bmm(g(gr).view(2, B * R, Fd).transpose(1, 2), xs0), Fd, g(keep), S)
+    for a, b_ in zip(g1 + g2 + [dWp1, dbp1, dWp2, dbp2], old[0] + old[1] + list(old[2:])):
+        assert rel_l2(a, b_) < 1e-5, rel_l2(a, b_)
+
+
+def test_row8_backward_with_a_pixel_sampled_hundreds_of_times():
+    """A mask with a single valid pixel puts all S samples of every image on it (contrast_trainer.py:685 draws with
+    replacement): the per-pixel entry lists are then 400 long.  r03's list construction was quadratic there (736 us at
+    the bench size); the sorted plan is linear -- and still exact."""
+    torch.manual_seed(5)
+    d = dev()
+    B, width, size, R = 4, 18, 64, 417
+    m1, m2 = make_maps(B, width, size, 3), make_maps(B, width, size, 4)
+    Ctot, Fd = 15 * width, 128
+    Wp = [torch.randn(Fd, Ctot, 1, 1) * 0.05 for _ in range(2)]
+    bp = [torch.randn(Fd) * 0.1 for _ in range(2)]
+    pix = torch.full((B, R), 1234)
+    pix[:, 400:] = torch.randint(0, size * size, (B, 17))
+    g = lambda t: t.to(d)
+    rows, xs, grows = ops().project_rows([g(t) for t in m1], [g(t) for t in m2], g(pix), g(Wp[0]), g(bp[0]), g(Wp[1]), g(bp[1]))
+    gr = torch.randn(2, B * R, Fd)
+    shapes = [tuple(t.shape) for t in m1]
+    g1, g2 = ops().project_rows_backward(g(gr), xs, g(Wp[0]), g(Wp[1]), None, None, g(pix), shapes)[:2]
+    md = [[t.double().requires_grad_(True) for t in m1], [t.double().requires_grad_(True) for t in m2]]
+    loss = 0
+    for k in range(2):
+        full = _project_full(md[k], Wp[k].double(), bp[k].double())
+        sel = full.flatten(2).gather(2, pix[:, None, :].expand(B, Fd, R)).transpose(1, 2).reshape(B * R, Fd)
+        loss = loss + (sel * gr[k].double()).sum()
+    loss.backward()
+    for k, gm in enumerate((g1, g2)):
+        for i in range(4):
+            assert rel_l2(gm[i], md[k][i].grad) < 1e-4
+
+
 def test_range_checked_draw_and_strided_update():
     """memory/mem_bank.py:CMCMem3: the kernels clamp out-of-range rows and raise a sticky device flag; the update reads
     column slices of ONE gathered matrix (row stride 386) without copies."""

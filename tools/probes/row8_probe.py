@@ -70,7 +70,17 @@ if hasattr(hip_ops, 'sample_branches'):
     timed('branch_grad (R = 0: pooling gradient only)', lambda: hip_ops.branch_grad(None, dpooled, None, nopix, shapes))
 bwd = getattr(hip_ops, 'project_rows_backward', None)
 if bwd is not None and fwd is not None:
-    out = fwd(maps1, maps2, pix, Wp[0], bp[0], Wp[1], bp[1])
+    rows_, xs_, _ = fwd(maps1, maps2, pix, Wp[0], bp[0], Wp[1], bp[1])
     gr = torch.randn(2, B * (S + J), F, device=d)
-    timed('project_rows_backward (dW + branch gradients)', lambda: bwd(out, gr, dpooled, scale, pix, shapes, Wp[0], Wp[1], keep, S))
+    gr.view(2, B, S + J, F)[:, keep == 0, :S] = 0
+    timed('project_rows_backward (plan + dW + branch tiles)',
+          lambda: bwd(gr, xs_, Wp[0], Wp[1], dpooled, scale, pix, shapes, keep, S))
+    timed('project_rows_backward (no weight gradients)',
+          lambda: bwd(gr, xs_, Wp[0], Wp[1], dpooled, scale, pix, shapes, keep, S, False))
+    timed('project_rows_backward (no image dropped: hub pixel 0)',
+          lambda: bwd(gr, xs_, Wp[0], Wp[1], dpooled, scale, pix, shapes, None, 0))
+    pj = pix[:, S:].contiguous()
+    rj, xj, _ = fwd(maps1, maps2, pj, Wp[0], bp[0], Wp[1], bp[1])
+    timed('project_rows_backward (R = J rows only)',
+          lambda: bwd(gr[:, :B * J].contiguous(), xj, Wp[0], Wp[1], dpooled, scale, pj, shapes, None, 0))
 print('done')
