@@ -82,7 +82,7 @@ def build(args, trainer, engine_device):
     return model, contrast, opt, data
 
 
-def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s, max_steps):
+def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s, max_steps, warmup_steps=3):
     """Runs in a fresh CPU-only process (see cpu_baseline): same step, same config, oracle losses."""
     import tempfile
     from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
@@ -94,8 +94,13 @@ def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s, max_step
     trainer.device = torch.device('cpu')
     model, contrast, opt, data = build(args, trainer, 'cpu')
     it = iter(data)
+    # SURVEY 8d asks for 3 warm-up + 10 timed steps; both are attempted inside the time budget (a step is ~5 s at batch
+    # 32), and the line says how many were actually taken
     t0 = time.perf_counter()
-    trainer.train_step(next(it), model, contrast, opt, stage2=True)          # warm-up
+    warmups = 0
+    while warmups < 1 or (warmups < warmup_steps and (time.perf_counter() - t0) * (1 + 1.0 / warmups) < 0.25 * budget_s):
+        trainer.train_step(next(it), model, contrast, opt, stage2=True)
+        warmups += 1
     warm = time.perf_counter() - t0
     steps, t0 = 0, time.perf_counter()
     while steps < 1 or (time.perf_counter() - t0 + warm + (time.perf_counter() - t0) / steps < budget_s
@@ -104,9 +109,9 @@ def cpu_baseline_worker(nce_k, n_data, size, skeleton, batch, budget_s, max_step
         steps += 1
     dt = time.perf_counter() - t0
     return {'value': round(batch * steps / dt, 3), 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-            'ms_per_step': round(1e3 * dt / steps, 1), 'batch': batch, 'timed_steps': steps, 'warmup_steps': 1,
-            'sample': '%d timed step(s) after 1 warm-up of the same stage-2 step at batch %d, K=%d, %dx%d, '
-                      'torch-CPU model + oracle losses, %d thread(s)' % (steps, batch, nce_k, size, size, threads)}
+            'ms_per_step': round(1e3 * dt / steps, 1), 'batch': batch, 'timed_steps': steps, 'warmup_steps': warmups,
+            'sample': '%d timed step(s) after %d warm-up of the same stage-2 step at batch %d, K=%d, %dx%d, '
+                      'torch-CPU model + oracle losses, %d thread(s)' % (steps, warmups, batch, nce_k, size, size, threads)}
 
 
 def check_step(records_path, timeout_s=600):
@@ -170,7 +175,7 @@ def cpu_baseline(nce_k, n_data, size, skeleton, batch):
     # step at batch 32 -- 8 threads 4.03, 16 threads 4.75, 32 threads 4.37, 64 threads 2.1 samples/s: HRNet's
     # small convolutions do not scale across sockets in torch-CPU
     threads = max(1, min(os.cpu_count() or 1, 16))
-    out = _cpu_leg(nce_k, n_data, size, skeleton, batch, threads, budget_s=25.0, max_steps=10, timeout_s=300)
+    out = _cpu_leg(nce_k, n_data, size, skeleton, batch, threads, budget_s=75.0, max_steps=10, timeout_s=400)
     out['cpu_model'] = cpu_model()
     out['host_threads_available'] = os.cpu_count()
     one = _cpu_leg(nce_k, n_data, size, skeleton, 4, 1, budget_s=20.0, max_steps=3, timeout_s=240)

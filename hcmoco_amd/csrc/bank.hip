@@ -973,6 +973,8 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;
       case 6: HCM_LAUNCH_PASS(6, 1); break;
+      case 25: HCM_LAUNCH_PASS(5, 2); break;         // r04: deeper rings HELD to two waves per SIMD (256 VGPRs)
+      case 26: HCM_LAUNCH_PASS(6, 2); break;
       case 12: HCM_LAUNCH_GLDS(2); break;
       case 13: HCM_LAUNCH_GLDS(3); break;
       case 14: HCM_LAUNCH_GLDS(4); break;

@@ -38,6 +38,15 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
   if (FMA) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
   return (dx * dx + dy * dy) + dz * dz;
 }
+// Two squared distances at once (two unknown points against one known point) on the packed fp32 lanes
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): element-wise IEEE operations, so each half is bit-identical to sqdist.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <bool FMA>
+__device__ __forceinline__ v2f sqdist2(v2f ax, v2f ay, v2f az, float bx, float by, float bz) {
+  const v2f dx = ax - bx, dy = ay - by, dz = az - bz;
+  if (FMA) return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+  return (dx * dx + dy * dy) + dz * dz;
+}
 template <bool FMA>
 __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
   if (FMA) return fmaf(a2, b2, fmaf(a0, b0, a1 * b1));
@@ -393,7 +402,22 @@ __global__ __launch_bounds__(kT) void three_nn_kernel(int n, int m,
       tile[e] = make_float4(c[0], c[1], c[2], 0.f);
     }
     __syncthreads();
-    for (int k = 0; k < len; ++k) {
+    // four known points per trip (their LDS reads and eight distances are independent), two unknowns per packed
+    // instruction; the insertion cascade is entered only by a lane whose distance beats its current third best
+    const v2f vx = {ux0, ux1}, vy = {uy0, uy1}, vz = {uz0, uz1};
+    int k = 0;
+    for (; k + 3 < len; k += 4) {
+      const float4 p0 = tile[k], p1 = tile[k + 1], p2 = tile[k + 2], p3 = tile[k + 3];
+      const v2f d0 = sqdist2<FMA>(vx, vy, vz, p0.x, p0.y, p0.z), d1 = sqdist2<FMA>(vx, vy, vz, p1.x, p1.y, p1.z);
+      const v2f d2 = sqdist2<FMA>(vx, vy, vz, p2.x, p2.y, p2.z), d3 = sqdist2<FMA>(vx, vy, vz, p3.x, p3.y, p3.z);
+      if (fminf(fminf(d0.x, d1.x), fminf(d2.x, d3.x)) < t0.b3) {
+        t0.push(d0.x, base + k); t0.push(d1.x, base + k + 1); t0.push(d2.x, base + k + 2); t0.push(d3.x, base + k + 3);
+      }
+      if (fminf(fminf(d0.y, d1.y), fminf(d2.y, d3.y)) < t1.b3) {
+        t1.push(d0.y, base + k); t1.push(d1.y, base + k + 1); t1.push(d2.y, base + k + 2); t1.push(d3.y, base + k + 3);
+      }
+    }
+    for (; k < len; ++k) {
       const float4 p = tile[k];
       t0.push(sqdist<FMA>(ux0, uy0, uz0, p.x, p.y, p.z), base + k);
       t1.push(sqdist<FMA>(ux1, uy1, uz1, p.x, p.y, p.z), base + k);

@@ -34,6 +34,19 @@ using namespace hcm;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DHCM_ROW8_TIMING, tools/probes/row8_timing.sh): s_memtime stamps of the phases of a workgroup,
+// 16 slots per workgroup in a buffer the probe hands over.  Compiled out of the product library.
+#ifdef HCM_ROW8_TIMING
+__device__ unsigned long long* g_row8_dbg = nullptr;
+#define HCM_STAMP(k)                                                                                              \
+  do {                                                                                                            \
+    if (g_row8_dbg != nullptr && threadIdx.x == 0)                                                                \
+      g_row8_dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = clock64(); \
+  } while (0)
+#else
+#define HCM_STAMP(k) do {} while (0)
+#endif
+
 constexpr int kPW = 512;     // forward workgroup: 8 waves, wave w owns output channels [16 w, 16 w + 16)
 constexpr int kSR = 32;      // rows per LDS tile: two 16-row MFMA tiles = two independent accumulator chains per wave
 constexpr int kF = 128;      // projected channels (the loss kernels' C)
@@ -57,14 +70,15 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     float* __restrict__ xs, int ld, float* __restrict__ rows, float* __restrict__ grows, int per, int off2, int off3) {
   constexpr int XS = 4 * KS + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ __attribute__((aligned(16))) int s_to[kSR][3][4];      // the tile's stencils: tap offsets ...
-  __shared__ __attribute__((aligned(16))) float s_tw[kSR][3][4];    // ... and (hy, ly, hx, lx)
-  __shared__ int s_pix[kSR];
+  __shared__ __attribute__((aligned(16))) int s_to[kSR][4][4];      // the tile's stencils: tap offsets ...
+  __shared__ __attribute__((aligned(16))) float s_tw[kSR][4][4];    // ... and (hy, ly, hx, lx); the finest branch is the
+                                                                    // stencil (p, p, p, p) / (1, 0, 1, 0): hy (hx a + 0 a) + 0 = a
   float* lx = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.z, b = blockIdx.y;
   const int r_begin = blockIdx.x * per, r_end = min(R, r_begin + per);
   if (r_begin >= r_end) return;
+  HCM_STAMP(0);
   const int n = lane & 15, g = lane >> 4;
   // ---- stage the coarse maps of this image: plane stride odd, so that the channel lanes of a tap hit different banks
   const int h0 = e.H[0], w0 = e.W[0];
@@ -77,12 +91,12 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     float* dst = lds + off;
     if ((hw & 3) == 0) {
       const int n4 = (C * hw) >> 2;
-      for (int base = tid; base < n4; base += 8 * kPW) {          // eight 16-byte loads in flight per thread
-        float4 v[8];
+      for (int base = tid; base < n4; base += 16 * kPW) {         // sixteen 16-byte loads in flight per thread
+        float4 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(src)[min(base + u * kPW, n4 - 1)];
+        for (int u = 0; u < 16; ++u) v[u] = reinterpret_cast<const float4*>(src)[min(base + u * kPW, n4 - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                   // (a clamped index rewrites the last quad with itself)
+        for (int u = 0; u < 16; ++u) {                   // (a clamped index rewrites the last quad with itself)
           {
             const int e0 = min(base + u * kPW, n4 - 1) << 2, c = e0 / hw, q = e0 - c * hw;
             float* d = dst + c * P + q;
@@ -114,64 +128,101 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
   const int64_t row0 = ((int64_t)m * B + b) * R;
   for (int r0 = r_begin; r0 < r_end; r0 += kSR) {
     __syncthreads();        // the staged maps are in place / the previous tile has been multiplied
-    // ---- the tile's stencils: one thread per (row, coarse branch)
-    if (tid < kSR * 3) {
-      const int lr = tid / 3, br = 1 + tid - 3 * lr, r = min(r0 + lr, r_end - 1);
+    if (r0 == r_begin) HCM_STAMP(1);
+    // ---- the tile's stencils: one thread per (row, branch)
+    if (tid < kSR * 4) {
+      const int lr = tid >> 2, br = tid & 3, r = min(r0 + lr, r_end - 1);
       const int p = (int)pix[(int64_t)b * R + r];
-      const int py = p / w0, px = p - py * w0;
-      const int hi = sel4(e.H, br), wi = sel4(e.W, br);
-      const Taps t = bilinear_taps(py, px, hi, wi, (float)hi / (float)h0, (float)wi / (float)w0);
-      int* o = &s_to[lr][br - 1][0];
-      float* w = &s_tw[lr][br - 1][0];
-      o[0] = t.y0 * wi + t.x0; o[1] = t.y0 * wi + t.x1; o[2] = t.y1 * wi + t.x0; o[3] = t.y1 * wi + t.x1;
-      w[0] = t.hy; w[1] = t.ly; w[2] = t.hx; w[3] = t.lx;
-      if (br == 1) s_pix[lr] = p;
+      int* o = &s_to[lr][br][0];
+      float* w = &s_tw[lr][br][0];
+      if (br == 0) {
+        o[0] = p; o[1] = p; o[2] = p; o[3] = p;
+        w[0] = 1.f; w[1] = 0.f; w[2] = 1.f; w[3] = 0.f;
+      } else {
+        const int py = p / w0, px = p - py * w0;
+        const int hi = sel4(e.H, br), wi = sel4(e.W, br);
+        const Taps t = bilinear_taps(py, px, hi, wi, (float)hi / (float)h0, (float)wi / (float)w0);
+        o[0] = t.y0 * wi + t.x0; o[1] = t.y0 * wi + t.x1; o[2] = t.y1 * wi + t.x0; o[3] = t.y1 * wi + t.x1;
+        w[0] = t.hy; w[1] = t.ly; w[2] = t.hx; w[3] = t.lx;
+      }
     }
     __syncthreads();
-    // ---- gather: every (row, channel) of the tile is one independent element; consecutive threads take consecutive
-    // channels of a row (coalesced xs stores), several elements per thread so that their loads are in flight together.
-    // Rows past the end repeat the last row's pixels; they are computed and never stored.
+    // ---- gather.  Every (row, channel) of the tile is one independent element; consecutive threads take consecutive
+    // channels of a row.  Rows past the end repeat the last row (computed, never stored).  Branches that are not in LDS
+    // first: the 16 loads of four elements per thread are requested together, with NO store between them -- on this
+    // part loads and stores retire through one in-order counter (vmcnt), so a store issued between two loads makes the
+    // second load's wait include the store's round trip (r04 stamps: 23 k cycles per tile with an xs store after every
+    // element).  xs is written once per tile from LDS, after the barrier, and retires under the MFMA phase.
     {
+      int gid[4], gend[4], gcol[4], ng = 0, ctot = 0, col = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool staged = (i == 2 && off2 >= 0) || (i == 3 && off3 >= 0);
+        if (!staged) { gid[ng] = i; ctot += e.C[i]; gend[ng] = ctot; gcol[ng] = col; ++ng; }
+        col += e.C[i];
+      }
+      for (int k = ng; k < 4; ++k) { gid[k] = gid[ng - 1]; gend[k] = ctot; gcol[k] = gcol[ng - 1]; }
+      const int total = kSR * ctot;
+      for (int base = tid; base < total; base += 4 * kPW) {
+        float rv[4][4];
+        int dst[4];
+        float4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ge = min(base + u * kPW, total - 1);
+          const int lr = ge / ctot, cg = ge - lr * ctot;
+          const int k = (cg >= gend[0]) + (cg >= gend[1]) + (cg >= gend[2]);
+          const int i = sel4(gid, k), c = cg - (k == 0 ? 0 : sel4(gend, k - 1));
+          const int C = sel4(e.C, i), hw = sel4(e.H, i) * sel4(e.W, i);
+          const float* x = sel8(e.p, m * 4 + i) + ((int64_t)b * C + c) * hw;
+          const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i][0]);
+          wv[u] = *reinterpret_cast<const float4*>(&s_tw[lr][i][0]);
+          rv[u][0] = x[o.x];
+          rv[u][1] = rv[u][2] = rv[u][3] = 0.f;
+          if (i != 0) { rv[u][1] = x[o.y]; rv[u][2] = x[o.z]; rv[u][3] = x[o.w]; }     // the finest branch is one word
+          dst[u] = lr * XS + sel4(gcol, k) + c;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          lx[dst[u]] = wv[u].x * (wv[u].z * rv[u][0] + wv[u].w * rv[u][1]) + wv[u].y * (wv[u].z * rv[u][2] + wv[u].w * rv[u][3]);
+      }
       int coff = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int C = e.C[i], hw = e.H[i] * e.W[i];
         const int off = i == 2 ? off2 : (i == 3 ? off3 : -1);
-        const float* xg = (m ? e.p[4 + i] : e.p[i]) + (int64_t)b * C * hw;
-        const float* xl = lds + (off >= 0 ? off : 0);
-        const int P = hw | 1, total = kSR * C;
-        // branch-free: a thread past the end repeats the last element (same value to the same addresses), so that the
-        // loads of several trips can be requested together
+        if (off >= 0) {                                     // block-uniform
+          const float* xl = lds + off;
+          const int P = hw | 1, tot = kSR * C;
 #pragma unroll 4
-        for (int e0 = tid; e0 < total + kPW - 1 - (total + kPW - 1) % kPW; e0 += kPW) {
-          const int ec = min(e0, total - 1);
-          const int lr = ec / C, c = ec - lr * C;
-          float v;
-          if (i == 0) {
-            v = xg[(int64_t)c * hw + s_pix[lr]];
-          } else {
-            const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i - 1][0]);
-            const float4 w = *reinterpret_cast<const float4*>(&s_tw[lr][i - 1][0]);
+          for (int e0 = tid; e0 < tot + kPW - 1 - (tot + kPW - 1) % kPW; e0 += kPW) {
+            const int ec = min(e0, tot - 1);
+            const int lr = ec / C, c = ec - lr * C;
+            const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i][0]);
+            const float4 w = *reinterpret_cast<const float4*>(&s_tw[lr][i][0]);
             RowTaps q;
             q.o00 = o.x; q.o01 = o.y; q.o10 = o.z; q.o11 = o.w;
             q.hy = w.x; q.ly = w.y; q.hx = w.z; q.lx = w.w;
-            if (off >= 0) v = tap4(xl + c * P, q);           // block-uniform
-            else v = tap4(xg + (int64_t)c * hw, q);
+            lx[lr * XS + coff + c] = tap4(xl + c * P, q);
           }
-          lx[lr * XS + coff + c] = v;
-          if (xs != nullptr) xs[(row0 + min(r0 + lr, r_end - 1)) * ld + coff + c] = v;
         }
         coff += C;
       }
       const int npad = 4 * KS - Ctot;                          // the bias column, then padding
       for (int e0 = tid; e0 < kSR * npad; e0 += kPW) {
         const int lr = e0 / npad, k = Ctot + e0 - lr * npad;
-        const float v = k == Ctot ? 1.f : 0.f;
-        lx[lr * XS + k] = v;
-        if (xs != nullptr && k < ld) xs[(row0 + min(r0 + lr, r_end - 1)) * ld + k] = v;
+        lx[lr * XS + k] = k == Ctot ? 1.f : 0.f;
       }
     }
     __syncthreads();
+    HCM_STAMP(2 + 2 * ((r0 - r_begin) / kSR));
+    if (xs != nullptr) {                                       // the sampled rows, coalesced 8-byte stores out of the tile
+      const int h2 = ld >> 1, nrow = min(kSR, r_end - r0);
+      for (int e0 = tid; e0 < nrow * h2; e0 += kPW) {
+        const int lr = e0 / h2, k2 = e0 - lr * h2;
+        *reinterpret_cast<float2*>(xs + (row0 + r0 + lr) * ld + 2 * k2) = *reinterpret_cast<const float2*>(lx + lr * XS + 2 * k2);
+      }
+    }
     // ---- multiply: two 16-row tiles, one accumulator chain each (an fp32 MFMA depends on its predecessor for 40 cycles
     // and issues every 32: two chains keep the pipe full with the second wave of the SIMD as further cover)
     v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -216,6 +267,7 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
         if (grows != nullptr) grows[o] = 0.f;
       }
     }
+    HCM_STAMP(3 + 2 * ((r0 - r_begin) / kSR));
   }
 }
 
@@ -414,27 +466,30 @@ constexpr int kTP = 64;       // pixels per sub-tile (a workgroup walks `span` o
 constexpr int kTS = 130;      // LDS row stride of T: the B-fragment read (lane (g, n) -> T[n][4 s + g]) is conflict-free
 struct TilePlan {
   int first[5];               // first workgroup (blockIdx.x) of branch i; first[4] = total
-  int span[4];                // 64-pixel sub-tiles per workgroup of branch i
+  int span[4];                // sub-tiles per workgroup of branch i
+  int tpix[4];                // pixels per sub-tile of branch i: 64, or 16 on the small maps, where every row of the image lands in
+                              // every tile (a 64-pixel tile of an 8 x 8 map collects all 4 R stencil entries: r04 timing stamps
+                              // showed that workgroup living 141 k cycles against a mean of 25 k)
 };
 
-constexpr int kGW = 256;      // 4 waves; <= 128 VGPRs -> four workgroups (16 waves) per CU
-__global__ __launch_bounds__(kGW, 4) void branch_grad_t_kernel(
-    const float* __restrict__ grows, const float* __restrict__ Wp1, const float* __restrict__ Wp2,
-    const float* __restrict__ dpooled, const float* __restrict__ scale, const int2* __restrict__ ent,
-    const int* __restrict__ off, int R, int B, int Ctot, Maps8Out g, TilePlan tp, PlanGeom gm) {
-  __shared__ __attribute__((aligned(16))) float T[kTP * kTS];
-  __shared__ int soff[kTP + 1];
+constexpr int kGW = 256;      // 4 waves; <= 256 VGPRs -> two workgroups per SIMD set (the row ring of the T phase is the cover)
+template <int TPX>
+__device__ __forceinline__ void branch_grad_tiles(
+    float* __restrict__ T, int* __restrict__ soff, const float* __restrict__ grows, const float* __restrict__ Wp1,
+    const float* __restrict__ Wp2, const float* __restrict__ dpooled, const float* __restrict__ scale,
+    const int2* __restrict__ ent, const int* __restrict__ off, int R, int B, int Ctot, const Maps8Out& g,
+    const TilePlan& tp, const PlanGeom& gm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, m = blockIdx.z;
   int i = 0;
   while (i < 3 && (int)blockIdx.x >= tp.first[i + 1]) ++i;
   const int wg = blockIdx.x - tp.first[i], span = sel4(tp.span, i);
+  constexpr int tpx = TPX, ppg = TPX >> 4, ntl = TPX >> 4;     // pixels per 16-lane group, 16-pixel MFMA tiles per sub-tile
   const int C = sel4(g.C, i), hw = sel4(g.H, i) * sel4(g.W, i);
   int coff = 0;
   for (int k = 0; k < i; ++k) coff += sel4(g.C, k);
   const int* offb = off + (int64_t)b * gm.off_per_image + sel4(gm.off_off, i);
   const int2* entb = ent + (int64_t)b * gm.ent_per_image + sel4(gm.ent_off, i);
-  const float* gb = grows + ((int64_t)m * B + b) * R * kF + 2 * lane;
   const int n = lane & 15, gq = lane >> 4;
   const float sc = scale != nullptr ? scale[0] : 1.f;
   const float inv = 1.f / (float)hw;
@@ -442,119 +497,181 @@ __global__ __launch_bounds__(kGW, 4) void branch_grad_t_kernel(
   const int nmt = (C + 15) >> 4;
   float* out = sel8(g.p, m * 4 + i) + (int64_t)b * C * hw;
   const float* dp = dpooled != nullptr ? dpooled + ((int64_t)m * B + b) * Ctot + coff : nullptr;
-  constexpr int kPPW = kTP / (kGW / 64);            // pixels per wave: a contiguous run, i.e. a contiguous run of entries
+  HCM_STAMP(0);
   for (int sub = 0; sub < span; ++sub) {
-    const int q0 = (wg * span + sub) * kTP;
+    const int q0 = (wg * span + sub) * tpx;
     if (q0 >= hw) break;
     if (sub > 0) __syncthreads();                   // the previous sub-tile's products have been formed
-    if (tid <= kTP) soff[tid] = offb[min(q0 + tid, hw)];
+    if (tid <= tpx) soff[tid] = offb[min(q0 + tid, hw)];
     __syncthreads();
-    const bool any = soff[kTP] > soff[0];           // block-uniform
+    const bool any = soff[tpx] > soff[0];           // block-uniform
+    HCM_STAMP(1);
     if (!any) {
       // nothing sampled here: the pooling gradient alone, 16-byte stores
       if ((hw & 3) == 0) {
-        for (int e0 = tid; e0 < C * (kTP / 4); e0 += kGW) {
-          const int c = e0 / (kTP / 4), q = q0 + 4 * (e0 - c * (kTP / 4));
+        for (int e0 = tid; e0 < C * (tpx >> 2); e0 += kGW) {
+          const int c = e0 / (tpx >> 2), q = q0 + 4 * (e0 - c * (tpx >> 2));
           if (q < hw) {
             const float pool = dp != nullptr ? dp[c] * inv : 0.f;
             *reinterpret_cast<float4*>(out + (int64_t)c * hw + q) = make_float4(pool, pool, pool, pool);
           }
         }
       } else {
-        for (int e0 = tid; e0 < C * kTP; e0 += kGW) {
-          const int c = e0 / kTP, q = q0 + e0 - c * kTP;
+        for (int e0 = tid; e0 < C * tpx; e0 += kGW) {
+          const int c = e0 / tpx, q = q0 + e0 - c * tpx;
           if (q < hw) out[(int64_t)c * hw + q] = dp != nullptr ? dp[c] * inv : 0.f;
         }
       }
+      HCM_STAMP(4);
       continue;
     }
-    // ---- T[pixel][f] = sum over the pixel's entries of weight * grows[row][f], entries in (row, tap) order.  A wave owns
-    // kPPW consecutive pixels = ONE run of the sorted entry list: eight entries (lanes 0-7) and their eight 512-byte rows
-    // are requested together, the adds follow in entry order, a pixel's sum is stored when the next pixel begins.
+    // ---- T[pixel][f] = sum over the pixel's entries of weight * grows[row][f], entries in (row, tap) order.  Sixteen
+    // lanes (one DPP row, 32 bytes of the 512-byte row each) own four consecutive pixels = ONE run of the sorted entry list;
+    // the sixteen groups of the workgroup walk their runs side by side.  Software pipeline per group: the entries of
+    // batch k + 2 and the rows of batch k + 1 are requested before the adds of batch k (four entries per batch); the adds
+    // stay in entry order and a pixel's sum is stored when the next pixel begins.
     {
+      const int grp = tid >> 4, l16 = tid & 15;
 #pragma unroll
-      for (int k = 0; k < kPPW; ++k) *reinterpret_cast<float2*>(&T[(wave * kPPW + k) * kTS + 2 * lane]) = make_float2(0.f, 0.f);
-      int j = soff[wave * kPPW];
-      const int jend = soff[wave * kPPW + kPPW];
+      for (int k = 0; k < ppg; ++k) {
+        float* z = &T[(grp * ppg + k) * kTS + 8 * l16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float2*>(z + 2 * u) = make_float2(0.f, 0.f);
+      }
+      int j = soff[grp * ppg];
+      const int jend = soff[grp * ppg + ppg], jlast = soff[tpx] - 1;      // jlast >= 0: the sub-tile has entries
+      const float* gl = grows + ((int64_t)m * B + b) * R * kF + 8 * l16;
+      int2 ec[4], en[4];
+      float4 rc[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ec[u] = entb[min(j + u, jlast)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) en[u] = entb[min(j + 4 + u, jlast)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* rp = gl + (int64_t)(ec[u].x & ((1 << kRowBits) - 1)) * kF;
+        rc[u][0] = *reinterpret_cast<const float4*>(rp);
+        rc[u][1] = *reinterpret_cast<const float4*>(rp + 4);
+      }
       int cur = -1;
-      float2 acc = make_float2(0.f, 0.f);
-      while (j < jend) {
-        const int n8 = min(8, jend - j);
-        const int2 en = lane < n8 ? entb[j + lane] : make_int2(0, 0);
-        float2 v[8];
+      float acc[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                 // unconditional: a lane past the run reads row 0 and is not added
-          const int r = __builtin_amdgcn_readlane(en.x, u) & ((1 << kRowBits) - 1);
-          v[u] = *reinterpret_cast<const float2*>(gb + (int64_t)r * kF);
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      while (j < jend) {
+        float4 rn[4][2];
+        int2 e2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* rp = gl + (int64_t)(en[u].x & ((1 << kRowBits) - 1)) * kF;
+          rn[u][0] = *reinterpret_cast<const float4*>(rp);
+          rn[u][1] = *reinterpret_cast<const float4*>(rp + 4);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (u < n8) {
-            const int px = (__builtin_amdgcn_readlane(en.x, u) >> kRowBits) - q0;
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(en.y, u));
+        for (int u = 0; u < 4; ++u) e2[u] = entb[min(j + 8 + u, jlast)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + u < jend) {
+            const int px = (ec[u].x >> kRowBits) - q0;
+            const float w = __builtin_bit_cast(float, ec[u].y);
             if (px != cur) {
-              if (cur >= 0) *reinterpret_cast<float2*>(&T[cur * kTS + 2 * lane]) = acc;
-              acc = make_float2(0.f, 0.f);
+              if (cur >= 0) {
+                float* z = &T[cur * kTS + 8 * l16];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 2 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);
+              }
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc[k] = 0.f;
               cur = px;
             }
-            acc.x = fmaf(w, v[u].x, acc.x);
-            acc.y = fmaf(w, v[u].y, acc.y);
+            acc[0] = fmaf(w, rc[u][0].x, acc[0]); acc[1] = fmaf(w, rc[u][0].y, acc[1]);
+            acc[2] = fmaf(w, rc[u][0].z, acc[2]); acc[3] = fmaf(w, rc[u][0].w, acc[3]);
+            acc[4] = fmaf(w, rc[u][1].x, acc[4]); acc[5] = fmaf(w, rc[u][1].y, acc[5]);
+            acc[6] = fmaf(w, rc[u][1].z, acc[6]); acc[7] = fmaf(w, rc[u][1].w, acc[7]);
           }
         }
-        j += 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ec[u] = en[u]; en[u] = e2[u]; rc[u][0] = rn[u][0]; rc[u][1] = rn[u][1]; }
+        j += 4;
       }
-      if (cur >= 0) *reinterpret_cast<float2*>(&T[cur * kTS + 2 * lane]) = acc;
+      if (cur >= 0) {
+        float* z = &T[cur * kTS + 8 * l16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 2 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);
+      }
     }
     __syncthreads();
-    // ---- dX[c][q] = sum_f W[f][coff + c] T[q][f]: a task = one 16-channel tile x two 16-pixel tiles (two accumulator
-    // chains sharing the A fragments, which come straight from W in global memory: 64-byte runs per lane group)
-    for (int task = wave; task < nmt * (kTP / 32); task += kGW / 64) {
-      const int mt = task / (kTP / 32), np = task - mt * (kTP / 32);
-      if (q0 + 32 * np >= hw) continue;
-      const bool z0 = soff[32 * np + 16] > soff[32 * np], z1 = soff[32 * np + 32] > soff[32 * np + 16];
-      v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      if (z0 || z1) {
-        float a[32];
-        const int c = 16 * mt + n, cc = min(c, C - 1);
+    HCM_STAMP(2);
+    // ---- dX[c][q] = sum_f W[f][coff + c] T[q][f]: a task = one 16-channel tile x the four 16-pixel tiles of the sub-tile
+    // (four accumulator chains sharing the A fragments).  A = W^T straight from global memory (64-byte runs per lane
+    // group); B = T from LDS, four k-steps ahead.
+    {
+      auto load_a = [&](int mt, float (&a)[32]) {
+        const int cc = min(16 * mt + n, C - 1);
 #pragma unroll
         for (int s = 0; s < 32; ++s) a[s] = Wp[(int64_t)(4 * s + gq) * Ctot + cc];
-        if (c >= C) {
+      };
+      for (int mt = wave; mt < nmt; mt += kGW / 64) {
+        float a[32];
+        load_a(mt, a);
+        if (16 * mt + n >= C) {
 #pragma unroll
           for (int s = 0; s < 32; ++s) a[s] = 0.f;
         }
-        const float* t0 = T + (32 * np + n) * kTS + gq;
-        const float* t1 = t0 + 16 * kTS;
-        // B fragments from LDS, eight k-steps requested ahead of the MFMAs that use them
-        float tb0[2][8], tb1[2][8];
+        v4f acc4[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { tb0[0][u] = t0[4 * u]; tb1[0][u] = t1[4 * u]; }
+        for (int t = 0; t < 4; ++t) acc4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+        const float* tq = T + n * kTS + gq;
+        float tb[2][4][4];                               // [buffer][k-step][pixel tile]
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (c < 3) {
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { tb0[(c + 1) & 1][u] = t0[4 * (8 * c + 8 + u)]; tb1[(c + 1) & 1][u] = t1[4 * (8 * c + 8 + u)]; }
+          for (int t = 0; t < 4; ++t) tb[0][u][t] = tq[(t < ntl ? 16 * t : 0) * kTS + 4 * u];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (c < 7) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) tb[(c + 1) & 1][u][t] = tq[(t < ntl ? 16 * t : 0) * kTS + 4 * (4 * c + 4 + u)];
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * c + u], tb0[c & 1][u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * c + u], tb1[c & 1][u], acc1, 0, 0, 0);
-          }
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (t < ntl) acc4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * c + u], tb[c & 1][u][t], acc4[t], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      // D: lane (gq, n) holds channels 16 mt + 4 gq + j, pixel 16 (2 np [+ 1]) + n
+        // D: lane (gq, n) holds channels 16 mt + 4 gq + j, pixel 16 t + n
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 16 * mt + 4 * gq + j;
-        if (c >= C) continue;
-        const float pool = dp != nullptr ? dp[c] * inv : 0.f;
-        const int qa = q0 + 32 * np + n, qb = qa + 16;
-        if (qa < hw) out[(int64_t)c * hw + qa] = fmaf(sc, acc0[j], pool);
-        if (qb < hw) out[(int64_t)c * hw + qb] = fmaf(sc, acc1[j], pool);
+        for (int j = 0; j < 4; ++j) {
+          const int c = 16 * mt + 4 * gq + j;
+          if (c >= C) continue;
+          const float pool = dp != nullptr ? dp[c] * inv : 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int q = q0 + 16 * t + n;
+            if (t < ntl && q < hw) out[(int64_t)c * hw + q] = fmaf(sc, acc4[t][j], pool);
+          }
+        }
       }
     }
+    HCM_STAMP(3);
   }
+}
+
+__global__ __launch_bounds__(kGW, 2) void branch_grad_t_kernel(
+    const float* __restrict__ grows, const float* __restrict__ Wp1, const float* __restrict__ Wp2,
+    const float* __restrict__ dpooled, const float* __restrict__ scale, const int2* __restrict__ ent,
+    const int* __restrict__ off, int R, int B, int Ctot, Maps8Out g, TilePlan tp, PlanGeom gm) {
+  __shared__ __attribute__((aligned(16))) float T[kTP * kTS];
+  __shared__ int soff[kTP + 1];
+  int i = 0;
+  while (i < 3 && (int)blockIdx.x >= tp.first[i + 1]) ++i;
+  if (sel4(tp.tpix, i) == 16)
+    branch_grad_tiles<16>(T, soff, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
+  else
+    branch_grad_tiles<kTP>(T, soff, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
 }
 
 int num_cus() {
@@ -608,6 +725,12 @@ int launch_project(const Maps8& e, int B, const int64_t* pix, int R, int Ctot, c
 }  // namespace
 
 extern "C" {
+
+#ifdef HCM_ROW8_TIMING
+int hcm_debug_row8_timing(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_row8_dbg), &buf, sizeof(buf));
+}
+#endif
 
 int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
                      const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
@@ -690,8 +813,9 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
     // keys are pixel * E + entry in 32 bits
     if ((uint64_t)g1.H[i] * g1.W[i] * 4ull * (uint64_t)R >= 0xffffffffull) return (int)hipErrorInvalidValue;
     if (g1.H[i] * g1.W[i] >= (1 << 17) || R >= (1 << kRowBits)) return (int)hipErrorInvalidValue;
-    const int nt = (g1.H[i] * g1.W[i] + kTP - 1) / kTP;
-    tp.span[i] = (nt + 127) / 128;                   // one 64-pixel sub-tile per workgroup up to 128 x 64 = 8192 pixels
+    tp.tpix[i] = g1.H[i] * g1.W[i] <= 256 ? 16 : kTP;
+    const int nt = (g1.H[i] * g1.W[i] + tp.tpix[i] - 1) / tp.tpix[i];
+    tp.span[i] = (nt + 127) / 128;                   // one sub-tile per workgroup up to 128 x 64 = 8192 pixels
     tp.first[i] = v;
     v += (nt + tp.span[i] - 1) / tp.span[i];
   }

@@ -58,7 +58,14 @@ class BaseTrainer(object):
         if use_gpu and world > 1:
             # per-replica device generator (pixel sampling); weights stay identical via the CPU seed
             torch.cuda.manual_seed((torch.initial_seed() + 7919 * rank) & 0x7fffffffffffffff)
-        ngpus_per_node = max(1, ngpus_per_node)
+        # ranks per node: torchrun says it (LOCAL_WORLD_SIZE); the reference's SLURM launch has one task per GPU
+        # (device_count).  The per-node groups below must tile the world exactly (a trailing partial node was
+        # left without a group and gathered over WORLD while its peers used their node group).
+        if 'LOCAL_WORLD_SIZE' in env:
+            ngpus_per_node = int(env['LOCAL_WORLD_SIZE'])
+        ngpus_per_node = max(1, min(ngpus_per_node, world))
+        if world % ngpus_per_node != 0:
+            raise ValueError('world size %d is not a multiple of the %d ranks per node' % (world, ngpus_per_node))
         args.distributed = True
         args.world_size = world
         args.rank = rank

@@ -159,6 +159,8 @@ class ContrastTrainer(BaseTrainer):
                 sampler = getattr(contrast, 'multinomial', None)
                 if sampler is not None and 'sampler' in ckpt:      # continue the negative stream, do not replay it
                     sampler.seed, sampler.offset = int(ckpt['sampler']['seed']), int(ckpt['sampler']['offset'])
+                    if hasattr(contrast, '_pixel_draws'):       # the pixel sampler's own Philox stream
+                        contrast._pixel_draws = int(ckpt['sampler'].get('pixel_draws', 0))
                 print("=> resume successfully '{}' (epoch {})".format(args.resume, ckpt['epoch']))
                 del ckpt
             else:
@@ -178,7 +180,8 @@ class ContrastTrainer(BaseTrainer):
         if sampler is not None and hasattr(sampler, 'offset'):
             # build-side key (the reference's sampler lives on torch's global generator, which it does not
             # checkpoint either): Philox (seed, offset) of the negative draws; loaders that index by key ignore it
-            state['sampler'] = {'seed': sampler.seed, 'offset': sampler.offset}
+            state['sampler'] = {'seed': sampler.seed, 'offset': sampler.offset,
+                                'pixel_draws': int(getattr(contrast, '_pixel_draws', 0))}
         torch.save(state, os.path.join(args.model_folder, 'current.pth'))
         if epoch % args.save_freq == 0:
             torch.save(state, os.path.join(args.model_folder, 'ckpt_epoch_{}.pth'.format(epoch)))
@@ -426,14 +429,19 @@ class ContrastTrainer(BaseTrainer):
         if multi:                                       # rank 0's permutation for everybody (:184-187)
             dist.broadcast(shuffle_ids, 0)
         reverse_ids = torch.argsort(shuffle_ids)
-        local = getattr(args, 'local_rank', 0) if multi else 0
+        # the slice this rank encodes = its position INSIDE the group the crops were gathered over (not torchrun's
+        # LOCAL_RANK: with fewer ranks than GPUs per node, or on gloo, the two differ -- ADVICE r03)
+        if multi:
+            local = dist.get_rank(self.local_group) if self.local_group is not None else dist.get_rank()
+        else:
+            local = 0
         this_ids = shuffle_ids[local * bsz:(local + 1) * bsz]
         with torch.no_grad():
             k = model_ema(node_x[this_ids], mode=1)
         if multi:
             all_k = torch.empty((dist.get_world_size() * bsz,) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
             dist.all_gather_into_tensor(all_k, k.contiguous())
-            node = getattr(args, 'node_rank', 0)
+            node = (dist.get_rank() // nlocal) if self.local_group is not None else 0      # groups are contiguous rank blocks
             node_k = all_k[node * nlocal * bsz:(node + 1) * nlocal * bsz]
         else:
             all_k = node_k = k

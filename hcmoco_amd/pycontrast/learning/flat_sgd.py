@@ -21,6 +21,8 @@ group (same hyper-parameters); anything else stays as it is.
 """
 import torch
 
+from . import grad_sync
+
 
 class FlatParamSGD(object):
     def __init__(self, optimizer, model):
@@ -152,7 +154,12 @@ class FlatParamSGD(object):
             # module-path step, a new program) gets the full walk again -- first and last can line up while the
             # middle is permuted
             g0 = params[0].grad
-            ptr = None if g0 is None else g0.untyped_storage().data_ptr()
+            # what identifies a validated layout: the allocation (address AND size: the caching allocator re-issues
+            # addresses), where the first gradient sits in it, the encoder program that laid it out, and GradSync's
+            # bucket generation (a re-built bucket can land on the old address with another interior order -- ADVICE r03)
+            ptr = None if g0 is None else (g0.untyped_storage().data_ptr(), g0.untyped_storage().nbytes(),
+                                           g0.storage_offset(), id(getattr(enc, 'last_program', None)),
+                                           grad_sync.GENERATION[0])
             known = ptr is not None and self._grad_ptr.get(id(flat)) == ptr
             fg = self._flat_grad(params, flat.numel(), full_check=not known)
             if fg is not None:

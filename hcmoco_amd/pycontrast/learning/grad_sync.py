@@ -37,6 +37,9 @@ import torch
 import torch.distributed as dist
 
 
+GENERATION = [0]      # bumped whenever a flat bucket is (re-)allocated: consumers that cached a validated layout re-check
+
+
 def broadcast_model(model, src=0):
     """Replica consistency at start-up when DistributedDataParallel is not wrapping the model."""
     if not dist.is_initialized():
@@ -166,6 +169,7 @@ class GradSync(object):
         if flat is None or flat.numel() != n + 1 or flat.device != group[0].device:
             # one slot more than the gradients: the step's ``changed`` flag rides in the last bucket (see _present)
             flat = self._flat[key] = torch.zeros(n + 1, dtype=group[0].dtype, device=group[0].device)
+            GENERATION[0] += 1
         views = [v.view_as(p) for v, p in zip(flat[:n].split([p.numel() for p in group]), group)]
         have = [(v, p.grad) for v, p in zip(views, group) if p.grad is not None]
         if len(have) != len(group):

@@ -28,7 +28,12 @@ def _scatter_backward(grad_out, idx, coef, m, div, legacy):
     original, or the CPU oracle shim used by tests), or a target axis too long for LDS, takes the
     ``*_grad_wrapper`` route."""
     fn = getattr(pointnet2, 'scatter_add_planned', None)     # r03: deterministic, no atomics, hub-proof
-    if fn is not None and SCATTER_BACKWARD == 'planned' and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0):
+    # a wave of the planned kernel owns ONE channel: with fewer than 8 channels (the grouped xyz coordinates, C = 3 -- not
+    # differentiated in training) a workgroup is one or two waves and the kernel is 3.6x slower than the LDS-atomic form
+    # (0.66 vs 0.19 ms at the first level).  Those shapes take the LDS form unless reproducibility was asked for.
+    narrow = grad_out.shape[1] < 8 and os.environ.get('HCM_DETERMINISTIC', '0') == '0'
+    if (fn is not None and SCATTER_BACKWARD == 'planned' and not narrow
+            and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0)):
         return fn(grad_out.contiguous(), idx, coef, m, div)
     fn = getattr(pointnet2, 'scatter_add_lds', None)
     if fn is not None and SCATTER_BACKWARD != 'atomic' and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0):

@@ -52,6 +52,36 @@ __global__ __launch_bounds__(256) void reg_kernel(const float* __restrict__ b1, 
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[group] = acc.x;
 }
 
+// r04: the bf16 banks' access pattern -- random 256-BYTE rows (128 bf16), one 16-byte load per lane and
+// bank, 16 lanes per row -- with nothing else in the way: what the part gives a gather of half-size rows.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void reg256_kernel(const uint4* __restrict__ b1, const uint4* __restrict__ b2,
+                                                     const uint4* __restrict__ b3, const int* __restrict__ idx,
+                                                     int rows_per_group, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, t = lane & 15;
+  const int group = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int* my = idx + (int64_t)group * rows_per_group;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  uint4 ring[DEPTH][3];
+  auto load = [&](int j, int k) {
+    const int64_t off = (int64_t)my[k] * 16 + t;              // a row = 16 uint4
+    ring[j][0] = b1[off];
+    ring[j][1] = b2[off];
+    ring[j][2] = b3[off];
+  };
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j) load(j, j);
+  for (int k0 = 0; k0 < rows_per_group; k0 += DEPTH) {
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+#pragma unroll
+      for (int v = 0; v < 3; ++v) { acc.x ^= ring[j][v].x; acc.y ^= ring[j][v].y; acc.z ^= ring[j][v].z; acc.w ^= ring[j][v].w; }
+      if (k0 + j + DEPTH < rows_per_group) load(j, k0 + j + DEPTH);
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[group] = (float)acc.x;
+}
+
 // one stage = 2 row triples per wave = 6 glds instructions = 3 KB of LDS per wave
 template <int DEPTH>
 __global__ __launch_bounds__(256) void glds_kernel(const float* __restrict__ b1, const float* __restrict__ b2,
@@ -163,6 +193,24 @@ int main(int argc, char** argv) {
   }
       GL(2) GL(3) GL(4) GL(6) GL(8) GL(12)
 #undef GL
+    }
+    {   // 256-byte rows: the same buffers read as [2 n][256 B] tables (the rows gathered are half as long)
+      const int64_t n2 = 2 * n;
+      std::vector<int> h2(total_rows);
+      uint64_t s2 = 0x9E3779B97F4A7C15ull;
+      for (auto& v : h2) { s2 ^= s2 << 13; s2 ^= s2 >> 7; s2 ^= s2 << 17; v = (int)(s2 % (uint64_t)n2); }
+      CK(hipMemcpy(idx, h2.data(), total_rows * 4, hipMemcpyHostToDevice));
+      for (int rows_per_group : {256, 1024}) {
+        const int groups = (int)(total_rows / rows_per_group), wgs = groups / 16;
+        const double gb = (double)wgs * 16 * rows_per_group * 3.0 * 256.0 / 1e9;
+        const uint4 *q1 = reinterpret_cast<const uint4*>(b1), *q2 = reinterpret_cast<const uint4*>(b2), *q3 = reinterpret_cast<const uint4*>(b3);
+        emit("reg256", 2, n, wgs, gb, time_ms([&] { reg256_kernel<2><<<wgs, 256>>>(q1, q2, q3, idx, rows_per_group, out); }, 10));
+        emit("reg256", 4, n, wgs, gb, time_ms([&] { reg256_kernel<4><<<wgs, 256>>>(q1, q2, q3, idx, rows_per_group, out); }, 10));
+        emit("reg256", 6, n, wgs, gb, time_ms([&] { reg256_kernel<6><<<wgs, 256>>>(q1, q2, q3, idx, rows_per_group, out); }, 10));
+        emit("reg256", 8, n, wgs, gb, time_ms([&] { reg256_kernel<8><<<wgs, 256>>>(q1, q2, q3, idx, rows_per_group, out); }, 10));
+        emit("reg256", 12, n, wgs, gb, time_ms([&] { reg256_kernel<12><<<wgs, 256>>>(q1, q2, q3, idx, rows_per_group, out); }, 10));
+        emit("reg256", 16, n, wgs, gb, time_ms([&] { reg256_kernel<16><<<wgs, 256>>>(q1, q2, q3, idx, rows_per_group, out); }, 10));
+      }
     }
     emit("stream", 0, n, 4096, 3.0 * n * 512.0 / 1e9,
          time_ms([&] { stream_kernel<<<4096, 256>>>(reinterpret_cast<const float4*>(b1), n * D / 4, out);
