@@ -962,13 +962,21 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
     bank_pass_glds_kernel<T, GL><<<grid, kWG, ldsb, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R, \
                                                          scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0); \
   } while (0)
-    // variants 1-6: register ring of that depth; 12 / 13 / 14 / 16: LDS-DMA ring of 2 / 3 / 4 / 6 stages.
+    // variants 1-6: register ring of that depth; 12 / 13 / 14 / 16: LDS-DMA ring of 2 / 3 / 4 / 6 stages; 25 / 26 (r04): ring 5 / 6
+    // with __launch_bounds__(256, 2).  r03 compiled ring 6 without an occupancy floor: the compiler took > 256 registers and
+    // the kernel ran one wave per SIMD (2.9-3.9 TB/s).  Held to 256 registers it needs 252, spills nothing, and carries 18 KB
+    // per wave in flight -- the fp32 variant's amount -- at two waves per SIMD: bf16 default since r04 (+3-7 % over ring 4 on
+    // HBM-resident banks, +7-10 % at K = 131072; tools/probes/bf16_variants.sh, profiles/r04_bf16_variants.txt).
+    // Also built and measured in r04, then removed: a 32-lanes-per-row bf16 kernel (8-byte loads, half the accumulator /
+    // query registers, rings of 12-20 stages = up to 240 KB per CU in flight, v_permlane16_swap for the 32-lane sums):
+    // 2.9-3.3 TB/s on the same cells, WORSE with every deeper ring -- the bf16 pass is bound by instruction issue (the
+    // softmax bookkeeping per row, twice as often per byte as in fp32), not by bytes in flight.
     // Defaults (r03 sweep, profiles/r03_bank_pass_sweep.json): the register ring -- depth 3 for fp32, 4 for bf16 -- with
     // 512 rows per workgroup.  The DMA form was built to lift the HBM-resident case and does, at equal geometry (1.6 GB of
     // banks, 256 rows: 5.73 vs 5.58 TB/s; K = 65536: 6.29 vs 6.19), but the longer streams help the register ring more
     // (5.92 TB/s at K = 16384 / 1.6 GB, 0.80-0.81 of peak inside the training step) and the DMA form not at all; a bf16
     // stage is only 3 KB and the DMA form loses 7-10 % there.  It stays selectable for the large-K / large-bank regime.
-    switch (variant > 0 ? variant : (kBf16 ? 4 : 3)) {
+    switch (variant > 0 ? variant : (kBf16 ? 26 : 3)) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;

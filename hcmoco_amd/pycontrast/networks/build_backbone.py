@@ -251,9 +251,36 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
                 side_g.wait_stream(main)
                 with torch.cuda.stream(side_g):
                     _feat3 = self.encoder3(s)
+            # Issue order (r04).  The HRNet is one compiled program whose launches a C++ loop issues in ~2 ms; the cloud
+            # branch is ~700 launches issued from Python.  HCM_PN_ORDER=hrnet_first issues the HRNet first, so that the GPU
+            # works on it while the host is still issuing the cloud branch; the default issues the cloud branch first, which
+            # gives the HRNet node the higher autograd sequence number and therefore the FIRST place in backward, where the
+            # same argument holds with the roles swapped (its reverse loop is issued by a helper thread).
+            first = os.environ.get('HCM_PN_ORDER', 'cloud_first') == 'hrnet_first'
+            trace = os.environ.get('HCM_TRACE_STREAMS', '0') != '0'      # probe: when each branch starts / ends on the GPU
+            if trace:
+                ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 'h0', 'h1', 'p0', 'p1')}
+                ev['t0'].record(main)
+            if first:
+                if trace:
+                    ev['h0'].record(main)
+                _feat1 = self.encoder1(x1)
+                if trace:
+                    ev['h1'].record(main)
             with torch.cuda.stream(side_pn):
+                if trace:
+                    ev['p0'].record(side_pn)
                 sample_pn, full_pn, _feat2 = cloud_branch()
-            _feat1 = self.encoder1(x1)
+                if trace:
+                    ev['p1'].record(side_pn)
+            if not first:
+                if trace:
+                    ev['h0'].record(main)
+                _feat1 = self.encoder1(x1)
+                if trace:
+                    ev['h1'].record(main)
+            if trace:
+                self._stream_trace = ev
             if side_g is None:
                 _feat3 = self.encoder3(s)          # behind the HRNet on the caller's stream (see CMC3HRNetSGCNSingleHead)
             main.wait_stream(side_pn)

@@ -200,7 +200,7 @@ int main(int argc, char** argv) {
       uint64_t s2 = 0x9E3779B97F4A7C15ull;
       for (auto& v : h2) { s2 ^= s2 << 13; s2 ^= s2 >> 7; s2 ^= s2 << 17; v = (int)(s2 % (uint64_t)n2); }
       CK(hipMemcpy(idx, h2.data(), total_rows * 4, hipMemcpyHostToDevice));
-      for (int rows_per_group : {256, 1024}) {
+      for (int rows_per_group : {32, 128, 512}) {          // 2048 / 512 / 128 workgroups
         const int groups = (int)(total_rows / rows_per_group), wgs = groups / 16;
         const double gb = (double)wgs * 16 * rows_per_group * 3.0 * 256.0 / 1e9;
         const uint4 *q1 = reinterpret_cast<const uint4*>(b1), *q2 = reinterpret_cast<const uint4*>(b2), *q3 = reinterpret_cast<const uint4*>(b3);

@@ -29,7 +29,8 @@ def main():
                     return True
             dist.all_reduce = lambda t, op=None, async_op=False, group=None: _Done()
     args = bench.make_args(32, 16384, 131072, 256, os.environ.get('SKELETON', 'coco17'), 'nccl',
-                           tempfile.mkdtemp(), 10 ** 6)
+                           tempfile.mkdtemp(), 10 ** 6, arch=os.environ.get('ARCH', 'HRNet'),
+                           width=int(os.environ.get('WIDTH', '18')))
     args.rank, args.world_size, args.local_rank, args.gpu = 0, 1, 0, 0
     args.channels_last = False
     trainer = ContrastTrainer(args)
