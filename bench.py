@@ -424,14 +424,17 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read live);
         # reported only when the committed measurement was taken at this exact configuration
         traffic, traffic_src = None, None
-        try:                                            # r03 sweep: one PMC cell per (n_data, K, dtype), B = 32, D = 128
-            sweep = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bank_pass_sweep.json')))
-            for c in sweep['pmc']:
-                if ((c['n_data'], c['K'], c['dtype']) == (a.n_data, a.nce_k, 'bf16' if a.bank_dtype == 'bf16' else 'fp32')
-                        and (B, D) == (32, 128) and c['algorithmic_bytes'] == bytes_per_launch):
-                    traffic, traffic_src = c['traffic_bytes'], 'profiles/r03_bank_pass_sweep.json'
-        except (OSError, KeyError, ValueError):
-            pass
+        for sweep_name in ('r04_bank_pass_sweep.json', 'r03_bank_pass_sweep.json'):
+            if traffic is not None:
+                break
+            try:                                        # one PMC cell per (n_data, K, dtype), B = 32, D = 128
+                sweep = json.load(open(os.path.join(ROOT, 'profiles', sweep_name)))
+                for c in sweep['pmc']:
+                    if ((c['n_data'], c['K'], c['dtype']) == (a.n_data, a.nce_k, 'bf16' if a.bank_dtype == 'bf16' else 'fp32')
+                            and (B, D) == (32, 128) and c['algorithmic_bytes'] == bytes_per_launch):
+                        traffic, traffic_src = c['traffic_bytes'], 'profiles/' + sweep_name
+            except (OSError, KeyError, ValueError):
+                pass
         for name in ('r02_bank_pass_pmc.json', 'r02_bank_pass_pmc_bf16_K131072.json'):
             if traffic is not None:
                 break

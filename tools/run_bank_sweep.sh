@@ -1,5 +1,5 @@
 #!/bin/bash
-# profiles/r03_bank_pass_sweep.json: timing sweep (tools/bank_sweep.py) + FETCH_SIZE / WRITE_SIZE of the default kernel
+# profiles/r04_bank_pass_sweep.json: timing sweep (tools/bank_sweep.py) + FETCH_SIZE / WRITE_SIZE of the default kernel
 # per configuration (separate --pmc passes, gfx950 read correction: /opt/skills/guides/MI355X_MICROARCH.md) + the
 # in-step duration from bench.py.   usage (GPU box, repo root): bash tools/run_bank_sweep.sh OUTDIR
 set -x
@@ -44,5 +44,5 @@ json.dump({'peak_GBps': 8000, 'mall_bytes': 256 * 2 ** 20,
                    'Infinity Cache, as between two training steps); pmc: default kernel variant, FETCH_SIZE and WRITE_SIZE in '
                    'separate rocprofv3 --pmc passes, read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction), back-to-back launches; '
                    'in_step: bench.py roofline (hipEvents inside the timed training steps)',
-           'time': rows, 'pmc': pmc, 'in_step': ins}, open(os.path.join(O, 'r03_bank_pass_sweep.json'), 'w'), indent=1)
+           'time': rows, 'pmc': pmc, 'in_step': ins}, open(os.path.join(O, 'r04_bank_pass_sweep.json'), 'w'), indent=1)
 PY
