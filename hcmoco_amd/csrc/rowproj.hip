@@ -472,10 +472,12 @@ struct TilePlan {
                               // showed that workgroup living 141 k cycles against a mean of 25 k)
 };
 
+constexpr int kSpanMax = 4;   // sub-tiles per workgroup on the large (mostly empty) maps
+constexpr int kEB = 2;        // stencil entries per batch and 16-lane group in the T phase
 constexpr int kGW = 256;      // 4 waves; <= 256 VGPRs -> two workgroups per SIMD set (the row ring of the T phase is the cover)
 template <int TPX>
 __device__ __forceinline__ void branch_grad_tiles(
-    float* __restrict__ T, int* __restrict__ soff, const float* __restrict__ grows, const float* __restrict__ Wp1,
+    float* __restrict__ T, int* soff, const float* __restrict__ grows, const float* __restrict__ Wp1,
     const float* __restrict__ Wp2, const float* __restrict__ dpooled, const float* __restrict__ scale,
     const int2* __restrict__ ent, const int* __restrict__ off, int R, int B, int Ctot, const Maps8Out& g,
     const TilePlan& tp, const PlanGeom& gm) {
@@ -498,13 +500,20 @@ __device__ __forceinline__ void branch_grad_tiles(
   float* out = sel8(g.p, m * 4 + i) + (int64_t)b * C * hw;
   const float* dp = dpooled != nullptr ? dpooled + ((int64_t)m * B + b) * Ctot + coff : nullptr;
   HCM_STAMP(0);
+  // the per-pixel offsets of ALL the workgroup's sub-tiles in one round trip (kSpanMax * 64 + 1 <= 257 words): a sub-tile
+  // without entries then costs its stores and nothing else (r04 stamps: an empty sub-tile alone, as its own workgroup, lived
+  // 5.4 k cycles, most of it this load; the finest maps are mostly empty tiles)
+  int* const soff_all = soff;
+  for (int e0 = tid; e0 <= span * tpx; e0 += kGW) soff_all[e0] = offb[min(wg * span * tpx + e0, hw)];
+  __syncthreads();
+  bool used_t = false;
   for (int sub = 0; sub < span; ++sub) {
     const int q0 = (wg * span + sub) * tpx;
     if (q0 >= hw) break;
-    if (sub > 0) __syncthreads();                   // the previous sub-tile's products have been formed
-    if (tid <= tpx) soff[tid] = offb[min(q0 + tid, hw)];
-    __syncthreads();
+    soff = soff_all + sub * tpx;
     const bool any = soff[tpx] > soff[0];           // block-uniform
+    if (any && used_t) __syncthreads();             // the previous sub-tile's products have been formed
+    used_t = used_t || any;
     HCM_STAMP(1);
     if (!any) {
       // nothing sampled here: the pooling gradient alone, 16-byte stores
@@ -541,14 +550,14 @@ __device__ __forceinline__ void branch_grad_tiles(
       int j = soff[grp * ppg];
       const int jend = soff[grp * ppg + ppg], jlast = soff[tpx] - 1;      // jlast >= 0: the sub-tile has entries
       const float* gl = grows + ((int64_t)m * B + b) * R * kF + 8 * l16;
-      int2 ec[4], en[4];
-      float4 rc[4][2];
+      int2 ec[kEB], en[kEB];
+      float4 rc[kEB][2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ec[u] = entb[min(j + u, jlast)];
+      for (int u = 0; u < kEB; ++u) ec[u] = entb[min(j + u, jlast)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) en[u] = entb[min(j + 4 + u, jlast)];
+      for (int u = 0; u < kEB; ++u) en[u] = entb[min(j + kEB + u, jlast)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kEB; ++u) {
         const float* rp = gl + (int64_t)(ec[u].x & ((1 << kRowBits) - 1)) * kF;
         rc[u][0] = *reinterpret_cast<const float4*>(rp);
         rc[u][1] = *reinterpret_cast<const float4*>(rp + 4);
@@ -558,18 +567,18 @@ __device__ __forceinline__ void branch_grad_tiles(
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] = 0.f;
       while (j < jend) {
-        float4 rn[4][2];
-        int2 e2[4];
+        float4 rn[kEB][2];
+        int2 e2[kEB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kEB; ++u) {
           const float* rp = gl + (int64_t)(en[u].x & ((1 << kRowBits) - 1)) * kF;
           rn[u][0] = *reinterpret_cast<const float4*>(rp);
           rn[u][1] = *reinterpret_cast<const float4*>(rp + 4);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e2[u] = entb[min(j + 8 + u, jlast)];
+        for (int u = 0; u < kEB; ++u) e2[u] = entb[min(j + 2 * kEB + u, jlast)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kEB; ++u) {
           if (j + u < jend) {
             const int px = (ec[u].x >> kRowBits) - q0;
             const float w = __builtin_bit_cast(float, ec[u].y);
@@ -590,8 +599,8 @@ __device__ __forceinline__ void branch_grad_tiles(
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { ec[u] = en[u]; en[u] = e2[u]; rc[u][0] = rn[u][0]; rc[u][1] = rn[u][1]; }
-        j += 4;
+        for (int u = 0; u < kEB; ++u) { ec[u] = en[u]; en[u] = e2[u]; rc[u][0] = rn[u][0]; rc[u][1] = rn[u][1]; }
+        j += kEB;
       }
       if (cur >= 0) {
         float* z = &T[cur * kTS + 8 * l16];
@@ -660,12 +669,12 @@ __device__ __forceinline__ void branch_grad_tiles(
   }
 }
 
-__global__ __launch_bounds__(kGW, 2) void branch_grad_t_kernel(
+__global__ __launch_bounds__(kGW, 3) void branch_grad_t_kernel(
     const float* __restrict__ grows, const float* __restrict__ Wp1, const float* __restrict__ Wp2,
     const float* __restrict__ dpooled, const float* __restrict__ scale, const int2* __restrict__ ent,
     const int* __restrict__ off, int R, int B, int Ctot, Maps8Out g, TilePlan tp, PlanGeom gm) {
   __shared__ __attribute__((aligned(16))) float T[kTP * kTS];
-  __shared__ int soff[kTP + 1];
+  __shared__ int soff[kSpanMax * kTP + 1];
   int i = 0;
   while (i < 3 && (int)blockIdx.x >= tp.first[i + 1]) ++i;
   if (sel4(tp.tpix, i) == 16)
@@ -815,7 +824,7 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
     if (g1.H[i] * g1.W[i] >= (1 << 17) || R >= (1 << kRowBits)) return (int)hipErrorInvalidValue;
     tp.tpix[i] = g1.H[i] * g1.W[i] <= 256 ? 16 : kTP;
     const int nt = (g1.H[i] * g1.W[i] + tp.tpix[i] - 1) / tp.tpix[i];
-    tp.span[i] = (nt + 127) / 128;                   // one sub-tile per workgroup up to 128 x 64 = 8192 pixels
+    tp.span[i] = nt >= 32 ? kSpanMax : 1;            // maps of >= 2048 pixels: four 64-pixel sub-tiles per workgroup
     tp.first[i] = v;
     v += (nt + tp.span[i] - 1) / tp.span[i];
   }
