@@ -85,6 +85,7 @@ class GradSync(object):
         self._presence = {}          # bucket key -> agreed pattern (union over the ranks): see _present
         self._changed = False        # this rank saw a gradient outside an agreed pattern during this reduce()
         self._flag_host = self._flag_event = None
+        self._flag_pinned = self._flag_done = None
         self.agreements = 0          # presence all-reduces issued so far (tests read it)
         # bench.py sets this to a list: every reduce() then appends a HIP event pair around the waits below -- the time the
         # trainer's stream stands still for collectives that backward did not cover (exposed communication)
@@ -246,9 +247,12 @@ class GradSync(object):
             self.wait_events.append(ev)
         # the reduced flag goes to the host without a sync; it is read at the top of the next reduce()
         if carrier.is_cuda:
-            self._flag_host = torch.empty(1, dtype=carrier.dtype, pin_memory=True)
+            if self._flag_pinned is None:            # one pinned word for the life of the object (a pinned allocation per
+                self._flag_pinned = torch.empty(1, dtype=carrier.dtype, pin_memory=True)      # step costs more than the step's
+                self._flag_done = torch.cuda.Event()                                            # whole exposed communication)
+            self._flag_host = self._flag_pinned
             self._flag_host.copy_(carrier[-1:], non_blocking=True)
-            self._flag_event = torch.cuda.Event()
+            self._flag_event = self._flag_done
             self._flag_event.record()
         else:
             self._flag_host = carrier[-1:].clone()
