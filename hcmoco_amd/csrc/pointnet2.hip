@@ -558,12 +558,13 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 // Every point k has the unique key (distance, ~(bitrev(k % bs) << 21 | k / bs)); the global maximum
 // of that key IS the reference winner whatever physical thread evaluated the point, so the physical
 // workgroup size P is a pure performance choice (fewer waves = cheaper barrier, more points each).
-template <int PER, bool FMA>
-__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log2bs,
-                                                   const float* __restrict__ dataset,
-                                                   float* __restrict__ temp,
-                                                   int* __restrict__ idxs) {
-  extern __shared__ __attribute__((aligned(16))) float sxyz[];  // [n*3] when PER > 0
+//
+// General form (clouds that do not fit the register / LDS form below): points and running minima in global memory,
+// per-wave 64-bit candidates exchanged through LDS slots.
+template <bool FMA>
+__global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, int bs, int log2bs,
+                                                           const float* __restrict__ dataset,
+                                                           float* __restrict__ temp, int* __restrict__ idxs) {
   __shared__ unsigned long long red[2][16];
   if (m <= 0) return;
   const int b = blockIdx.x, tid = threadIdx.x, P = blockDim.x;
@@ -577,54 +578,20 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
     const unsigned brev = (log2bs == 0) ? 0u : (__brev(vt) >> shift);
     return 0xFFFFFFFFu - ((brev << 21) | (unsigned)(k >> log2bs));
   };
-
-  float px[PER > 0 ? PER : 1], py[PER > 0 ? PER : 1], pz[PER > 0 ? PER : 1], pt[PER > 0 ? PER : 1];
-  unsigned pk[PER > 0 ? PER : 1];
-  if (PER > 0) {
-    for (int e = tid; e < n * 3; e += P) sxyz[e] = cloud[e];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int k = tid + j * P;
-      if (k < n) {
-        px[j] = cloud[3 * k]; py[j] = cloud[3 * k + 1]; pz[j] = cloud[3 * k + 2];
-        pt[j] = tmp[k];
-        pk[j] = point_key(k);
-      } else {
-        px[j] = py[j] = pz[j] = 0.f; pt[j] = 0.f; pk[j] = 0u;
-      }
-    }
-  }
   if (tid < 32) red[tid >> 4][tid & 15] = 0ull;  // slots of absent waves stay "lowest"
   if (tid == 0) out[0] = 0;
   __syncthreads();
-
   int old = 0;
   for (int r = 1; r < m; ++r) {
-    float ox, oy, oz;
-    if (PER > 0) { ox = sxyz[3 * old]; oy = sxyz[3 * old + 1]; oz = sxyz[3 * old + 2]; }
-    else { ox = cloud[3 * old]; oy = cloud[3 * old + 1]; oz = cloud[3 * old + 2]; }
+    const float ox = cloud[3 * old], oy = cloud[3 * old + 1], oz = cloud[3 * old + 2];
     unsigned long long c = 0ull;
-    if (PER > 0) {
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        if (tid + j * P < n) {
-          const float d = sqdist<FMA>(px[j], py[j], pz[j], ox, oy, oz);
-          const float d2 = fminf(d, pt[j]);
-          pt[j] = d2;
-          c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | pk[j]);
-        }
-      }
-    } else {
-      for (int k = tid; k < n; k += P) {
-        const float d = sqdist<FMA>(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
-        const float d2 = fminf(d, tmp[k]);
-        tmp[k] = d2;
-        c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | point_key(k));
-      }
+    for (int k = tid; k < n; k += P) {
+      const float d = sqdist<FMA>(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
+      const float d2 = fminf(d, tmp[k]);
+      tmp[k] = d2;
+      c = umax64(c, ((unsigned long long)__float_as_uint(d2) << 32) | point_key(k));
     }
     c = row16_umax64(c);
-    // every lane of a DPP row holds its row's maximum: the four rows meet in scalar registers (v_readlane + s_max),
-    // not through the LDS crossbar (r02: two 64-bit ds_bpermute exchanges, ~10 % of a round)
     c = umax64(umax64(readlane64(c, 0), readlane64(c, 16)), umax64(readlane64(c, 32), readlane64(c, 48)));
     const int par = r & 1;
     if ((tid & 63) == 0) red[par][wave] = c;
@@ -637,12 +604,143 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log
     old = (int)wvt + (int)(wj << log2bs);
     if (tid == 0) out[r] = old;
   }
-  if (PER > 0) {
+}
+
+// Register form: thread t owns points t, t+P, ... (coordinates, running minima and key low words in registers), the
+// cloud also sits in LDS for the look-up of the picked point.
+// r04: a round is a SERIAL chain -- a wave issues one instruction per four cycles whatever its kind, and every wave
+// walks the same chain (profiles/r04_fps_counters.txt: 220 instructions per wave and round = half of the round,
+// most of the rest at the LDS exchange; n = 256 costs 0.4 us a round, n = 4096 0.72) -- so the round is written for
+// the LENGTH of that chain:
+//   * two points per packed instruction (v_pk_add / v_pk_mul / v_pk_fma: element-wise IEEE, bit-identical);
+//   * running minima are kept as BIT PATTERNS and compared as unsigned integers (distances are >= +0, where the two
+//     orders agree): v_min_u32 / v_max3_u32 need no canonicalising v_max_f32 x, x in front of them and the DPP steps
+//     fuse into v_max_u32_dpp.  Empty slots (k >= n) carry the minimum 0 and the key 0: they never raise a
+//     maximum, and key 0 loses to every point;
+//   * per point only distance, v_min and half a v_max3 -- no 64-bit compare-and-select.  The wave reduces the VALUE
+//     alone (six v_max_u32_dpp, result in a scalar register); only the lanes that hold it (one, unless points
+//     coincide) form a key, max over their matching points' low words;
+//   * the workgroup's winner is ONE LDS word: the holding lane of each wave posts its 64-bit key with ds_max_u64 (when
+//     several lanes of a wave hold the maximum -- duplicated points, the constant clouds of empty-mask images --
+//     their low words are reduced first so that a wave never posts more than once), and after the barrier every lane
+//     reads that word: no per-wave slots, no second reduction.  Three words rotate: the one of round r+1 is cleared
+//     in round r, after barrier r-1 (its readers, round r-2, have consumed it to get there) and before barrier r
+//     (its writers, round r+1, come after).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+  return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, ROWS == 0xF));
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {     // scalar result: the maximum over the 64 lanes
+  v = dpp_umax<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+  v = dpp_umax<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+  v = dpp_umax<0x141, 0xF>(v);     // row_half_mirror
+  v = dpp_umax<0x140, 0xF>(v);     // row_mirror
+  v = dpp_umax<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+  v = dpp_umax<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_umax_step(unsigned v, int step) {   // step is a compile-time constant at every call
+  switch (step) {
+    case 0: return dpp_umax<0xB1, 0xF>(v);
+    case 1: return dpp_umax<0x4E, 0xF>(v);
+    case 2: return dpp_umax<0x141, 0xF>(v);
+    case 3: return dpp_umax<0x140, 0xF>(v);
+    case 4: return dpp_umax<0x142, 0xA>(v);
+    default: return dpp_umax<0x143, 0xC>(v);
+  }
+}
+template <int PER, bool FMA>
+__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int bs, int log2bs,
+                                                   const float* __restrict__ dataset,
+                                                   float* __restrict__ temp,
+                                                   int* __restrict__ idxs) {
+  extern __shared__ __attribute__((aligned(16))) float sxyz[];  // [n*3]
+  __shared__ unsigned long long win[3];
+  if (m <= 0) return;
+  const int b = blockIdx.x, tid = threadIdx.x, P = blockDim.x;
+  const float* cloud = dataset + (int64_t)b * n * 3;
+  float* tmp = temp + (int64_t)b * n;
+  int* out = idxs + (int64_t)b * m;
+  const int shift = 32 - log2bs;
+  auto point_key = [&](int k) -> unsigned {   // low word of the candidate key of point k
+    const unsigned vt = (unsigned)k & (unsigned)(bs - 1);
+    const unsigned brev = (log2bs == 0) ? 0u : (__brev(vt) >> shift);
+    return 0xFFFFFFFFu - ((brev << 21) | (unsigned)(k >> log2bs));
+  };
+
+  constexpr int NP = (PER + 1) / 2;                   // point pairs per thread: slots 2*jj and 2*jj+1
+  v2f px[NP], py[NP], pz[NP];
+  unsigned pt[2 * NP];                                // running minima, as bit patterns
+  unsigned pk[2 * NP];
+  for (int e = tid; e < n * 3; e += P) sxyz[e] = cloud[e];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int k = tid + j * P;
-      if (k < n) tmp[k] = pt[j];
+  for (int j = 0; j < 2 * NP; ++j) {
+    const int k = tid + j * P;
+    float x = 0.f, y = 0.f, z = 0.f, t = 0.f;
+    unsigned key = 0u;
+    if (j < PER && k < n) { x = cloud[3 * k]; y = cloud[3 * k + 1]; z = cloud[3 * k + 2]; t = tmp[k]; key = point_key(k); }
+    if (j & 1) { px[j >> 1].y = x; py[j >> 1].y = y; pz[j >> 1].y = z; }
+    else { px[j >> 1].x = x; py[j >> 1].x = y; pz[j >> 1].x = z; }
+    pt[j] = __float_as_uint(t);
+    pk[j] = key;
+  }
+  if (tid < 3) win[tid] = 0ull;
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+
+  int old = 0, slot = 1;       // slot = r % 3
+  for (int r = 1; r < m; ++r) {
+    const float ox = sxyz[3 * old], oy = sxyz[3 * old + 1], oz = sxyz[3 * old + 2];
+    // stage by stage over the pairs: consecutive packed instructions are independent (a dependent pair costs a wait state)
+    v2f dx[NP], dy[NP], dz[NP], acc[NP];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) { dx[jj] = px[jj] - ox; dy[jj] = py[jj] - oy; dz[jj] = pz[jj] - oz; }
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) acc[jj] = dy[jj] * dy[jj];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) acc[jj] = FMA ? __builtin_elementwise_fma(dx[jj], dx[jj], acc[jj]) : dx[jj] * dx[jj] + acc[jj];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) acc[jj] = FMA ? __builtin_elementwise_fma(dz[jj], dz[jj], acc[jj]) : acc[jj] + dz[jj] * dz[jj];
+    unsigned best = 0u;
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+      pt[2 * jj] = min(__float_as_uint(acc[jj].x), pt[2 * jj]);
+      pt[2 * jj + 1] = min(__float_as_uint(acc[jj].y), pt[2 * jj + 1]);
+      best = max(best, max(pt[2 * jj], pt[2 * jj + 1]));
     }
+    // every lane's own candidate, a step of it between two DPP steps of the wave's maximum (each fills the other's wait
+    // states: v_cmp -> v_cndmask on the mask and DPP on a register just written both want two)
+    unsigned v = 0u, wred = best;
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) {
+      v = max(v, pt[j] == best ? pk[j] : 0u);
+      if (j < 6) wred = wave_umax_step(wred, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 2 * NP; j < 6; ++j) wred = wave_umax_step(wred, j);
+    const unsigned wbits = (unsigned)__builtin_amdgcn_readlane((int)wred, 63);
+    const bool mine = best == wbits;
+    bool post = mine;
+    if (__popcll(__builtin_amdgcn_ballot_w64(mine)) != 1) {       // coincident points: one post per wave all the same
+      v = wave_umax(mine ? v : 0u);
+      post = (tid & 63) == 0;
+    }
+    const int next = slot == 2 ? 0 : slot + 1;
+    if (post) atomicMax(&win[slot], ((unsigned long long)wbits << 32) | v);
+    if (tid == 0) win[next] = 0ull;
+    __syncthreads();
+    const unsigned low = 0xFFFFFFFFu - (unsigned)win[slot];
+    const unsigned wkey = low >> 21, wj = low & 0x1FFFFFu;
+    const unsigned wvt = (log2bs == 0) ? 0u : (__brev(wkey) >> shift);
+    old = (int)wvt + (int)(wj << log2bs);
+    if (tid == 0) out[r] = old;
+    slot = next;
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int k = tid + j * P;
+    if (k < n) tmp[k] = __uint_as_float(pt[j]);
   }
 }
 
@@ -940,8 +1038,8 @@ int hcm_furthest_point_sampling_contract(int b, int n, int m, const float* datas
   else if (per <= 4 && lds <= 150 * 1024) HCM_FPS(4);
   else if (per <= 8 && lds <= 150 * 1024) HCM_FPS(8);
   else if (per <= 16 && lds <= 150 * 1024) HCM_FPS(16);
-  else if (fma) fps_kernel<0, true><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
-  else fps_kernel<0, false><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
+  else if (fma) fps_generic_kernel<true><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
+  else fps_generic_kernel<false><<<b, threads, 0, st>>>(n, m, bs, log2bs, dataset, temp, idxs);
 #undef HCM_FPS
 #undef HCM_FPS1
   HCM_CHECK_LAUNCH();
