@@ -232,6 +232,33 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         out = pointnet2_utils.three_interpolate(feat.contiguous(), idx, weight)
         return out.reshape(feat.shape[0], feat.shape[1], h, w)
 
+    _kept_pixels = {}
+
+    @classmethod
+    def kept_pixels(cls, h, w, oh, ow, device):
+        """Linear indices (into the h x w input) of the pixels ``F.interpolate(.., size=(oh, ow))`` (nearest) reads, obtained
+        from F.interpolate itself on a grid of pixel numbers (exact in fp32 below 2^24), cached per shape."""
+        key = (h, w, oh, ow, str(device))
+        if key not in cls._kept_pixels:
+            assert h * w < (1 << 24)
+            grid = torch.arange(h * w, dtype=torch.float32, device=device).view(1, 1, h, w)
+            cls._kept_pixels[key] = F.interpolate(grid, size=(oh, ow)).reshape(-1).long()
+        return cls._kept_pixels[key]
+
+    @classmethod
+    def pts2depth_resized(cls, sampled_pts, pts, feat, h, w, oh, ow):
+        """``F.interpolate(pts2depth(sampled_pts, pts, feat, h, w), size=(oh, ow))`` (:299-300 of the reference) without the
+        pixels the nearest resize throws away: at 256^2 -> 64^2 it keeps one pixel in sixteen, so three_nn, three_interpolate
+        and their backward run on 4096 pixels per image instead of 65 536 and the [B, 128, 256, 256] map (1 GB at B = 32) is
+        never written.  Every kept pixel is computed exactly as in the full map (three_nn / three_interpolate are
+        per-pixel), and the discarded pixels carry exact-zero gradients in the full flow.  HCM_PTS2DEPTH_FULL=1 takes
+        the two-step route."""
+        if os.environ.get('HCM_PTS2DEPTH_FULL', '0') != '0':
+            return F.interpolate(cls.pts2depth(sampled_pts, pts, feat, h, w), size=(oh, ow))
+        keep = cls.kept_pixels(h, w, oh, ow, pts.device)
+        out = cls.pts2depth(sampled_pts, pts.index_select(2, keep), feat, oh, ow)
+        return out
+
     def forward(self, x, s, depth_mask, grid_xy, original_h, original_w, mean, mode=0, return_fm=False):
         x1, x2 = torch.split(x, self.in_channel_list, dim=1)
         h, w = x1.shape[-2:]
@@ -303,8 +330,8 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         if self.linear_feat_map:
             merge1 = self.merge_all_res(_feat1)
             linear_merge1 = self.encoder1_linear(merge1)
-            linear_merge2 = self.pts2depth(sample_pn, full_pn, self.encoder2_linear(_feat2), h, w)
-            linear_merge2 = F.interpolate(linear_merge2, size=linear_merge1.shape[-2:])
+            linear_merge2 = self.pts2depth_resized(sample_pn, full_pn, self.encoder2_linear(_feat2), h, w,
+                                                   *linear_merge1.shape[-2:])
             return _feat1, _feat2, _feat3, f, {'merge1': merge1, 'merge2': _feat2,
                                                'linear_merge1': linear_merge1, 'linear_merge2': linear_merge2}
         return _feat1, _feat2, _feat3, avg1, avg2, avg3, f

@@ -379,3 +379,27 @@ def test_shared_mlp_fused_layer_matches_stock_ops():
         close(res[True][2][n], gb, 1e-3)
     for n, bb in res[False][3].items():
         assert torch.allclose(res[True][3][n].float(), bb.float(), rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.parametrize('h,oh', [(64, 16), (80, 20), (36, 10), (20, 20)])
+def test_pts2depth_at_the_pixels_the_nearest_resize_keeps(h, oh):
+    """HRNetPN's depth feature map (networks/build_backbone.py:299-300 of the reference): pts2depth over every pixel, then a
+    nearest resize that keeps a fraction of them.  The product interpolates the kept pixels only; same values bit for bit
+    (each pixel's three_nn / three_interpolate is independent), same gradient of the point features (the discarded pixels
+    contribute exact zeros in the two-step flow), including an empty-mask image (all-zero cloud) and a resize whose ratio is
+    not an integer."""
+    import torch.nn.functional as F
+    from hcmoco_amd.pycontrast.networks.build_backbone import CMC3HRNetSGCNPN2SingleHead as M
+    torch.manual_seed(h * 100 + oh)
+    B, Cc, m = 3, 24, 512
+    pts = torch.randn(B, 3, h * h, device=d())
+    pts[1] = 0
+    sampled = torch.gather(pts, 2, torch.randint(0, h * h, (B, 1, m), device=d()).expand(B, 3, m)).contiguous()
+    feat = torch.randn(B, Cc, m, device=d(), requires_grad=True)
+    full = F.interpolate(M.pts2depth(sampled, pts, feat, h, h), size=(oh, oh))
+    go = torch.randn_like(full)
+    gfull, = torch.autograd.grad(full, feat, go)
+    fused = M.pts2depth_resized(sampled, pts, feat, h, h, oh, oh)
+    gfused, = torch.autograd.grad(fused, feat, go)
+    assert fused.shape == full.shape and torch.equal(fused, full)
+    assert torch.allclose(gfused, gfull, rtol=1e-5, atol=1e-6)
