@@ -192,7 +192,7 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         sgcn_dim = 128
         self.encoder3 = create_sgcn(opt.skeleton_meta_name, sgcn_dim, 4)
         self.head1 = nn.Sequential(nn.Linear(dim_in, feat_dim), Normalize(2))
-        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '3'))
+        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '7'))
         self._side_streams = {}
         self.head2 = nn.Sequential(nn.Linear(self.pn_dim, feat_dim), Normalize(2))
         self.head3 = nn.Sequential(nn.Linear(sgcn_dim, feat_dim), Normalize(2))
@@ -259,13 +259,30 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         out = cls.pts2depth(sampled_pts, pts.index_select(2, keep), feat, oh, ow)
         return out
 
+    @staticmethod
+    def _stem_hw(n):
+        """Side of the HRNet's first-branch map for an n-pixel side: two 3x3 stride-2 pad-1 convolutions (hrnet.py stem)."""
+        n = (n - 1) // 2 + 1
+        return (n - 1) // 2 + 1
+
     def forward(self, x, s, depth_mask, grid_xy, original_h, original_w, mean, mode=0, return_fm=False):
         x1, x2 = torch.split(x, self.in_channel_list, dim=1)
         h, w = x1.shape[-2:]
+        want_map = return_fm and self.linear_feat_map
+        oh, ow = self._stem_hw(h), self._stem_hw(w)
+        linear_merge2 = None
 
         def cloud_branch():
             sample, full, _ = self.depth2pts(x2, depth_mask, grid_xy, original_h, original_w, mean)
             return sample, full, self.encoder2(sample.transpose(1, 2))           # [B, 128, 4096]
+
+        def depth_map(sample, full, feat2, neighbours=None):
+            # networks/build_backbone.py:299-300 of the reference, at the pixels the resize keeps (pts2depth_resized)
+            lin = self.encoder2_linear(feat2)
+            if neighbours is None:
+                return self.pts2depth_resized(sample, full, lin, h, w, oh, ow)
+            from .pointnet2 import pointnet2_utils
+            return pointnet2_utils.three_interpolate(lin.contiguous(), *neighbours).reshape(lin.shape[0], lin.shape[1], oh, ow)
 
         if x.is_cuda and self.two_streams:
             # the point-cloud branch (back-projection, PointNet++) and the SemGCN on side HIP streams,
@@ -273,11 +290,32 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             main = torch.cuda.current_stream(x.device)
             side_pn = self._side(1, x.device)
             side_g = self._side(0, x.device) if self.two_streams & 1 else None
+            side_geo = self._side(2, x.device) if self.two_streams & 4 else None
             side_pn.wait_stream(main)
             if side_g is not None:
                 side_g.wait_stream(main)
                 with torch.cuda.stream(side_g):
                     _feat3 = self.encoder3(s)
+            # r04: the GEOMETRY of the cloud branch (back-projection, the four FPS levels, eight ball queries, the three_nn of
+            # the four FP levels and of pts2depth) depends on the depth input alone.  It goes first, on a stream of its own
+            # (bit 2 of HCM_TWO_STREAMS): 40 launches of serial, low-occupancy kernels (an FPS level is 32 workgroups
+            # walking a chain of rounds) that run underneath the HRNet instead of in front of the cloud branch's MLPs.
+            plan = None
+            if side_geo is not None:
+                side_geo.wait_stream(main)
+                with torch.cuda.stream(side_geo):
+                    from .pointnet2.pointnet2_modules import PointnetFPModule
+                    sample_pn, full_pn, _ = self.depth2pts(x2, depth_mask, grid_xy, original_h, original_w, mean)
+                    cloud_in = sample_pn.transpose(1, 2)
+                    plan = self.encoder2.plan(cloud_in, events=True)
+                    plan.extra['cloud'] = (sample_pn, full_pn, cloud_in)
+                    if want_map:
+                        keep = self.kept_pixels(h, w, oh, ow, x.device)
+                        plan.extra['map'] = PointnetFPModule.neighbours(
+                            full_pn.index_select(2, keep).transpose(1, 2).contiguous(), sample_pn.transpose(1, 2).contiguous())
+                        plan.extra['map_ready'] = plan.mark(True)
+                    plan.share(side_pn)
+                    plan.share(main)
             # Issue order (r04).  The HRNet is one compiled program whose launches a C++ loop issues in ~2 ms; the cloud
             # branch is ~700 launches issued from Python.  HCM_PN_ORDER=hrnet_first issues the HRNet first, so that the GPU
             # works on it while the host is still issuing the cloud branch; the default issues the cloud branch first, which
@@ -297,7 +335,15 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             with torch.cuda.stream(side_pn):
                 if trace:
                     ev['p0'].record(side_pn)
-                sample_pn, full_pn, _feat2 = cloud_branch()
+                if plan is None:
+                    sample_pn, full_pn, _feat2 = cloud_branch()
+                    if want_map:
+                        linear_merge2 = depth_map(sample_pn, full_pn, _feat2)
+                else:
+                    _feat2 = self.encoder2(cloud_in, plan=plan)
+                    if want_map:
+                        plan.wait(plan.extra['map_ready'])
+                        linear_merge2 = depth_map(sample_pn, full_pn, _feat2, plan.extra['map'])
                 if trace:
                     ev['p1'].record(side_pn)
             if not first:
@@ -313,12 +359,15 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             main.wait_stream(side_pn)
             if side_g is not None:
                 main.wait_stream(side_g)
-            for t in (sample_pn, full_pn, _feat2, _feat3):
-                t.record_stream(main)
+            for t in (sample_pn, full_pn, _feat2, _feat3, linear_merge2):
+                if t is not None:
+                    t.record_stream(main)
         else:
             _feat1 = self.encoder1(x1)
             sample_pn, full_pn, _feat2 = cloud_branch()
             _feat3 = self.encoder3(s)
+            if want_map:
+                linear_merge2 = depth_map(sample_pn, full_pn, _feat2)
         avg1, avg2, avg3 = self._pool(_feat1), _feat2.mean(-1), _feat3.mean(1)
         if mode in (0, 1):
             feat1, feat2, feat3 = self.head1(avg1), self.head2(avg2), self.head3(avg3)
@@ -330,8 +379,7 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         if self.linear_feat_map:
             merge1 = self.merge_all_res(_feat1)
             linear_merge1 = self.encoder1_linear(merge1)
-            linear_merge2 = self.pts2depth_resized(sample_pn, full_pn, self.encoder2_linear(_feat2), h, w,
-                                                   *linear_merge1.shape[-2:])
+            assert tuple(linear_merge1.shape[-2:]) == (oh, ow), (linear_merge1.shape, oh, ow)
             return _feat1, _feat2, _feat3, f, {'merge1': merge1, 'merge2': _feat2,
                                                'linear_merge1': linear_merge1, 'linear_merge2': linear_merge2}
         return _feat1, _feat2, _feat3, avg1, avg2, avg3, f

@@ -24,13 +24,27 @@ class PointnetSAModuleMSG(nn.Module):
                 spec[0] += 3
             self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
 
-    def forward(self, xyz, features=None, new_xyz=None):
+    def geometry(self, xyz, new_xyz=None):
+        """The feature-independent half of forward: FPS picks -> centres, ball indices of every scale."""
         if new_xyz is None and self.npoint is not None:
             picks = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
+        idx = [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) if self.npoint is not None else None
+               for g in self.groupers]
+        return new_xyz, idx
+
+    def forward(self, xyz, features=None, new_xyz=None, geometry=None):
+        """``geometry``: the (new_xyz, idx per scale) pair of ``self.geometry(xyz)`` when it was computed ahead."""
+        if geometry is not None:
+            new_xyz, ball_idx = geometry
+        else:
+            ball_idx = [None] * len(self.groupers)
+            if new_xyz is None and self.npoint is not None:
+                picks = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+                new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
         outs = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            y = mlp(grouper(xyz, new_xyz, features))                       # (B, C, npoint, nsample)
+        for grouper, mlp, bidx in zip(self.groupers, self.mlps, ball_idx):
+            y = mlp(grouper(xyz, new_xyz, features, idx=bidx))             # (B, C, npoint, nsample)
             if self.pool_method == 'max_pool':
                 if y.is_cuda and y.dtype == torch.float32:   # hcm_rowmax_*: same values, same (first-index) tie rule
                     from .... import pointnet2_hip
@@ -58,11 +72,16 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    def neighbours(unknown, known):
+        """three nearest known points of every unknown point and their inverse-distance weights (feature-independent)."""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        dist_recip = 1.0 / (dist + 1e-8)
+        return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+
+    def forward(self, unknown, known, unknow_feats, known_feats, neighbours=None):
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            idx, weight = neighbours if neighbours is not None else self.neighbours(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

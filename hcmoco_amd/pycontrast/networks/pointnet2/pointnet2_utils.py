@@ -188,8 +188,11 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz, new_xyz, features=None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+    def forward(self, xyz, new_xyz, features=None, idx=None):
+        """``idx``: the ball indices when the caller already has them (Pointnet2MSG.plan: the geometry of a cloud does not
+        depend on the features, so it can be worked out ahead of the feature path, on a stream of its own)."""
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
         grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
         if features is None:
@@ -204,7 +207,7 @@ class GroupAll(nn.Module):
         super().__init__()
         self.use_xyz = use_xyz
 
-    def forward(self, xyz, new_xyz, features=None):
+    def forward(self, xyz, new_xyz, features=None, idx=None):
         grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
         if features is None:
             return grouped_xyz
