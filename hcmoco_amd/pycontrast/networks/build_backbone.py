@@ -317,11 +317,11 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
                     plan.share(side_pn)
                     plan.share(main)
             # Issue order (r04).  The HRNet is one compiled program whose launches a C++ loop issues in ~2 ms; the cloud
-            # branch is ~700 launches issued from Python.  HCM_PN_ORDER=hrnet_first issues the HRNet first, so that the GPU
-            # works on it while the host is still issuing the cloud branch; the default issues the cloud branch first, which
-            # gives the HRNet node the higher autograd sequence number and therefore the FIRST place in backward, where the
-            # same argument holds with the roles swapped (its reverse loop is issued by a helper thread).
-            first = os.environ.get('HCM_PN_ORDER', 'cloud_first') == 'hrnet_first'
+            # branch is ~700 launches issued from Python.  With the geometry on its own stream the HRNet goes first: the FPS
+            # levels then run underneath its kernels (61.4 vs 62.1 ms per synchronised step; with the geometry inside the
+            # cloud branch the order made no difference, 63.0 vs 63.4: whichever branch is issued second finishes last).
+            # HCM_PN_ORDER=cloud_first / hrnet_first forces one.
+            first = os.environ.get('HCM_PN_ORDER', 'hrnet_first' if plan is not None else 'cloud_first') == 'hrnet_first'
             trace = os.environ.get('HCM_TRACE_STREAMS', '0') != '0'      # probe: when each branch starts / ends on the GPU
             if trace:
                 ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 'h0', 'h1', 'p0', 'p1')}
