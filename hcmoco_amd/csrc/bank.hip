@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "hcm_common.h"
+#include "bank_lean.h"
 #include "../../include/hcmoco_hip.h"
 
 namespace {
@@ -976,13 +977,20 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
     // banks, 256 rows: 5.73 vs 5.58 TB/s; K = 65536: 6.29 vs 6.19), but the longer streams help the register ring more
     // (5.92 TB/s at K = 16384 / 1.6 GB, 0.80-0.81 of peak inside the training step) and the DMA form not at all; a bf16
     // stage is only 3 KB and the DMA form loses 7-10 % there.  It stays selectable for the large-K / large-bank regime.
-    switch (variant > 0 ? variant : (kBf16 ? 26 : 3)) {
+    // r04: the bf16 default is the instruction-lean kernel of csrc/bank_lean.hip at ring depth 4 (variant 34): 5.66 / 5.05 /
+    // 5.76 TB/s on the HBM-resident cells (1M rows K=16384, 4M rows K=16384, 4M rows K=65536) against 4.30 / 4.18 / 4.65 for
+    // variant 26, 7.58 against 5.68 at K = 131072; its rings 5 and 6 spill at two waves per SIMD and lose.
+    switch (variant > 0 ? variant : (kBf16 ? 34 : 3)) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;
       case 6: HCM_LAUNCH_PASS(6, 1); break;
       case 25: HCM_LAUNCH_PASS(5, 2); break;         // r04: deeper rings HELD to two waves per SIMD (256 VGPRs)
       case 26: HCM_LAUNCH_PASS(6, 2); break;
+      case 32: case 33: case 34: case 35: case 36: case 38:      // r04: csrc/bank_lean.hip, ring depth = variant - 30
+        hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, variant - 30, bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R, scale2,
+                                   ws.part_m, ws.part_s, ws.part_acc, ws.l0, stream);
+        break;
       case 12: HCM_LAUNCH_GLDS(2); break;
       case 13: HCM_LAUNCH_GLDS(3); break;
       case 14: HCM_LAUNCH_GLDS(4); break;
