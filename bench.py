@@ -504,8 +504,8 @@ def main():
                        'backend': a.backend if (world > 1 or forced) else None,
                        'cpu_affinity': None if pinned is None else {'numa_node': pinned[0], 'cpus': len(pinned[1])},
                        'final_loss': round(loss, 4)},
-            'roofline': {'kernel': ('bank_pass_kernel<bf16,fused,ring 6>' if a.bank_dtype == 'bf16' else
-                                    'bank_pass_kernel<f32,fused,ring 3>') + ' (gather + 6 logit sets + online softmax + d/dx)',
+            'roofline': {'kernel': ('bank_pass_lean_kernel<bf16,ring 4>' if a.bank_dtype == 'bf16' else
+                                    'bank_pass_lean_kernel<f32,ring 2>') + ' (gather + 6 logit sets + softmax + d/dx)',
                          'bound': bound, 'bank_bytes': bank_bytes, 'bound_note': bound_note,
                          'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -980,7 +980,9 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
     // r04: the bf16 default is the instruction-lean kernel of csrc/bank_lean.hip at ring depth 4 (variant 34): 5.66 / 5.05 /
     // 5.76 TB/s on the HBM-resident cells (1M rows K=16384, 4M rows K=16384, 4M rows K=65536) against 4.30 / 4.18 / 4.65 for
     // variant 26, 7.58 against 5.68 at K = 131072; its rings 5 and 6 spill at two waves per SIMD and lose.
-    switch (variant > 0 ? variant : (kBf16 ? 34 : 3)) {
+    // fp32: the lean kernel at ring depth 2 (variant 32): 6.22 / 5.90 / 6.22 TB/s on the same cells against 5.94 / 5.65 / 6.14
+    // for variant 3, 0.83-0.84 of the 8 TB/s peak inside the training step against 0.80.
+    switch (variant > 0 ? variant : (kBf16 ? 34 : 32)) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;

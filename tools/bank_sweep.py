@@ -83,8 +83,9 @@ def main():
             for dtype in ('fp32', 'bf16'):
                 # (name, HCM_BANK_VARIANT, HCM_BANK_ROWS): register ring of depth 3 / 4, LDS-DMA ring of 2 / 4 stages,
                 # 256 (r02) or 512 rows per workgroup; the library's default is the first entry
-                variants = {'fp32': (('reg3_r512', 3, 512), ('reg3_r256', 3, 256), ('glds2_r256', 12, 256), ('glds2_r512', 12, 512)),
-                            'bf16': (('reg6w2_r512', 26, 512), ('reg4_r512', 4, 512), ('reg4_r256', 4, 256), ('glds4_r256', 14, 256))}[dtype]
+                # r04: lean = csrc/bank_lean.hip (ring 2 fp32 / ring 4 bf16), the defaults; reg* = the general kernel of bank.hip
+                variants = {'fp32': (('lean2_r512', 32, 512), ('reg3_r512', 3, 512), ('lean2_r256', 32, 256), ('glds2_r256', 12, 256)),
+                            'bf16': (('lean4_r512', 34, 512), ('reg6w2_r512', 26, 512), ('reg4_r512', 4, 512), ('glds4_r256', 14, 256))}[dtype]
                 for name, var, nrows in variants:
                     env = dict(os.environ, HCM_BANK_VARIANT=str(var), HCM_BANK_ROWS=str(nrows))
                     res = subprocess.run([sys.executable, os.path.abspath(__file__), 'worker', str(n), str(K), dtype],

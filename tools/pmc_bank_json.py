@@ -12,7 +12,7 @@ out, fcsv, wcsv, K, n, dtype = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.ar
 
 def mean(path, counter):
     v = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
-         if 'bank_pass_kernel' in r.get('Kernel_Name', '') and r['Counter_Name'] == counter]
+         if 'bank_pass_' in r.get('Kernel_Name', '') and r['Counter_Name'] == counter]
     return sum(v) / len(v), len(v)
 
 
