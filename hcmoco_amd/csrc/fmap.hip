@@ -1344,7 +1344,7 @@ struct DenseWs {
 };
 // the target table of the lean path: problems without padded tiles, at most 64 MB of table (B = 32, S = 400: 20 MB)
 inline bool dense_table_ok(int B, int S) {
-  static const bool on = !(getenv("HCM_DENSE_TABLE") && getenv("HCM_DENSE_TABLE")[0] == '0');
+  static const bool on = getenv("HCM_DENSE_TABLE") && getenv("HCM_DENSE_TABLE")[0] == '1';      // off until measured
   return on && S % 16 == 0 && (size_t)B * S * S * sizeof(float) <= ((size_t)64 << 20);
 }
 DenseWs carve_dense(void* ws, int B, int S) {
