@@ -15,8 +15,6 @@
 //   joint_nce_kernel     one workgroup per image (J<=32 joints, launch/latency bound): VALU.
 //   scatter_rows_kernel  deterministic owner-computes scatter-add of the sampled-pixel gradients
 //                        into the map gradient (duplicates summed in index order, no atomics).
-#include <type_traits>
-
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
 
@@ -137,10 +135,6 @@ struct StripArgs {
   int nkc;              // 1: no split, results are final
   float* pstat;         // [nkc][N][8] = running max, sum, target dot, target mass, best logit, its column
   float* pdq;           // [nkc][N][128]
-  // Dense problems with S % 16 == 0 (r04): the soft targets exp(-|q_r - q_c|) of an image as a table, symmetric, row
-  // stride S (dense_prep_kernel), and their row sums; null -> the element-wise code evaluates them.
-  const float* wtab;    // [nbatch][S][S]
-  const float* zrow;    // [nbatch][S]
 };
 
 // LDS image of a key tile (16 rows x 32 float4 slots): row stride 128 floats, NO padding, slot s of row r stored at
@@ -173,7 +167,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   // bounded by (MFMA + VALU) instruction time: fewer VALU instructions per element is the only lever left in fp32.
   __shared__ __attribute__((aligned(16))) float sKb[3][16 * kKS];
   __shared__ int sMetaCb[3][16];
-  __shared__ __attribute__((aligned(16))) float sStatCb[3][3][16];      // [buffer][lse, alpha, beta][key of the tile]
+  __shared__ float sStatCb[3][16][3];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int np = lane & 15, g = lane >> 4;
@@ -195,14 +189,6 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   const int64_t statK = a.symmetric ? 0 : ((int64_t)(1 - o) * rows_total + base);  // other orientation
 
   const int row0 = blockIdx.x * 64 + wave * 16;  // first row of this wave's strip
-  // Lean element-wise code (r04; dense problems whose S is a multiple of 16, unit rows): the soft targets come from a
-  // table (a.wtab: they used to be re-evaluated -- two subtractions, two conversions, v_sqrt, v_exp -- four times per
-  // pair: two orientations x two passes), the queries are pre-multiplied by log2(e) / tau so that the accumulator IS the
-  // base-2 logit, the arg-max of the accuracy is tracked as two running maxima (left / right of the diagonal), and the
-  // constant factors of the gradient are applied once to dQ.  Strips are full or empty then (no padded rows or columns).
-  constexpr float kLog2e = 1.4426950408889634f;
-  const bool lean = std::is_same<Policy, DensePolicy>::value && a.wtab != nullptr && (GRAD || BND);
-  const float qscale = lean ? a.inv_tau * kLog2e : 1.f;
   // A operand: lane (m = np, kslot = g) holds Q[row0+np][16j + 4g + e], j<8, e<4
   // (BF16: Q[row0+np][32j + 8g + e], j<4, e<8, rounded to bf16)
   float4 qf[BF16 ? 1 : 8];
@@ -218,15 +204,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
           hi = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g + 4);
         }
         const v8f v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        qh[j] = __builtin_convertvector(v * qscale, v8bf);
+        qh[j] = __builtin_convertvector(v, v8bf);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 8; ++j)
         qf[j] = (r < S) ? *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 16 * j + 4 * g)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
-        qf[j].x *= qscale; qf[j].y *= qscale; qf[j].z *= qscale; qf[j].w *= qscale;
-      }
     }
   }
   // rows owned in the C layout: row0 + 4g + reg (stats pass: P = Q K^T) or row0 + np for every reg (grad pass: the
@@ -236,7 +220,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = GRAD ? row0 + np : row0 + 4 * g + q;
-    mrow[q] = (r < S && !lean) ? pol.pack(metaQ[r]) : 0;
+    mrow[q] = (r < S) ? pol.pack(metaQ[r]) : 0;
     if (GRAD) {
       lse_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 0] : 0.f;
       al_r[q] = (r < S) ? a.stat[(statQ + r) * 4 + 1] : 0.f;
@@ -254,24 +238,6 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   }
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) dq[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-  // lean: this lane's four targets of a tile are one float4 of the table.  Stats pass: rows row0+4g+q, column c0+np ->
-  // W[c][r..r+3] (the table is symmetric); grad pass: row row0+np, columns c0+4g+q -> W[r][c..c+3].
-  const bool strip_live = row0 < S;
-  const float* wbase = nullptr;
-  float mlt[4], mge[4], pd[4];
-  float4 wcur = make_float4(0.f, 0.f, 0.f, 0.f), wnext = wcur;
-  if (lean) {
-    wbase = a.wtab + (int64_t)b * S * S + (GRAD ? (int64_t)min(row0 + np, S - 1) * S + 4 * g : (int64_t)np * S + min(row0, S - 16) + 4 * g);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      mlt[q] = mge[q] = pd[q] = -3.0e38f;
-      if (GRAD) lse_r[q] *= kLog2e;
-    }
-  }
-  auto wload = [&](int tile) -> float4 {
-    return *reinterpret_cast<const float4*>(wbase + (GRAD ? (int64_t)tile * 16 : (int64_t)tile * 16 * S));
-  };
 
   const int ntiles = (S + 15) / 16;
   const int tiles_per = (ntiles + a.nkc - 1) / a.nkc;
@@ -292,11 +258,10 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
     }
     if (threadIdx.x < 16) {
       const int c = c0 + threadIdx.x;
-      mreg = (c < S && !lean) ? pol.pack(metaK[c]) : 0;
+      mreg = (c < S) ? pol.pack(metaK[c]) : 0;
       if (GRAD) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) sreg[i] = (c < S) ? a.stat[(statK + c) * 4 + i] : 0.f;
-        if (lean) sreg[0] *= kLog2e;
       }
     }
   };
@@ -310,13 +275,11 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
       sMetaCb[buf][threadIdx.x] = mreg;
       if (GRAD) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) sStatCb[buf][i][threadIdx.x] = sreg[i];
+        for (int i = 0; i < 3; ++i) sStatCb[buf][threadIdx.x][i] = sreg[i];
       }
     }
   };
   // GEMM 1: P[16 x 16] = Qstrip . Ktile^T   (32 x v_mfma_f32_16x16x4_f32) into four independent accumulators
-  // (fp32: two chains are enough -- a dependent v_mfma_f32_16x16x4_f32 can issue 40 cycles after its producer and the
-  // other chain's instruction takes 32 -- and halve the adds that fold the chains)
   auto gemm1 = [&](const float* sK, v4f (&ap)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ap[i] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -336,13 +299,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         if (GRAD) {      // A <-> B: the accumulator holds P^T, i.e. lane (np, g) reg q = P[row0 + np][c0 + 4g + q]
           ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.x, qf[j].x, ap[0], 0, 0, 0);
           ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.y, qf[j].y, ap[1], 0, 0, 0);
-          ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.z, qf[j].z, ap[0], 0, 0, 0);
-          ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qf[j].w, ap[1], 0, 0, 0);
+          ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.z, qf[j].z, ap[2], 0, 0, 0);
+          ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qf[j].w, ap[3], 0, 0, 0);
         } else {
           ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, ap[0], 0, 0, 0);
           ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, ap[1], 0, 0, 0);
-          ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, ap[0], 0, 0, 0);
-          ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, ap[1], 0, 0, 0);
+          ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, ap[2], 0, 0, 0);
+          ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, ap[3], 0, 0, 0);
         }
       }
     }
@@ -355,18 +318,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   __syncthreads();
   gemm1(sKb[0], apn);
   if (tile_lo + 1 < tile_hi) fetch(tile_lo + 1);
-  if (lean && tile_lo < tile_hi) wnext = wload(tile_lo);
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int c0 = tile * 16;
     const int ib = (tile - tile_lo) % 3, nb = (ib + 1) % 3;
     const float* sK = sKb[ib];
     const int* sMetaC = sMetaCb[ib];
-    const float (*sStatC)[16] = sStatCb[ib];
-    const v4f acc = BF16 ? (apn[0] + apn[1]) + (apn[2] + apn[3]) : apn[0] + apn[1];
-    if (lean) {
-      wcur = wnext;
-      if (tile + 1 < tile_hi) wnext = wload(tile + 1);
-    }
+    const float (*sStatC)[3] = sStatCb[ib];
+    const v4f acc = (apn[0] + apn[1]) + (apn[2] + apn[3]);
     if (tile + 1 < tile_hi) commit(nb);             // buffer nb was last read two barriers ago
     __syncthreads();                                // tile t+1 is in LDS
     if (tile + 2 < tile_hi) fetch(tile + 2);
@@ -381,62 +339,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
     // VALU cycles per tile as the tile's 32 MFMAs.  Unit rows bound every logit by 1/tau, so when exp(-2/tau) is
     // far from underflow (a.bounded; tau = 0.07: 4e-13) the row maximum is replaced by that bound -- one exp per
     // element, no rescaling; otherwise the running-maximum form.
-    if (lean) {
-      if (!strip_live) continue;                    // (the strip's waves still stage tiles and meet the barriers above)
-      const float w4[4] = {wcur.x, wcur.y, wcur.z, wcur.w};
-      if (!GRAD) {
-        const float bound2 = a.inv_tau * kLog2e;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ssum[q] += __builtin_amdgcn_exp2f(acc[q] - bound2);
-          td[q] = fmaf(w4[q], acc[q], td[q]);
-        }
-        if (c0 < row0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) mlt[q] = fmaxf(mlt[q], acc[q]);
-        } else if (c0 > row0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) mge[q] = fmaxf(mge[q], acc[q]);
-        } else {                                    // the tile of the diagonal: column np against row 4g + q
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int dr = 4 * g + q;
-            mlt[q] = np < dr ? fmaxf(mlt[q], acc[q]) : mlt[q];
-            mge[q] = np > dr ? fmaxf(mge[q], acc[q]) : mge[q];
-            pd[q] = np == dr ? acc[q] : pd[q];
-          }
-        }
-      } else {
-        const float4 lc = *reinterpret_cast<const float4*>(&sStatC[0][4 * g]);
-        const float4 bc = *reinterpret_cast<const float4*>(&sStatC[2][4 * g]);
-        const float lse_c[4] = {lc.x, lc.y, lc.z, lc.w}, be_c[4] = {bc.x, bc.y, bc.z, bc.w};
-        float ga[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)      // alpha = 1 for the dense loss (DensePolicy::finish); gs / tau goes onto dQ at the end
-          ga[q] = __builtin_amdgcn_exp2f(acc[q] - lse_r[q]) + __builtin_amdgcn_exp2f(acc[q] - lse_c[q]) - (be_r[q] + be_c[q]) * w4[q];
-        if constexpr (BF16) {
-          const v4f gv = {ga[0], ga[1], ga[2], ga[3]};
-          const v4s gb = __builtin_bit_cast(v4s, __builtin_convertvector(gv, v4bf));
-#pragma unroll
-          for (int nt = 0; nt < 8; ++nt) {
-            const int sl = 4 * nt + (np >> 2), el = np & 3;
-            const v4f kv = {sK[ksw(4 * g, sl) + el], sK[ksw(4 * g + 1, sl) + el], sK[ksw(4 * g + 2, sl) + el],
-                            sK[ksw(4 * g + 3, sl) + el]};
-            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gb, __builtin_bit_cast(v4s, __builtin_convertvector(kv, v4bf)),
-                                                               dq[nt], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-              const float bv = sK[ksw(4 * g + ks, 4 * nt + (np >> 2)) + (np & 3)];
-              dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], bv, dq[nt], 0, 0, 0);
-            }
-          }
-        }
-      }
-    } else if (!GRAD) {
+    if (!GRAD) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = row0 + 4 * g + q;
@@ -471,7 +374,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         const float okf = (cq < S && r < S) ? gs * a.inv_tau : 0.f;
         const float P = fminf(acc[q] * a.inv_tau, 2.f * a.inv_tau);      // (clamp: padded rows must not make inf * 0)
         const float wgt = pol.weight(mrow[q], sMetaC[kq], r, cq);
-        const float lse_c = sStatC[0][kq], al_c = sStatC[1][kq], be_c = sStatC[2][kq];
+        const float lse_c = sStatC[kq][0], al_c = sStatC[kq][1], be_c = sStatC[kq][2];
         const float G = al_r[q] * __expf(P - lse_r[q]) - be_r[q] * wgt + al_c * __expf(P - lse_c) - be_c * wgt;
         ga[q] = G * okf;
       }
@@ -501,28 +404,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
     }
   }
 
-  if (!GRAD && lean) {
-    if (!strip_live) return;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float sAll = row16_sum(ssum[q]);
-      const float tdAll = row16_sum(td[q]) * (1.f / kLog2e);        // the accumulator held base-2 logits
-      const float left = row16_max(mlt[q]), right = row16_max(mge[q]), diag = row16_max(pd[q]);
-      const int r = row0 + 4 * g + q;
-      if (np == 0) {
-        const float lse = a.inv_tau + __logf(sAll);
-        float loss, alpha, beta;
-        pol.finish(lse, tdAll, a.zrow[(int64_t)b * S + r], loss, alpha, beta);
-        a.stat[(statQ + r) * 4 + 0] = lse;
-        a.stat[(statQ + r) * 4 + 1] = alpha;
-        a.stat[(statQ + r) * 4 + 2] = beta;
-        a.rowloss[statQ + r] = loss;
-        // torch.argmax returns the FIRST maximum: the diagonal wins iff it beats everything before it and ties at most
-        // with what follows
-        a.rowcorrect[statQ + r] = (diag > left && diag >= right) ? 1.f : 0.f;
-      }
-    }
-  } else if (!GRAD) {
+  if (!GRAD) {
     // merge the 16 lanes (columns) that share each row: they sit in one DPP row
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -556,11 +438,6 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   } else {
     // dq[nt][q] = d loss / d qhat[row0+4g+q][16nt+np]; push it through F.normalize
     const int64_t qrow_base = (int64_t)qmod * rows_total + base;
-    if (lean) {
-      const float sc = gs * a.inv_tau;
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) dq[nt] *= sc;
-    }
     if (a.nkc > 1) {       // partial over this chunk's keys: strip_merge_grad_kernel sums and normalises
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -654,40 +531,6 @@ __global__ void dense_prep_kernel(const int32_t* __restrict__ keep, int B, int S
   }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * S; e += gridDim.x * blockDim.x)
     meta[e] = (int)sample_ind[e];
-}
-
-// dense, S % 16 == 0: the same, plus the soft targets of every kept image as a table (workgroup (c, b) writes row c:
-// W[b][c][r] = exp(-|pix_r - pix_c|), the expression of DensePolicy::weight, and its sum = z of row c -- the table is
-// symmetric) for the lean element-wise code of strip_kernel.
-__global__ __launch_bounds__(256) void dense_prep_table_kernel(const int32_t* __restrict__ keep, int B, int S,
-                                                               const int64_t* __restrict__ ind, int w, int* __restrict__ meta,
-                                                               float* __restrict__ gscale, float* __restrict__ wtab,
-                                                               float* __restrict__ zrow) {
-  __shared__ float part[4];
-  const int c = blockIdx.x, b = blockIdx.y;
-  if (c == 0 && b == 0 && threadIdx.x == 0) {
-    int cnt = 0;
-    for (int i = 0; i < B; ++i) cnt += keep[i] != 0;
-    *gscale = cnt > 0 ? 1.f / ((float)cnt * (float)S) : 0.f;
-  }
-  const int mc = (int)ind[(int64_t)b * S + c];
-  if (threadIdx.x == 0) meta[b * S + c] = mc;
-  if (keep[b] == 0) return;
-  const int yc = mc / w, xc = mc - yc * w;
-  float* row = wtab + ((int64_t)b * S + c) * S;
-  float zsum = 0.f;
-  for (int r = threadIdx.x; r < S; r += 256) {
-    const int mr = (int)ind[(int64_t)b * S + r];
-    const int yr = mr / w, xr = mr - yr * w;
-    const float dy = (float)(yr - yc), dx = (float)(xr - xc);
-    const float wv = __expf(-__builtin_amdgcn_sqrtf(dy * dy + dx * dx));
-    row[r] = wv;
-    zsum += wv;
-  }
-  zsum = wave_sum(zsum);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = zsum;
-  __syncthreads();
-  if (threadIdx.x == 0) zrow[(int64_t)b * S + c] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // scl: rows u = (mod, b, j); meta = j | valid<<16 ; gscale = 1/N, or 0 when use_depth.sum()==0
@@ -1338,15 +1181,10 @@ struct Carver {
 };
 
 struct DenseWs {
-  float *F, *invn, *stat, *rowloss, *rowcorrect, *dX, *gscale, *wtab, *zrow;
+  float *F, *invn, *stat, *rowloss, *rowcorrect, *dX, *gscale;
   int* meta;
   size_t bytes;
 };
-// the target table of the lean path: problems without padded tiles, at most 64 MB of table (B = 32, S = 400: 20 MB)
-inline bool dense_table_ok(int B, int S) {
-  static const bool on = getenv("HCM_DENSE_TABLE") && getenv("HCM_DENSE_TABLE")[0] == '1';      // off until measured
-  return on && S % 16 == 0 && (size_t)B * S * S * sizeof(float) <= ((size_t)64 << 20);
-}
 DenseWs carve_dense(void* ws, int B, int S) {
   Carver c(ws);
   DenseWs o;
@@ -1359,11 +1197,6 @@ DenseWs carve_dense(void* ws, int B, int S) {
   o.rowcorrect = c.take<float>(2 * rows);
   o.meta = c.take<int>(rows);
   o.gscale = c.take<float>(4);
-  o.wtab = o.zrow = nullptr;
-  if (dense_table_ok(B, S)) {
-    o.wtab = c.take<float>((size_t)B * S * S);
-    o.zrow = c.take<float>(rows);
-  }
   o.bytes = c.off;
   return o;
 }
@@ -1470,10 +1303,7 @@ static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int
   hipStream_t s = (hipStream_t)stream;
   const int rows = B * S;
   const MapView mv = view(st, w);
-  if (ws.wtab != nullptr)
-    dense_prep_table_kernel<<<dim3(S, B), 256, 0, s>>>(keep, B, S, coord_ind, coord_w, ws.meta, ws.gscale, ws.wtab, ws.zrow);
-  else
-    dense_prep_kernel<<<(rows + 255) / 256, 256, 0, s>>>(keep, B, S, coord_ind, ws.meta, ws.gscale);
+  dense_prep_kernel<<<(rows + 255) / 256, 256, 0, s>>>(keep, B, S, coord_ind, ws.meta, ws.gscale);
   HCM_CHECK_LAUNCH();
   gather_norm_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(map1, map2, mv, sample_ind, S, rows,
                                                              keep, ws.F, ws.invn);
@@ -1483,7 +1313,6 @@ static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int
   a.symmetric = 0; a.inv_tau = (float)(1.0 / (double)temperature); a.bounded = 2.0 / (double)temperature < 80.0 ? 1 : 0; a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
   a.nkc = 1; a.pstat = nullptr; a.pdq = nullptr;
-  a.wtab = ws.wtab; a.zrow = ws.zrow;
   const dim3 grid((S + 63) / 64, B, 2);
   DensePolicy pol{coord_w};
   {
@@ -1560,7 +1389,6 @@ static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B
   a.symmetric = 1; a.inv_tau = (float)(1.0 / (double)temperature); a.bounded = 2.0 / (double)temperature < 80.0 ? 1 : 0; a.gscale = ws.gscale;
   a.stat = ws.stat; a.rowloss = ws.rowloss; a.rowcorrect = ws.rowcorrect; a.dX = ws.dX;
   a.nkc = ws.nkc; a.pstat = ws.pstat; a.pdq = ws.pdq;
-  a.wtab = nullptr; a.zrow = nullptr;
   const dim3 grid((N + 63) / 64, ws.nkc, 1);
   SclPolicy pol;
   {
