@@ -982,7 +982,8 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
     // variant 26, 7.58 against 5.68 at K = 131072; its rings 5 and 6 spill at two waves per SIMD and lose.
     // fp32: the lean kernel at ring depth 2 (variant 32): 6.22 / 5.90 / 6.22 TB/s on the same cells against 5.94 / 5.65 / 6.14
     // for variant 3, 0.83-0.84 of the 8 TB/s peak inside the training step against 0.80.
-    switch (variant > 0 ? variant : (kBf16 ? 34 : 32)) {
+    const int pass_variant = variant > 0 ? variant : (kBf16 ? 34 : 32);
+    switch (pass_variant) {
       case 2: HCM_LAUNCH_PASS(2, 1); break;
       case 3: HCM_LAUNCH_PASS(3, 1); break;
       case 4: HCM_LAUNCH_PASS(4, 1); break;
@@ -990,7 +991,7 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
       case 25: HCM_LAUNCH_PASS(5, 2); break;         // r04: deeper rings HELD to two waves per SIMD (256 VGPRs)
       case 26: HCM_LAUNCH_PASS(6, 2); break;
       case 32: case 33: case 34: case 35: case 36: case 38:      // r04: csrc/bank_lean.hip, ring depth = variant - 30
-        hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, variant - 30, bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R, scale2,
+        hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, pass_variant - 30, bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R, scale2,
                                    ws.part_m, ws.part_s, ws.part_acc, ws.l0, stream);
         break;
       case 12: HCM_LAUNCH_GLDS(2); break;

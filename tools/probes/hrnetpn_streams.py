@@ -34,5 +34,5 @@ for _ in range(20):
     for k, v in row.items():
         acc[k] = acc.get(k, 0.0) + v
     n += 1
-print('order %s (ms after the forward began on the GPU; synchronised steps):' % os.environ.get('HCM_PN_ORDER', 'cloud_first'),
+print('order %s, HCM_TWO_STREAMS=%s (ms after the forward began on the GPU; synchronised steps):' % (os.environ.get('HCM_PN_ORDER', 'default (HRNet first when the geometry has its own stream)'), os.environ.get('HCM_TWO_STREAMS', 'default')),
       {k: round(v / n, 2) for k, v in acc.items()})
