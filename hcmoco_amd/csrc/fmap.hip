@@ -155,8 +155,25 @@ __device__ __forceinline__ int ksw(int row, int slot) { return (row * 32 + (slot
 // are rounded to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) in registers on their way from the
 // fp32 unit rows / the fp32 LDS tile into the MFMA; everything else (softmax statistics, targets,
 // normalisation backward) stays fp32.  Parity is stated against the fp32 oracle at 1e-2.
+// Diagnostic build only (-DHCM_STRIP_TIMING, tools/probes/strip_timing.sh): s_memtime stamps of wave 0 of every workgroup,
+// summed per phase of the key-tile loop.
+#ifdef HCM_STRIP_TIMING
+__device__ unsigned long long* g_strip_dbg = nullptr;
+#define HCM_TS(k)                                                                    \
+  do {                                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+    tacc_[k] += now_ - tlast_;                                                        \
+    tlast_ = now_;                                                                   \
+  } while (0)
+#else
+#define HCM_TS(k) do {} while (0)
+#endif
 template <class Policy, bool GRAD, bool BF16, bool BND>
 __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
+#ifdef HCM_STRIP_TIMING
+  unsigned long long tacc_[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tlast_ = __builtin_amdgcn_s_memtime();
+#endif
   // Software pipeline over the key tiles, three LDS buffers, ONE barrier per tile: while tile t is in its element-wise
   // phase (softmax / targets / gradient entries) the similarity of tile t+1 has already been issued and tile t+2 is
   // travelling global -> registers, so no phase waits for a load or for a matrix result.
@@ -318,6 +335,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   __syncthreads();
   gemm1(sKb[0], apn);
   if (tile_lo + 1 < tile_hi) fetch(tile_lo + 1);
+  HCM_TS(0);                                          // prologue: query fragments, first tile staged, first GEMM issued
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int c0 = tile * 16;
     const int ib = (tile - tile_lo) % 3, nb = (ib + 1) % 3;
@@ -326,10 +344,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
     const float (*sStatC)[3] = sStatCb[ib];
     const v4f acc = (apn[0] + apn[1]) + (apn[2] + apn[3]);
     if (tile + 1 < tile_hi) commit(nb);             // buffer nb was last read two barriers ago
+    HCM_TS(1);                                      // accumulator read (the previous GEMM must have finished) + commit
     __syncthreads();                                // tile t+1 is in LDS
+    HCM_TS(2);
     if (tile + 2 < tile_hi) fetch(tile + 2);
     gemm1(sKb[nb], apn);                            // unconditional (a stale buffer after the last tile): keeps the
                                                     // MFMAs and the element-wise code below in one basic block
+    HCM_TS(3);                                      // operand reads + MFMA issue
     // C layout: acc[q] = P[row0 + 4g + q][c0 + np]
     const int c = c0 + np;
     const bool cvalid = c < S;
@@ -402,7 +423,15 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         }
       }
     }
+    HCM_TS(4);                                      // element-wise code (+ GEMM 2 issue in the grad pass)
   }
+#ifdef HCM_STRIP_TIMING
+  if (g_strip_dbg != nullptr && threadIdx.x == 0) {
+    unsigned long long* o_ = g_strip_dbg + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 + (GRAD ? 1 : 0)) * 8;
+    for (int k = 0; k < 5; ++k) o_[k] = tacc_[k];
+    o_[5] = (unsigned long long)(tile_hi - tile_lo);
+  }
+#endif
 
   if (!GRAD) {
     // merge the 16 lanes (columns) that share each row: they sit in one DPP row
@@ -1570,3 +1599,9 @@ int hcm_joint_pixels(const float* joints2d, int BJ, int h, int64_t* pix, hcm_str
 }
 
 }  // extern "C"
+
+#ifdef HCM_STRIP_TIMING
+extern "C" int hcm_debug_strip_timing(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_strip_dbg), &buf, sizeof(buf));
+}
+#endif
