@@ -13,6 +13,12 @@ for flags in "--width 32" "--arch HRNetPN" "--arch HRNetPN --width 32" "--bank_d
   echo "== $flags" >> $OUT/${TAG}_secondary_configs.log
   python bench.py --steps 20 --warmup 5 --no_cpu_baseline $flags 2>/dev/null | grep "^{" | tail -1 >> $OUT/${TAG}_secondary_configs.log
 done
+# the reference's recipe of record (scripts/SecondStage/train_ntumpiirgbd2s_hrnet_w18.sh: 320 x 320, 56 per GPU, MPII-16)
+: > $OUT/${TAG}_recipe_320_b56_mpii16.log
+for flags in "--size 320 --batch_per_gpu 56 --skeleton mpii" "--size 320 --batch_per_gpu 56 --skeleton mpii --arch HRNetPN"; do
+  echo "== $flags" >> $OUT/${TAG}_recipe_320_b56_mpii16.log
+  python bench.py --steps 12 --warmup 4 --no_cpu_baseline $flags 2>/dev/null | grep "^{" | tail -1 >> $OUT/${TAG}_recipe_320_b56_mpii16.log
+done
 HCM_DETERMINISTIC=1 python bench.py --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null | grep "^{" | tail -1 > $OUT/${TAG}_deterministic_mode_bench_line.json
 python bench.py --gpus 2 --backend gloo --steps 10 --warmup 3 --no_cpu_baseline --no_check 2>/dev/null | grep "^{" | tail -1 > $OUT/${TAG}_two_ranks_one_gpu_gloo_bench_line.json || true
 (python tools/bench_pointnet2.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_pointnet2_ops_config4.txt
