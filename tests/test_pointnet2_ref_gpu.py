@@ -109,6 +109,24 @@ def test_fps_tie_break_of_the_reference_kernel():
     assert torch.equal(res[0], P.furthest_point_sampling(g.contiguous(), 256)[0])
 
 
+def test_fps_constant_and_two_valued_clouds():
+    """The clouds of empty-mask images are all zeros (networks/build_backbone.py:427-445): every round of FPS is a 4096-way
+    tie, which in the r04 kernel is the path where every lane of every wave holds the maximum (one ds_max_u64 post per wave
+    after a second wave reduction).  Also a cloud of two coincident clusters, and one with a single point that differs."""
+    n, m = 4096, 192
+    clouds = torch.zeros(3, n, 3)
+    clouds[1, n // 3:] = torch.tensor([0.25, -1.0, 2.0])
+    clouds[2, 1234] = torch.tensor([1.0, 1.0, 1.0])
+    res = []
+    for mod_ in (R, mod()):
+        out = torch.zeros(3, m, dtype=torch.int32, device=d())
+        temp = torch.full((3, n), 1e10, device=d())
+        mod_.furthest_point_sampling_wrapper(3, n, m, clouds.to(d()), temp, out)
+        res.append((out.cpu(), temp.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[1][0], P.furthest_point_sampling(clouds, m)[0])
+
+
 @pytest.mark.parametrize('N,M,r,ns', [(10, 4, 0.3, 3), (300, 300, 0.2, 16), (4096, 1024, 0.125, 32),
                                       (2500, 777, 0.05, 16), (1024, 256, 1.0, 32), (4096, 1024, 0.1, 16)])
 def test_ball_query_reference_kernel_vs_hip_vs_c_restatement(N, M, r, ns):
