@@ -49,7 +49,7 @@ def run(fn, name, nslots):
     t = t[used]
     print('%s: %d workgroups stamped' % (name, t.shape[0]))
     t0 = t[:, 0].min()
-    print('  kernel span (first start -> last stamp) %d cycles @100MHz-counter units' % int((t.max() - t0)))
+    print('  kernel span (first start -> last stamp) %d s_memtime counts (shader clock: ~2.4 counts per ns)' % int((t.max() - t0)))
     return t, t0
 
 
