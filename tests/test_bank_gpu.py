@@ -370,3 +370,46 @@ def test_baseline_sizes_against_the_oracle(K, dtype, masked):
             assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all())
         else:
             assert float(err.max()) <= 1e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# The lean pass (csrc/bank_lean.hip) starts its exponentials at the bound 1.01 |x| log2(e) / T, which unit bank rows
+# cannot exceed.  Inputs that break that assumption take its other paths: rows longer than 1 (a logit above the reference
+# point: the merged online-softmax rescale), queries so long that the bound is useless (reference point "minus infinity":
+# the branch chases the maximum), and both at once.  Same oracle, same fp32 tolerances.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', ['long_rows', 'long_queries', 'both', 'mixed_batch', 'tiny_T'])
+def test_lean_pass_outside_the_unit_row_assumption(case, dtype):
+    torch.manual_seed(len(case) * 7 + len(dtype))
+    d = dev()
+    B, K, n, D, T = 6, 1500, 5000, 128, 0.07
+    nrm = torch.nn.functional.normalize
+    banks = [nrm(torch.randn(n, D)) for _ in range(3)]
+    xs = [nrm(torch.randn(B, D)) for _ in range(3)]
+    if case in ('long_rows', 'both'):
+        for b in banks:
+            b[::7] *= 1.8                      # a seventh of the rows exceeds the bound by far
+            b[3::11] *= 1.02                   # and some only just
+    if case in ('long_queries', 'both'):
+        xs = [x * 3.5 for x in xs]             # bound above 60 log2 units: chase mode
+    if case == 'mixed_batch':
+        for x in xs:
+            x[1] *= 4.0                        # one sample in chase mode, its neighbours at the bound
+            x[4] *= 0.05
+        banks[1][5::13] *= 1.5
+    if case == 'tiny_T':
+        T = 0.02                               # |x| log2(e) / T = 72: chase mode for unit queries
+    if dtype == 'bf16':
+        banks = [b.to(torch.bfloat16) for b in banks]
+    banks32 = [b.float() for b in banks]
+    idx = torch.randint(0, n, (B, K + 1))
+    ud = torch.tensor([1, 0, 1, 1, 0, 1])
+    lo, ao, go, _ = O.bank_nce(banks32, idx, xs, T, use_depth=ud)
+    l, a, gx = ops().bank_nce_fused_raw([b.to(d) for b in banks], idx.to(d), [x.to(d) for x in xs], T, ud.to(d))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(l).all())
+    assert torch.allclose(l.cpu(), lo, rtol=LOSS_RTOL, atol=1e-6), (l.cpu(), lo)
+    assert torch.allclose(a.cpu(), ao, atol=1e-3)
+    for i in range(3):
+        assert rel_l2(gx[i], go[i]) < GRAD_REL_L2, (i, rel_l2(gx[i], go[i]))
