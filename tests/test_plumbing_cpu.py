@@ -369,3 +369,19 @@ def test_cpu_affinity_helper_parses_sysfs_lists_and_is_a_no_op_without_a_gpu():
     before = os.sched_getaffinity(0)
     assert affinity.pin_to_gpu_node(0) is None and affinity.pin_to_gpu_node(0, mode='0') is None
     assert os.sched_getaffinity(0) == before
+
+
+def test_kept_pixels_are_the_ones_the_nearest_resize_reads():
+    """CMC3HRNetSGCNPN2SingleHead.pts2depth_resized (networks/build_backbone.py:299-300 of the reference, fused) interpolates
+    the depth feature map only at the pixels F.interpolate(size=..., mode='nearest') keeps; the index list must BE torch's
+    rounding for every ratio, integer or not, and the side of the HRNet's first map must be what the stem produces."""
+    import torch.nn.functional as F
+    from hcmoco_amd.pycontrast.networks.build_backbone import CMC3HRNetSGCNPN2SingleHead as M
+    for h, w, oh, ow in [(256, 256, 64, 64), (320, 320, 80, 80), (36, 52, 10, 13), (17, 9, 5, 3), (8, 8, 8, 8), (12, 20, 24, 40)]:
+        x = torch.randn(2, 3, h, w)
+        keep = M.kept_pixels(h, w, oh, ow, x.device)
+        assert keep.shape == (oh * ow,) and int(keep.min()) >= 0 and int(keep.max()) < h * w
+        assert torch.equal(x.reshape(2, 3, h * w).index_select(2, keep).reshape(2, 3, oh, ow), F.interpolate(x, size=(oh, ow)))
+    stem = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, 2, 1, bias=False), torch.nn.Conv2d(4, 4, 3, 2, 1, bias=False))
+    for n in (224, 256, 288, 320, 33, 7):
+        assert stem(torch.zeros(1, 3, n, n + 2)).shape[-2:] == (M._stem_hw(n), M._stem_hw(n + 2))
