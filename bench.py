@@ -190,6 +190,144 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def rccl_report(max_lines=12):
+    """What RCCL itself said about this job (NCCL_DEBUG=INFO, subsystems INIT + GRAPH, written to NCCL_DEBUG_FILE by this
+    process): the version banner and the first ring / tree / transport lines, so that the line of the first real N > 1 run
+    says which topology its numbers were measured on.  {'version': ..., 'lines': [...]} or a reason."""
+    out = {'version': None, 'lines': [], 'nccl_debug': os.environ.get('NCCL_DEBUG')}
+    try:
+        out['version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                    # noqa: BLE001
+        out['version'] = 'unavailable: %s' % e
+    pat = os.environ.get('NCCL_DEBUG_FILE')
+    if not pat:
+        return out
+    import socket
+    path = pat.replace('%h', socket.gethostname()).replace('%p', str(os.getpid()))
+    try:
+        keep = ('NCCL version', 'RCCL version', 'Ring 00', 'Channel 00', 'Trees', 'nranks', 'via', 'XGMI', 'xgmi', 'P2P',
+                'Connected all', 'channels')
+        with open(path, errors='replace') as f:
+            for ln in f:
+                ln = ln.strip()
+                if any(k in ln for k in keep) and len(out['lines']) < max_lines:
+                    out['lines'].append(ln[-220:])
+    except OSError as e:
+        out['lines'] = ['no RCCL log at %s: %s' % (path, e)]
+    return out
+
+
+class FailSafe(object):
+    """The N > 1 line must not fail silently: whatever goes wrong on ANY rank, rank 0 still prints ONE
+    JSON line -- the usual keys, ``value`` null, ``error`` and ``phase`` saying what happened where, and the ``comm`` block
+    with what was known by then.  Three channels, all watched by a daemon thread of rank 0 (the main thread may be blocked
+    inside a collective; torch releases the GIL there):
+      * a rank that catches an exception writes it under ``hcm_bench_error/<rank>`` into the rendez-vous TCPStore;
+      * a rank that dies without a word makes the launcher tear the job down with SIGTERM: ``signal.set_wakeup_fd``
+        hands the signal number to the thread at C level, whatever the main thread is doing;
+      * a phase that makes no progress for ``limit`` seconds (a mis-wired rank: the peers sit in a collective) -- chosen
+        BELOW the process group's own timeout (120 s), whose RCCL watchdog aborts the process without unwinding Python."""
+    PG_TIMEOUT_S = 120
+    STALL_S = {'default': 100.0, 'build': 400.0, 'first steps': 400.0}
+
+    def __init__(self, rank, world, header):
+        import threading
+        self.rank, self.world, self.header = rank, world, dict(header)
+        self.phase, self.t_phase = 'start', time.monotonic()
+        self.comm = {}
+        self.lock = threading.Lock()
+        self.printed = False
+        self.store = None
+        self.armed = world > 1
+        self._stop = False
+        if rank == 0 and self.armed:
+            import signal
+            import socket
+            self._rd, self._wr = socket.socketpair()
+            self._rd.setblocking(False)
+            self._wr.setblocking(False)
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                signal.signal(sig, lambda *_: None)          # a Python-level handler makes the C handler feed the fd
+            signal.set_wakeup_fd(self._wr.fileno(), warn_on_full_buffer=False)
+            threading.Thread(target=self._watch, name='bench-failsafe', daemon=True).start()
+
+    def enter(self, phase):
+        self.phase, self.t_phase = phase, time.monotonic()
+
+    def connect_store(self):
+        """A client connection of our own to the rendez-vous store (the process group's is not shared across threads)."""
+        try:
+            from datetime import timedelta
+            self.store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), is_master=False,
+                                       timeout=timedelta(seconds=10))
+        except Exception as e:                # noqa: BLE001 -- the other two channels still work
+            self.comm['failsafe_store'] = 'unavailable: %s' % e
+
+    def done(self):
+        self._stop = True
+
+    def error_line(self, msg):
+        out = dict(self.header)
+        out.update(value=None, error=str(msg)[:2000], phase=self.phase, comm=self.comm or None, checked=False,
+                   roofline=None, cpu_baseline=None)
+        return out
+
+    def emit(self, msg):
+        """Print the error line once (rank 0)."""
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            import ctypes
+            sys.stdout.flush()
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:                 # noqa: BLE001
+                pass
+            print(json.dumps(self.error_line(msg)), flush=True)
+
+    def report(self, msg):
+        """Called by the rank that caught an exception."""
+        if self.rank == 0:
+            self.emit(msg)
+            return
+        if self.store is not None:
+            try:
+                self.store.set('hcm_bench_error/%d' % self.rank, str(msg)[:2000])
+            except Exception:                 # noqa: BLE001
+                pass
+
+    def _watch(self):
+        import select
+        while not self._stop:
+            r, _, _ = select.select([self._rd], [], [], 0.5)
+            if self._stop:
+                return
+            if r:
+                try:
+                    sigs = list(self._rd.recv(64))
+                except OSError:
+                    sigs = []
+                if sigs:
+                    self.emit('rank 0 received signal %s in phase %r: the launcher tore the job down (a peer rank died?)'
+                              % (sigs, self.phase))
+                    os._exit(3)
+            if self.store is not None:
+                try:
+                    keys = ['hcm_bench_error/%d' % r_ for r_ in range(1, self.world)]
+                    hit = [k for k in keys if self.store.check([k])]
+                    if hit:
+                        self.emit('%s: %s' % (hit[0], self.store.get(hit[0]).decode(errors='replace')))
+                        os._exit(3)
+                except Exception:             # noqa: BLE001 -- store gone: the launcher's SIGTERM follows
+                    pass
+            limit = self.STALL_S.get(self.phase, self.STALL_S['default'])
+            if time.monotonic() - self.t_phase > limit:
+                self.emit('no progress for %.0f s in phase %r (a peer rank is not answering a collective?)'
+                          % (limit, self.phase))
+                os._exit(4)
+
+
 def self_launch(n):
     """Re-run this command line under torch.distributed.run with n ranks on this node (rendez-vous on
     127.0.0.1, a free port).  The ranks' stdout is relayed as it comes, except that rank 0's JSON line is held
@@ -246,6 +384,7 @@ def main():
                          'batch-norm statistics / master weights / loss section); not the headline config')
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
+    ap.add_argument('--fault', type=str, default=None, help=argparse.SUPPRESS)      # tests: "rank:step:exit|raise|hang"
     ap.add_argument('--backend', type=str, default='nccl',
                     help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '
                          'multi-rank control flow be exercised on a single-GPU box')
@@ -262,9 +401,42 @@ def main():
         raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    hsa_ipc_inherited = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
     if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the HIP runtime comes up (first device call)
+        # dmabuf IPC between the ranks' processes (the image exports it already; hipIpcGetMemHandle fails without it on this
+        # host driver).  Must be in place before the HIP runtime comes up, i.e. it cannot be retried in-process: the value
+        # used and where it came from go into the line's `comm` block.
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if a.backend == 'nccl':
+            # RCCL's own account of the job (version, rings / trees, transports) into a per-rank file, INIT + GRAPH only:
+            # nothing is logged per collective.  Rank 0 quotes the topology lines in `comm`.
+            os.environ.setdefault('NCCL_DEBUG', 'INFO')
+            os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH')
+            os.environ.setdefault('NCCL_DEBUG_FILE', os.path.join(__import__('tempfile').gettempdir(), 'hcm_rccl_%h_%p.log'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    header = {'metric': 'pretrain samples/sec (RGB+depth+kpt triples) HRNet-w18', 'value': None, 'unit': 'samples/s',
+              'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'higher_is_better': True, 'scaling': 'weak',
+              'vs_baseline': None, 'data': 'synthetic'}
+    fs = FailSafe(rank, world, header)
+    fs.comm.update(world_size=world, rank=rank, backend=a.backend,
+                   hsa_enable_ipc_mode_legacy={'value': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                                               'source': 'inherited' if hsa_ipc_inherited is not None else 'set by bench.py'})
+    try:
+        run(a, rank, world, local, fs)
+    except BaseException as e:            # noqa: BLE001 -- SystemExit with a message included: the line must still come out
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        msg = '%s: %s' % (type(e).__name__, e)
+        tb = traceback.format_exc().strip().splitlines()
+        fs.report('rank %d, phase %r: %s | %s' % (rank, fs.phase, msg, ' <- '.join(tb[-6:])))
+        fs.done()
+        if world > 1:
+            os._exit(1)                   # no interpreter teardown: a half-dead communicator can hang in its destructor
+        raise
+
+
+def run(a, rank, world, local, fs):
     if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (a.gpus, world, a.gpus))
@@ -282,7 +454,17 @@ def main():
     pinned = pin_to_gpu_node(dev.index)           # the cores of the GPU's own socket (HCM_PIN_NUMA=0: leave it to the OS)
     forced = world == 1 and os.environ.get('HCM_FORCE_COLLECTIVES', '0') != '0'
     if world > 1 or forced:      # forced: a 1-rank group that still runs every collective (cost of the N>1 path)
-        dist.init_process_group(a.backend, rank=rank, world_size=world, device_id=dev)   # nccl = RCCL over xGMI
+        from datetime import timedelta
+        fs.enter('init_process_group')
+        # 120 s, not the default 10 minutes: a mis-wired rank must not burn the lease without a JSON line
+        dist.init_process_group(a.backend, rank=rank, world_size=world, device_id=dev,
+                                timeout=timedelta(seconds=FailSafe.PG_TIMEOUT_S))      # nccl = RCCL over xGMI
+        fs.connect_store()
+    fault = None
+    if a.fault:
+        fr, fstep, fkind = a.fault.split(':')
+        fault = (int(fstep), fkind) if int(fr) == rank else None
+    fs.enter('build')
 
     import tempfile
     from hcmoco_amd import hip_ops
@@ -307,6 +489,7 @@ def main():
 
     it = iter(data)
     records_path = None
+    fs.enter('first steps')
     if not a.no_check:
         # two extra untimed steps on every rank (the collectives must match): the quiet-Find step, then a step of
         # the default runtime that rank 0 records for the checker
@@ -320,6 +503,7 @@ def main():
             records_path = os.path.join(tempfile.mkdtemp(), 'step_records.pt')
             torch.save(recorder.records, records_path)
             recorder.records = []
+    fs.enter('warmup')
     for _ in range(a.warmup):
         trainer.train_step(next(it), model, contrast, opt, stage2=True)
     ranks_seen = None
@@ -330,6 +514,7 @@ def main():
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
+        fs.comm['ranks_seen'] = ranks_seen
         if trainer.grad_sync is not None:
             trainer.grad_sync.wait_events = []
         hip_ops.GATHER_WAIT_EVENTS = []
@@ -341,8 +526,16 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     last = None
-    for _ in range(a.steps):
+    fs.enter('timed steps')
+    for step_ in range(a.steps):
+        if fault is not None and step_ == fault[0]:
+            if fault[1] == 'exit':
+                os._exit(17)                  # dies without a word: the launcher's SIGTERM is what rank 0 hears
+            if fault[1] == 'hang':
+                time.sleep(10 ** 6)
+            raise RuntimeError('injected fault (bench.py --fault)')
         last = trainer.train_step(next(it), model, contrast, opt, stage2=True)
+        fs.t_phase = time.monotonic()         # progress
     ev1.record()                 # main stream: it is ordered behind the side streams / RCCL at the end of a step
     torch.cuda.synchronize()
     if world > 1:
@@ -354,13 +547,15 @@ def main():
         ar = trainer.grad_sync.wait_events if trainer.grad_sync is not None else []
         ag = hip_ops.GATHER_WAIT_EVENTS or []
         mean_ms = lambda evs: round(sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs), 4) if evs else None
-        comm = {'allreduce_exposed_ms': mean_ms(ar), 'allgather_wait_ms': mean_ms(ag),
+        comm = dict(fs.comm)
+        comm.update(rccl=rccl_report() if a.backend == 'nccl' else None)
+        comm.update({'allreduce_exposed_ms': mean_ms(ar), 'allgather_wait_ms': mean_ms(ag),
                 'launches': trainer.grad_sync.launched if trainer.grad_sync is not None else 0,
                 'ranks_seen': ranks_seen, 'world_size': world, 'backend': dist.get_backend(),
                 'steps_measured': len(ar), 'rank': rank,
                 'note': 'HIP events on the trainer stream around work.wait() of the gradient all-reduces (after backward '
                         'returned) and around the wait for the packed feature/index all-gather in front of the bank '
-                        'update: the time the stream stands still for communication that compute did not cover'}
+                        'update: the time the stream stands still for communication that compute did not cover'})
         if trainer.grad_sync is not None:
             trainer.grad_sync.wait_events = None
         hip_ops.GATHER_WAIT_EVENTS = None
@@ -399,8 +594,10 @@ def main():
         # every rank leaves the process group HERE, together: what follows (stand-alone kernel timings, the oracle check
         # of the recorded step, the CPU baseline) is rank 0's own work and takes a minute; the other ranks must not sit in
         # a communicator teardown -- or trip its watchdog -- while it runs
+        fs.enter('finish')
         dist.barrier()
         dist.destroy_process_group()
+    fs.done()
     if not (loss == loss):
         raise SystemExit('non-finite loss in the timed region')
 

@@ -991,8 +991,11 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
       case 25: HCM_LAUNCH_PASS(5, 2); break;         // r04: deeper rings HELD to two waves per SIMD (256 VGPRs)
       case 26: HCM_LAUNCH_PASS(6, 2); break;
       case 32: case 33: case 34: case 35: case 36: case 38:      // r04: csrc/bank_lean.hip, ring depth = variant - 30
-        hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, pass_variant - 30, bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R, scale2,
-                                   ws.part_m, ws.part_s, ws.part_acc, ws.l0, stream);
+        {   // the helper returns (and clears) the launch status itself: HCM_CHECK_LAUNCH below would see hipSuccess
+          const int rc = hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, pass_variant - 30, bank1, bank2, bank3, idx, x1, x2, x3, B,
+                                                    K1, R, scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0, stream);
+          if (rc != 0) { span.stop(); return rc; }
+        }
         break;
       case 12: HCM_LAUNCH_GLDS(2); break;
       case 13: HCM_LAUNCH_GLDS(3); break;

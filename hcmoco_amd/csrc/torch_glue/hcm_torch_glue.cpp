@@ -1022,11 +1022,18 @@ void run_encoder_backward_impl(const c10::intrusive_ptr<Tape>& tape, const std::
   S.finish();
 }
 
-struct EncoderFn : public torch::autograd::Function<EncoderFn> {
-  // params: 3 per layer (w, gamma, beta); buffers: 2 per layer (running_mean, running_var)
-  static variable_list forward(AutogradContext* ctx, const Tensor& x_in, at::TensorList params, at::TensorList buffers,
-                               std::vector<int64_t> prog, std::vector<int64_t> out_slots, int64_t n_values,
-                               double momentum, double eps, int64_t tag) {
+// The forward pass of a program without any autograd bookkeeping: the launches, the tape the reverse loop reads, the
+// output tensors.  Called inside EncoderFn::forward (run_encoder) or, for encoder_forward_async, on a helper thread
+// AHEAD of the node's creation: the node is then made by encoder_forward_wait on the caller's thread, which gives it
+// the caller's position in autograd's execution order (sequence numbers are per thread; a node made on the helper
+// thread carries a tiny number and is the LAST ready node the engine picks -- r05: the HRNetPN model's HRNet backward
+// started only after autograd had walked the whole cloud branch).
+struct ForwardResult { c10::intrusive_ptr<Tape> tape; variable_list outs; int64_t layers = 0; };
+
+ForwardResult encoder_forward_compute(const Tensor& x_in, at::TensorList params, at::TensorList buffers,
+                                      std::vector<int64_t> prog, const std::vector<int64_t>& out_slots, int64_t n_values,
+                                      double momentum, double eps, int64_t tag) {
+  {
     TORCH_CHECK(prog.size() % kInstrInts == 0 && params.size() % 3 == 0 && buffers.size() * 3 == params.size() * 2,
                 "hcmoco::run_encoder: malformed program");
     TORCH_CHECK(x_in.is_cuda(), "hcmoco::run_encoder needs ROCm tensors (no CPU fallback exists)");
@@ -1107,10 +1114,35 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
     }
     T.val[0] = T.val[0].detach();
     T.prog = std::move(prog);
-    ctx->saved_data["tape"] = c10::IValue::make_capsule(tape);
+    ForwardResult r;
+    r.tape = tape; r.outs = std::move(outs); r.layers = layers;
+    return r;
+  }
+}
+
+std::mutex g_precomputed_mutex;
+std::unordered_map<int64_t, ForwardResult> g_precomputed;   // encoder_forward_async results waiting for their node
+
+struct EncoderFn : public torch::autograd::Function<EncoderFn> {
+  // params: 3 per layer (w, gamma, beta); buffers: 2 per layer (running_mean, running_var)
+  // pre_id != 0: the launches were issued ahead (encoder_forward_async); this call only makes the node
+  static variable_list forward(AutogradContext* ctx, const Tensor& x_in, at::TensorList params, at::TensorList buffers,
+                               std::vector<int64_t> prog, std::vector<int64_t> out_slots, int64_t n_values,
+                               double momentum, double eps, int64_t tag, int64_t pre_id) {
+    ForwardResult r;
+    if (pre_id != 0) {
+      std::lock_guard<std::mutex> lk(g_precomputed_mutex);
+      auto it = g_precomputed.find(pre_id);
+      TORCH_CHECK(it != g_precomputed.end(), "hcmoco::run_encoder: no forward pass was issued under handle ", pre_id);
+      r = std::move(it->second);
+      g_precomputed.erase(it);
+    } else {
+      r = encoder_forward_compute(x_in, params, buffers, std::move(prog), out_slots, n_values, momentum, eps, tag);
+    }
+    ctx->saved_data["tape"] = c10::IValue::make_capsule(r.tape);
     ctx->saved_data["outs"] = out_slots;
-    ctx->saved_data["layers"] = layers;
-    return outs;
+    ctx->saved_data["layers"] = r.layers;
+    return r.outs;
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -1127,7 +1159,7 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
     Tensor flat = at::zeros({T.flat_numel}, T.w[0].options());
     Tensor scratch = at::empty({std::max<int64_t>(T.scratch_numel, 1)}, T.w[0].options());
     std::shared_ptr<GradChunks> gc = make_chunks(T, flat);
-    variable_list out(1 + 5 * layers + 6);           // x, params, buffers, then the six non-tensor arguments
+    variable_list out(1 + 5 * layers + 7);           // x, params, buffers, then the seven non-tensor arguments
     for (int64_t L = 0; L < layers; ++L) {
       const int64_t C = T.gamma[L].numel(), off = T.layer_off[L], wn = T.w[L].numel();
       out[1 + 3 * L] = flat.narrow(0, off, wn).view(T.w[L].sizes());
@@ -1149,11 +1181,18 @@ struct EncoderFn : public torch::autograd::Function<EncoderFn> {
 
 std::vector<Tensor> run_encoder(const Tensor& x, at::TensorList params, at::TensorList buffers, std::vector<int64_t> prog,
                                 std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps, int64_t tag) {
-  return EncoderFn::apply(x, params, buffers, std::move(prog), std::move(out_slots), n_values, momentum, eps, tag);
+  return EncoderFn::apply(x, params, buffers, std::move(prog), std::move(out_slots), n_values, momentum, eps, tag, (int64_t)0);
 }
 
-// Forward on the helper thread of the current stream; the caller collects the outputs with _wait.
-struct PendingForward { std::mutex m; std::condition_variable cv; bool done = false; std::vector<Tensor> outs; std::string error; };
+// Forward on the helper thread of the current stream; the caller collects the outputs with _wait, which is also where
+// the autograd node is made (on the caller's thread, under the stream the forward ran on).
+struct PendingForward {
+  std::mutex m; std::condition_variable cv; bool done = false; std::string error;
+  ForwardResult result;
+  Tensor x; std::vector<Tensor> params, buffers; std::vector<int64_t> prog, out_slots;
+  int64_t n_values = 0, tag = 0; double momentum = 0, eps = 0; bool grad = false;
+  c10::hip::HIPStream stream = c10::hip::getDefaultHIPStream();
+};
 std::mutex g_pending_mutex;
 std::unordered_map<int64_t, std::shared_ptr<PendingForward>> g_pending;
 int64_t g_pending_next = 1;
@@ -1167,23 +1206,28 @@ int64_t encoder_forward_async(const Tensor& x, at::TensorList params, at::Tensor
     id = g_pending_next++;
     g_pending[id] = pend;
   }
-  std::vector<Tensor> pv(params.begin(), params.end()), bv(buffers.begin(), buffers.end());
-  const bool grad = at::GradMode::is_enabled();
-  worker_for(c10::hip::getCurrentHIPStream(x.get_device())).push(
-      [pend, x, pv, bv, prog, out_slots, n_values, momentum, eps, grad, tag](Tensor*) mutable {
-        std::vector<Tensor> outs;
-        std::string err;
-        try {
-          at::AutoGradMode mode(grad);
-          outs = EncoderFn::apply(x, at::TensorList(pv), at::TensorList(bv), std::move(prog), std::move(out_slots), n_values,
-                                  momentum, eps, tag);
-        } catch (const std::exception& e) { err = e.what(); }
-        {
-          std::lock_guard<std::mutex> lk(pend->m);
-          pend->outs = std::move(outs); pend->error = err; pend->done = true;
-        }
-        pend->cv.notify_all();
-      });
+  pend->x = x;
+  pend->params.assign(params.begin(), params.end());
+  pend->buffers.assign(buffers.begin(), buffers.end());
+  pend->prog = std::move(prog);
+  pend->out_slots = std::move(out_slots);
+  pend->n_values = n_values; pend->momentum = momentum; pend->eps = eps; pend->tag = tag;
+  pend->grad = at::GradMode::is_enabled();
+  pend->stream = c10::hip::getCurrentHIPStream(x.get_device());
+  worker_for(pend->stream).push([pend](Tensor*) mutable {
+    ForwardResult r;
+    std::string err;
+    try {
+      at::AutoGradMode mode(false);           // raw launches only; the node is made by encoder_forward_wait
+      r = encoder_forward_compute(pend->x, at::TensorList(pend->params), at::TensorList(pend->buffers), pend->prog,
+                                  pend->out_slots, pend->n_values, pend->momentum, pend->eps, pend->tag);
+    } catch (const std::exception& e) { err = e.what(); }
+    {
+      std::lock_guard<std::mutex> lk(pend->m);
+      pend->result = std::move(r); pend->error = err; pend->done = true;
+    }
+    pend->cv.notify_all();
+  });
   return id;
 }
 
@@ -1196,10 +1240,20 @@ std::vector<Tensor> encoder_forward_wait(int64_t id) {
     pend = it->second;
     g_pending.erase(it);
   }
-  std::unique_lock<std::mutex> lk(pend->m);
-  pend->cv.wait(lk, [&] { return pend->done; });
+  {
+    std::unique_lock<std::mutex> lk(pend->m);
+    pend->cv.wait(lk, [&] { return pend->done; });
+  }
   TORCH_CHECK(pend->error.empty(), "hcmoco::encoder_forward_async failed: ", pend->error);
-  return std::move(pend->outs);
+  if (!pend->grad || !at::GradMode::is_enabled()) return std::move(pend->result.outs);
+  {
+    std::lock_guard<std::mutex> lk(g_precomputed_mutex);
+    g_precomputed[id] = std::move(pend->result);
+  }
+  // the node remembers the stream that is current while it is made: backward replays on the forward's stream
+  c10::hip::HIPStreamGuard guard(pend->stream);
+  return EncoderFn::apply(pend->x, at::TensorList(pend->params), at::TensorList(pend->buffers), std::move(pend->prog),
+                          std::move(pend->out_slots), pend->n_values, pend->momentum, pend->eps, pend->tag, id);
 }
 
 }  // namespace

@@ -243,6 +243,10 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             assert h * w < (1 << 24)
             grid = torch.arange(h * w, dtype=torch.float32, device=device).view(1, 1, h, w)
             cls._kept_pixels[key] = F.interpolate(grid, size=(oh, ow)).reshape(-1).long()
+            if grid.is_cuda:
+                # shared by every model (and model_ema) of the process and by every stream, never freed: finish it HERE,
+                # once, so no later reader on another stream can get ahead of the kernels that fill it
+                torch.cuda.current_stream(grid.device).synchronize()
         return cls._kept_pixels[key]
 
     @classmethod
@@ -326,12 +330,21 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             if trace:
                 ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 'h0', 'h1', 'p0', 'p1')}
                 ev['t0'].record(main)
+            # r05: the HRNet's forward goes to the C++ helper thread of the caller's stream (encoder_forward_async) and is
+            # collected BEHIND the cloud branch: (i) its ~360 launches and the cloud branch's ~700 Python-issued launches are
+            # issued by two threads at once, (ii) encoder_forward_wait makes the program's autograd node on this thread at
+            # that point, i.e. AFTER every node of the cloud branch, so the engine -- which runs the ready node that was
+            # created last -- starts the HRNet's reverse loop (one push to its helper thread) before it walks the cloud
+            # branch's ~700 nodes instead of after them (r04: the HRNet queue idle for the first ~15 ms of backward).
+            hr_pending = None
             if first:
                 if trace:
                     ev['h0'].record(main)
-                _feat1 = self.encoder1(x1)
-                if trace:
-                    ev['h1'].record(main)
+                hr_pending = self.encoder1.forward_async(x1) if hasattr(self.encoder1, 'forward_async') else None
+                if hr_pending is None:
+                    _feat1 = self.encoder1(x1)
+                    if trace:
+                        ev['h1'].record(main)
             with torch.cuda.stream(side_pn):
                 if trace:
                     ev['p0'].record(side_pn)
@@ -346,6 +359,10 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
                         linear_merge2 = depth_map(sample_pn, full_pn, _feat2, plan.extra['map'])
                 if trace:
                     ev['p1'].record(side_pn)
+            if hr_pending is not None:
+                _feat1 = self.encoder1.forward_wait(hr_pending)
+                if trace:
+                    ev['h1'].record(main)
             if not first:
                 if trace:
                     ev['h0'].record(main)
@@ -379,7 +396,9 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         if self.linear_feat_map:
             merge1 = self.merge_all_res(_feat1)
             linear_merge1 = self.encoder1_linear(merge1)
-            assert tuple(linear_merge1.shape[-2:]) == (oh, ow), (linear_merge1.shape, oh, ow)
+            if tuple(linear_merge1.shape[-2:]) != (oh, ow):      # _stem_hw restates the HRNet stem: fail loudly if it drifts
+                raise RuntimeError('HRNetPN: the depth map was resized to %s but the RGB map is %s'
+                                   % ((oh, ow), tuple(linear_merge1.shape[-2:])))
             return _feat1, _feat2, _feat3, f, {'merge1': merge1, 'merge2': _feat2,
                                                'linear_merge1': linear_merge1, 'linear_merge2': linear_merge2}
         return _feat1, _feat2, _feat3, avg1, avg2, avg3, f

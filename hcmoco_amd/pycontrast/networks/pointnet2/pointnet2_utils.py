@@ -18,6 +18,9 @@ from .... import pointnet2_hip as pointnet2
 # backward of the gather-type ops: 'planned' (deterministic ranked LDS rounds, csrc/scatter.hip), 'lds' (r02: LDS float
 # atomics) or 'atomic' (the reference's global atomics, *_grad_wrapper)
 SCATTER_BACKWARD = os.environ.get('HCM_PN2_BACKWARD', 'planned')
+# Resolved ONCE, next to the mode: the narrow-channel shortcut below applies only when the mode was left at its
+# default and reproducibility was not asked for; an explicit HCM_PN2_BACKWARD=planned means planned for every shape.
+_NARROW_SHORTCUT = 'HCM_PN2_BACKWARD' not in os.environ and os.environ.get('HCM_DETERMINISTIC', '0') == '0'
 
 
 def _scatter_backward(grad_out, idx, coef, m, div, legacy):
@@ -31,7 +34,7 @@ def _scatter_backward(grad_out, idx, coef, m, div, legacy):
     # a wave of the planned kernel owns ONE channel: with fewer than 8 channels (the grouped xyz coordinates, C = 3 -- not
     # differentiated in training) a workgroup is one or two waves and the kernel is 3.6x slower than the LDS-atomic form
     # (0.66 vs 0.19 ms at the first level).  Those shapes take the LDS form unless reproducibility was asked for.
-    narrow = grad_out.shape[1] < 8 and os.environ.get('HCM_DETERMINISTIC', '0') == '0'
+    narrow = grad_out.shape[1] < 8 and _NARROW_SHORTCUT
     if (fn is not None and SCATTER_BACKWARD == 'planned' and not narrow
             and m <= getattr(pointnet2, 'LDS_SCATTER_MAX_TARGETS', 0)):
         return fn(grad_out.contiguous(), idx, coef, m, div)

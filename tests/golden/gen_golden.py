@@ -393,6 +393,51 @@ def gen_model():
         npz('model_hrnet_w18_' + skel, **arrays)
 
 
+def gen_model_bwd():
+    """Backward of the reference model (encoders + SemGCN + heads + 1x1 projections) on CPU, train mode, for the
+    ``model`` fixture's inputs and deterministic weights: the loss is <f, cf> + <feat3, c3> + <lm1, c1> + <lm2, c2>
+    with seeded cotangents (cf, c3 stored; c1, c2 re-drawn from the same generator by the test).  Stored: d loss / d skeleton (full), every SemGCN / head / projection gradient in
+    full, and for EVERY parameter its gradient's L2 norm and its inner product with a name-keyed random vector (the
+    same generator as ``deterministic_fill``, seed + 1) -- enough to pin the encoder programs' backward without
+    storing 78 MB.  Reference: networks/SGCN/sem_graph_conv.py:34-48, sem_gcn.py:60-95, build_backbone.py:256-303."""
+    import zlib
+    from networks.build_backbone import build_model
+    for skel, J in (('mpii', 16), ('coco_reduce', 13)):
+        opt = argparse.Namespace(modal='RGBD2S', arch='HRNet', jigsaw=False, head='linear', feat_dim=128,
+                                 in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
+                                 skeleton_meta_name=skel, IN_Pretrain=None, depth_Pretrain=None, mem='bank')
+        model, _ = build_model(opt)
+        model.load_state_dict(deterministic_fill(model.state_dict()))
+        model.train()
+        # B = 4 at 128 x 128 (not gen_model's 2 x 64 x 64): the coarsest HRNet branch then normalises over 4 x 4 x 4 values
+        # instead of 2 x 2 x 2, and a 360-layer reverse chain through train-mode BatchNorm stays well conditioned in fp32.
+        # The inputs are seeded, not stored (like the weights): x alone would be 1.5 MB of noise.
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(4, 6, 128, 128, generator=g)
+        s = (torch.rand(4, J, 2, generator=g) * 2 - 1).requires_grad_(True)
+        f1, f2, f3, f, aux = model(x, s, return_fm=True)
+        gc = torch.Generator().manual_seed(11)
+        cf = torch.randn(f.shape, generator=gc)
+        c3 = torch.randn(f3.shape, generator=gc) * 0.1
+        c1 = torch.randn(aux['linear_merge1'].shape, generator=gc) * 0.05
+        c2 = torch.randn(aux['linear_merge2'].shape, generator=gc) * 0.05
+        loss = (f * cf).sum() + (f3 * c3).sum() + (aux['linear_merge1'] * c1).sum() + (aux['linear_merge2'] * c2).sum()
+        loss.backward()
+        names, norms, dots = [], [], []
+        arrays = dict(s=s.detach(), cf=cf, c3=c3, loss=loss.detach(), grad_s=s.grad, x_checksum=x.double().sum())
+        for k, p_ in model.named_parameters():
+            assert p_.grad is not None, k
+            gg = torch.Generator().manual_seed((zlib.crc32(k.encode()) + 1) & 0x7fffffff)
+            r = torch.randn(p_.shape, generator=gg)
+            names.append(k)
+            norms.append(float(p_.grad.double().norm()))
+            dots.append(float((p_.grad.double() * r.double()).sum()))
+            if not k.startswith(('encoder1.', 'encoder2.')):
+                arrays['g:' + k] = p_.grad
+        arrays.update(names=np.array(names), norms=np.array(norms), dots=np.array(dots))
+        npz('model_bwd_hrnet_w18_' + skel, **arrays)
+
+
 def gen_model_pn():
     """HRNetPN arch: state_dict keys/shapes only (its forward needs the CUDA point ops)."""
     from networks.build_backbone import build_model
@@ -861,7 +906,7 @@ if __name__ == '__main__':
     only = set(sys.argv[1:])
     sys.argv = sys.argv[:1]
     gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
-                scl=gen_scl, model=gen_model, model_pn=gen_model_pn, options=gen_options, trace=gen_trace,
+                scl=gen_scl, model=gen_model, model_bwd=gen_model_bwd, model_pn=gen_model_pn, options=gen_options, trace=gen_trace,
                 trace_moco=gen_trace_moco, dataset=gen_dataset)
     for name, fn in gens.items():
         if not only or name in only:

@@ -64,6 +64,84 @@ def test_state_dict_and_forward_match_reference(golden, skel):
         assert f.shape == (2, 384) and aux['linear_merge1'].shape == (2, 128, 16, 16)
 
 
+def check_backward_against_fixture(gb, model, device, tol_full=2e-3, tol_proj=5e-3, report=None):
+    """Run ``model`` (train mode, deterministic weights) on the fixture's inputs with the fixture's cotangents, backward,
+    and compare with the REFERENCE's backward (tests/golden/gen_golden.py:gen_model_bwd).  ``tol_full`` bounds the
+    relative L2 error of every gradient stored in full (skeleton input, SemGCN, heads, projections); ``tol_proj`` bounds,
+    for every parameter of the model, |norm - norm_ref| / norm_ref and |<g, r> - <g_ref, r>| / (|g_ref| |r|) for the
+    name-keyed random vector r.  Shared by the CPU test below and tests/test_model_surface_gpu.py."""
+    J = gb['s'].shape[1]
+    g = torch.Generator().manual_seed(7)                   # gen_model_bwd's inputs: seeded, not stored
+    x = torch.randn(4, 6, 128, 128, generator=g)
+    s_ref = torch.rand(4, J, 2, generator=g) * 2 - 1
+    assert torch.equal(s_ref, gb['s']) and abs(float(x.double().sum()) - float(gb['x_checksum'])) < 1e-9
+    x = x.to(device)
+    s = s_ref.to(device).requires_grad_(True)
+    f1, f2, f3, f, aux = model(x, s, return_fm=True)
+    gc = torch.Generator().manual_seed(11)
+    cf = torch.randn(f.shape, generator=gc)
+    c3 = torch.randn(f3.shape, generator=gc) * 0.1
+    c1 = torch.randn(aux['linear_merge1'].shape, generator=gc) * 0.05
+    c2 = torch.randn(aux['linear_merge2'].shape, generator=gc) * 0.05
+    assert torch.equal(cf, gb['cf']) and torch.equal(c3, gb['c3'])
+    loss = ((f * cf.to(device)).sum() + (f3 * c3.to(device)).sum() + (aux['linear_merge1'] * c1.to(device)).sum()
+            + (aux['linear_merge2'] * c2.to(device)).sum())
+    loss.backward()
+    if device.type == 'cuda':
+        torch.cuda.synchronize()
+    loss = loss.detach()
+    assert abs(float(loss) - float(gb["loss"])) <= 1e-4 * abs(float(gb['loss'])) + 1e-4, (float(loss), float(gb['loss']))
+
+    def rel(a, b):
+        return float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+    worst = {'full': 0.0, 'norm': 0.0, 'dot': 0.0}
+    table = []
+    e = rel(s.grad, gb['grad_s'])
+    worst['full'] = max(worst['full'], e)
+    assert e < tol_full, ('grad_s', e)
+    params = dict(model.named_parameters())
+    names = [str(k) for k in gb['names']]
+    assert names == list(params.keys())
+    scale = max(float(v) for v in gb['norms'])
+    for k, n_ref, d_ref in zip(names, gb['norms'].tolist(), gb['dots'].tolist()):
+        g = params[k].grad
+        assert g is not None, k
+        g = g.double().cpu()
+        if 'g:' + k in gb:
+            # a bias in front of a train-mode BatchNorm has an analytically zero gradient: round-off on both sides
+            err = float((g - gb['g:' + k].double()).norm())
+            assert err < tol_full * n_ref + 1e-6 * scale, (k, err, n_ref)
+            worst['full'] = max(worst['full'], err / max(n_ref, 1e-6 * scale))
+        gen = torch.Generator().manual_seed((zlib.crc32(k.encode()) + 1) & 0x7fffffff)
+        r = torch.randn(g.shape, generator=gen).double()
+        en = abs(float(g.norm()) - n_ref)
+        ed = abs(float((g * r).sum()) - d_ref) / float(r.norm())
+        floor = 1e-6 * scale
+        table.append((max(en, ed) / max(n_ref, floor), k, en, ed, n_ref))
+        worst['norm'] = max(worst['norm'], en / max(n_ref, floor))
+        worst['dot'] = max(worst['dot'], ed / max(n_ref, floor))
+    table.sort(reverse=True)
+    if report is not None:
+        report.update(worst)
+        report['table'] = table
+    for relerr, k, en, ed, n_ref in table:
+        assert en < tol_proj * n_ref + 1e-6 * scale and ed < tol_proj * n_ref + 1e-6 * scale, (
+            'worst first', [(round(t[0], 5), t[1]) for t in table[:8]])
+    return worst
+
+
+@pytest.mark.parametrize('skel', ['mpii', 'coco_reduce'])
+def test_backward_matches_reference(golden, skel):
+    """The host-side (CPU) module path of the product against the reference's backward; the GPU runtime is checked against
+    the same fixture in tests/test_model_surface_gpu.py."""
+    model, _ = build_model(make_opt(skel))
+    model.load_state_dict(deterministic_fill(model.state_dict()))
+    model.train()
+    worst = check_backward_against_fixture(golden('model_bwd_hrnet_w18_' + skel), model, torch.device('cpu'))
+    print(skel, worst)
+
+
 def test_w18_parameter_count_and_plain_forward():
     model, _ = build_model(make_opt('mpii'))
     assert sum(p.numel() for p in model.parameters()) == 19579252          # SURVEY 2.4 [probed]

@@ -1,0 +1,86 @@
+"""The DEFAULT GPU runtime of the encoder plugin -- the HRNet encoder programs (csrc/torch_glue, conv.hip, bnact.hip,
+wgrad.hip), the fused SemGCN layer (sgcn.hip), the heads and the 1x1 projections -- against outputs and gradients of the
+REFERENCE model, recorded by tests/golden/gen_golden.py (``gen_model``: forward in eval and train mode; ``gen_model_bwd``:
+the reference's backward on CPU).  This closes SURVEY 8f-3's parity chain: until r05 the fused SemGCN layer was only
+compared with the product's own eager modules (tests/test_sgcn_gpu.py).
+
+Reference: networks/SGCN/sem_graph_conv.py:34-48, sem_gcn.py:60-95, build_backbone.py:256-303.
+Tolerances: forward 1e-4 relative / 1e-5 absolute (the CPU test's); gradients by relative L2 norm, stated per check."""
+import pytest
+import torch
+
+from hcmoco_amd.pycontrast.networks.build_backbone import build_model
+from test_model_surface import deterministic_fill, make_opt, check_backward_against_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _model(skel):
+    model, _ = build_model(make_opt(skel))
+    model.load_state_dict(deterministic_fill(model.state_dict()))
+    return model.to(dev())
+
+
+@pytest.mark.parametrize('skel', ['mpii', 'coco_reduce'])
+def test_default_runtime_forward_matches_reference(golden, skel):
+    g = golden('model_hrnet_w18_' + skel)
+    model = _model(skel)
+    d = dev()
+    x, s = g['x'].to(d), g['s'].to(d)
+    for mode in ('eval', 'train'):
+        getattr(model, mode)()
+        with torch.no_grad():
+            f1, f2, f3, f, aux = model(x, s, return_fm=True)
+        torch.cuda.synchronize()
+        c = lambda t: t.float().cpu()
+        tol = dict(rtol=1e-4, atol=1e-5)
+        assert torch.allclose(c(f3), g[mode + '_feat3'], **tol), (mode, float((c(f3) - g[mode + '_feat3']).abs().max()))
+        assert torch.allclose(c(f), g[mode + '_f'], **tol), (mode, float((c(f) - g[mode + '_f']).abs().max()))
+
+        def close(got, ref, what):
+            # feature maps: with the name-keyed weights they reach |x| ~ 1e3 and every element is a sum of 270..2000
+            # products taken in another order than ATen's CPU convolution (MIOpen Winograd / MFMA tiles): 1e-4 relative
+            # to the element plus 1e-5 of the TENSOR's largest magnitude (a cancelled element keeps the sum's round-off)
+            bound = 1e-4 * ref.abs() + 1e-5 * float(ref.abs().max())
+            bad = (got - ref).abs() > bound
+            assert not bool(bad.any()), (mode, what, float((got - ref).abs().max()), float(ref.abs().max()))
+
+        close(c(aux['linear_merge1'])[:, :8, ::5, ::5], g[mode + '_lm1_slice'], 'linear_merge1')
+        close(c(aux['linear_merge2'])[:, :8, ::5, ::5], g[mode + '_lm2_slice'], 'linear_merge2')
+        close(c(f1[3]), g[mode + '_feat1_3'], 'feat1[3]')
+        close(c(f2[0])[:, :, ::7, ::7], g[mode + '_feat2_0_slice'], 'feat2[0]')
+
+
+@pytest.mark.parametrize('skel', ['mpii', 'coco_reduce'])
+def test_fused_semgcn_layer_is_the_path_under_test(skel):
+    """The forward above must have gone through sgcn.hip and the encoder programs, not through eager modules."""
+    from torch.profiler import profile, ProfilerActivity
+    model = _model(skel).train()
+    d = dev()
+    J = 16 if skel == 'mpii' else 13
+    x, s = torch.randn(2, 6, 64, 64, device=d), torch.rand(2, J, 2, device=d)
+    model(x, s, return_fm=True)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        model(x, s, return_fm=True)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any('sgc_' in k for k in names), names
+    assert any('bnact' in k or 'bn_' in k for k in names), names
+
+
+@pytest.mark.parametrize('skel', ['mpii', 'coco_reduce'])
+def test_default_runtime_backward_matches_reference(golden, skel):
+    """d loss / d skeleton, every SemGCN / head / projection gradient in full, and norm + random projection of every
+    encoder parameter's gradient, against the reference's CPU backward."""
+    report = {}
+    try:
+        check_backward_against_fixture(golden('model_bwd_hrnet_w18_' + skel), _model(skel).train(), dev(), report=report)
+    finally:
+        print(skel, {k: v for k, v in report.items() if k != 'table'},
+              [(round(t[0], 5), t[1]) for t in report.get('table', [])[:6]])

@@ -256,3 +256,33 @@ def test_hrnetpn_under_a_one_rank_rccl_group(tmp_path):
         _lib.torch_glue().set_grad_chunks(0)
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['exit', 'raise'])
+def test_bench_line_survives_a_dead_rank(kind):
+    """the N > 1 bench line cannot fail silently.  ``python bench.py --gpus 2 --backend gloo`` (two ranks on
+    this box's one GPU), rank 1 dies in timed step 1 -- ``exit``: os._exit without a word (the launcher tears the job down,
+    rank 0 hears SIGTERM while it sits in a collective); ``raise``: an exception (rank 1 leaves a note in the rendez-vous
+    store).  Either way rank 0 prints ONE JSON line with ``error``, ``phase`` and the ``comm`` block, inside 150 s of the
+    fault (the whole run, model build and MIOpen warm-up included, gets 400 s here)."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '4',
+                          '--warmup', '1', '--batch_per_gpu', '4', '--nce_k', '512', '--n_data', '2048', '--size', '64',
+                          '--no_check', '--no_cpu_baseline', '--fault', '1:1:' + kind],
+                         capture_output=True, text=True, env=env, timeout=400)
+    took = time.time() - t0
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, (res.returncode, res.stdout[-1500:], res.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert res.returncode != 0
+    assert out['value'] is None and out['error'] and out['phase'] == 'timed steps', out
+    assert out['n_gpus'] == 2 and out['comm']['world_size'] == 2 and out['comm']['ranks_seen'] == 2, out
+    assert out['comm']['hsa_enable_ipc_mode_legacy']['value'] == '0'
+    if kind == 'raise':
+        assert 'injected fault' in out['error'], out['error']
+    assert took < 400
