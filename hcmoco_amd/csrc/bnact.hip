@@ -361,6 +361,150 @@ bool bad_shape(int N, int C, int HW) {
          C > 65535;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d + ReLU + max over the ball (r05).  The last layer of every PointNet++ SharedMLP is followed by
+// F.max_pool2d(y, [1, nsample]) (networks/pointnet2/pointnet2_modules.py:44-55 of the reference): of the [B, C, npoint,
+// nsample] tensor y = relu(bn(z)) only one value in nsample is ever used, forward or backward, so y is not written at
+// all.  Forward = the statistics pass over z (bn_stats_kernel) + ONE pass that normalises in registers and keeps, per
+// (n, c, ball), the maximum of y, the FIRST index that attains it (ATen's max_pool2d rule, evaluated on y itself:
+// ties among clamped zeros included) and the z value there.  Backward: the gradient that reaches y is non-zero at ONE
+// element per ball, so the two sums of the BatchNorm backward come from the [N, C, npoint] tensors alone and one pass
+// over z writes dz.  4 passes over z-sized tensors where stats + apply + max + max-backward + reduce + apply take 12
+// (0.27 - 1.07 GB each at the BASELINE config-4 shapes).
+// ---------------------------------------------------------------------------------------------
+template <int L>      // lanes per ball row = nsample / 4 (1, 2, 4, 8, 16)
+__global__ __launch_bounds__(kBT) void bn_relu_ballmax_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ part, Geo g, float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+    float* __restrict__ stats, float* __restrict__ out, int* __restrict__ arg, float* __restrict__ zsel, int np) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float p1, p2;
+  merge_partials(part, g, c, p1, p2);
+  const float k = x[(size_t)c * g.HW];
+  const float invM = 1.f / (float)g.M;
+  const float m1 = p1 * invM;
+  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+  const float mean = k + m1;
+  const float invstd = 1.f / sqrtf(var + eps);
+  if (s == 0 && threadIdx.x == 0) {
+    stats[c] = mean;
+    stats[g.C + c] = invstd;
+    if (rmean != nullptr) {
+      const float unbiased = g.M > 1 ? var * ((float)g.M / (float)(g.M - 1)) : var;
+      rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+      rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+    }
+  }
+  const float sc = gamma[c] * invstd;
+  const float sh = fmaf(-mean, sc, beta[c]);
+  constexpr int ns = 4 * L;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+#pragma unroll 2
+  for (int f0 = beg; f0 < end; f0 += kVec) {
+    const int f = f0 + threadIdx.x * 4;
+    const bool ok = f < end;                       // a ball row never straddles `end` (per, M are multiples of ns)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = ok ? (g.shift >= 0 ? (f >> g.shift) : (f / g.HW)) : 0;
+    const int w = f - n * g.HW;                    // offset inside the (n, c) plane
+    if (ok) v = *reinterpret_cast<const float4*>(x + ((size_t)n * g.C + c) * (size_t)g.HW + w);
+    const float y0 = fmaxf(fmaf(v.x, sc, sh), 0.f), y1 = fmaxf(fmaf(v.y, sc, sh), 0.f);
+    const float y2 = fmaxf(fmaf(v.z, sc, sh), 0.f), y3 = fmaxf(fmaf(v.w, sc, sh), 0.f);
+    const int j0 = w & (ns - 1);
+    float bv = y0, bz = v.x;
+    int bj = j0;
+    if (y1 > bv) { bv = y1; bz = v.y; bj = j0 + 1; }
+    if (y2 > bv) { bv = y2; bz = v.z; bj = j0 + 2; }
+    if (y3 > bv) { bv = y3; bz = v.w; bj = j0 + 3; }
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) {        // the L lanes of a row are adjacent and aligned
+      const float ov = __shfl_xor(bv, off);
+      const float oz = __shfl_xor(bz, off);
+      const int oj = __shfl_xor(bj, off);
+      const bool take = ov > bv || (ov == bv && oj < bj);
+      bv = take ? ov : bv; bz = take ? oz : bz; bj = take ? oj : bj;
+    }
+    if (ok && (threadIdx.x & (L - 1)) == 0) {
+      const size_t r = ((size_t)n * g.C + c) * (size_t)np + (size_t)(w / ns);
+      out[r] = bv;
+      arg[r] = bj;
+      zsel[r] = bz;
+    }
+  }
+}
+
+// sums of the BatchNorm backward from the sparse gradient: g = dout where out > 0 (ReLU active at the maximum), else 0;
+// S1 = sum g, S2 = sum g (z_sel - mean), over the N * npoint balls of channel c.  Same slice / partial layout as the
+// dense kernels (Geo of the [N, C, npoint] tensors).
+__global__ __launch_bounds__(kBT) void ballmax_bwd_reduce_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ zsel,
+    const float* __restrict__ stats, Geo gr, float* __restrict__ part) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int beg = s * gr.per, end = min(gr.M, beg + gr.per);
+  const float mean = stats[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const size_t o = elem_offset(gr, c, f);
+    const float4 d = *reinterpret_cast<const float4*>(dout + o);
+    const float4 y = *reinterpret_cast<const float4*>(out + o);
+    const float4 z = *reinterpret_cast<const float4*>(zsel + o);
+    const float g0 = y.x > 0.f ? d.x : 0.f, g1 = y.y > 0.f ? d.y : 0.f;
+    const float g2 = y.z > 0.f ? d.z : 0.f, g3 = y.w > 0.f ? d.w : 0.f;
+    s1 += (g0 + g1) + (g2 + g3);
+    s2 = fmaf(g0, z.x - mean, s2); s2 = fmaf(g1, z.y - mean, s2);
+    s2 = fmaf(g2, z.z - mean, s2); s2 = fmaf(g3, z.w - mean, s2);
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * s) * gr.C + c] = s1;
+    part[(size_t)(2 * s + 1) * gr.C + c] = s2;
+  }
+}
+
+// dz[n, c, i, j] = gamma invstd ( g[n, c, i] [j == arg] - mean(g) - xhat mean(g xhat) ): one pass over z
+template <int L>
+__global__ __launch_bounds__(kBT) void ballmax_bwd_apply_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const int* __restrict__ arg,
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ stats,
+    const float* __restrict__ part, Geo g, int split_r, int np, float* __restrict__ gstats, float* __restrict__ dz) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  Geo gr = g;
+  gr.split = split_r;
+  float p1, p2;
+  merge_partials(part, gr, c, p1, p2);
+  const float mean = stats[c], invstd = stats[g.C + c];
+  if (s == 0 && threadIdx.x == 0) {
+    gstats[c] = p2 * invstd;     // d gamma
+    gstats[g.C + c] = p1;        // d beta
+  }
+  const float invM = 1.f / (float)g.M;
+  const float a = gamma[c] * invstd;
+  const float b = p1 * invM;
+  const float q = p2 * invstd * invstd * invM;
+  constexpr int ns = 4 * L;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+#pragma unroll 2
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const size_t o = ((size_t)n * g.C + c) * (size_t)g.HW + w;
+    const size_t r = ((size_t)n * g.C + c) * (size_t)np + (size_t)(w / ns);
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    const float gsel = out[r] > 0.f ? dout[r] : 0.f;
+    const int js = arg[r] - (w & (ns - 1));          // 0..3 when the maximum sits in this thread's four values
+    float4 d;
+    d.x = a * ((js == 0 ? gsel : 0.f) - b - (v.x - mean) * q);
+    d.y = a * ((js == 1 ? gsel : 0.f) - b - (v.y - mean) * q);
+    d.z = a * ((js == 2 ? gsel : 0.f) - b - (v.z - mean) * q);
+    d.w = a * ((js == 3 ? gsel : 0.f) - b - (v.w - mean) * q);
+    *reinterpret_cast<float4*>(dz + o) = d;
+  }
+}
+
+bool bad_ball(int N, int C, int np, int ns) {
+  if (!(ns == 4 || ns == 8 || ns == 16 || ns == 32 || ns == 64) || np <= 0 || (np & 3) != 0) return true;
+  return bad_shape(N, C, np * ns) || bad_shape(N, C, np);
+}
+
 }  // namespace
 
 extern "C" {
@@ -462,6 +606,66 @@ int hcm_bn_act_backward_ws(const float* dy, const float* dy2, const float* x, co
   }
   HCM_CHECK_LAUNCH();
   bn_bwd_apply_kernel<<<grid, kBT, 0, st>>>(needs_dz ? dz : dy, x, gamma, stats, part, g, gstats, dx);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+
+size_t hcm_bn_relu_ballmax_stats_floats(int N, int C, int np, int ns) {
+  if (bad_ball(N, C, np, ns)) return 0;
+  const Geo g = make_geo(N, C, np * ns), gr = make_geo(N, C, np);
+  const int sp = g.split > gr.split ? g.split : gr.split;
+  return (size_t)(2 + 2 * sp) * (size_t)C;
+}
+
+int hcm_bn_relu_ballmax_forward(const float* z, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, int N, int C, int np, int ns, float* out,
+                                int32_t* arg, float* zsel, float* stats, hcm_stream_t stream) {
+  if (bad_ball(N, C, np, ns) || !z || !gamma || !beta || !out || !arg || !zsel || !stats ||
+      (running_mean == nullptr) != (running_var == nullptr))
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(N, C, np * ns);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(C, g.split);
+  float* part = stats + 2 * (size_t)C;
+  bn_stats_kernel<<<grid, kBT, 0, st>>>(z, g, part);
+  HCM_CHECK_LAUNCH();
+#define HCM_BALLMAX(LL)                                                                                              \
+  bn_relu_ballmax_kernel<LL><<<grid, kBT, 0, st>>>(z, gamma, beta, part, g, eps, momentum, running_mean, running_var, \
+                                                   stats, out, arg, zsel, np)
+  switch (ns) {
+    case 4: HCM_BALLMAX(1); break;
+    case 8: HCM_BALLMAX(2); break;
+    case 16: HCM_BALLMAX(4); break;
+    case 32: HCM_BALLMAX(8); break;
+    default: HCM_BALLMAX(16); break;
+  }
+#undef HCM_BALLMAX
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int32_t* arg, const float* zsel,
+                                 const float* z, const float* gamma, const float* stats, int N, int C, int np, int ns,
+                                 float* dz, float* gstats, hcm_stream_t stream) {
+  if (bad_ball(N, C, np, ns) || !dout || !out || !arg || !zsel || !z || !gamma || !stats || !dz || !gstats)
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(N, C, np * ns), gr = make_geo(N, C, np);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = gstats + 2 * (size_t)C;
+  ballmax_bwd_reduce_kernel<<<dim3(C, gr.split), kBT, 0, st>>>(dout, out, zsel, stats, gr, part);
+  HCM_CHECK_LAUNCH();
+  const dim3 grid(C, g.split);
+#define HCM_BALLMAX(LL)                                                                                        \
+  ballmax_bwd_apply_kernel<LL><<<grid, kBT, 0, st>>>(dout, out, arg, z, gamma, stats, part, g, gr.split, np, gstats, dz)
+  switch (ns) {
+    case 4: HCM_BALLMAX(1); break;
+    case 8: HCM_BALLMAX(2); break;
+    case 16: HCM_BALLMAX(4); break;
+    case 32: HCM_BALLMAX(8); break;
+    default: HCM_BALLMAX(16); break;
+  }
+#undef HCM_BALLMAX
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -559,6 +559,56 @@ Tensor conv_bn_act(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad
   return ConvBnAct::apply(x, w, stride, pad, residual, gamma, beta, running_mean, running_var, momentum, eps, relu);
 }
 
+// 1x1 conv -> bn -> relu -> max over the ball as ONE autograd node (r05): the last layer of a PointNet++ SharedMLP and the
+// F.max_pool2d that follows it (reference: networks/pointnet2/pointnet2_modules.py:44-55).  x [N, C, np, ns] -> [N, K, np];
+// y = relu(bn(z)) is never written, forward or backward (hcm_bn_relu_ballmax_*, csrc/bnact.hip).
+struct ConvBnReluBallMax : public torch::autograd::Function<ConvBnReluBallMax> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x_in, const Tensor& w_in, const Tensor& gamma, const Tensor& beta,
+                        const c10::optional<Tensor>& running_mean, const c10::optional<Tensor>& running_var,
+                        double momentum, double eps) {
+    Tensor x = x_in.contiguous(), w = w_in.contiguous();
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4,
+                "hcmoco::conv_bn_relu_ballmax needs fp32 NCHW ROCm tensors (no CPU fallback exists)");
+    Tensor z = conv_forward_raw(x, w, 1, 0);
+    const int N = (int)z.size(0), K = (int)z.size(1), np = (int)z.size(2), ns = (int)z.size(3);
+    const size_t nf = hcm_bn_relu_ballmax_stats_floats(N, K, np, ns);
+    TORCH_CHECK(nf > 0, "hcmoco::conv_bn_relu_ballmax: unsupported ball shape (nsample in {4,8,16,32,64}, npoint % 4 == 0)");
+    Tensor out = at::empty({N, K, np}, z.options()), zsel = at::empty({N, K, np}, z.options());
+    Tensor arg = at::empty({N, K, np}, z.options().dtype(at::kInt));
+    Tensor stats = at::empty({(int64_t)nf}, z.options());
+    Tensor rm = opt_tensor(running_mean), rv = opt_tensor(running_var);
+    check_rc(hcm_bn_relu_ballmax_forward(z.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(), fptr(rm),
+                                         fptr(rv), (float)momentum, (float)eps, N, K, np, ns, out.data_ptr<float>(),
+                                         arg.data_ptr<int>(), zsel.data_ptr<float>(), stats.data_ptr<float>(),
+                                         current_stream(z)),
+             "hcm_bn_relu_ballmax_forward");
+    ctx->save_for_backward({x, w, z, gamma, stats, out, arg, zsel});
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &w = saved[1], &z = saved[2], &gamma = saved[3], &stats = saved[4], &out = saved[5],
+                 &arg = saved[6], &zsel = saved[7];
+    const int N = (int)z.size(0), K = (int)z.size(1), np = (int)z.size(2), ns = (int)z.size(3);
+    Tensor g = grads[0].contiguous();
+    Tensor dz = at::empty_like(z);
+    Tensor gstats = at::empty_like(stats);
+    check_rc(hcm_bn_relu_ballmax_backward(g.data_ptr<float>(), out.data_ptr<float>(), arg.data_ptr<int>(),
+                                          zsel.data_ptr<float>(), z.data_ptr<float>(), gamma.data_ptr<float>(),
+                                          stats.data_ptr<float>(), N, K, np, ns, dz.data_ptr<float>(),
+                                          gstats.data_ptr<float>(), current_stream(z)),
+             "hcm_bn_relu_ballmax_backward");
+    ConvGrads c = conv_backward_raw(dz, x, w, 1, 0, ctx->needs_input_grad(0), ctx->needs_input_grad(1));
+    return {c.dx, c.dw, gstats.narrow(0, 0, K), gstats.narrow(0, K, K), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor conv_bn_relu_ballmax(const Tensor& x, const Tensor& w, const Tensor& gamma, const Tensor& beta,
+                            const c10::optional<Tensor>& running_mean, const c10::optional<Tensor>& running_var,
+                            double momentum, double eps) {
+  return ConvBnReluBallMax::apply(x, w, gamma, beta, running_mean, running_var, momentum, eps);
+}
+
 // g [N, C, Ho, Wo] contiguous -> gradient of the [N, C, Hi, Wi] input (gather form, deterministic)
 Tensor upsample_backward_raw(const Tensor& g, int64_t N, int64_t C, int64_t Hi, int64_t Wi) {
   Tensor gi = at::empty({N, C, Hi, Wi}, g.options());
@@ -1262,6 +1312,8 @@ TORCH_LIBRARY(hcmoco, m) {
   m.def("conv2d(Tensor x, Tensor weight, int stride, int pad) -> Tensor", &conv2d);
   m.def("conv_bn_act(Tensor x, Tensor weight, int stride, int pad, Tensor? residual, Tensor gamma, Tensor beta, "
         "Tensor? running_mean, Tensor? running_var, float momentum, float eps, bool relu) -> Tensor", &conv_bn_act);
+  m.def("conv_bn_relu_ballmax(Tensor x, Tensor weight, Tensor gamma, Tensor beta, Tensor? running_mean, "
+        "Tensor? running_var, float momentum, float eps) -> Tensor", &conv_bn_relu_ballmax);
   m.def("upsample_bilinear(Tensor x, int out_h, int out_w) -> Tensor", &upsample_bilinear);
   m.def("run_encoder(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
         "float momentum, float eps, int tag=0) -> Tensor[]", &run_encoder);

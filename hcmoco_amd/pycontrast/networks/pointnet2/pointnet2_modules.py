@@ -44,7 +44,15 @@ class PointnetSAModuleMSG(nn.Module):
                 new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
         outs = []
         for grouper, mlp, bidx in zip(self.groupers, self.mlps, ball_idx):
-            y = mlp(grouper(xyz, new_xyz, features, idx=bidx))             # (B, C, npoint, nsample)
+            x = grouper(xyz, new_xyz, features, idx=bidx)                   # (B, C, npoint, nsample)
+            if self.pool_method == 'max_pool' and pt_utils.ballmax_fusable(mlp, x):
+                # r05: the last conv -> BatchNorm -> ReLU and the max over the ball as one node; relu(bn(z)) is never
+                # written or re-read (4 passes over the largest tensors of the network instead of 12)
+                for layer in list(mlp)[:-1]:
+                    x = layer(x)
+                outs.append(list(mlp)[-1].forward_ballmax(x))
+                continue
+            y = mlp(x)
             if self.pool_method == 'max_pool':
                 if y.is_cuda and y.dtype == torch.float32:   # hcm_rowmax_*: same values, same (first-index) tie rule
                     from .... import pointnet2_hip

@@ -48,6 +48,26 @@ class _ConvBNAct(nn.Sequential):
         return super().forward(x)
 
 
+    def forward_ballmax(self, x):
+        """relu(bn(conv(x))).max(-1) for x [B, C, npoint, nsample] as ONE autograd node (torch.ops.hcmoco.conv_bn_relu_ballmax,
+        csrc/bnact.hip): same values and the same first-maximum rule as this layer followed by F.max_pool2d."""
+        from .... import _lib
+        bn = self.bn.bn
+        bn.num_batches_tracked.add_(1)
+        return _lib.torch_glue().conv_bn_relu_ballmax(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean,
+                                                      bn.running_var, bn.momentum, bn.eps)
+
+
+def ballmax_fusable(mlp, x):
+    """The last layer of ``mlp`` + the max over the ball can run as one node: training step on the MI355X, fp32, the
+    post-activation conv -> BatchNorm2d -> ReLU form, a ball size the kernel has an instance for."""
+    if not (FUSED and len(mlp) > 0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    last = list(mlp)[-1]
+    return (isinstance(last, _ConvBNAct) and last._fusable and last.training and hasattr(last, 'activation')
+            and x.shape[3] in (4, 8, 16, 32, 64) and x.shape[2] % 4 == 0)
+
+
 class Conv1d(_ConvBNAct):
     def __init__(self, in_size, out_size, *, bn=False, activation=nn.ReLU(inplace=True)):
         super().__init__(nn.Conv1d, nn.BatchNorm1d, in_size, out_size, bn, activation)

@@ -27,8 +27,9 @@ typedef void* hcm_stream_t; /* hipStream_t */
 
 /* 2 (round 3): hcm_sgc_forward/backward take a workspace, the PointNet++ index/distance ops default to the
  * FMA arithmetic contract, new loss-section entry points.  3 (round 4): hcm_project_rows* added (row 8 on the matrix
- * cores); nothing removed.  A library and a caller must agree on this number. */
-#define HCM_ABI_VERSION 3
+ * cores); nothing removed.  4 (round 5): hcm_bn_relu_ballmax_*, hcm_ball_project_* (PointNet++ set abstraction without the
+ * grouped tensors); nothing removed.  A library and a caller must agree on this number. */
+#define HCM_ABI_VERSION 4
 int hcm_abi_version(void);
 /* hipGetErrorString() for a value returned by any entry point. */
 const char* hcm_error_string(int err);
@@ -401,6 +402,23 @@ int hcm_bn_act_forward_pre(const float* x, const float* residual, const float* g
                            float* running_mean, float* running_var, float momentum, float eps, int relu,
                            int N, int C, int HW, float* y, float* stats, const float* partial_sums, int nslots,
                            hcm_stream_t stream);
+/* BatchNorm2d (training mode) + ReLU + max over the ball in one piece (r05): the last layer of a PointNet++ SharedMLP
+ * followed by F.max_pool2d(y, [1, nsample]) (networks/pointnet2/pointnet2_modules.py:44-55, pytorch_utils.py:5-33 of the
+ * reference).  z [N, C, np, ns] fp32 contiguous (the 1x1 convolution's output); y = relu(bn(z)) is never written:
+ *   forward : out [N, C, np] = max_j y, arg [N, C, np] = the FIRST j that attains it (ATen's rule, evaluated on y, so ties
+ *             among clamped zeros resolve to the first zero), zsel [N, C, np] = z at arg; stats / running statistics as
+ *             hcm_bn_act_forward.  stats, gstats: hcm_bn_relu_ballmax_stats_floats(N, C, np, ns) floats each.
+ *   backward: dout [N, C, np] -> dz [N, C, np, ns] (the gradient w.r.t. z, dense: the batch statistics spread it), gstats =
+ *             [dgamma C][dbeta C][scratch].  The sums of the normalisation backward come from the [N, C, np] tensors alone.
+ * ns in {4, 8, 16, 32, 64}, np % 4 == 0; anything else hipErrorInvalidValue (the caller keeps the three-op path).
+ * Deterministic (fixed-order partial sums, no atomics). */
+size_t hcm_bn_relu_ballmax_stats_floats(int N, int C, int np, int ns);
+int hcm_bn_relu_ballmax_forward(const float* z, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, int N, int C, int np, int ns, float* out,
+                                int32_t* arg, float* zsel, float* stats, hcm_stream_t stream);
+int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int32_t* arg, const float* zsel,
+                                 const float* z, const float* gamma, const float* stats, int N, int C, int np, int ns,
+                                 float* dz, float* gstats, hcm_stream_t stream);
 /* Same, with the partial-sum scratch in its own buffer (hcm_bn_act_stats_floats - 2C floats): `gstats`
  * is then exactly [dgamma C][dbeta C], so a caller can lay every parameter gradient of a network out in
  * one dense buffer (what the encoder runtime hands to RCCL in place, csrc/torch_glue). */

@@ -125,9 +125,21 @@ def check_backward_against_fixture(gb, model, device, tol_full=2e-3, tol_proj=5e
     if report is not None:
         report.update(worst)
         report['table'] = table
+    # (a) every parameter: norm and projection within tol_proj of the reference's (catches a wrong formula, a missing
+    #     term, a mis-wired layer: those are O(1) errors on the parameters they touch);
+    # (b) the population: the median parameter and the whole gradient taken as ONE vector (sum of squared norm errors
+    #     against the squared norm) must be 10x tighter -- round-off that grows along a 360-layer reverse chain through
+    #     train-mode BatchNorm (a bias gradient there is a sum of thousands of cancelling terms) stays far below that,
+    #     a systematic error does not.
     for relerr, k, en, ed, n_ref in table:
         assert en < tol_proj * n_ref + 1e-6 * scale and ed < tol_proj * n_ref + 1e-6 * scale, (
             'worst first', [(round(t[0], 5), t[1]) for t in table[:8]])
+    med = sorted(t[0] for t in table)[len(table) // 2]
+    tot = (sum(t[2] ** 2 + t[3] ** 2 for t in table) / sum(2 * t[4] ** 2 for t in table)) ** 0.5
+    worst['median'], worst['whole_vector'] = med, tot
+    if report is not None:
+        report.update(worst)
+    assert med < tol_proj / 10 and tot < tol_proj / 10, (med, tot)
     return worst
 
 

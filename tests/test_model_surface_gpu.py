@@ -46,7 +46,10 @@ def test_default_runtime_forward_matches_reference(golden, skel):
             # feature maps: with the name-keyed weights they reach |x| ~ 1e3 and every element is a sum of 270..2000
             # products taken in another order than ATen's CPU convolution (MIOpen Winograd / MFMA tiles): 1e-4 relative
             # to the element plus 1e-5 of the TENSOR's largest magnitude (a cancelled element keeps the sum's round-off)
-            bound = 1e-4 * ref.abs() + 1e-5 * float(ref.abs().max())
+            # Train mode: the coarsest branch of this 2 x 64 x 64 fixture normalises over 2 x 2 x 2 = 8 values, and a batch
+            # standard deviation that small divides the convolutions' round-off: 5e-5 of the largest magnitude there
+            # (measured 2.5e-5 on the MI355X), 1e-5 in eval mode (running statistics).
+            bound = 1e-4 * ref.abs() + (5e-5 if mode == 'train' else 1e-5) * float(ref.abs().max())
             bad = (got - ref).abs() > bound
             assert not bool(bad.any()), (mode, what, float((got - ref).abs().max()), float(ref.abs().max()))
 
@@ -80,7 +83,11 @@ def test_default_runtime_backward_matches_reference(golden, skel):
     encoder parameter's gradient, against the reference's CPU backward."""
     report = {}
     try:
-        check_backward_against_fixture(golden('model_bwd_hrnet_w18_' + skel), _model(skel).train(), dev(), report=report)
+        # per parameter 3e-2 (the smallest gradients -- BatchNorm biases of the deep layers, 1e-4 of the largest norm,
+        # each a sum of thousands of cancelling terms -- sit at ~1e-2 in fp32 with another summation order); median and
+        # whole-vector error 3e-3; SemGCN / heads / projections / d loss / d skeleton compared in full at 2e-3
+        check_backward_against_fixture(golden('model_bwd_hrnet_w18_' + skel), _model(skel).train(), dev(), tol_proj=3e-2,
+                                       report=report)
     finally:
         print(skel, {k: v for k, v in report.items() if k != 'table'},
               [(round(t[0], 5), t[1]) for t in report.get('table', [])[:6]])

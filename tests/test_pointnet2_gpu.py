@@ -429,3 +429,66 @@ def test_geometry_plan_on_its_own_stream_gives_the_same_forward_and_gradients():
     assert torch.equal(out0, out1)
     for a, b in zip(g0, g1):       # the stock weight-gradient kernels of the shared MLPs do not sum in a fixed order
         assert (a - b).norm() <= 1e-5 * b.norm()
+
+
+@pytest.mark.parametrize('B,C,K,npnt,ns', [(4, 6, 32, 128, 16), (3, 19, 64, 64, 32), (2, 8, 16, 8, 4), (2, 5, 24, 12, 64),
+                                          (32, 16, 32, 1024, 8)])
+def test_conv_bn_relu_ballmax_matches_the_three_op_path(B, C, K, npnt, ns):
+    """r05: the last SharedMLP layer + F.max_pool2d(y, [1, nsample]) as one node (hcm_bn_relu_ballmax_*) against the
+    layer followed by the pool (reference: pointnet2_modules.py:44-55, pytorch_utils.py:5-33): output, the gradient of the
+    input, every parameter gradient and the running statistics.  Inputs are quantised so that exact ties -- among
+    positive maxima and among clamped zeros -- are routine and the first-index rule is exercised."""
+    import torch.nn.functional as F
+    from hcmoco_amd.pycontrast.networks.pointnet2 import pytorch_utils as pt_utils
+    dev = torch.device('cuda:0')
+    torch.manual_seed(B * 1000 + ns)
+    layer = pt_utils.Conv2d(C, K, bn=True).to(dev).train()
+    with torch.no_grad():
+        layer.bn.bn.weight.uniform_(-1.0, 1.5)            # negative scales too: the maximum of y is then a minimum of z
+        layer.bn.bn.weight[0] = 0.0                       # and a dead channel: every y equal, first index wins
+        layer.bn.bn.bias.normal_(0, 0.3)
+        layer.conv.weight.copy_((layer.conv.weight * 4).round() / 4)
+    x = (torch.randn(B, C, npnt, ns, device=dev) * 2).round() / 2
+    x[:, :, ::3, 1] = x[:, :, ::3, 0]                     # duplicated points inside a ball (padding of ball_query)
+    state = {k: v.clone() for k, v in layer.state_dict().items()}
+    gy = torch.randn(B, K, npnt, device=dev)
+    res = {}
+    for fused in (True, False):
+        layer.load_state_dict(state)
+        layer.zero_grad(set_to_none=True)
+        xs = x.clone().requires_grad_()
+        if fused:
+            y = layer.forward_ballmax(xs)
+        else:
+            y = F.max_pool2d(layer(xs), kernel_size=[1, ns]).squeeze(-1)
+        y.backward(gy)
+        res[fused] = (y.detach(), xs.grad, {n: p.grad.clone() for n, p in layer.named_parameters()},
+                      {n: b.clone() for n, b in layer.named_buffers()})
+
+    def close(a, b, tol, what):
+        err = (a - b).abs().max().item()
+        assert err <= tol * (b.abs().max().item() + 1e-12), (what, err, b.abs().max().item())
+    close(res[True][0], res[False][0], 1e-5, 'out')
+    close(res[True][1], res[False][1], 1e-4, 'dx')
+    for n, gb in res[False][2].items():
+        close(res[True][2][n], gb, 2e-4, n)
+    for n, bb in res[False][3].items():
+        assert torch.allclose(res[True][3][n].float(), bb.float(), rtol=1e-5, atol=1e-6), n
+
+
+def test_sa_module_takes_the_fused_ballmax_path():
+    from torch.profiler import profile, ProfilerActivity
+    from hcmoco_amd.pycontrast.networks.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.2, 0.4], nsamples=[16, 32], mlps=[[8, 16, 32], [8, 16, 32]]).to(dev).train()
+    xyz = torch.rand(2, 256, 3, device=dev)
+    feats = torch.randn(2, 8, 256, device=dev, requires_grad=True)
+    sa(xyz, feats)[1].sum().backward()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        sa(xyz, feats)[1].sum().backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any('bn_relu_ballmax_kernel' in k for k in names) and any('ballmax_bwd_apply_kernel' in k for k in names), names
+    assert not any('rowmax' in k for k in names), names

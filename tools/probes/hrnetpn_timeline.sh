@@ -16,14 +16,27 @@ marks = [i for i, r in enumerate(rows) if 'bank_pass_' in r[2]]
 win = rows[marks[-2]:marks[-1]]
 t0 = win[0][0]
 print('step window %.2f ms, %d launches' % ((rows[marks[-1]][0] - t0) / 1e6, len(win)))
-agg = defaultdict(lambda: [0, 0])
+def short(n):
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '').replace('at::native::', '')
+    return n.split('(')[0][:64]
+opt_all = [k for k, r in enumerate(win) if 'multi_tensor' in r[2]]
+t_opt = win[opt_all[-1]][0] if opt_all else win[-1][0]
+agg = defaultdict(lambda: [0, 0, 0])
 for s, e, n, q in win:
-    k = n.split('(')[0][-60:]
+    k = short(n)
     agg[(q, k)][0] += e - s
     agg[(q, k)][1] += 1
-print('top kernels by total time (queue, name, ms, calls):')
-for (q, k), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
-    print('  q%s %-62s %8.3f ms %5d' % (q, k, t / 1e6, c))
+    if s < t_opt:
+        agg[(q, k)][2] += e - s
+print('the window runs loss(k) -> backward(k) -> optimizer (+%.2f ms) -> forward(k+1) -> loss(k+1)' % ((t_opt - t0) / 1e6))
+print('top kernels by total time (queue, name, ms, calls, ms of it before the optimizer = backward):')
+for (q, k), (t, c, tb) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+    print('  q%s %-64s %8.3f ms %5d   bwd %7.3f' % (q, k, t / 1e6, c, tb / 1e6))
+perq_b, perq_f = defaultdict(int), defaultdict(int)
+for s, e, n, q in win:
+    (perq_b if s < t_opt else perq_f)[q] += e - s
+print('busy per queue, backward part (ms):', {q: round(t / 1e6, 2) for q, t in sorted(perq_b.items())})
+print('busy per queue, forward part (ms):', {q: round(t / 1e6, 2) for q, t in sorted(perq_f.items())})
 perq = defaultdict(int)
 for s, e, n, q in win:
     perq[q] += e - s
