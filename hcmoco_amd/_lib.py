@@ -105,6 +105,9 @@ SIGNATURES = {
     'hcm_bn_relu_ballmax_stats_floats': (_sz, [_i] * 4),
     'hcm_bn_relu_ballmax_forward': (_i, [_p] * 5 + [_f, _f] + [_i] * 4 + [_p] * 5),
     'hcm_bn_relu_ballmax_backward': (_i, [_p] * 7 + [_i] * 4 + [_p] * 3),
+    'hcm_ball_project_stats_floats': (_sz, [_i] * 4),
+    'hcm_ball_project_forward': (_i, [_p] * 7 + [_f, _f] + [_i] * 6 + [_p] * 3),
+    'hcm_ball_project_backward': (_i, [_p] * 7 + [_i] * 6 + [_p] * 4),
     'hcm_rowmax_forward': (_i, [_p, C.c_longlong, _i, _p, _p, _p]),
     'hcm_rowmax_backward': (_i, [_p, _p, C.c_longlong, _i, _p, _p]),
     'hcm_heads_forward': (_i, [Branches, Branches, _p] + [_i] * 5 + [_p] * 11 + [_i, _p, _p]),

@@ -500,6 +500,172 @@ __global__ __launch_bounds__(kBT) void ballmax_bwd_apply_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// First layer of a PointNet++ SharedMLP without the grouped tensor (r05).  QueryAndGroup builds x[b, :, i, j] =
+// [xyz[idx] - centre_i ; features[idx]] ([B, 3 + C, npoint, nsample], up to 415 MB) and the first 1x1 convolution
+// multiplies it by W (networks/pointnet2/pointnet2_utils.py:231-268, pytorch_utils.py:5-33 of the reference).  The
+// convolution commutes with the gather:  W x[b, :, i, j] = P[b, :, idx[b, i, j]] - Q[b, :, i]  with
+// P = W [xyz ; features] ([B, C1, N]: nsample x fewer products, a library GEMM on the host side) and Q = W_xyz centre.
+// These kernels take z = P[idx] - Q as an implicit tensor: statistics and normalisation read it through the gather
+// (P's row of one (b, c) is N floats: cache resident), the backward hands dz out once for the planned scatter into dP
+// and row-sums it into dQ.  Neither x nor z nor their gradients exist in memory.
+// ---------------------------------------------------------------------------------------------
+struct BallGeo {
+  int N, np, ns;      // source points, centres, ball size
+};
+
+__device__ __forceinline__ float4 ball_z(const float* __restrict__ Prow, float qv, const int* __restrict__ idx, size_t o) {
+  const int4 id = *reinterpret_cast<const int4*>(idx + o);
+  return make_float4(Prow[id.x] - qv, Prow[id.y] - qv, Prow[id.z] - qv, Prow[id.w] - qv);
+}
+
+// slice sums of (z - k), (z - k)^2; k = z of the channel's first element.  Geo g describes [B, C, np * ns].
+__global__ __launch_bounds__(kBT) void ball_stats_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                         const int* __restrict__ idx, Geo g, BallGeo bg,
+                                                         float* __restrict__ part) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  const float k = P[(size_t)c * bg.N + idx[0]] - Q[(size_t)c * bg.np];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
+                            (size_t)n * g.HW + w);
+    const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
+    s1 += (a + b) + (cc + d);
+    s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(cc, cc, s2); s2 = fmaf(d, d, s2);
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * s) * g.C + c] = s1;
+    part[(size_t)(2 * s + 1) * g.C + c] = s2;
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void ball_apply_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const int* __restrict__ idx, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ part, Geo g, BallGeo bg, float eps, float momentum,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float p1, p2;
+  merge_partials(part, g, c, p1, p2);
+  const float k = P[(size_t)c * bg.N + idx[0]] - Q[(size_t)c * bg.np];
+  const float invM = 1.f / (float)g.M;
+  const float m1 = p1 * invM;
+  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+  const float mean = k + m1;
+  const float invstd = 1.f / sqrtf(var + eps);
+  if (s == 0 && threadIdx.x == 0) {
+    stats[c] = mean;
+    stats[g.C + c] = invstd;
+    if (rmean != nullptr) {
+      const float unbiased = g.M > 1 ? var * ((float)g.M / (float)(g.M - 1)) : var;
+      rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+      rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+    }
+  }
+  const float sc = gamma[c] * invstd;
+  const float sh = fmaf(-mean, sc, beta[c]);
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+#pragma unroll 2
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
+                            (size_t)n * g.HW + w);
+    float4 r = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
+    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *reinterpret_cast<float4*>(y + ((size_t)n * g.C + c) * (size_t)g.HW + w) = r;
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void ball_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ Q,
+    const int* __restrict__ idx, const float* __restrict__ stats, Geo g, BallGeo bg, float* __restrict__ part) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  const float mean = stats[c];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const size_t o = ((size_t)n * g.C + c) * (size_t)g.HW + w;
+    float4 d = *reinterpret_cast<const float4*>(dy + o);
+    if (RELU) {
+      const float4 out = *reinterpret_cast<const float4*>(y + o);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+    }
+    const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
+                            (size_t)n * g.HW + w);
+    s1 += (d.x + d.y) + (d.z + d.w);
+    s2 = fmaf(d.x, v.x - mean, s2); s2 = fmaf(d.y, v.y - mean, s2);
+    s2 = fmaf(d.z, v.z - mean, s2); s2 = fmaf(d.w, v.w - mean, s2);
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * s) * g.C + c] = s1;
+    part[(size_t)(2 * s + 1) * g.C + c] = s2;
+  }
+}
+
+// dz (for the scatter into dP) and dQ[b, c, i] = - sum_j dz[b, c, i, j] (L = ns / 4 adjacent lanes hold a ball)
+template <bool RELU, int L>
+__global__ __launch_bounds__(kBT) void ball_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ Q,
+    const int* __restrict__ idx, const float* __restrict__ gamma, const float* __restrict__ stats,
+    const float* __restrict__ part, Geo g, BallGeo bg, float* __restrict__ gstats, float* __restrict__ dz,
+    float* __restrict__ dQ) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float p1, p2;
+  merge_partials(part, g, c, p1, p2);
+  const float mean = stats[c], invstd = stats[g.C + c];
+  if (s == 0 && threadIdx.x == 0) {
+    gstats[c] = p2 * invstd;     // d gamma
+    gstats[g.C + c] = p1;        // d beta
+  }
+  const float invM = 1.f / (float)g.M;
+  const float a = gamma[c] * invstd;
+  const float b = p1 * invM;
+  const float q = p2 * invstd * invstd * invM;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+#pragma unroll 2
+  for (int f0 = beg; f0 < end; f0 += kVec) {
+    const int f = f0 + threadIdx.x * 4;
+    const bool ok = f < end;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    int n = 0, w = 0;
+    if (ok) {
+      n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+      w = f - n * g.HW;
+      const size_t o = ((size_t)n * g.C + c) * (size_t)g.HW + w;
+      float4 d = *reinterpret_cast<const float4*>(dy + o);
+      if (RELU) {
+        const float4 out = *reinterpret_cast<const float4*>(y + o);
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
+                              (size_t)n * g.HW + w);
+      r.x = a * (d.x - b - (v.x - mean) * q);
+      r.y = a * (d.y - b - (v.y - mean) * q);
+      r.z = a * (d.z - b - (v.z - mean) * q);
+      r.w = a * (d.w - b - (v.w - mean) * q);
+      *reinterpret_cast<float4*>(dz + o) = r;
+    }
+    float rs = (r.x + r.y) + (r.z + r.w);
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) rs += __shfl_xor(rs, off);
+    if (ok && (threadIdx.x & (L - 1)) == 0) dQ[((size_t)n * g.C + c) * bg.np + w / bg.ns] = -rs;
+  }
+}
+
 bool bad_ball(int N, int C, int np, int ns) {
   if (!(ns == 4 || ns == 8 || ns == 16 || ns == 32 || ns == 64) || np <= 0 || (np & 3) != 0) return true;
   return bad_shape(N, C, np * ns) || bad_shape(N, C, np);
@@ -666,6 +832,64 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
     default: HCM_BALLMAX(16); break;
   }
 #undef HCM_BALLMAX
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+
+size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns) {
+  if (bad_ball(B, C, np, ns)) return 0;
+  const Geo g = make_geo(B, C, np * ns);
+  return (size_t)(2 + 2 * g.split) * (size_t)C;
+}
+
+int hcm_ball_project_forward(const float* P, const float* Q, const int32_t* idx, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, int relu, int B, int C,
+                             int N, int np, int ns, float* y, float* stats, hcm_stream_t stream) {
+  if (bad_ball(B, C, np, ns) || N <= 0 || !P || !Q || !idx || !gamma || !beta || !y || !stats ||
+      (running_mean == nullptr) != (running_var == nullptr))
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(B, C, np * ns);
+  const BallGeo bg = {N, np, ns};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(C, g.split);
+  float* part = stats + 2 * (size_t)C;
+  ball_stats_kernel<<<grid, kBT, 0, st>>>(P, Q, idx, g, bg, part);
+  HCM_CHECK_LAUNCH();
+  if (relu) ball_apply_kernel<true><<<grid, kBT, 0, st>>>(P, Q, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
+                                                          running_var, stats, y);
+  else ball_apply_kernel<false><<<grid, kBT, 0, st>>>(P, Q, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
+                                                      running_var, stats, y);
+  HCM_CHECK_LAUNCH();
+  return 0;
+}
+
+int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* Q, const int32_t* idx,
+                              const float* gamma, const float* stats, int relu, int B, int C, int N, int np, int ns,
+                              float* dz, float* dQ, float* gstats, hcm_stream_t stream) {
+  if (bad_ball(B, C, np, ns) || N <= 0 || !dy || (relu && !y) || !P || !Q || !idx || !gamma || !stats || !dz || !dQ || !gstats)
+    return (int)hipErrorInvalidValue;
+  const Geo g = make_geo(B, C, np * ns);
+  const BallGeo bg = {N, np, ns};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(C, g.split);
+  float* part = gstats + 2 * (size_t)C;
+  if (relu) ball_bwd_reduce_kernel<true><<<grid, kBT, 0, st>>>(dy, y, P, Q, idx, stats, g, bg, part);
+  else ball_bwd_reduce_kernel<false><<<grid, kBT, 0, st>>>(dy, y, P, Q, idx, stats, g, bg, part);
+  HCM_CHECK_LAUNCH();
+#define HCM_BALL_BWD(R, LL) \
+  ball_bwd_apply_kernel<R, LL><<<grid, kBT, 0, st>>>(dy, y, P, Q, idx, gamma, stats, part, g, bg, gstats, dz, dQ)
+#define HCM_BALL_BWD_L(R)                    \
+  switch (ns) {                              \
+    case 4: HCM_BALL_BWD(R, 1); break;       \
+    case 8: HCM_BALL_BWD(R, 2); break;       \
+    case 16: HCM_BALL_BWD(R, 4); break;      \
+    case 32: HCM_BALL_BWD(R, 8); break;      \
+    default: HCM_BALL_BWD(R, 16); break;     \
+  }
+  if (relu) { HCM_BALL_BWD_L(true) } else { HCM_BALL_BWD_L(false) }
+#undef HCM_BALL_BWD_L
+#undef HCM_BALL_BWD
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -158,6 +158,63 @@ def scatter_add_planned(grad_out, idx, coef, m, div=1):
     return out
 
 
+class _BallProject(torch.autograd.Function):
+    """y = relu?(batchnorm(P[b, :, idx[b, i, j]] - Q[b, :, i])) -> [B, C, np, ns]: the first SharedMLP layer on the implicit
+    grouped tensor (hcm_ball_project_*, csrc/bnact.hip).  Backward returns dP (planned scatter of dz, deterministic), dQ,
+    dgamma, dbeta."""
+
+    @staticmethod
+    def forward(ctx, P, Q, idx, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        for t in (P, Q, gamma, beta):
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError('hcmoco_amd.ball_project needs fp32 ROCm tensors (no CPU fallback exists)')
+        P, Q, idx = P.contiguous(), Q.contiguous(), idx.contiguous()
+        B, Cc, N = P.shape
+        _, npnt, ns = idx.shape
+        L = _lib.lib()
+        nf = int(L.hcm_ball_project_stats_floats(B, Cc, npnt, ns))
+        if nf == 0 or Q.shape != (B, Cc, npnt):
+            raise ValueError('ball_project: unsupported shape P %s Q %s idx %s' % (tuple(P.shape), tuple(Q.shape), tuple(idx.shape)))
+        y = torch.empty(B, Cc, npnt, ns, dtype=torch.float32, device=P.device)
+        stats = torch.empty(nf, dtype=torch.float32, device=P.device)
+        rm = C.c_void_p(0) if running_mean is None else _f(running_mean, 'ball_project')
+        rv = C.c_void_p(0) if running_var is None else _f(running_var, 'ball_project')
+        check(L.hcm_ball_project_forward(_f(P, 'ball_project'), _f(Q, 'ball_project'), _i(idx, 'ball_project'),
+                                         _f(gamma, 'ball_project'), _f(beta, 'ball_project'), rm, rv, float(momentum),
+                                         float(eps), int(bool(relu)), B, Cc, N, npnt, ns, _f(y, 'ball_project'),
+                                         _f(stats, 'ball_project'), _stream()), 'hcm_ball_project_forward')
+        ctx.save_for_backward(P, Q, gamma, stats, y)
+        ctx.idx, ctx.relu = idx, bool(relu)          # the same tensor OBJECT: the scatter plan is cached on it
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        P, Q, gamma, stats, y = ctx.saved_tensors
+        idx = ctx.idx
+        B, Cc, N = P.shape
+        _, npnt, ns = idx.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(y)
+        dQ = torch.empty_like(Q)
+        gstats = torch.empty_like(stats)
+        check(_lib.lib().hcm_ball_project_backward(_f(dy, 'ball_project'), _f(y, 'ball_project'), _f(P, 'ball_project'),
+                                                   _f(Q, 'ball_project'), _i(idx, 'ball_project'), _f(gamma, 'ball_project'),
+                                                   _f(stats, 'ball_project'), int(ctx.relu), B, Cc, N, npnt, ns,
+                                                   _f(dz, 'ball_project'), _f(dQ, 'ball_project'), _f(gstats, 'ball_project'),
+                                                   _stream()), 'hcm_ball_project_backward')
+        if N <= LDS_SCATTER_MAX_TARGETS:
+            dP = scatter_add_planned(dz.view(B, Cc, npnt * ns), idx, None, N, 1)
+        else:                                   # a target axis too long for LDS: ATen's scatter (atomics)
+            dP = torch.zeros_like(P).scatter_add_(2, idx.view(B, 1, -1).long().expand(B, Cc, -1), dz.view(B, Cc, -1))
+        return dP, dQ, None, gstats[:Cc], gstats[Cc:2 * Cc], None, None, None, None, None
+
+
+def ball_project(P, Q, idx, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True):
+    """The first conv -> BatchNorm2d -> ReLU of a PointNet++ SharedMLP applied to the grouped tensor WITHOUT building it:
+    P [B, C1, N] = W [xyz ; features], Q [B, C1, np] = W_xyz centres, idx [B, np, ns] the ball members."""
+    return _BallProject.apply(P, Q, idx, gamma, beta, running_mean, running_var, momentum, eps, relu)
+
+
 class _BallMax(torch.autograd.Function):
     """max over the last axis with ATen max_pool2d's tie rule (first index); hcm_rowmax_*."""
 

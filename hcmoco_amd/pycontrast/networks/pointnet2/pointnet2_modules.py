@@ -44,7 +44,17 @@ class PointnetSAModuleMSG(nn.Module):
                 new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
         outs = []
         for grouper, mlp, bidx in zip(self.groupers, self.mlps, ball_idx):
-            x = grouper(xyz, new_xyz, features, idx=bidx)                   # (B, C, npoint, nsample)
+            layers = list(mlp)
+            fuse_first = (self.npoint is not None and grouper.use_xyz and len(layers) > 1 and grouper.nsample in (4, 8, 16, 32, 64)
+                          and self.npoint % 4 == 0 and pt_utils.first_layer_fusable(mlp, xyz))
+            if fuse_first and bidx is None:
+                bidx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            if fuse_first:
+                # r05: the first layer on the IMPLICIT grouped tensor -- [B, 3 + C, npoint, nsample] is never built
+                x = layers[0].forward_grouped(xyz, new_xyz, features, bidx)
+                mlp = layers[1:]
+            else:
+                x = grouper(xyz, new_xyz, features, idx=bidx)               # (B, C, npoint, nsample)
             if self.pool_method == 'max_pool' and pt_utils.ballmax_fusable(mlp, x):
                 # r05: the last conv -> BatchNorm -> ReLU and the max over the ball as one node; relu(bn(z)) is never
                 # written or re-read (4 passes over the largest tensors of the network instead of 12)
@@ -52,7 +62,9 @@ class PointnetSAModuleMSG(nn.Module):
                     x = layer(x)
                 outs.append(list(mlp)[-1].forward_ballmax(x))
                 continue
-            y = mlp(x)
+            y = x
+            for layer in mlp:
+                y = layer(y)
             if self.pool_method == 'max_pool':
                 if y.is_cuda and y.dtype == torch.float32:   # hcm_rowmax_*: same values, same (first-index) tie rule
                     from .... import pointnet2_hip

@@ -48,6 +48,25 @@ class _ConvBNAct(nn.Sequential):
         return super().forward(x)
 
 
+    def forward_grouped(self, xyz, new_xyz, features, idx):
+        """This layer applied to QueryAndGroup's output [xyz[idx] - centre ; features[idx]] without building it (r05): a 1x1
+        convolution commutes with the gather, so the N source points are projected once -- P = W [xyz ; features], a GEMM
+        nsample times smaller than the convolution over the grouped tensor --, the centres contribute Q = W_xyz centre, and
+        normalisation + ReLU read z = P[idx] - Q through the gather (``pointnet2_hip.ball_project``).  xyz [B, N, 3],
+        new_xyz [B, np, 3], features [B, C, N] or None, idx [B, np, ns] -> [B, C1, np, ns].
+        Reference: pointnet2_utils.py:231-268 + pytorch_utils.py:5-33."""
+        from .... import pointnet2_hip
+        bn = self.bn.bn
+        W = self.conv.weight.view(self.conv.weight.shape[0], -1)            # [C1, 3 + C], xyz columns first
+        src = xyz.transpose(1, 2)
+        if features is not None:
+            src = torch.cat([src, features], dim=1)
+        P = torch.matmul(W, src)                                             # [B, C1, N]
+        Q = torch.matmul(W[:, :3], new_xyz.transpose(1, 2))                  # [B, C1, np]
+        bn.num_batches_tracked.add_(1)
+        return pointnet2_hip.ball_project(P, Q, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
+                                          bn.eps, hasattr(self, 'activation'))
+
     def forward_ballmax(self, x):
         """relu(bn(conv(x))).max(-1) for x [B, C, npoint, nsample] as ONE autograd node (torch.ops.hcmoco.conv_bn_relu_ballmax,
         csrc/bnact.hip): same values and the same first-maximum rule as this layer followed by F.max_pool2d."""
@@ -56,6 +75,15 @@ class _ConvBNAct(nn.Sequential):
         bn.num_batches_tracked.add_(1)
         return _lib.torch_glue().conv_bn_relu_ballmax(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean,
                                                       bn.running_var, bn.momentum, bn.eps)
+
+
+def first_layer_fusable(mlp, xyz):
+    """The first layer of ``mlp`` can run on the implicit grouped tensor (``Conv2d.forward_grouped``): training step on the
+    MI355X, fp32, conv -> BatchNorm2d [-> ReLU] form (the caller checks the ball shape)."""
+    if not (FUSED and len(mlp) > 0 and xyz.is_cuda and xyz.dtype == torch.float32):
+        return False
+    first = list(mlp)[0]
+    return isinstance(first, _ConvBNAct) and first._fusable and first.training
 
 
 def ballmax_fusable(mlp, x):

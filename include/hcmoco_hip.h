@@ -419,6 +419,24 @@ int hcm_bn_relu_ballmax_forward(const float* z, const float* gamma, const float*
 int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int32_t* arg, const float* zsel,
                                  const float* z, const float* gamma, const float* stats, int N, int C, int np, int ns,
                                  float* dz, float* gstats, hcm_stream_t stream);
+/* First layer of a PointNet++ SharedMLP WITHOUT the grouped tensor (r05).  QueryAndGroup + the first 1x1 convolution
+ * (networks/pointnet2/pointnet2_utils.py:231-268, pytorch_utils.py:5-33 of the reference) compute, for ball i of image b and
+ * its j-th member n = idx[b, i, j],  z[b, :, i, j] = W [xyz_n - centre_i ; features_n] = P[b, :, n] - Q[b, :, i]  with
+ * P = W [xyz ; features] [B, C, N] and Q = W_xyz centre [B, C, np] (two small GEMMs, the caller's).  These entry points take
+ * z as that implicit tensor:
+ *   forward : y [B, C, np, ns] = relu?(batchnorm(z)) with batch statistics over all B * np * ns members (running statistics
+ *             updated like hcm_bn_act_forward); stats: hcm_ball_project_stats_floats(B, C, np, ns) floats.
+ *   backward: dy [B, C, np, ns] (and y, for the ReLU mask) -> dz [B, C, np, ns] = d loss / d z (the caller scatters it into
+ *             dP[b, c, idx], hcm_scatter_add_planned), dQ [B, C, np] = - sum_j dz, gstats = [dgamma C][dbeta C][scratch] (same
+ *             size as stats).
+ * idx [B, np, ns] int32 in [0, N); ns in {4, 8, 16, 32, 64}, np % 4 == 0.  Deterministic. */
+size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns);
+int hcm_ball_project_forward(const float* P, const float* Q, const int32_t* idx, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, int relu, int B, int C,
+                             int N, int np, int ns, float* y, float* stats, hcm_stream_t stream);
+int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* Q, const int32_t* idx,
+                              const float* gamma, const float* stats, int relu, int B, int C, int N, int np, int ns,
+                              float* dz, float* dQ, float* gstats, hcm_stream_t stream);
 /* Same, with the partial-sum scratch in its own buffer (hcm_bn_act_stats_floats - 2C floats): `gstats`
  * is then exactly [dgamma C][dbeta C], so a caller can lay every parameter gradient of a network out in
  * one dense buffer (what the encoder runtime hands to RCCL in place, csrc/torch_glue). */

@@ -492,3 +492,53 @@ def test_sa_module_takes_the_fused_ballmax_path():
     names = [e.key for e in prof.key_averages()]
     assert any('bn_relu_ballmax_kernel' in k for k in names) and any('ballmax_bwd_apply_kernel' in k for k in names), names
     assert not any('rowmax' in k for k in names), names
+
+
+@pytest.mark.parametrize('B,C,C1,N,npnt,ns,radius', [(3, 0, 16, 512, 128, 16, 0.15), (2, 13, 32, 256, 64, 32, 0.3),
+                                                      (2, 5, 8, 64, 16, 4, 0.2), (32, 96, 64, 4096, 1024, 16, 0.125)])
+def test_first_layer_on_the_implicit_grouped_tensor(B, C, C1, N, npnt, ns, radius):
+    """r05: QueryAndGroup + the first conv -> BatchNorm2d -> ReLU WITHOUT the grouped tensor (Conv2d.forward_grouped:
+    P = W [xyz ; features], Q = W_xyz centre, hcm_ball_project_* on z = P[idx] - Q) against the module path that builds
+    [B, 3 + C, npoint, nsample] (reference: pointnet2_utils.py:231-268, pytorch_utils.py:5-33): output, gradients of the
+    features and of every parameter, running statistics.  The backward is bit-reproducible (planned scatter)."""
+    from hcmoco_amd.pycontrast.networks.pointnet2 import pointnet2_utils as U, pytorch_utils as pt_utils
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N + ns)
+    xyz = torch.rand(B, N, 3, device=dev)
+    picks = U.furthest_point_sample(xyz, npnt)
+    new_xyz = U.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
+    idx = U.ball_query(radius, ns, xyz, new_xyz)
+    feats = torch.randn(B, C, N, device=dev) if C else None
+    layer = pt_utils.Conv2d(3 + C, C1, bn=True).to(dev).train()
+    with torch.no_grad():
+        layer.bn.bn.weight.uniform_(0.5, 1.5)
+        layer.bn.bn.bias.normal_(0, 0.3)
+    grouper = U.QueryAndGroup(radius, ns, use_xyz=True)
+    state = {k: v.clone() for k, v in layer.state_dict().items()}
+    gy = torch.randn(B, C1, npnt, ns, device=dev)
+    res = {}
+    for mode in ('fused', 'fused', 'module'):
+        layer.load_state_dict(state)
+        layer.zero_grad(set_to_none=True)
+        f = feats.clone().requires_grad_() if C else None
+        if mode == 'fused':
+            y = layer.forward_grouped(xyz, new_xyz, f, idx)
+        else:
+            y = layer(grouper(xyz, new_xyz, f, idx=idx))
+        y.backward(gy)
+        res.setdefault(mode, []).append((y.detach(), None if f is None else f.grad.clone(),
+                                         {n: p.grad.clone() for n, p in layer.named_parameters()},
+                                         {n: b.clone() for n, b in layer.named_buffers()}))
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    a, a2, m = res['fused'][0], res['fused'][1], res['module'][0]
+    assert torch.equal(a[0], a2[0]) and (a[1] is None or torch.equal(a[1], a2[1]))
+    assert all(torch.equal(a[2][n], a2[2][n]) for n in a[2])
+    assert (a[0] - m[0]).abs().max().item() <= 2e-5 * m[0].abs().max().item(), (a[0] - m[0]).abs().max().item()
+    if C:
+        assert rel(a[1], m[1]) < 2e-4, rel(a[1], m[1])
+    for n, gb in m[2].items():
+        assert rel(a[2][n], gb) < 5e-4, (n, rel(a[2][n], gb))
+    for n, bb in m[3].items():
+        assert torch.allclose(a[3][n].float(), bb.float(), rtol=1e-4, atol=1e-6), n
