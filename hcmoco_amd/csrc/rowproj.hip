@@ -700,7 +700,7 @@ int dw_chunks(int B) {
 }
 
 template <int KS>
-int launch_project(const Maps8& e, int B, const int64_t* pix, int R, int Ctot, const float* Wp1, const float* bp1,
+int launch_project(const Maps8& e, int nmod, int B, const int64_t* pix, int R, int Ctot, const float* Wp1, const float* bp1,
                    const float* Wp2, const float* bp2, float* xs, int ld, float* rows, float* grows, hipStream_t s) {
   constexpr int XS = 4 * KS + 2;
   // LDS budget: the tile, then branch 3, then branch 2 if they fit in 160 KiB
@@ -716,7 +716,7 @@ int launch_project(const Maps8& e, int B, const int64_t* pix, int R, int Ctot, c
   double best_cost = 1e30;
   for (int ns = 1; ns <= 32 && ns <= R; ++ns) {
     const int per = (R + ns - 1) / ns, tiles = (per + kSR - 1) / kSR;
-    const int rounds = (2 * B * ns + cus - 1) / cus;
+    const int rounds = (nmod * B * ns + cus - 1) / cus;
     const double cost = rounds * (tiles + 1.5);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
   }
@@ -725,7 +725,7 @@ int launch_project(const Maps8& e, int B, const int64_t* pix, int R, int Ctot, c
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(project_rows_kernel<KS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (err != hipSuccess) return (int)err;
-  project_rows_kernel<KS><<<dim3(best, B, 2), kPW, bytes, s>>>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows,
+  project_rows_kernel<KS><<<dim3(best, B, nmod), kPW, bytes, s>>>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows,
                                                              per, off2, off3);
   HCM_CHECK_LAUNCH();
   return 0;
@@ -744,18 +744,19 @@ int hcm_debug_row8_timing(unsigned long long* buf) {
 int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
                      const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
                      float* grows, hcm_stream_t stream) {
+  const int nmod = absent(enc2) ? 1 : 2;          // absent: rows[1] / xs[1] / grows[1] are left to the caller
   if (B <= 0 || R <= 0 || F != kF || pix == nullptr || rows == nullptr || !branches_ok(enc1, Ctot) ||
-      !branches_ok(enc2, Ctot))
+      (nmod == 2 && !branches_ok(enc2, Ctot)))
     return (int)hipErrorInvalidValue;
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4 && nmod == 2; ++i)
     if (enc1.C[i] != enc2.C[i] || enc1.H[i] != enc2.H[i] || enc1.W[i] != enc2.W[i]) return (int)hipErrorInvalidValue;
   const int ld = hcm_sample_branches_ld(Ctot);
-  const Maps8 e = pack8(enc1, enc2);
+  const Maps8 e = pack8(enc1, nmod == 2 ? enc2 : enc1);
   hipStream_t s = (hipStream_t)stream;
   // HRNet-w18 / w32 / w48: 270 / 480 / 720 channels + the bias column
-  if (Ctot + 1 <= 4 * 68) return launch_project<68>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
-  if (Ctot + 1 <= 4 * 121) return launch_project<121>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
-  if (Ctot + 1 <= 4 * 181) return launch_project<181>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  if (Ctot + 1 <= 4 * 68) return launch_project<68>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  if (Ctot + 1 <= 4 * 121) return launch_project<121>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  if (Ctot + 1 <= 4 * 181) return launch_project<181>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
   return (int)hipErrorInvalidValue;
 }
 
@@ -766,9 +767,10 @@ size_t hcm_project_rows_dw_workspace_bytes(int B, int Ctot) {
 int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale, int B, int R, int Ctot, int F,
                         float* dWp1, float* dbp1, float* dWp2, float* dbp2, void* workspace, size_t workspace_bytes,
                         hcm_stream_t stream) {
-  if (B <= 0 || R <= 0 || Ctot <= 0 || F != kF || !grows || !xs || !dWp1 || !dbp1 || !dWp2 || !dbp2 || !workspace ||
-      workspace_bytes < hcm_project_rows_dw_workspace_bytes(B, Ctot))
+  if (B <= 0 || R <= 0 || Ctot <= 0 || F != kF || !grows || !xs || !dWp1 || !dbp1 || (dWp2 == nullptr) != (dbp2 == nullptr) ||
+      !workspace || workspace_bytes < hcm_project_rows_dw_workspace_bytes(B, Ctot))
     return (int)hipErrorInvalidValue;
+  const int nmod = dWp2 != nullptr ? 2 : 1;        // dWp2 == NULL: modality 0 only (the second encoder is absent)
   hipStream_t s = (hipStream_t)stream;
   const int ld = hcm_sample_branches_ld(Ctot), M = B * R;
   const int nchunk = dw_chunks(B);
@@ -776,9 +778,9 @@ int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale,
   rpc = (rpc + 3) & ~3;
   const int ncg = (ld + kNT * 16 - 1) / (kNT * 16);
   float* part = static_cast<float*>(workspace);
-  proj_dw_partial_kernel<<<dim3(nchunk, ncg, 2), kDW, 0, s>>>(grows, xs, M, ld, rpc, part);
+  proj_dw_partial_kernel<<<dim3(nchunk, ncg, nmod), kDW, 0, s>>>(grows, xs, M, ld, rpc, part);
   HCM_CHECK_LAUNCH();
-  proj_dw_reduce_kernel<<<dim3((kF * ld + 255) / 256, 2), 256, 0, s>>>(part, nchunk, ld, Ctot, scale, dWp1, dbp1, dWp2, dbp2);
+  proj_dw_reduce_kernel<<<dim3((kF * ld + 255) / 256, nmod), 256, 0, s>>>(part, nchunk, ld, Ctot, scale, dWp1, dbp1, dWp2, dbp2);
   HCM_CHECK_LAUNCH();
   return 0;
 }
@@ -809,8 +811,10 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
                               int F, hcm_branches_out g1, hcm_branches_out g2, const int32_t* keep, int S, float* dWp1,
                               float* dbp1, float* dWp2, float* dbp2, void* workspace, size_t workspace_bytes,
                               hcm_stream_t stream) {
-  if (B <= 0 || R <= 0 || F != kF || !grows || !xs || !Wp1 || !Wp2 || !pix || !workspace || !branches_ok(g1, Ctot) ||
-      !branches_ok(g2, Ctot) || workspace_bytes < hcm_project_rows_backward_workspace_bytes(B, R, Ctot, g1))
+  const int nmod = absent(g2) ? 1 : 2;             // absent: modality 0's maps and weight gradients only
+  if (B <= 0 || R <= 0 || F != kF || !grows || !xs || !Wp1 || (nmod == 2 && !Wp2) || !pix || !workspace ||
+      !branches_ok(g1, Ctot) || (nmod == 2 && !branches_ok(g2, Ctot)) || (nmod == 1 && (dWp2 != nullptr || dbp2 != nullptr)) ||
+      workspace_bytes < hcm_project_rows_backward_workspace_bytes(B, R, Ctot, g1))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   PlanGeom gm;
@@ -818,7 +822,7 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
   TilePlan tp;
   int v = 0, n2 = 2;
   for (int i = 0; i < 4; ++i) {
-    if (g1.C[i] != g2.C[i] || g1.H[i] != g2.H[i] || g1.W[i] != g2.W[i]) return (int)hipErrorInvalidValue;
+    if (nmod == 2 && (g1.C[i] != g2.C[i] || g1.H[i] != g2.H[i] || g1.W[i] != g2.W[i])) return (int)hipErrorInvalidValue;
     // keys are pixel * E + entry in 32 bits
     if ((uint64_t)g1.H[i] * g1.W[i] * 4ull * (uint64_t)R >= 0xffffffffull) return (int)hipErrorInvalidValue;
     if (g1.H[i] * g1.W[i] >= (1 << 17) || R >= (1 << kRowBits)) return (int)hipErrorInvalidValue;
@@ -845,8 +849,8 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
     const int rc = hcm_project_rows_dw(grows, xs, scale, B, R, Ctot, F, dWp1, dbp1, dWp2, dbp2, workspace, dwb, stream);
     if (rc != 0) return rc;
   }
-  branch_grad_t_kernel<<<dim3(v, B, 2), kGW, 0, s>>>(grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot,
-                                                     pack8(g1, g2), tp, gm);
+  branch_grad_t_kernel<<<dim3(v, B, nmod), kGW, 0, s>>>(grows, Wp1, nmod == 2 ? Wp2 : Wp1, dpooled, scale, ent, off, R, B, Ctot,
+                                                        pack8(g1, nmod == 2 ? g2 : g1), tp, gm);
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -32,10 +32,10 @@ constexpr int kMaxIn = 1024;   // widest head input (HRNet-w48: 720 pooled chann
 // ------------------------------------------------------------------------------------------
 // one wave per (modality, image, channel) plane
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWG) void head_pool_kernel(Maps8 e, int B, int Ctot, float* __restrict__ pooled) {
+__global__ __launch_bounds__(kWG) void head_pool_kernel(Maps8 e, int B, int Ctot, float* __restrict__ pooled, int nmod) {
   const int lane = threadIdx.x & 63;
   const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (plane >= 2 * B * Ctot) return;
+  if (plane >= nmod * B * Ctot) return;
   const int m = plane / (B * Ctot), rem = plane - m * B * Ctot;
   const int b = rem / Ctot;
   int c = rem - b * Ctot;
@@ -584,13 +584,14 @@ int hcm_heads_forward(hcm_branches enc1, hcm_branches enc2, const float* feat3, 
                       const float* b3, const int64_t* index, float* pooled, float* mean3, float* ypre, float* f,
                       int ldf, float* fT, hcm_stream_t stream) {
   if (B <= 0 || J <= 0 || F <= 0 || F > kWG || Ctot <= 0 || Ctot > kMaxIn || D3 <= 0 || D3 > kMaxIn ||
-      ldf < 3 * F + (index != nullptr ? 2 : 0) || !branches_ok(enc1, Ctot) || !branches_ok(enc2, Ctot))
+      ldf < 3 * F + (index != nullptr ? 2 : 0) || !branches_ok(enc1, Ctot) || (!absent(enc2) && !branches_ok(enc2, Ctot)))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const int planes = 2 * B * Ctot;
-  for (int i = 0; i < 4; ++i)
+  const int nmod = absent(enc2) ? 1 : 2;          // absent: pooled[1] is the caller's (already filled, same stream)
+  const int planes = nmod * B * Ctot;
+  for (int i = 0; i < 4 && nmod == 2; ++i)
     if (enc1.C[i] != enc2.C[i] || enc1.H[i] != enc2.H[i] || enc1.W[i] != enc2.W[i]) return (int)hipErrorInvalidValue;
-  head_pool_kernel<<<(planes + 3) / 4, kWG, 0, s>>>(pack8(enc1, enc2), B, Ctot, pooled);
+  head_pool_kernel<<<(planes + 3) / 4, kWG, 0, s>>>(pack8(enc1, nmod == 2 ? enc2 : enc1), B, Ctot, pooled, nmod);
   HCM_CHECK_LAUNCH();
   heads_fwd_kernel<<<dim3(B, 3), kWG, 0, s>>>(pooled, feat3, B, J, Ctot, D3, F, W1, b1, W2, b2, W3, b3, mean3, ypre,
                                               f, ldf, fT, index);

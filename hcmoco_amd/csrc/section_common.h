@@ -57,6 +57,11 @@ __device__ __forceinline__ Taps bilinear_taps(int py, int px, int hi, int wi, fl
   return t;
 }
 
+// r05: an encoder whose map[0] is NULL is ABSENT -- the second modality does not come from an HRNet (HRNetPN: a point
+// cloud encoder); the entry points then work on modality 0 alone and leave modality 1's slices to the caller.
+inline bool absent(const hcm_branches& e) { return e.map[0] == nullptr; }
+inline bool absent(const hcm_branches_out& e) { return e.map[0] == nullptr; }
+
 inline bool branches_ok(const hcm_branches& e, int Ctot) {
   int s = 0;
   for (int i = 0; i < 4; ++i) {

@@ -772,7 +772,10 @@ def conv3x3_wgrad(x, dy, ksize=3, stride=1):
 # branch gradients.  ~35 launches where the module-by-module form needed ~220.
 # --------------------------------------------------------------------------- #
 def _branches(maps, name):
-    """hcm_branches for the four NCHW maps of one HRNet (keeps the tensors alive through the struct)."""
+    """hcm_branches for the four NCHW maps of one HRNet (keeps the tensors alive through the struct).  ``None`` = the
+    ABSENT encoder of include/hcmoco_hip.h (HRNetPN: the second modality is not an HRNet)."""
+    if maps is None:
+        return _lib.Branches()                      # zero-initialised: map[0] == NULL
     if len(maps) != 4:
         raise ValueError('%s: an HRNet returns four branch maps' % name)
     br = _lib.Branches()
@@ -787,9 +790,10 @@ def _branches(maps, name):
     return br
 
 
-def heads_forward(maps1, maps2, feat3, W1, b1, W2, b2, W3, b3, index=None):
+def heads_forward(maps1, maps2, feat3, W1, b1, W2, b2, W3, b3, index=None, pooled2=None):
     """(pooled [2,B,Ctot], mean3 [B,D3], ypre [3,B,F], f [B,3F(+2)], fT [3,B,F]) -- build_backbone.py:265-288.
-    With ``index`` the rows of ``f`` are the packed rows of the feature/index all-gather."""
+    With ``index`` the rows of ``f`` are the packed rows of the feature/index all-gather.  ``maps2=None`` (absent second
+    encoder): ``pooled2 [B, C2]`` is the second head's input, zero-padded to Ctot here (W2 must be [F, Ctot])."""
     B = maps1[0].shape[0]
     Ctot = sum(m.shape[1] for m in maps1)
     J, D3 = feat3.shape[1], feat3.shape[2]
@@ -797,6 +801,9 @@ def heads_forward(maps1, maps2, feat3, W1, b1, W2, b2, W3, b3, index=None):
     dev = feat3.device
     ldf = 3 * F + (2 if index is not None else 0)
     pooled = torch.empty(2, B, Ctot, dtype=torch.float32, device=dev)
+    if maps2 is None:
+        pooled[1].zero_()
+        pooled[1, :, :pooled2.shape[1]].copy_(pooled2)
     mean3 = torch.empty(B, D3, dtype=torch.float32, device=dev)
     ypre = torch.empty(3, B, F, dtype=torch.float32, device=dev)
     f = torch.empty(B, ldf, dtype=torch.float32, device=dev)
@@ -903,12 +910,17 @@ def project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, save=True, zero_grows=Tr
     ld = int(_lib.lib().hcm_sample_branches_ld(Ctot))
     dev = pix.device
     rows = torch.empty(2, B * R, F, dtype=torch.float32, device=dev)
-    xs = torch.empty(2, B * R, ld, dtype=torch.float32, device=dev) if save else None
+    nmod = 1 if maps2 is None else 2          # absent second encoder: the [1] slices are the caller's
+    xs = torch.empty(nmod, B * R, ld, dtype=torch.float32, device=dev) if save else None
     grows = torch.empty(2, B * R, F, dtype=torch.float32, device=dev) if zero_grows else None
+    if grows is not None and maps2 is None:
+        grows[1].zero_()
     d = lambda t: _dev(t, torch.float32, 'project_rows')
+    w2 = C.c_void_p(0) if maps2 is None else d(Wp2.reshape(F, Ctot))
+    b2 = C.c_void_p(0) if maps2 is None else d(bp2)
     check(_lib.lib().hcm_project_rows(
         _branches(maps1, 'project_rows'), _branches(maps2, 'project_rows'), B, _dev(pix, torch.int64, 'project_rows'), R,
-        Ctot, F, d(Wp1.reshape(F, Ctot)), d(bp1), d(Wp2.reshape(F, Ctot)), d(bp2), _opt(xs, torch.float32, 'project_rows'),
+        Ctot, F, d(Wp1.reshape(F, Ctot)), d(bp1), w2, b2, _opt(xs, torch.float32, 'project_rows'),
         d(rows), _opt(grows, torch.float32, 'project_rows'), _stream()), 'hcm_project_rows')
     return rows, xs, grows
 
@@ -920,13 +932,16 @@ def project_rows_backward(grows, xs, Wp1, Wp2, dpooled, scale, pix, shapes, keep
     dev = pix.device
     Ctot = sum(s[1] for s in shapes)
     F = grows.shape[-1]
+    one = Wp2 is None                           # absent second encoder: modality 0 only
     g1 = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
-    g2 = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    g2 = None if one else [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
     dWp1 = dbp1 = dWp2 = dbp2 = None
     if weight_grads:
-        dWp = torch.empty(2, F, Ctot, dtype=torch.float32, device=dev)
-        dbp = torch.empty(2, F, dtype=torch.float32, device=dev)
-        dWp1, dWp2, dbp1, dbp2 = dWp[0], dWp[1], dbp[0], dbp[1]
+        dWp = torch.empty(1 if one else 2, F, Ctot, dtype=torch.float32, device=dev)
+        dbp = torch.empty(1 if one else 2, F, dtype=torch.float32, device=dev)
+        dWp1, dbp1 = dWp[0], dbp[0]
+        if not one:
+            dWp2, dbp2 = dWp[1], dbp[1]
     b1, b2 = _branches(g1, 'project_rows_backward'), _branches(g2, 'project_rows_backward')
     L = _lib.lib()
     nb = L.hcm_project_rows_backward_workspace_bytes(B, R, Ctot, b1)
@@ -934,7 +949,8 @@ def project_rows_backward(grows, xs, Wp1, Wp2, dpooled, scale, pix, shapes, keep
     p = lambda t: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
     d = lambda t: _dev(t, torch.float32, 'project_rows_backward')
     check(L.hcm_project_rows_backward(
-        d(grows), d(xs), d(Wp1.reshape(F, Ctot)), d(Wp2.reshape(F, Ctot)), _opt(dpooled, torch.float32, 'project_rows_backward'),
+        d(grows), d(xs), d(Wp1.reshape(F, Ctot)), C.c_void_p(0) if one else d(Wp2.reshape(F, Ctot)),
+        _opt(dpooled, torch.float32, 'project_rows_backward'),
         _opt(scale, torch.float32, 'project_rows_backward'), _dev(pix, torch.int64, 'project_rows_backward'), R, B, Ctot, F,
         b1, b2, _opt(keep, torch.int32, 'project_rows_backward'), int(S), p(dWp1), p(dbp1), p(dWp2), p(dbp2),
         C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_project_rows_backward')
@@ -1103,6 +1119,123 @@ class _Stage2Section(torch.autograd.Function):
         g1, g2, _, _, _, _ = branch_grad(None, dpooled, None, nopix, ctx.shapes)
         return (gfeat3, dW1, db1, dW2, db2, dW3, db3, None, None, None, None,
                 g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3], None)
+
+
+class _Stage2SectionPN(torch.autograd.Function):
+    """The loss section of the ``HRNetPN`` model (networks/build_backbone.py:305-514 of the reference; r05) as ONE autograd
+    node.  Same kernels as ``_Stage2Section``; the second modality is not an HRNet, so (include/hcmoco_hip.h, "absent second
+    encoder") head 2 pools the cloud features ``feat2 [B, C2, Npts]`` (mean over the points, :486) and its rows are a plain
+    gather of the already projected depth map ``lm2 [B, F, h, w]`` (:499-505: Conv1d + pts2depth + nearest resize run in the
+    model).  forward(feat3, W1, b1, W2, b2, W3, b3, Wp1, bp1, m10..m13, feat2, lm2, cfg) -> like ``_Stage2Section``."""
+
+    @staticmethod
+    def forward(ctx, feat3, W1, b1, W2, b2, W3, b3, Wp1, bp1, m10, m11, m12, m13, feat2, lm2, cfg):
+        maps1 = [m10, m11, m12, m13]
+        mem, tape = cfg['contrast'], cfg.get('tape')
+        index = cfg['index'].contiguous()
+        B, J = feat3.shape[0], feat3.shape[1]
+        F = W1.shape[0]
+        Ctot = sum(m.shape[1] for m in maps1)
+        C2 = feat2.shape[1]
+        if C2 > Ctot or lm2.shape[1] != F or tuple(lm2.shape[-2:]) != tuple(m10.shape[-2:]):
+            raise ValueError('stage2_section_pn: feat2 %s / lm2 %s do not fit the HRNet maps %s'
+                             % (tuple(feat2.shape), tuple(lm2.shape), tuple(m10.shape)))
+        feat3c = feat3.contiguous()
+        gather = cfg.get('gather')
+        # ---- heads: head 2's input is the mean over the points, zero-padded to the HRNet's channel count
+        pooled2 = feat2.mean(-1)
+        W2pad = torch.zeros(F, Ctot, dtype=torch.float32, device=W2.device)
+        W2pad[:, :C2].copy_(W2)
+        pooled, mean3, ypre, f, fT = heads_forward(maps1, None, feat3c, W1, b1, W2pad, b2, W3, b3,
+                                                   index if gather is not None else None, pooled2=pooled2)
+        pending = None
+        if gather is not None:
+            allp, pending = gather(f)
+            if pending is not None and (tape is not None or os.environ.get('HCM_SYNC_GATHER', '0') != '0'):
+                pending.wait()
+                pending = None
+            all_x = [allp[:, i * F:(i + 1) * F] for i in range(3)]
+            all_index_of = lambda: allp[:, 3 * F:].contiguous().view(torch.int64).view(-1)
+            ldx = allp.shape[1]
+        else:
+            all_x, ldx = [fT[0], fT[1], fT[2]], F
+            all_index_of = lambda: index
+        ud, ur = _i32(cfg.get('use_depth')), _i32(cfg.get('use_rgb'))
+        idx = cfg.get('idx')
+        idx = mem.draw(index) if idx is None else mem._in_range(idx).contiguous()
+        if tape is not None:
+            tape.update(banks0=[b.detach().clone() for b in mem.banks()], idx=idx, f=f[:, :3 * F], fT=fT,
+                        all_x=[a.detach().clone() for a in all_x], all_index=all_index_of())
+        losses, accs, gxT = bank_nce_fused_raw(mem.banks(), idx, [fT[0], fT[1], fT[2]], mem.T, ud, None, stacked=True)
+
+        def update_banks():
+            if pending is not None:
+                pending.wait()
+            mem.update_strided(all_x, ldx, all_index_of())
+        if pending is None:
+            update_banks()
+        h, w = m10.shape[-2:]
+        S = int(cfg['num_samples'])
+        vis = _i32(cfg['joints_vis'])
+        if cfg.get('sample_ind') is not None:
+            pj = joint_pixels(cfg['joints2d'], h)
+            coord = cfg['sample_ind'].contiguous()
+            pix = torch.cat([coord, pj], dim=1).contiguous()
+            keep = _i32(cfg['keep'])
+        else:
+            pix, coord, keep = pixel_sample(cfg['depth_mask'], h, w, S, ud, cfg['joints2d'], *mem.next_pixel_key())
+        R = pix.shape[1]
+        # ---- rows: modality 0 = merge + projection at the sampled pixels (MFMA), modality 1 = gather of the depth map
+        rows, xs, grows = project_rows(maps1, None, pix, Wp1, bp1, None, None)
+        lm2c = _dense_map(lm2)
+        check(_lib.lib().hcm_sample_rows(C.c_void_p(lm2c.data_ptr()), _strides(lm2c), B, F, h, w, h, w,
+                                         _dev(pix, torch.int64, 'section_pn'), R, C.c_void_p(rows[1].data_ptr()), F, 0,
+                                         _stream()), 'hcm_sample_rows')
+        meters, gj = fmap_losses_on_rows(rows.view(2, B, R, F), grows.view(2, B, R, F), feat3c, S, coord, w, keep, vis, ud,
+                                         ur, cfg['temperature'], cfg.get('gemm_dtype', 'fp32'))
+        if tape is not None:
+            tape.update(pix=pix, coord=coord, keep=keep, rows=rows, meters=meters)
+        ctx.save_for_backward(pooled, mean3, ypre, W1, W2pad, W3, gxT, gj, xs, Wp1, grows, pix, keep)
+        ctx.S, ctx.J, ctx.C2 = S, J, C2
+        ctx.shapes = [tuple(m.shape) for m in maps1]
+        ctx.feat2_shape, ctx.lm2_shape = tuple(feat2.shape), tuple(lm2.shape)
+        if pending is not None:
+            update_banks()
+        total = torch.empty((), dtype=torch.float32, device=losses.device)
+        check(_lib.lib().hcm_section_total(_dev(losses, torch.float32, 'section'), _dev(meters, torch.float32, 'section'),
+                                           C.c_void_p(total.data_ptr()), _stream()), 'hcm_section_total')
+        outs = (total, losses, accs, meters)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        scale = g_total.contiguous().to(torch.float32)
+        pooled, mean3, ypre, W1, W2pad, W3, gxT, gj, xs, Wp1, grows, pix, keep = ctx.saved_tensors
+        F = W1.shape[0]
+        C2 = ctx.C2
+        B, R = pix.shape
+        dW1, db1, dW2pad, db2, dW3, db3, dpooled, gfeat3 = heads_backward(gxT, scale, pooled, mean3, ypre, W1, W2pad, W3,
+                                                                         gj, ctx.J)
+        g1, _, dWp1, dbp1, _, _ = project_rows_backward(grows, xs, Wp1, None, dpooled, scale, pix, ctx.shapes, keep, ctx.S)
+        # head 2: d mean over the points; depth map: owner-computes scatter of its (scaled) row gradients
+        npts = ctx.feat2_shape[2]
+        dfeat2 = (dpooled[1, :, :C2] * (1.0 / npts)).unsqueeze(-1).expand(ctx.feat2_shape)
+        g2rows = (grows[1] * scale).contiguous()
+        dlm2 = torch.zeros(ctx.lm2_shape, dtype=torch.float32, device=g2rows.device)
+        h, w = ctx.lm2_shape[-2:]
+        check(_lib.lib().hcm_sample_rows_grad(C.c_void_p(g2rows.data_ptr()), F, 0, _strides(dlm2), B, F, h, w, h, w,
+                                              _dev(pix, torch.int64, 'section_pn'), R, C.c_void_p(dlm2.data_ptr()),
+                                              _stream()), 'hcm_sample_rows_grad')
+        Ctot = dWp1.shape[1]
+        return (gfeat3, dW1, db1, dW2pad[:, :C2].contiguous(), db2, dW3, db3, dWp1.view(F, Ctot, 1, 1), dbp1,
+                g1[0], g1[1], g1[2], g1[3], dfeat2, dlm2, None)
+
+
+def stage2_section_pn(feat3, heads, proj1, maps1, feat2, lm2, cfg):
+    """``stage2_section`` for the HRNetPN model: heads = (W1,b1,W2,b2,W3,b3) with W2 [F, C2] over the cloud features,
+    proj1 = (Wp1, bp1) of ``encoder1_linear``; feat2 [B, C2, Npts], lm2 [B, F, h, w] (see ``_Stage2SectionPN``)."""
+    return _Stage2SectionPN.apply(feat3, *heads, *proj1, *maps1, feat2, lm2, cfg)
 
 
 def stage2_section(feat3, heads, projs, maps1, maps2, cfg):

@@ -286,6 +286,10 @@ class ContrastTrainer(BaseTrainer):
             # the model ran with defer_heads: pooling, heads, all-gather, bank NCE + update, pixel sampling,
             # sampled projection and the three feature-map losses are ONE autograd node (engine.section)
             net = self.unwrap(model)
+            if args.arch == 'HRNetPN':          # second modality: (cloud features, depth map at the HRNet's resolution)
+                # (a view of the cloud features: the section's gradient w.r.t. its own input stays apart from the one
+                # that reaches the same tensor through encoder2_linear -> the depth map -- what a recorder compares)
+                _feat2 = (_feat2.view_as(_feat2), aux['linear_merge2'])
             loss, losses, accs, meters = self.engine.section(
                 net, _feat1, _feat2, _feat3, index, contrast, True, depth_mask=self._to_dev(data[7]),
                 joints2d=self._to_dev(data[4]), joints_vis=self._to_dev(data[5]), use_depth=use_depth, use_rgb=use_rgb,

@@ -80,10 +80,14 @@ class HipLossEngine(object):
     # ---- rows 1-9 of a step as one autograd node ------------------------------
     @staticmethod
     def supports_section(net, stage2=True):
-        """The fused section covers the RGBD2S HRNet model with mean pooling and linear heads."""
-        return (type(net).__name__ == 'CMC3HRNetSGCNSingleHead' and net.pool_method == 'mean'
-                and (not stage2 or bool(net.linear_feat_map)) and net.head1[0].weight.shape[0] <= 256
-                and net.head1[0].weight.is_cuda)
+        """The fused section covers the RGBD2S HRNet model -- and, for stage 2, the HRNetPN model (r05) -- with mean pooling
+        and linear heads."""
+        kind = type(net).__name__
+        if kind == 'CMC3HRNetSGCNPN2SingleHead':
+            ok = stage2 and bool(net.linear_feat_map) and net.head2[0].weight.shape[1] <= net.head1[0].weight.shape[1]
+        else:
+            ok = kind == 'CMC3HRNetSGCNSingleHead' and (not stage2 or bool(net.linear_feat_map))
+        return (ok and net.pool_method == 'mean' and net.head1[0].weight.shape[0] <= 256 and net.head1[0].weight.is_cuda)
 
     def section(self, net, branches1, branches2, feat3, index, contrast, stage2, depth_mask=None, joints2d=None,
                 joints_vis=None, use_depth=None, use_rgb=None, num_samples=0, temperature=0.07, gather=None,
@@ -97,6 +101,16 @@ class HipLossEngine(object):
         -> (total, bank_losses[6], bank_accs[6], meters[9])."""
         heads = (net.head1[0].weight, net.head1[0].bias, net.head2[0].weight, net.head2[0].bias,
                  net.head3[0].weight, net.head3[0].bias)
+        if type(net).__name__ == 'CMC3HRNetSGCNPN2SingleHead':
+            # HRNetPN: ``branches2`` = (cloud features [B, C2, Npts], depth map [B, F, h, w]) -- hip_ops.stage2_section_pn
+            feat2, lm2 = branches2
+            h, w = branches1[0].shape[-2:]
+            assert h == w and stage2
+            cfg = dict(contrast=contrast, index=index, use_depth=use_depth, use_rgb=use_rgb, depth_mask=depth_mask,
+                       joints2d=joints2d, joints_vis=joints_vis, num_samples=num_samples, temperature=temperature,
+                       gemm_dtype=self.fmap_dtype, gather=gather, idx=idx, sample_ind=sample_ind, keep=keep, tape=tape)
+            return hip_ops.stage2_section_pn(feat3, heads, (net.encoder1_linear.weight, net.encoder1_linear.bias),
+                                             list(branches1), feat2, lm2, cfg)
         if stage2:
             projs = (net.encoder1_linear.weight, net.encoder1_linear.bias, net.encoder2_linear.weight,
                      net.encoder2_linear.bias)
@@ -233,8 +247,9 @@ class RecordingEngine(object):
         c = self._cpu
         tape = {} if tape is None else tape
         heads = [net.head1[0], net.head2[0], net.head3[0]]
-        projs = [net.encoder1_linear, net.encoder2_linear] if stage2 else []
-        rec = {'kind': 'section', 'stage2': bool(stage2), 'T': contrast.T, 'm': contrast.m,
+        pn = type(net).__name__ == 'CMC3HRNetSGCNPN2SingleHead'
+        projs = ([net.encoder1_linear] if pn else [net.encoder1_linear, net.encoder2_linear]) if stage2 else []
+        rec = {'kind': 'section_pn' if pn else 'section', 'stage2': bool(stage2), 'T': contrast.T, 'm': contrast.m,
                'branches1': c(list(branches1)), 'branches2': c(list(branches2)), 'feat3': c(feat3),
                'heads': [(c(l.weight), c(l.bias)) for l in heads], 'projs': [(c(l.weight), c(l.bias)) for l in projs],
                'index': c(index), 'depth_mask': c(depth_mask), 'joints2d': c(joints2d), 'joints_vis': c(joints_vis),
@@ -254,7 +269,8 @@ class RecordingEngine(object):
         rec['after_rows'] = [c(b.index_select(0, ai)) for b in banks]
         rec['untouched_rows_unchanged'] = [bool(torch.equal(b[~touched], b0[~touched]))
                                            for b, b0 in zip(banks, tape['banks0'])]
-        named = [('b1_%d' % i, t) for i, t in enumerate(branches1)] + [('b2_%d' % i, t) for i, t in enumerate(branches2)]
+        named = [('b1_%d' % i, t) for i, t in enumerate(branches1)]
+        named += [('feat2', branches2[0]), ('lm2', branches2[1])] if pn else [('b2_%d' % i, t) for i, t in enumerate(branches2)]
         named += [('feat3', feat3)]
         named += [('head%d_%s' % (i + 1, n), getattr(l, a)) for i, l in enumerate(heads) for n, a in (('w', 'weight'), ('b', 'bias'))]
         named += [('proj%d_%s' % (i + 1, n), getattr(l, a)) for i, l in enumerate(projs) for n, a in (('w', 'weight'), ('b', 'bias'))]

@@ -199,6 +199,11 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         if self.linear_feat_map:
             self.encoder1_linear = nn.Conv2d(dim_in, sgcn_dim, kernel_size=1, stride=1, bias=True)
             self.encoder2_linear = pt_utils.Conv1d(self.pn_dim, sgcn_dim, bn=True)
+        # set by a trainer whose loss engine runs pooling, heads, merge_all_res + encoder1_linear at the sampled pixels
+        # and the losses as one node (engine.section -> hip_ops.stage2_section_pn): ``return_fm`` then returns f = None,
+        # the raw HRNet branch maps, the cloud features and the depth map in aux['linear_merge2']
+        self.defer_projection = False
+        self.defer_heads = False
 
     merge_all_res = staticmethod(CMC3HRNetSGCNSingleHead.merge_all_res)
     _pool = CMC3HRNetSGCNSingleHead._pool
@@ -385,6 +390,9 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             _feat3 = self.encoder3(s)
             if want_map:
                 linear_merge2 = depth_map(sample_pn, full_pn, _feat2)
+        if (self.defer_heads and self.defer_projection and want_map and mode in (0, 1) and self.pool_method == 'mean'):
+            return _feat1, _feat2, _feat3, None, {'merge1': None, 'merge2': _feat2, 'linear_merge1': None,
+                                                  'linear_merge2': linear_merge2}
         avg1, avg2, avg3 = self._pool(_feat1), _feat2.mean(-1), _feat3.mean(1)
         if mode in (0, 1):
             feat1, feat2, feat3 = self.head1(avg1), self.head2(avg2), self.head3(avg3)

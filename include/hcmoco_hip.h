@@ -253,6 +253,15 @@ typedef struct {
   float* map[4];
   int C[4], H[4], W[4];
 } hcm_branches_out;
+/* ABSENT second encoder (r05; ABI 4): an hcm_branches / hcm_branches_out whose map[0] is NULL.  The HRNetPN model
+ * (networks/build_backbone.py:305-514) has ONE HRNet; its second modality is a point-cloud encoder that hands over a pooled
+ * feature vector and an already projected [B, F, h, w] map.  With an absent enc2 / g2:
+ *   hcm_heads_forward          pools modality 0 only; pooled[1] ([B, Ctot], e.g. [mean over the points | 0]) is an INPUT the
+ *                              caller has filled on the same stream (W2 padded to [F, Ctot] accordingly);
+ *   hcm_project_rows           writes rows[0] / xs[0] / zero-fills grows[0]; the [1] slices are the caller's
+ *                              (rows[1] = a plain gather of the map, hcm_sample_rows; grows[1] zero-filled by the caller);
+ *   hcm_project_rows_backward  modality 0's branch gradients and dWp1 / dbp1 only (Wp2, dWp2, dbp2 NULL; dpooled[0] is read);
+ *   hcm_project_rows_dw        dWp2 == dbp2 == NULL selects the same. */
 
 /* Heads (networks/build_backbone.py:265-288, networks/util.py:74-80): pooled[m] = cat_i mean_HW(enc_m.map[i])
  * [2, B, Ctot]; mean3 = mean_j feat3[b, j, :] [B, D3] (feat3 [B, J, D3]); ypre[h] = W_h x_h + b_h [3, B, F]

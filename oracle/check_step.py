@@ -234,6 +234,73 @@ def check_section(rec, tol):
     return rep
 
 
+def check_section_pn(rec, tol):
+    """The fused loss section of the HRNetPN model (hip_ops.stage2_section_pn; reference: networks/build_backbone.py:457-514,
+    learning/contrast_trainer.py:894-1039).  Same oracle flow as ``check_section``; the second modality is the point-cloud
+    encoder: head 2 reads the mean over the points of ``feat2 [B, C2, Npts]`` (:486) and the depth feature map
+    ``lm2 [B, F, h, w]`` enters the losses as it is (the model produced it: Conv1d + pts2depth + nearest resize, :499-505).
+    Compared: f, idx[:, 0], sampled pixels, 6 + 6 + 9 meters, the bank update, and the gradients of the four HRNet branch
+    maps, feat2, lm2, the SemGCN output, the three heads and encoder1_linear."""
+    rep = {}
+
+    def leaf(t):
+        return t.float().clone().requires_grad_(True)
+
+    b1 = [leaf(t) for t in rec['branches1']]
+    feat2, lm2 = leaf(rec['branches2'][0]), leaf(rec['branches2'][1])
+    feat3 = leaf(rec['feat3'])
+    hw = [leaf(w) for w, _ in rec['heads']]
+    hb = [leaf(b) for _, b in rec['heads']]
+    x = [torch.cat([m.mean(dim=(2, 3)) for m in b1], 1), feat2.mean(-1), feat3.mean(1)]
+    f = torch.cat([F.normalize(F.linear(xi, Wi, bi), p=2, dim=1) for xi, Wi, bi in zip(x, hw, hb)], 1)
+    F_ = f.shape[1] // 3
+    assert torch.allclose(rec['f'].float(), f.detach(), rtol=1e-5, atol=1e-6), ('heads f', float((rec['f'] - f.detach()).abs().max()))
+    rep['f_max_abs'] = float((rec['f'].float() - f.detach()).abs().max())
+    fr = rec['f'].float()
+    xs = [fr[:, i * F_:(i + 1) * F_].contiguous() for i in range(3)]
+    banks = [b.float() for b in rec['banks0']]
+    idx = rec['idx']
+    assert torch.equal(idx[:, 0], rec['index'].clamp(0, banks[0].shape[0] - 1)), 'idx[:,0] != index'
+    lo, ao, go = O.bank_nce_chunked(banks, idx, xs, rec['T'], rec['use_depth'], None)
+    l, a = rec['losses'].double(), rec['accs'].double()
+    assert torch.allclose(l, lo, rtol=tol['loss_rtol'], atol=tol['loss_atol']), ('bank losses', l, lo)
+    assert torch.allclose(a, ao, atol=1e-3), ('bank accs', a, ao)
+    rep['bank_loss_max_rel'] = float(((l - lo).abs() / lo.abs().clamp_min(1e-12)).max())
+    assert all(rec['untouched_rows_unchanged']), 'bank rows outside all_index changed'
+    upd = []
+    for i in range(3):
+        ref = O.bank_update(banks[i], rec['all_x'][i].float(), rec['all_index'], rec['m']).index_select(0, rec['all_index'])
+        err = (rec['after_rows'][i].float() - ref).abs()
+        assert float(err.max()) <= tol['update_atol'], ('bank update', i, float(err.max()))
+        upd.append(float(err.max()))
+    rep['bank_update_max_abs'] = max(upd)
+    gf = torch.cat([g.float() for g in go], 1)
+    h, w = rec['branches1'][0].shape[-2:]
+    keep_ref, m = O.dense_keep(rec['depth_mask'], h, w)
+    ud = rec['use_depth']
+    if ud is not None:
+        keep_ref = keep_ref & bool(ud.sum() > 0)
+    assert torch.equal(rec['keep'].bool(), keep_ref), 'keep flags'
+    si = rec['sample_ind']
+    assert bool((m.gather(1, si)[keep_ref] > 0).all()), 'a sampled pixel lies outside the depth mask'
+    assert torch.equal(rec['pix'][:, si.shape[1]:], O.joint_pixels(rec['joints2d'], h)), 'joint pixels'
+    pw, pb = leaf(rec['projs'][0][0]), leaf(rec['projs'][0][1])
+    up = [b1[0]] + [F.interpolate(t, size=(h, w), mode='bilinear', align_corners=False) for t in b1[1:]]
+    map1 = F.conv2d(torch.cat(up, 1), pw, pb)
+    want, g1, g2, g3 = _fmap_oracle(map1.detach(), lm2.detach(), rec)
+    fm = dict(rec)
+    fm['total'] = rec['total'] - float(rec['losses'].sum())
+    _cmp_meters(fm, want, tol, rep)
+    torch.autograd.backward([f, map1, lm2, feat3], [gf, g1, g2, g3])
+    ref = {'feat3': feat3.grad, 'feat2': feat2.grad, 'lm2': lm2.grad, 'proj1_w': pw.grad, 'proj1_b': pb.grad}
+    ref.update({'b1_%d' % i: t.grad for i, t in enumerate(b1)})
+    for i in range(3):
+        ref['head%d_w' % (i + 1)] = hw[i].grad
+        ref['head%d_b' % (i + 1)] = hb[i].grad
+    _cmp_grads(rec, ref, tol, rep)
+    return rep
+
+
 def check_records(records, tol=None):
     """-> report dict; raises AssertionError on the first disagreement."""
     report = {'calls': {}}
@@ -243,7 +310,8 @@ def check_records(records, tol=None):
             t.update(BF16_FMAP)
         if tol:
             t.update(tol)
-        fn = {'bank': check_bank, 'fmap': check_fmap, 'fmap_sampled': check_fmap_sampled, 'section': check_section}[rec['kind']]
+        fn = {'bank': check_bank, 'fmap': check_fmap, 'fmap_sampled': check_fmap_sampled, 'section': check_section,
+              'section_pn': check_section_pn}[rec['kind']]
         rep = fn(rec, t)
         report['calls'][rec['kind']] = report['calls'].get(rec['kind'], 0) + 1
         for k, v in rep.items():

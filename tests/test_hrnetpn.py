@@ -148,3 +148,39 @@ def test_hrnetpn_w32_stage2_steps_at_256(tmp_path):
             assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in enc.parameters())
     finally:
         _lib.torch_glue().set_async_wgrad(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('width,size,B', [(18, 64, 4), (18, 96, 3)])
+def test_hrnetpn_fused_section_against_the_oracle(width, size, B, tmp_path):
+    """r05: the HRNetPN model's loss section as ONE autograd node (hip_ops.stage2_section_pn -- the C ABI's "absent
+    second encoder": head 2 over the cloud features, rows of modality 2 gathered from the depth map) at small sizes,
+    every output and gradient re-evaluated by oracle/check_step.py:check_section_pn (reference data flow:
+    networks/build_backbone.py:457-514, learning/contrast_trainer.py:894-1039).  The BASELINE-size form of the same check
+    is tests/test_whole_step_gpu.py::config4_hrnetpn_w32."""
+    import bench
+    from hcmoco_amd import _lib
+    from hcmoco_amd.pycontrast.learning.contrast_trainer import ContrastTrainer
+    from hcmoco_amd.pycontrast.learning.engine import RecordingEngine
+    from oracle.check_step import check_records
+    dev = torch.device('cuda:0')
+    args = bench.make_args(B, 512, 2048, size, 'mpii', 'nccl', str(tmp_path), 3, arch='HRNetPN', width=width)
+    args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
+    eng = RecordingEngine('fp32')
+    tr = ContrastTrainer(args, engine=eng)
+    tr.device = dev
+    try:
+        model, contrast, opt, data = bench.build(args, tr, dev)
+        assert model.defer_heads and model.defer_projection
+        it = iter(data)
+        eng.armed = False
+        tr.train_step(next(it), model, contrast, opt, True)
+        eng.armed = True
+        out = tr.train_step(next(it), model, contrast, opt, True)
+        torch.cuda.synchronize()
+        assert [r['kind'] for r in eng.records] == ['section_pn']
+        rep = check_records(eng.records)
+        print(rep)
+        assert abs(float(out['loss']) - float(eng.records[0]['total'])) <= 1e-4 * abs(float(out['loss']))
+    finally:
+        _lib.torch_glue().set_async_wgrad(False)

@@ -75,16 +75,12 @@ def test_one_step_at_the_configs_own_size_against_the_oracle(name):
             print(name, rep)
             assert abs(float(out['loss']) - float(bank['total'])) <= 1e-4 * abs(float(out['loss']))
             return
-        if arch == 'HRNetPN':                # module path: heads inside the model, bank and feature-map calls apart
-            assert kinds == ['bank', 'fmap'], kinds
-            bank, fm = eng.records
-            assert bank['idx'].shape == (B, K + 1) and bank['x'][0].shape == (B, 128)
-            total = float(bank['total']) + float(fm['total'])
-        else:                                # the fused loss section: ONE record holds rows 1-9
-            assert kinds == ['section'], kinds
-            fm = eng.records[0]
-            assert fm['idx'].shape == (B, K + 1) and fm['f'].shape == (B, 384)
-            total = float(fm['total'])
+        # the fused loss section: ONE record holds rows 1-9 -- since r05 for the HRNetPN model too (second modality:
+        # cloud features + depth map, hip_ops.stage2_section_pn, checked by oracle/check_step.py:check_section_pn)
+        assert kinds == (['section_pn'] if arch == 'HRNetPN' else ['section']), kinds
+        fm = eng.records[0]
+        assert fm['idx'].shape == (B, K + 1) and fm['f'].shape == (B, 384)
+        total = float(fm['total'])
         assert fm['sample_ind'].shape == (B, 400)
         rep = check_records(eng.records)
         print(name, rep)
