@@ -24,6 +24,10 @@ cpu_baseline: the same training step on the host CPU (model in torch-CPU, losses
               as fit ~25 s (SURVEY 8d asks 3 + 10 steps; at ~5 s per step that is minutes, so the sample
               is bounded and its size reported); (b) ONE thread at batch 4 for a per-core figure.  A
               reported baseline, never the thing measured.
+              Row 8's three kernels (sampled merge + projection, its weight gradient, the branch-map gradients) carry both
+              their algorithmic flops and bytes.  NOTE: the hipEvent pairs behind `roofline` / `roofline_secondary`
+              (hcm_prof_enable) are recorded INSIDE the timed loop, on the kernels' own streams -- ~20 event records per
+              step; `ms_per_step` and `ms_per_step_hipevent` agree to microseconds with and without them.
 ms_per_step : wall clock (perf_counter around K steps, barrier + synchronize on both sides); the
               hipEvent-timed duration of the same K steps on the main stream is `ms_per_step_hipevent`.
 """
@@ -561,7 +565,7 @@ def run(a, rank, world, local, fs):
         hip_ops.GATHER_WAIT_EVENTS = None
     kern_ms, kern_n = hip_ops.prof_read()
     secondary_raw = {tag: hip_ops.prof_read(tag) for tag in ('dense_stats', 'dense_grad', 'scl_stats', 'scl_grad',
-                                                               'sgc_fwd', 'sgc_bwd')}
+                                                               'sgc_fwd', 'sgc_bwd', 'row8_fwd', 'row8_dw', 'row8_bwd', 'joint')}
     hip_ops.prof_enable(False)
     # The SemGCN runs on a side stream next to two encoder streams: a hipEvent pair around its launches inside the step
     # spans queueing behind them, not kernel time (r02: 0.0696 ms reported against 14.8 us of kernels in rocprofv3).
@@ -651,10 +655,32 @@ def run(a, rank, world, local, fs):
         scl_gemm = 2.0 * (2 * B * J) ** 2 * D
         sgc_fwd_bytes = B * J * (2 * D + 2 * D) * 4                  # read H [B*J, 2C]; write out + xhat [B*J, C]
         sgc_bwd_bytes = B * J * (2 * D + 3 * D + 2 * D) * 4          # read H, dOut, out, xhat; write dH [B*J, 2C]
+        # row 8 at the sampled pixels (csrc/rowproj.hip; networks/build_backbone.py:243-254, :290-300), both modalities (one for
+        # HRNetPN): R = S + J rows per image; a row reads 1 tap of the finest branch and 4 of each coarse one
+        net_ = trainer.unwrap(model)
+        widths = [a.width * 2 ** i for i in range(4)]
+        Ctot, ld = sum(widths), (sum(widths) + 1 + 3) // 4 * 4
+        R, nmod = S + J, (2 if a.arch == 'HRNet' else 1)
+        hw0 = (a.size // 4) ** 2
+        row8_fwd_bytes = nmod * B * R * ((widths[0] + 4 * (Ctot - widths[0])) * 4 + (D + ld + D) * 4)
+        row8_fwd_flops = nmod * B * R * 2.0 * (Ctot + 1) * D
+        row8_dw_flops = nmod * 2.0 * (B * R) * D * ld
+        row8_dw_bytes = nmod * B * R * (D + ld) * 4
+        pix_c = sum(widths[i] * (hw0 >> (2 * i)) for i in range(4))            # sum_i C_i H_i W_i
+        row8_bwd_flops = nmod * B * 2.0 * pix_c * D
+        row8_bwd_bytes = nmod * B * (pix_c * 4 + R * D * 4)
+        joint_bytes = 3 * B * J * D * 4 * 2                                    # rows in, row gradients out
         spec = [('dense_stats', 'strip_kernel<Dense, stats> (S x S similarity + online softmax / soft targets)', 'mfma', dense_gemm),
                 ('dense_grad', 'strip_kernel<Dense, grad> (similarity re-formed + G K contraction)', 'mfma', 2 * dense_gemm),
                 ('scl_stats', 'strip_kernel<Scl, stats> + chunk merge (N x N, N = 2BJ)', 'mfma', scl_gemm),
                 ('scl_grad', 'strip_kernel<Scl, grad> + chunk merge', 'mfma', 2 * scl_gemm),
+                ('row8_fwd', 'project_rows_kernel (merge_all_res + 1x1 projection at the sampled pixels, fp32 MFMA)', 'mfma+bytes',
+                 (row8_fwd_flops, row8_fwd_bytes)),
+                ('row8_dw', 'proj_dw_partial + proj_dw_reduce (d[W | b] = grows^T xs, fp32 MFMA)', 'mfma+bytes',
+                 (row8_dw_flops, row8_dw_bytes)),
+                ('row8_bwd', 'branch_grad_t_kernel (branch-map gradients W_i^T (S_i^T grows) + pooling gradient, fp32 MFMA)',
+                 'mfma+bytes', (row8_bwd_flops, row8_bwd_bytes)),
+                ('joint', 'joint_nce_kernel + joint_finish_kernel (joint <-> graph-node InfoNCE)', 'latency', joint_bytes),
                 ('sgc_fwd', 'SemGCN layer forward (sgc_mix + sgc_norm), per layer', 'latency', sgc_fwd_bytes),
                 ('sgc_bwd', 'SemGCN layer backward (stats + bwd + finish), per layer', 'latency', sgc_bwd_bytes)]
         secondary = []
@@ -668,7 +694,16 @@ def run(a, rank, world, local, fs):
                 in_step = round(avg, 5)
                 avg = sgc_idle[tag][0] / sgc_idle[tag][1]
                 n = sgc_idle[tag][1]
-            if kind == 'mfma':
+            if kind == 'mfma+bytes':
+                fl, by = work
+                ach = fl / (avg * 1e-3) / 1e12
+                gbs = by / (avg * 1e-3) / 1e9
+                secondary.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFS,
+                                  'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TFS, 4), 'flops_per_launch': int(fl),
+                                  'bytes_per_launch': int(by), 'achieved_gbs': round(gbs, 1),
+                                  'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(avg, 5),
+                                  'launches_timed': n})
+            elif kind == 'mfma':
                 ach = work / (avg * 1e-3) / 1e12
                 secondary.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak,
                                   'unit': 'TFLOP/s', 'frac': round(ach / mfma_peak, 4), 'flops_per_launch': int(work),

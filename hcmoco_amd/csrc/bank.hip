@@ -888,7 +888,7 @@ inline FusedWs carve(void* ws, int B, int K1, int D) {
 
 // ---- optional in-library timing of selected kernels (bench.py roofline objects) ----------------
 // The only process-global state of the library; off by default; mutex-protected.
-constexpr int kProfTags = 8;
+constexpr int kProfTags = 12;
 struct ProfState {
   std::mutex mu;
   bool on = false;

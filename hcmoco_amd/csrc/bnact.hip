@@ -399,7 +399,6 @@ __global__ __launch_bounds__(kBT) void bn_relu_ballmax_kernel(
   const float sh = fmaf(-mean, sc, beta[c]);
   constexpr int ns = 4 * L;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
-#pragma unroll 2
   for (int f0 = beg; f0 < end; f0 += kVec) {
     const int f = f0 + threadIdx.x * 4;
     const bool ok = f < end;                       // a ball row never straddles `end` (per, M are multiples of ns)
@@ -635,7 +634,6 @@ __global__ __launch_bounds__(kBT) void ball_bwd_apply_kernel(
   const float b = p1 * invM;
   const float q = p2 * invstd * invstd * invM;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
-#pragma unroll 2
   for (int f0 = beg; f0 < end; f0 += kVec) {
     const int f = f0 + threadIdx.x * 4;
     const bool ok = f < end;

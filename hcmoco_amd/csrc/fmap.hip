@@ -77,6 +77,10 @@ __global__ __launch_bounds__(kWG) void gather_norm_kernel(const float* __restric
 // Target / weight policies of the strip kernel.  meta is one int per row.
 // ------------------------------------------------------------------------------------------
 struct DensePolicy {
+  // split-bf16 contraction (see strip_kernel): hi.hi + hi.mid + mid.hi.  Q and K are different modalities' rows, the dropped
+  // terms (~2^-16 |q||k|, random sign) leave 3e-9..8e-8 on the loss and 4e-6..6e-6 on the gradients against float64
+  // (tools/studies/split_bf16_error.py, profiles/r05_split_bf16_error_study.txt; gate 1e-5 / 1e-4)
+  static constexpr int kTerms = 3;
   // soft target exp(-|q_r - q_c|_2) from integer pixel coordinates (contrast_trainer.py:702-706)
   // meta arrives as the flat pixel index; pack() turns it into (row << 16 | column) ONCE per query row and once
   // per staged key (the divisions by the run-time map width used to sit in weight(): 16 integer divisions per
@@ -98,6 +102,9 @@ struct DensePolicy {
   }
 };
 struct SclPolicy {
+  // + mid.mid: Q = K here, and on the diagonal x.x the dropped mid.mid term is a SUM OF SQUARES (systematic, 3.5e-6 on the
+  // loss with three terms, 9e-8 with four)
+  static constexpr int kTerms = 4;
   // positives: same joint id, different row, both rows' modality present (:873-885)
   // meta = joint id | (valid << 16)
   __device__ __forceinline__ int pack(int m) const { return m; }
@@ -149,6 +156,18 @@ struct StripArgs {
 constexpr int kKS = 128;
 __device__ __forceinline__ int ksw(int row, int slot) { return (row * 32 + (slot ^ row)) * 4; }   // float index
 
+// FP32-ACCURATE CONTRACTIONS ON THE BF16 MATRIX CORES (r05; the `BF16 == false` instantiations).  v_mfma_f32_16x16x4_f32 runs
+// at the fp32 VECTOR rate: the 32 of them a key tile's similarity needs are 1024 cycles per SIMD, 47 % of the critical
+// workgroups' time in r04 (profiles/r04_strip_phase_stamps.txt), and the gradient contraction takes 32 more.  Every fp32
+// operand is split once into bf16 pieces, x = hi + mid (+ 2^-16 |x|): hi = bf16(x), mid = bf16(x - hi); a product of two bf16
+// values is exact in the fp32 accumulator, so  x y = hi hi + hi mid + mid hi (+ mid mid)  carries ~2^-16 relative error per
+// PRODUCT but 2^-24-class error per SUM of 128 random-sign products (Policy::kTerms, error study above).  Per tile that is
+// 12 (16) v_mfma_f32_16x16x32_bf16 for the similarity (~17 cycles each) and 24 (32) v_mfma_f32_16x16x16_bf16 for G K.
+// The key tile is split ONCE per workgroup on its way into LDS (commit): two row-major bf16 planes [16 rows][128] for the
+// similarity (16-byte slot s of row r at slot s ^ r: conflict-free ds_read_b128); the second contraction's B operand -- key
+// index = reduction index -- is read out of the SAME planes with the LDS transpose read (ds_read_b64_tr_b16).  The query
+// fragments are split once per wave, the logit gradient G (four values per lane and tile) in registers.
+//
 // BF16 (BASELINE config 5, "bf16 feature-map GEMMs"): both contractions run on the bf16 matrix cores with
 // fp32 accumulation -- the similarity P = Q K^T as 4 x v_mfma_f32_16x16x32_bf16 per tile (32 fp32 MFMAs
 // otherwise) and the gradient contraction G K as 8 x v_mfma_f32_16x16x16_bf16 (32 otherwise).  Operands
@@ -182,7 +201,10 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   // SIMD's waves do not overlap -- their times ADD (removing either phase removes its full time; interleaving them
   // in the instruction stream, independent accumulators, conflict-free LDS strides each changed nothing).  The pass is
   // bounded by (MFMA + VALU) instruction time: fewer VALU instructions per element is the only lever left in fp32.
-  __shared__ __attribute__((aligned(16))) float sKb[3][16 * kKS];
+  // BF16: the fp32 tile (operands rounded on their way into the MFMA).  Split: hi / mid planes, row-major [2][16][128] bf16 = 8 KB.
+  constexpr int kBufFloats = BF16 ? 16 * kKS : 8192 / 4;
+  constexpr int kT = Policy::kTerms;
+  __shared__ __attribute__((aligned(16))) float sKb[3][kBufFloats];
   __shared__ int sMetaCb[3][16];
   __shared__ float sStatCb[3][16][3];
 
@@ -208,26 +230,20 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   const int row0 = blockIdx.x * 64 + wave * 16;  // first row of this wave's strip
   // A operand: lane (m = np, kslot = g) holds Q[row0+np][16j + 4g + e], j<8, e<4
   // (BF16: Q[row0+np][32j + 8g + e], j<4, e<8, rounded to bf16)
-  float4 qf[BF16 ? 1 : 8];
-  v8bf qh[BF16 ? 4 : 1];
+  // lane (m = np, kslot = g) holds Q[row0+np][32j + 8g + e], j<4, e<8, as bf16: rounded (BF16) or split into hi + mid
+  v8bf qh[4], qm[BF16 ? 1 : 4];
   {
     const int r = row0 + np;
-    if constexpr (BF16) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        if (r < S) {
-          lo = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g);
-          hi = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g + 4);
-        }
-        const v8f v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        qh[j] = __builtin_convertvector(v, v8bf);
+    for (int j = 0; j < 4; ++j) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (r < S) {
+        lo = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g);
+        hi = *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 32 * j + 8 * g + 4);
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        qf[j] = (r < S) ? *reinterpret_cast<const float4*>(Q + (int64_t)r * kC + 16 * j + 4 * g)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      const v8f v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      qh[j] = __builtin_convertvector(v, v8bf);
+      if constexpr (!BF16) qm[j] = __builtin_convertvector(v - __builtin_convertvector(qh[j], v8f), v8bf);
     }
   }
   // rows owned in the C layout: row0 + 4g + reg (stats pass: P = Q K^T) or row0 + np for every reg (grad pass: the
@@ -286,7 +302,19 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int e = threadIdx.x + h * kWG;
-      *reinterpret_cast<float4*>(&sKb[buf][ksw(e >> 5, e & 31)]) = kreg[h];
+      if constexpr (BF16) {
+        *reinterpret_cast<float4*>(&sKb[buf][ksw(e >> 5, e & 31)]) = kreg[h];
+      } else {
+        // split the four values once for the whole workgroup: hi = bf16(x), mid = bf16(x - hi)
+        const int rr = e >> 5, c4 = e & 31;
+        const v4f v = {kreg[h].x, kreg[h].y, kreg[h].z, kreg[h].w};
+        const v4bf hi = __builtin_convertvector(v, v4bf);
+        const v4bf mid = __builtin_convertvector(v - __builtin_convertvector(hi, v4f), v4bf);
+        char* base = reinterpret_cast<char*>(sKb[buf]);
+        const int o = rr * 256 + (((c4 >> 1) ^ rr) << 4) + ((c4 & 1) << 3);
+        *reinterpret_cast<v4bf*>(base + o) = hi;
+        *reinterpret_cast<v4bf*>(base + 4096 + o) = mid;
+      }
     }
     if (threadIdx.x < 16) {
       sMetaCb[buf][threadIdx.x] = mreg;
@@ -310,21 +338,27 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         else ap[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[j], __builtin_convertvector(kv, v8bf), ap[j], 0, 0, 0);
       }
     } else {
+      // split operands: the smallest terms go in first.  GRAD: A <-> B, the accumulator holds P^T, i.e. lane (np, g) reg q =
+      // P[row0 + np][c0 + 4g + q]
+      const char* base = reinterpret_cast<const char*>(sK);
+      v8bf kh[4], km[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 kb = *reinterpret_cast<const float4*>(&sK[ksw(np, 4 * j + g)]);
-        if (GRAD) {      // A <-> B: the accumulator holds P^T, i.e. lane (np, g) reg q = P[row0 + np][c0 + 4g + q]
-          ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.x, qf[j].x, ap[0], 0, 0, 0);
-          ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.y, qf[j].y, ap[1], 0, 0, 0);
-          ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.z, qf[j].z, ap[2], 0, 0, 0);
-          ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb.w, qf[j].w, ap[3], 0, 0, 0);
-        } else {
-          ap[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].x, kb.x, ap[0], 0, 0, 0);
-          ap[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].y, kb.y, ap[1], 0, 0, 0);
-          ap[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].z, kb.z, ap[2], 0, 0, 0);
-          ap[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j].w, kb.w, ap[3], 0, 0, 0);
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int o = np * 256 + (((4 * j + g) ^ np) << 4);
+        kh[j] = *reinterpret_cast<const v8bf*>(base + o);
+        km[j] = *reinterpret_cast<const v8bf*>(base + 4096 + o);
       }
+      // term-major issue order: the four accumulators take turns, so no MFMA waits for the one before it (a dependent
+      // v_mfma_f32_16x16x32_bf16 issues ~40 cycles after its producer, an independent one after ~17)
+#define HCM_TERM(QA, KB)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+      ap[j] = GRAD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(KB[j], QA[j], ap[j], 0, 0, 0)                           \
+                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA[j], KB[j], ap[j], 0, 0, 0)
+      if constexpr (kT >= 4) { HCM_TERM(qm, km); }
+      HCM_TERM(qh, km);
+      HCM_TERM(qm, kh);
+      HCM_TERM(qh, kh);
+#undef HCM_TERM
     }
   };
   v4f apn[4];                                       // similarity of the NEXT tile (in flight)
@@ -413,14 +447,33 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
                                                              dq[nt], 0, 0, 0);
         }
       } else {
+        // split: G = ghi + gmid in registers.  B[key 4g + i][channel 16nt + np], i < 4, comes out of the ROW-MAJOR planes through
+        // the LDS transpose read (ds_read_b64_tr_b16; tools/probes/tr16_probe.hip pins its gather: lane l receives, for i < 4,
+        // element (l & 3) of the 8-byte chunk that lane 4 i + ((l & 15) >> 2) of its 16-lane group points at): lane (np, g)
+        // points at key row 4g + (np >> 2), channels 16nt + 4 (np & 3) .. + 3.  (A first version kept transposed copies of
+        // the planes: their sixteen ds_write_b16 per thread and tile, 4-8 way conflicted, cost 700 cycles per tile.)
+        const v4f gv = {ga[0], ga[1], ga[2], ga[3]};
+        const v4bf gh4 = __builtin_convertvector(gv, v4bf);
+        const v4bf gm4 = __builtin_convertvector(gv - __builtin_convertvector(gh4, v4f), v4bf);
+        const v4s gh = __builtin_bit_cast(v4s, gh4), gm = __builtin_bit_cast(v4s, gm4);
+        typedef v4s __attribute__((address_space(3))) * lds_v4s;
+        const char* tb = reinterpret_cast<const char*>(sK);
+        const int trow = 4 * g + (np >> 2), tq = np & 3;
+        v4s th[8], tm[8];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-          for (int nt = 0; nt < 8; ++nt) {
-            const float bv = sK[ksw(4 * g + ks, 4 * nt + (np >> 2)) + (np & 3)];
-            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], bv, dq[nt], 0, 0, 0);
-          }
+        for (int nt = 0; nt < 8; ++nt) {
+          const int c4 = 4 * nt + tq;
+          const int o = trow * 256 + (((c4 >> 1) ^ trow) << 4) + ((c4 & 1) << 3);
+          th[nt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + o));
+          tm[nt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 4096 + o));
         }
+#define HCM_TERM2(GA, TB) \
+  _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) dq[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(GA, TB[nt], dq[nt], 0, 0, 0)
+        if constexpr (kT >= 4) { HCM_TERM2(gm, tm); }
+        HCM_TERM2(gh, tm);
+        HCM_TERM2(gm, th);
+        HCM_TERM2(gh, th);
+#undef HCM_TERM2
       }
     }
     HCM_TS(4);                                      // element-wise code (+ GEMM 2 issue in the grad pass)
@@ -674,156 +727,182 @@ __global__ __launch_bounds__(kWG) void scatter_rows_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// Row 6: joint <-> graph-node InfoNCE, one workgroup per image.
+// Row 6: joint <-> graph-node InfoNCE (learning/contrast_trainer.py:744-828).
+// r05: one workgroup per (image, MODALITY), 512 threads, and a finish kernel -- the r01 form ran one 256-thread workgroup per
+// image: 32 of 256 CUs, 39 us for 0.8 MB and 4.7 MFLOP, most of it two serial stretches (a J-long column softmax on 2 J
+// lanes, a 3 J x 128 gradient loop of 2 J fmas on four waves).  Now the two modalities of an image are independent until
+// the graph rows' gradient (sum of the two partials, formed and pushed through F.normalize by the finish kernel), the
+// softmax of column j is evaluated redundantly by the J threads (i, j) -- J LDS reads each, no serial lane --, and the
+// gradient loops are J fmas on eight waves.
 // ------------------------------------------------------------------------------------------
 constexpr int kJMax = 32;
-constexpr int kLS = kC + 1;  // LDS row stride
+constexpr int kLS = kC + 4;  // LDS row stride: 16-byte aligned rows (ds_read_b128), consecutive rows 4 banks apart
+constexpr int kJT = 512;     // threads of a joint workgroup
 
-__global__ __launch_bounds__(kWG) void joint_nce_kernel(
+__global__ __launch_bounds__(kJT) void joint_nce_kernel(
     const float* __restrict__ map1, const float* __restrict__ map2, MapView mv,
     const float* __restrict__ feat3, const int64_t* __restrict__ pix,
     const int32_t* __restrict__ vis, const int32_t* __restrict__ use_depth, int B, int J,
     float inv_tau, float* __restrict__ part /*[B][6]*/, float* __restrict__ dX /*[2][B*J][128]*/,
-    float* __restrict__ gfeat3) {
+    float* __restrict__ gpart /*[2][B*J][128]: d loss / d ghat, this modality's share*/) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sV = lds;                     // [3][J][kLS] unit rows: graph nodes, rgb joints, depth joints
-  float* sD = sV + 3 * J * kLS;        // [3][J][kLS] gradients wrt the unit rows
-  float* sA = sD + 3 * J * kLS;        // [2][J][J+1] logits -> logit gradients
-  float* sInv = sA + 2 * J * (J + 1);  // [3][J]
-  float* sRaw = sInv + 3 * J;          // [3][J] dot(d, vhat) scratch
-  __shared__ int sCnt[2];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sV = lds;                     // [2][J][kLS] unit rows: graph nodes, this modality's joints
+  float* sD = sV + 2 * J * kLS;        // [J][kLS] gradient wrt the modality's unit rows
+  float* sA = sD + J * kLS;            // [J][J+1] logits
+  float* sG = sA + J * (J + 1);        // [J][J+1] logit gradients
+  float* sInv = sG + J * (J + 1);      // [J] of the modality's rows
+  __shared__ int sCnt;
+  __shared__ float sRed[3][kJMax];
+  const int b = blockIdx.x, mm = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* map = mm == 0 ? map1 : map2;
 
-  if (tid == 0) { sCnt[0] = 0; sCnt[1] = 0; }
-  __syncthreads();
-  {  // global counts of valid targets (rgb: visible; depth: visible and use_depth)
-    int c0 = 0, c1 = 0;
-    for (int e = tid; e < B * J; e += kWG) {
-      const int v = vis[e] != 0;
-      c0 += v;
-      c1 += v && (use_depth == nullptr || use_depth[e / J] != 0);
+  if (tid == 0) sCnt = 0;
+  // 1. load + normalise 2 J rows, one wave per row.  A wave owns up to kRows rows; ALL their loads (pixel index, then the
+  //    two halves of the row) are issued before the first is used: the rows are independent, and a dependent pair of
+  //    global loads per round was 5 x ~2.5 us of this kernel's 20.
+  constexpr int kRows = 2 * kJMax / (kJT / 64);
+  int prow[kRows];
+  float x0[kRows], x1[kRows];
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int rr = wave + k * (kJT / 64);
+    prow[k] = (rr >= J && rr < 2 * J) ? (int)pix[(int64_t)b * J + (rr - J)] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int rr = wave + k * (kJT / 64);
+    x0[k] = 0.f; x1[k] = 0.f;
+    if (rr < J) {
+      x0[k] = feat3[((int64_t)b * J + rr) * kC + lane];
+      x1[k] = feat3[((int64_t)b * J + rr) * kC + lane + 64];
+    } else if (rr < 2 * J) {
+      x0[k] = map[mv.at(b, lane, prow[k])];
+      x1[k] = map[mv.at(b, lane + 64, prow[k])];
     }
-    if (c0) atomicAdd(&sCnt[0], c0);
-    if (c1) atomicAdd(&sCnt[1], c1);
   }
-  // 1. load + normalise 3J rows, one wave per row
-  for (int rr = wave; rr < 3 * J; rr += 4) {
-    const int which = rr / J, j = rr - which * J;
-    float x0, x1;
-    if (which == 0) {
-      x0 = feat3[((int64_t)b * J + j) * kC + lane];
-      x1 = feat3[((int64_t)b * J + j) * kC + lane + 64];
-    } else {
-      const float* map = which == 1 ? map1 : map2;
-      const int p = (int)pix[(int64_t)b * J + j];
-      x0 = map[mv.at(b, lane, p)];
-      x1 = map[mv.at(b, lane + 64, p)];
+  __syncthreads();                     // sCnt = 0 is visible
+  {  // global count of valid targets (rgb: visible; depth: visible and use_depth), underneath the row loads
+    int c0 = 0;
+    for (int e = tid; e < B * J; e += kJT)
+      c0 += (vis[e] != 0) && (mm == 0 || use_depth == nullptr || use_depth[e / J] != 0);
+    if (c0) atomicAdd(&sCnt, c0);
+  }
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    const int rr = wave + k * (kJT / 64);
+    if (rr < 2 * J) {                  // wave-uniform
+      const float nrm = sqrtf(wave_sum(fmaf(x0[k], x0[k], x1[k] * x1[k])));
+      const float den = fmaxf(nrm, 1e-12f);
+      sV[rr * kLS + lane] = x0[k] / den;
+      sV[rr * kLS + lane + 64] = x1[k] / den;
+      if (rr >= J && lane == 0) sInv[rr - J] = (nrm < 1e-12f) ? -1.f / den : 1.f / den;
     }
-    const float nrm = sqrtf(wave_sum(fmaf(x0, x0, x1 * x1)));
-    const float den = fmaxf(nrm, 1e-12f);
-    sV[(which * J + j) * kLS + lane] = x0 / den;
-    sV[(which * J + j) * kLS + lane + 64] = x1 / den;
-    if (lane == 0) sInv[which * J + j] = (nrm < 1e-12f) ? -1.f / den : 1.f / den;
   }
   __syncthreads();
-  const int cnt[2] = {sCnt[0], sCnt[1]};
-  // 2. logits A_m[i][j] = ghat_i . fhat_{m,j} / tau
-  for (int e = tid; e < 2 * J * J; e += kWG) {
-    const int mm = e / (J * J), i = (e / J) % J, j = e % J;
-    const float* gi = sV + i * kLS;
-    const float* fj = sV + ((1 + mm) * J + j) * kLS;
-    float d = 0.f;
-    for (int c = 0; c < kC; ++c) d = fmaf(gi[c], fj[c], d);
-    sA[(mm * J + i) * (J + 1) + j] = d * inv_tau;
+  const int cnt = sCnt;
+  // 2. logits A[i][j] = ghat_i . fhat_j / tau
+  for (int e = tid; e < J * J; e += kJT) {
+    const int i = e / J, j = e - i * J;
+    const float4* gi = reinterpret_cast<const float4*>(sV + i * kLS);
+    const float4* fj = reinterpret_cast<const float4*>(sV + (J + j) * kLS);
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < kC / 4; ++c) {
+      const float4 a = gi[c], f4 = fj[c];
+      d0 = fmaf(a.x, f4.x, d0); d1 = fmaf(a.y, f4.y, d1); d2 = fmaf(a.z, f4.z, d2); d3 = fmaf(a.w, f4.w, d3);
+    }
+    sA[i * (J + 1) + j] = ((d0 + d1) + (d2 + d3)) * inv_tau;
   }
   __syncthreads();
-  // 3. column softmax over nodes i, CE target j, arg-max; A <- dA
-  float lossnum = 0.f, ncorrect = 0.f, nvalid = 0.f;
-  if (tid < 2 * J) {
-    const int mm = tid / J, j = tid - mm * J;
-    float* col = sA + mm * J * (J + 1) + j;
+  // 3. column softmax over the nodes i, CE target j, arg-max (first maximum); every thread (i, j) walks its column
+  for (int e = tid; e < J * J; e += kJT) {
+    const int i = e / J, j = e - i * J;
+    const float* col = sA + j;
     float mx = -3.0e38f;
     int arg = 0;
-    for (int i = 0; i < J; ++i) {
-      const float v = col[i * (J + 1)];
-      if (v > mx) { mx = v; arg = i; }
+    for (int k = 0; k < J; ++k) {
+      const float v = col[k * (J + 1)];
+      if (v > mx) { mx = v; arg = k; }
     }
     float se = 0.f;
-    for (int i = 0; i < J; ++i) se += __expf(col[i * (J + 1)] - mx);
+    for (int k = 0; k < J; ++k) se += __expf(col[k * (J + 1)] - mx);
     const float lse = mx + __logf(se);
-    const bool valid = vis[(int64_t)b * J + j] != 0 &&
-                       (mm == 0 || use_depth == nullptr || use_depth[b] != 0);
-    const float diag = col[j * (J + 1)];
-    if (valid) {
-      lossnum = lse - diag;
-      ncorrect = (arg == j) ? 1.f : 0.f;
-      nvalid = 1.f;
-    }
-    const float sc = (valid && cnt[mm] > 0) ? 1.f / (float)cnt[mm] : 0.f;
-    for (int i = 0; i < J; ++i) {
-      const float pr = __expf(col[i * (J + 1)] - lse);
-      col[i * (J + 1)] = (pr - (i == j ? 1.f : 0.f)) * sc;
-    }
-  }
-  // per-image partial sums (fixed order): lanes 0..J-1 -> rgb, J..2J-1 -> depth
-  {
-    __shared__ float sRed[3][2 * kJMax];
-    if (tid < 2 * J) { sRed[0][tid] = lossnum; sRed[1][tid] = ncorrect; sRed[2][tid] = nvalid; }
-    __syncthreads();
-    if (tid < 6) {
-      const int mm = tid & 1, what = tid >> 1;
-      float s = 0.f;
-      for (int j = 0; j < J; ++j) s += sRed[what][mm * J + j];
-      part[(int64_t)b * 6 + what * 2 + mm] = s;
+    const bool valid = vis[(int64_t)b * J + j] != 0 && (mm == 0 || use_depth == nullptr || use_depth[b] != 0);
+    const float sc = (valid && cnt > 0) ? 1.f / (float)cnt : 0.f;
+    const float pr = __expf(col[i * (J + 1)] - lse);
+    sG[i * (J + 1) + j] = (pr - (i == j ? 1.f : 0.f)) * sc;
+    if (i == 0) {
+      sRed[0][j] = valid ? lse - col[j * (J + 1)] : 0.f;
+      sRed[1][j] = (valid && arg == j) ? 1.f : 0.f;
+      sRed[2][j] = valid ? 1.f : 0.f;
     }
   }
   __syncthreads();
-  // 4. gradients wrt the unit rows
-  for (int e = tid; e < 3 * J * kC; e += kWG) {
-    const int which = e / (J * kC), r = (e / kC) % J, c = e % kC;
-    float d = 0.f;
-    if (which == 0) {  // d ghat[i=r] = sum_m sum_j dA_m[i][j] fhat_m[j]
-      for (int mm = 0; mm < 2; ++mm)
-        for (int j = 0; j < J; ++j)
-          d = fmaf(sA[(mm * J + r) * (J + 1) + j], sV[((1 + mm) * J + j) * kLS + c], d);
-    } else {           // d fhat_m[j=r] = sum_i dA_m[i][j] ghat[i]
-      const int mm = which - 1;
-      for (int i = 0; i < J; ++i) d = fmaf(sA[(mm * J + i) * (J + 1) + r], sV[i * kLS + c], d);
+  if (tid < 3) {      // per-image partial sums in column order
+    float sum = 0.f;
+    for (int j = 0; j < J; ++j) sum += sRed[tid][j];
+    part[(int64_t)b * 6 + tid * 2 + mm] = sum;
+  }
+  // 4. gradients wrt the unit rows: d fhat[j] = sum_i dA[i][j] ghat[i]  (LDS, then F.normalize's backward);
+  //    this modality's share of d ghat[i] = sum_j dA[i][j] fhat[j]       (straight to global memory)
+  for (int e = tid; e < 2 * J * (kC / 4); e += kJT) {          // four channels per thread: one 16-byte LDS read per term
+    const int which = e / (J * (kC / 4)), r = (e / (kC / 4)) % J, c = (e % (kC / 4)) * 4;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (which == 0) {
+      for (int jj = 0; jj < J; ++jj)
+        fma4(d, sG[r * (J + 1) + jj], *reinterpret_cast<const float4*>(sV + (J + jj) * kLS + c));
+      scale4(d, inv_tau);
+      *reinterpret_cast<float4*>(gpart + ((int64_t)mm * B * J + (int64_t)b * J + r) * kC + c) = d;
+    } else {
+      for (int ii = 0; ii < J; ++ii)
+        fma4(d, sG[ii * (J + 1) + r], *reinterpret_cast<const float4*>(sV + ii * kLS + c));
+      scale4(d, inv_tau);
+      *reinterpret_cast<float4*>(sD + r * kLS + c) = d;
     }
-    sD[(which * J + r) * kLS + c] = d * inv_tau;
   }
   __syncthreads();
-  // 5. normalize backward, one wave per row
-  for (int rr = wave; rr < 3 * J; rr += 4) {
-    const int which = rr / J, j = rr - which * J;
-    const float v0 = sV[rr * kLS + lane], v1 = sV[rr * kLS + lane + 64];
-    const float d0 = sD[rr * kLS + lane], d1 = sD[rr * kLS + lane + 64];
+  // 5. normalize backward of the modality's rows, one wave per row
+  for (int j = wave; j < J; j += kJT / 64) {
+    const float v0 = sV[(J + j) * kLS + lane], v1 = sV[(J + j) * kLS + lane + 64];
+    const float d0 = sD[j * kLS + lane], d1 = sD[j * kLS + lane + 64];
     const float dot = wave_sum(fmaf(d0, v0, d1 * v1));
-    const float inv = sInv[rr];
-    const float o0 = inv < 0.f ? d0 * (-inv) : (d0 - dot * v0) * inv;
-    const float o1 = inv < 0.f ? d1 * (-inv) : (d1 - dot * v1) * inv;
-    float* dst = which == 0 ? gfeat3 + ((int64_t)b * J + j) * kC
-                            : dX + ((int64_t)(which - 1) * B * J + (int64_t)b * J + j) * kC;
-    dst[lane] = o0;
-    dst[lane + 64] = o1;
+    const float inv = sInv[j];
+    float* dst = dX + ((int64_t)mm * B * J + (int64_t)b * J + j) * kC;
+    dst[lane] = inv < 0.f ? d0 * (-inv) : (d0 - dot * v0) * inv;
+    dst[lane + 64] = inv < 0.f ? d1 * (-inv) : (d1 - dot * v1) * inv;
   }
-  (void)sRaw;
 }
 
-// out4 = {loss_rgb, loss_d, acc_rgb, acc_d}.  An empty target set gives 0/0 = NaN like
+// One wave per graph row: d ghat = the two modalities' shares (rgb first), pushed through F.normalize; block 0 also
+// reduces the per-image partial sums: out4 = {loss_rgb, loss_d, acc_rgb, acc_d}.  An empty target set gives 0/0 = NaN like
 // nn.CrossEntropyLoss; accuracy averages ncorrect/nvalid over images with nvalid > 0 (:812-822).
-__global__ void joint_finish_kernel(const float* __restrict__ part, int B, float* __restrict__ out4) {
-  const int mm = threadIdx.x;
-  if (mm >= 2) return;
-  float lsum = 0.f, cnt = 0.f, accsum = 0.f, nimg = 0.f;
-  for (int b = 0; b < B; ++b) {
-    lsum += part[b * 6 + 0 + mm];
-    const float nv = part[b * 6 + 4 + mm];
-    cnt += nv;
-    if (nv > 0.f) { accsum += part[b * 6 + 2 + mm] / nv; nimg += 1.f; }
+__global__ __launch_bounds__(kWG) void joint_finish_kernel(const float* __restrict__ part, const float* __restrict__ gpart,
+                                                           const float* __restrict__ feat3, int B, int J,
+                                                           float* __restrict__ out4, float* __restrict__ gfeat3) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    const int mm = threadIdx.x;
+    float lsum = 0.f, cnt = 0.f, accsum = 0.f, nimg = 0.f;
+    for (int b = 0; b < B; ++b) {
+      lsum += part[b * 6 + 0 + mm];
+      const float nv = part[b * 6 + 4 + mm];
+      cnt += nv;
+      if (nv > 0.f) { accsum += part[b * 6 + 2 + mm] / nv; nimg += 1.f; }
+    }
+    out4[mm] = lsum / cnt;
+    out4[2 + mm] = accsum / nimg;
   }
-  out4[mm] = lsum / cnt;
-  out4[2 + mm] = accsum / nimg;
+  if (row >= B * J) return;
+  const float x0 = feat3[(int64_t)row * kC + lane], x1 = feat3[(int64_t)row * kC + lane + 64];
+  const float nrm = sqrtf(wave_sum(fmaf(x0, x0, x1 * x1)));
+  const float den = fmaxf(nrm, 1e-12f);
+  const float v0 = x0 / den, v1 = x1 / den;
+  const int64_t o = (int64_t)row * kC, o2 = ((int64_t)B * J + row) * kC;
+  const float d0 = gpart[o + lane] + gpart[o2 + lane], d1 = gpart[o + lane + 64] + gpart[o2 + lane + 64];
+  const float dot = wave_sum(fmaf(d0, v0, d1 * v1));
+  gfeat3[o + lane] = nrm < 1e-12f ? d0 / den : (d0 - dot * v0) / den;
+  gfeat3[o + lane + 64] = nrm < 1e-12f ? d1 / den : (d1 - dot * v1) / den;
 }
 
 __global__ void joint_pixels_kernel(const float* __restrict__ j2d, int n, int h,
@@ -1264,7 +1343,7 @@ SclWs carve_scl(void* ws, int B, int J) {
   return o;
 }
 struct JointWs {
-  float *part, *dX;
+  float *part, *dX, *gpart;
   size_t bytes;
 };
 JointWs carve_joint(void* ws, int B, int J) {
@@ -1272,6 +1351,7 @@ JointWs carve_joint(void* ws, int B, int J) {
   JointWs o;
   o.part = c.take<float>((size_t)B * 6);
   o.dX = c.take<float>((size_t)2 * B * J * kC);
+  o.gpart = c.take<float>((size_t)2 * B * J * kC);
   o.bytes = c.off;
   return o;
 }
@@ -1471,14 +1551,16 @@ int hcm_joint_nce(const float* map1, const float* map2, hcm_strides4 st, int B, 
   if (workspace == nullptr || workspace_bytes < ws.bytes) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const MapView mv = view(st, w);
-  const size_t lds = (size_t)(6 * J * kLS + 2 * J * (J + 1) + 6 * J) * sizeof(float);
+  const size_t lds = (size_t)(3 * J * kLS + 2 * J * (J + 1) + J) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(joint_nce_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  joint_nce_kernel<<<B, kWG, lds, s>>>(map1, map2, mv, feat3, pix, joints_vis, use_depth, B, J,
-                                       (float)(1.0 / (double)temperature), ws.part, ws.dX, gfeat3);
+  ProfSpan span(HCM_PROF_JOINT, s);
+  joint_nce_kernel<<<dim3(B, 2), kJT, lds, s>>>(map1, map2, mv, feat3, pix, joints_vis, use_depth, B, J,
+                                                (float)(1.0 / (double)temperature), ws.part, ws.dX, ws.gpart);
   HCM_CHECK_LAUNCH();
-  joint_finish_kernel<<<1, 64, 0, s>>>(ws.part, B, out4);
+  joint_finish_kernel<<<(B * J + 3) / 4, kWG, 0, s>>>(ws.part, ws.gpart, feat3, B, J, out4, gfeat3);
+  span.stop();
   HCM_CHECK_LAUNCH();
   const int rows = B * J;
   scatter_rows_kernel<<<dim3((rows + 3) / 4, 2), kWG, 0, s>>>(ws.dX, pix, J, rows, nullptr, mv,

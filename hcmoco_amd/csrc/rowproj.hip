@@ -725,8 +725,10 @@ int launch_project(const Maps8& e, int nmod, int B, const int64_t* pix, int R, i
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(project_rows_kernel<KS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (err != hipSuccess) return (int)err;
+  hcm::ProfSpan span(HCM_PROF_ROW8_FWD, s);
   project_rows_kernel<KS><<<dim3(best, B, nmod), kPW, bytes, s>>>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows,
                                                              per, off2, off3);
+  span.stop();
   HCM_CHECK_LAUNCH();
   return 0;
 }
@@ -778,9 +780,11 @@ int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale,
   rpc = (rpc + 3) & ~3;
   const int ncg = (ld + kNT * 16 - 1) / (kNT * 16);
   float* part = static_cast<float*>(workspace);
+  hcm::ProfSpan span(HCM_PROF_ROW8_DW, s);
   proj_dw_partial_kernel<<<dim3(nchunk, ncg, nmod), kDW, 0, s>>>(grows, xs, M, ld, rpc, part);
   HCM_CHECK_LAUNCH();
   proj_dw_reduce_kernel<<<dim3((kF * ld + 255) / 256, nmod), 256, 0, s>>>(part, nchunk, ld, Ctot, scale, dWp1, dbp1, dWp2, dbp2);
+  span.stop();
   HCM_CHECK_LAUNCH();
   return 0;
 }
@@ -849,8 +853,10 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
     const int rc = hcm_project_rows_dw(grows, xs, scale, B, R, Ctot, F, dWp1, dbp1, dWp2, dbp2, workspace, dwb, stream);
     if (rc != 0) return rc;
   }
+  hcm::ProfSpan span(HCM_PROF_ROW8_BWD, s);
   branch_grad_t_kernel<<<dim3(v, B, nmod), kGW, 0, s>>>(grows, Wp1, nmod == 2 ? Wp2 : Wp1, dpooled, scale, ent, off, R, B, Ctot,
                                                         pack8(g1, nmod == 2 ? g2 : g1), tp, gm);
+  span.stop();
   HCM_CHECK_LAUNCH();
   return 0;
 }

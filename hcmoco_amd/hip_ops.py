@@ -179,7 +179,7 @@ def prof_enable(on):
 
 
 PROF_TAGS = {'bank_pass': 0, 'dense_stats': 1, 'dense_grad': 2, 'scl_stats': 3, 'scl_grad': 4, 'sgc_fwd': 5,
-             'sgc_bwd': 6}
+             'sgc_bwd': 6, 'row8_fwd': 7, 'row8_dw': 8, 'row8_bwd': 9, 'joint': 10}
 
 
 def prof_read(tag='bank_pass'):

@@ -607,6 +607,10 @@ int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2, 
 #define HCM_PROF_SCL_GRAD 4     /* strip_kernel<Scl, grad> (+ its chunk merge)                */
 #define HCM_PROF_SGC_FWD 5      /* the kernels of hcm_sgc_forward                             */
 #define HCM_PROF_SGC_BWD 6      /* the kernels of hcm_sgc_backward                            */
+#define HCM_PROF_ROW8_FWD 7     /* project_rows_kernel of hcm_project_rows                     */
+#define HCM_PROF_ROW8_DW 8      /* proj_dw_partial + proj_dw_reduce of hcm_project_rows_dw     */
+#define HCM_PROF_ROW8_BWD 9     /* branch_grad_t_kernel of hcm_project_rows_backward           */
+#define HCM_PROF_JOINT 10       /* the kernels of hcm_joint_nce                                */
 int hcm_prof_enable(int enable);
 int hcm_prof_read(double* total_ms_host, int64_t* launches_host);
 int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host);
