@@ -293,6 +293,19 @@ class FailSafe(object):
     def report(self, msg):
         """Called by the rank that caught an exception."""
         if self.rank == 0:
+            # a peer's failure usually reaches rank 0 twice -- as the peer's note in the store and as a transport error
+            # of rank 0's own next collective -- in either order: give the note a moment, the cause goes first in the line
+            if self.store is not None and self.world > 1:
+                t_end = time.monotonic() + 3.0
+                while time.monotonic() < t_end and not self.printed:
+                    try:
+                        hit = [k for k in ('hcm_bench_error/%d' % r_ for r_ in range(1, self.world)) if self.store.check([k])]
+                    except Exception:         # noqa: BLE001
+                        break
+                    if hit:
+                        msg = '%s: %s || rank 0 then saw: %s' % (hit[0], self.store.get(hit[0]).decode(errors='replace'), msg)
+                        break
+                    time.sleep(0.1)
             self.emit(msg)
             return
         if self.store is not None:
@@ -374,8 +387,8 @@ def main():
     ap.add_argument('--cpu_baseline_worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu_budget_s', type=float, default=20.0)
     ap.add_argument('--cpu_max_steps', type=int, default=10, help=argparse.SUPPRESS)
-    ap.add_argument('--channels_last', type=int, default=int(os.environ.get('HCMOCO_CHANNELS_LAST', '0')))
-    ap.add_argument('--miopen_find', type=int, default=int(os.environ.get('HCMOCO_MIOPEN_FIND', '0')))
+    ap.add_argument('--channels_last', type=int, default=0, help=argparse.SUPPRESS)     # r01 experiment; refused with the encoder runtime
+    ap.add_argument('--miopen_find', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--arch', type=str, default='HRNet', choices=['HRNet', 'HRNetPN'],
                     help='HRNetPN = BASELINE config 4 (PointNet++ depth encoder); not the headline config')
     ap.add_argument('--width', type=int, default=18, choices=[18, 32, 48])

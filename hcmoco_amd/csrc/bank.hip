@@ -42,10 +42,6 @@ enum Mode { kFused = 0, kLogitsFwd = 1, kLogitsBwd = 2 };
 __device__ __constant__ const int kPairBank[6] = {1, 0, 2, 1, 2, 0};
 
 __host__ __device__ inline int rows_per_wg(int B, int K1) {
-#ifndef __HIP_DEVICE_COMPILE__
-  static const int forced = getenv("HCM_BANK_ROWS") ? atoi(getenv("HCM_BANK_ROWS")) : 0;
-  if (forced > 0) return forced;
-#endif
   // 512 rows = 32 iterations per stream: the prologue (first gathered rows: a full HBM round trip) and the merge are
   // amortised over twice the work of r02's 256 -- the lever the r03 sweep found: in the training step 0.1244-0.1266 ms
   // against 0.1279-0.1297 ms (0.80-0.81 of the 8 TB/s peak against 0.78-0.79), 5.92 against 5.58 TB/s with 1.6 GB of banks
@@ -333,240 +329,6 @@ __global__ __launch_bounds__(kWG, MINW) void bank_pass_kernel(
       }
     } else {
       out = lds_acc[0][p][col] + lds_acc[1][p][col] + lds_acc[2][p][col] + lds_acc[3][p][col];
-    }
-    part_acc[(pbase + p) * D + col] = out;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Pass 1, LDS-DMA form of the fused mode (D = 128): the gathered rows travel global -> LDS by
-// global_load_lds_dwordx4 instead of through a register ring.  tools/probes/gather_ceiling.hip (r03) measures what the
-// part gives THIS access pattern with nothing else in the way: with 1.6 GB of banks (HBM-resident) a register ring
-// lands anywhere between 5.8 and 6.5 TB/s depending on depth and geometry, the DMA form sits at 6.56-6.63 TB/s
-// whatever its depth (streaming copy on the same box: 6.2) -- the loads of a DMA stage cost no VGPRs, so the wave keeps
-// its occupancy, and the request stream is not paced by the consumer's s_waitcnt pattern.
-//   * a STAGE = the 4 row triples one wave consumes per iteration (its four 16-lane DPP rows): fp32 6 DMA
-//     instructions (one instruction = 64 lanes x 16 B = two 512-byte rows of one bank: lanes 0-31 the first row, 32-63
-//     the second), bf16 3 instructions (four 256-byte rows each).  The LDS image is lane-linear per instruction, as the
-//     DMA requires (wave-uniform base + lane * 16); the consumer reads its own row with ds_read_b128.
-//   * GL stages per wave in flight (LDS ring private to the wave: no barrier in the loop); the oldest stage has landed
-//     when at most (GL - 1) x 6 (3) DMA instructions are outstanding -> counted s_waitcnt vmcnt(N).  Nothing else of the
-//     loop touches the vector-memory counter: the row indices come by SCALAR loads (they are wave-uniform), the
-//     positive's logits are kept in registers until after the loop.
-//   * the merge of the four waves re-uses the ring's LDS.
-// ---------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void wait_vm() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | (((N >> 4) & 0x3) << 14));      // expcnt / lgkmcnt left alone
-}
-template <int PER> __device__ __forceinline__ void wait_stages(int outstanding) {   // stages that may stay in flight
-  switch (outstanding) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<PER>(); break;
-    case 2: wait_vm<2 * PER>(); break;
-    case 3: wait_vm<3 * PER>(); break;
-    case 4: wait_vm<4 * PER>(); break;
-    default: wait_vm<5 * PER>(); break;
-  }
-}
-
-// (fp32 fits 168 VGPRs = three waves per SIMD without a spill; bf16 needs 176 -- and a spill would put scratch
-// traffic on the vector-memory counter the DMA waits count on -- so it stays at two.)
-template <class T, int GL>
-__global__ __launch_bounds__(kWG, sizeof(T) == 4 ? 3 : 2) void bank_pass_glds_kernel(
-    const T* __restrict__ b1, const T* __restrict__ b2, const T* __restrict__ b3,
-    const int64_t* __restrict__ idx, const float* __restrict__ x1, const float* __restrict__ x2,
-    const float* __restrict__ x3, int B, int K1, int R, float scale, float* __restrict__ part_m,
-    float* __restrict__ part_s, float* __restrict__ part_acc, float* __restrict__ l0_out) {
-  constexpr int NV = 2, D = 128;
-  constexpr bool kBf = sizeof(T) == 2;
-  constexpr int PER = kBf ? 3 : 6;                          // DMA instructions per stage
-  constexpr int kStage = 3 * 4 * D * (int)sizeof(T);        // bytes: 4 rows x 3 banks
-  static_assert(GL >= 2 && GL <= 6, "ring depth");
-  extern __shared__ __attribute__((aligned(16))) char ring_raw[];
-  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int t = lane & 15, g = lane >> 4;
-  const int s = wave * 4 + g;
-  const int kbeg = chunk * R;
-  const int kend = min(K1, kbeg + R);
-  const int niter = (kend - kbeg + kStreams - 1) / kStreams;
-  const int64_t* __restrict__ idxb = idx + (int64_t)b * K1;
-  char* wring = ring_raw + (size_t)wv * GL * kStage;
-
-  float4 xq[3][NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    xq[0][v] = *reinterpret_cast<const float4*>(x1 + (int64_t)b * D + colbase<T>(t, v));
-    xq[1][v] = *reinterpret_cast<const float4*>(x2 + (int64_t)b * D + colbase<T>(t, v));
-    xq[2][v] = *reinterpret_cast<const float4*>(x3 + (int64_t)b * D + colbase<T>(t, v));
-  }
-  float m[6], ssum[6], l0[6];
-  float4 acc[6][NV];
-#pragma unroll
-  for (int p = 0; p < 6; ++p) {
-    m[p] = kNegBig;
-    ssum[p] = 0.f;
-    l0[p] = 0.f;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) acc[p][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  wait_vm<0>();                                            // the query loads are done: only DMA counts from here on
-
-  // rows of iteration `it` for THIS wave: k = kbeg + 16 it + 4 wave + j, j = 0..3 (wave-uniform -> scalar loads)
-  auto issue = [&](int slot, int it) {
-    const int k0 = kbeg + it * kStreams + wv * 4;
-    int64_t r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = (k0 + j < kend) ? idxb[k0 + j] : (int64_t)0;
-    char* dst = wring + slot * kStage;
-    if constexpr (!kBf) {
-      const int half = lane >> 5;
-      const int64_t colb = (int64_t)(lane & 31) * 16;
-      const int64_t ra = (half ? r[1] : r[0]) * (D * 4) + colb, rb_ = (half ? r[3] : r[2]) * (D * 4) + colb;
-      const char* p1 = reinterpret_cast<const char*>(b1);
-      const char* p2 = reinterpret_cast<const char*>(b2);
-      const char* p3 = reinterpret_cast<const char*>(b3);
-      __builtin_amdgcn_global_load_lds(p1 + ra, (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(p1 + rb_, (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(p2 + ra, (__attribute__((address_space(3))) void*)(dst + 2048), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(p2 + rb_, (__attribute__((address_space(3))) void*)(dst + 3072), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(p3 + ra, (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(p3 + rb_, (__attribute__((address_space(3))) void*)(dst + 5120), 16, 0, 0);
-    } else {
-      const int64_t rr = (g == 0 ? r[0] : (g == 1 ? r[1] : (g == 2 ? r[2] : r[3]))) * (D * 2) + (int64_t)t * 16;
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(b1) + rr, (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(b2) + rr, (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(b3) + rr, (__attribute__((address_space(3))) void*)(dst + 2048), 16, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int j = 0; j < GL; ++j)
-    if (j < niter) issue(j, j);
-
-  int slot = 0;
-  for (int it = 0; it < niter; ++it) {
-    const int ahead = min(GL - 1, niter - 1 - it);          // stages issued after stage `it`
-    wait_stages<PER>(ahead);
-    Row3<NV> cur;
-    const char* src = wring + slot * kStage;
-    if constexpr (!kBf) {
-      // row g of the stage: instruction (bank, g >> 1) holds it in its half (g & 1); lane t owns floats [4t,4t+4), [64+4t,..)
-      const char* rowp = src + (g >> 1) * 1024 + (g & 1) * 512 + t * 16;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        cur.v[c][0] = *reinterpret_cast<const float4*>(rowp + c * 2048);
-        cur.v[c][1] = *reinterpret_cast<const float4*>(rowp + c * 2048 + 256);
-      }
-    } else {
-      const char* rowp = src + lane * 16;                   // exactly the slot this lane's DMA wrote
-      Packed<bf16_t, 2> pk;
-      pk.q[0] = *reinterpret_cast<const uint4*>(rowp);
-      pk.q[1] = *reinterpret_cast<const uint4*>(rowp + 1024);
-      pk.q[2] = *reinterpret_cast<const uint4*>(rowp + 2048);
-      unpack(pk, cur);
-    }
-    // the LDS reads must have returned before the slot is handed back to the DMA engine
-    __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0), vmcnt / expcnt left alone
-    if (it + GL < niter) issue(slot, it + GL);
-    slot = slot + 1 == GL ? 0 : slot + 1;
-
-    const int k = kbeg + it * kStreams + s;
-    const bool valid = k < kend;
-    float d[6];
-    d[1] = dotv<NV>(xq[1], cur.v[0]);  // x2 . M1
-    d[5] = dotv<NV>(xq[2], cur.v[0]);  // x3 . M1
-    d[0] = dotv<NV>(xq[0], cur.v[1]);  // x1 . M2
-    d[3] = dotv<NV>(xq[2], cur.v[1]);  // x3 . M2
-    d[2] = dotv<NV>(xq[1], cur.v[2]);  // x2 . M3
-    d[4] = dotv<NV>(xq[0], cur.v[2]);  // x1 . M3
-#pragma unroll
-    for (int p = 0; p < 6; ++p) d[p] = row16_sum(d[p]) * scale;
-    if (k == 0) {
-#pragma unroll
-      for (int p = 0; p < 6; ++p) l0[p] = d[p];
-    }
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-      const float l = valid ? d[p] : kInvalid;
-      if (__any(l > m[p])) {
-        const float mn = fmaxf(m[p], l);
-        const float a = fast_exp2(m[p] - mn);
-        ssum[p] *= a;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) scale4(acc[p][v], a);
-        m[p] = mn;
-      }
-      const float pr = fast_exp2(l - m[p]);
-      ssum[p] += pr;
-      const int c = (p == 1 || p == 5) ? 0 : ((p == 0 || p == 3) ? 1 : 2);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) fma4(acc[p][v], pr, cur.v[c][v]);
-    }
-  }
-  if (chunk == 0 && s == 0 && t == 0) {                    // the positive is row k = 0: stream 0 of chunk 0
-#pragma unroll
-    for (int p = 0; p < 6; ++p) l0_out[b * 6 + p] = l0[p];
-  }
-
-  // ---- merge the 4 lane-rows of the wave (lanes ^16, ^32) ----
-#pragma unroll
-  for (int p = 0; p < 6; ++p) {
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const float mo = __shfl_xor(m[p], off, 64);
-      const float so = __shfl_xor(ssum[p], off, 64);
-      const float mn = fmaxf(m[p], mo);
-      const float a = fast_exp2(m[p] - mn);
-      const float bs = fast_exp2(mo - mn);
-      ssum[p] = ssum[p] * a + so * bs;
-      m[p] = mn;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        float4 o;
-        o.x = __shfl_xor(acc[p][v].x, off, 64);
-        o.y = __shfl_xor(acc[p][v].y, off, 64);
-        o.z = __shfl_xor(acc[p][v].z, off, 64);
-        o.w = __shfl_xor(acc[p][v].w, off, 64);
-        acc[p][v].x = acc[p][v].x * a + o.x * bs;
-        acc[p][v].y = acc[p][v].y * a + o.y * bs;
-        acc[p][v].z = acc[p][v].z * a + o.z * bs;
-        acc[p][v].w = acc[p][v].w * a + o.w * bs;
-      }
-    }
-  }
-
-  // ---- merge the 4 waves through LDS (the ring's memory: every wave is past its last stage), one partial per workgroup ----
-  __syncthreads();
-  float (*lds_acc)[6][D] = reinterpret_cast<float (*)[6][D]>(ring_raw);                      // [4][6][D]
-  float (*lds_m)[6] = reinterpret_cast<float (*)[6]>(ring_raw + 4 * 6 * D * sizeof(float));  // [4][6]
-  float (*lds_s)[6] = lds_m + 4;
-  if (g == 0) {
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v)
-        *reinterpret_cast<float4*>(&lds_acc[wave][p][colbase<T>(t, v)]) = acc[p][v];
-      if (t == 0) {
-        lds_m[wave][p] = m[p];
-        lds_s[wave][p] = ssum[p];
-      }
-    }
-  }
-  __syncthreads();
-  const int64_t pbase = ((int64_t)b * nchunks + chunk) * 6;
-  for (int e = threadIdx.x; e < 6 * D; e += kWG) {
-    const int p = e / D, col = e - p * D;
-    const float M = fmaxf(fmaxf(lds_m[0][p], lds_m[1][p]), fmaxf(lds_m[2][p], lds_m[3][p]));
-    float sc[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) sc[w] = fast_exp2(lds_m[w][p] - M);
-    const float out = lds_acc[0][p][col] * sc[0] + lds_acc[1][p][col] * sc[1] + lds_acc[2][p][col] * sc[2] +
-                      lds_acc[3][p][col] * sc[3];
-    if (col == 0) {
-      part_m[pbase + p] = M;
-      part_s[pbase + p] = lds_s[0][p] * sc[0] + lds_s[1][p] * sc[1] + lds_s[2][p] * sc[2] + lds_s[3][p] * sc[3];
     }
     part_acc[(pbase + p) * D + col] = out;
   }
@@ -945,66 +707,17 @@ int fused_impl(const T* bank1, const T* bank2, const T* bank3, const int64_t* id
   dim3 grid(nch, B);
   hcm::ProfSpan span(HCM_PROF_BANK_PASS, st);  // brackets the dominant kernel only
   if (D == 128) {
-    static const int variant = getenv("HCM_BANK_VARIANT") ? atoi(getenv("HCM_BANK_VARIANT")) : 0;
-#define HCM_LAUNCH_PASS(NPF, MINW)                                                                   \
-  bank_pass_kernel<T, 2, kFused, NPF, MINW><<<grid, kWG, 0, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, \
-                                                                  nullptr, B, K1, R, scale2, ws.part_m, \
-                                                                  ws.part_s, ws.part_acc, ws.l0, nullptr)
-    // prefetch depth (row triples in flight per stream).  Measured (tools/tune_bank.py and the
-    // in-bench hipEvents): fp32 3 > 2 > 1 (0.129 / 0.137 / 0.159 ms on the same box), bf16 best at 4;
-    // depth 4+ for fp32 drops to one wave per SIMD and loses.  HCM_BANK_VARIANT overrides for tuning.
-#define HCM_LAUNCH_GLDS(GL)                                                                           \
-  do {                                                                                                  \
-    const size_t ring = (size_t)4 * GL * 3 * 4 * 128 * sizeof(T);                                        \
-    const size_t merge = (size_t)(4 * 6 * 128 + 2 * 4 * 6) * sizeof(float);                              \
-    const size_t ldsb = ring > merge ? ring : merge;                                                     \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(bank_pass_glds_kernel<T, GL>),                     \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);                          \
-    bank_pass_glds_kernel<T, GL><<<grid, kWG, ldsb, st>>>(bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R, \
-                                                         scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0); \
-  } while (0)
-    // variants 1-6: register ring of that depth; 12 / 13 / 14 / 16: LDS-DMA ring of 2 / 3 / 4 / 6 stages; 25 / 26 (r04): ring 5 / 6
-    // with __launch_bounds__(256, 2).  r03 compiled ring 6 without an occupancy floor: the compiler took > 256 registers and
-    // the kernel ran one wave per SIMD (2.9-3.9 TB/s).  Held to 256 registers it needs 252, spills nothing, and carries 18 KB
-    // per wave in flight -- the fp32 variant's amount -- at two waves per SIMD: bf16 default since r04 (+3-7 % over ring 4 on
-    // HBM-resident banks, +7-10 % at K = 131072; tools/probes/bf16_variants.sh, profiles/r04_bf16_variants.txt).
-    // Also built and measured in r04, then removed: a 32-lanes-per-row bf16 kernel (8-byte loads, half the accumulator /
-    // query registers, rings of 12-20 stages = up to 240 KB per CU in flight, v_permlane16_swap for the 32-lane sums):
-    // 2.9-3.3 TB/s on the same cells, WORSE with every deeper ring -- the bf16 pass is bound by instruction issue (the
-    // softmax bookkeeping per row, twice as often per byte as in fp32), not by bytes in flight.
-    // Defaults (r03 sweep, profiles/r03_bank_pass_sweep.json): the register ring -- depth 3 for fp32, 4 for bf16 -- with
-    // 512 rows per workgroup.  The DMA form was built to lift the HBM-resident case and does, at equal geometry (1.6 GB of
-    // banks, 256 rows: 5.73 vs 5.58 TB/s; K = 65536: 6.29 vs 6.19), but the longer streams help the register ring more
-    // (5.92 TB/s at K = 16384 / 1.6 GB, 0.80-0.81 of peak inside the training step) and the DMA form not at all; a bf16
-    // stage is only 3 KB and the DMA form loses 7-10 % there.  It stays selectable for the large-K / large-bank regime.
-    // r04: the bf16 default is the instruction-lean kernel of csrc/bank_lean.hip at ring depth 4 (variant 34): 5.66 / 5.05 /
-    // 5.76 TB/s on the HBM-resident cells (1M rows K=16384, 4M rows K=16384, 4M rows K=65536) against 4.30 / 4.18 / 4.65 for
-    // variant 26, 7.58 against 5.68 at K = 131072; its rings 5 and 6 spill at two waves per SIMD and lose.
-    // fp32: the lean kernel at ring depth 2 (variant 32): 6.22 / 5.90 / 6.22 TB/s on the same cells against 5.94 / 5.65 / 6.14
-    // for variant 3, 0.83-0.84 of the 8 TB/s peak inside the training step against 0.80.
-    const int pass_variant = variant > 0 ? variant : (kBf16 ? 34 : 32);
-    switch (pass_variant) {
-      case 2: HCM_LAUNCH_PASS(2, 1); break;
-      case 3: HCM_LAUNCH_PASS(3, 1); break;
-      case 4: HCM_LAUNCH_PASS(4, 1); break;
-      case 6: HCM_LAUNCH_PASS(6, 1); break;
-      case 25: HCM_LAUNCH_PASS(5, 2); break;         // r04: deeper rings HELD to two waves per SIMD (256 VGPRs)
-      case 26: HCM_LAUNCH_PASS(6, 2); break;
-      case 32: case 33: case 34: case 35: case 36: case 38:      // r04: csrc/bank_lean.hip, ring depth = variant - 30
-        {   // the helper returns (and clears) the launch status itself: HCM_CHECK_LAUNCH below would see hipSuccess
-          const int rc = hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, pass_variant - 30, bank1, bank2, bank3, idx, x1, x2, x3, B,
-                                                    K1, R, scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0, stream);
-          if (rc != 0) { span.stop(); return rc; }
-        }
-        break;
-      case 12: HCM_LAUNCH_GLDS(2); break;
-      case 13: HCM_LAUNCH_GLDS(3); break;
-      case 14: HCM_LAUNCH_GLDS(4); break;
-      case 16: HCM_LAUNCH_GLDS(6); break;
-      default: HCM_LAUNCH_PASS(1, 1); break;
+    // D = 128: the instruction-lean kernel of csrc/bank_lean.hip -- ring depth 2 for fp32 rows (6.22 / 5.90 / 6.22 TB/s on the
+    // HBM-resident cells 1M rows K=16384, 4M rows K=16384, 4M rows K=65536; 0.83-0.85 of the 8 TB/s peak inside the training
+    // step), ring depth 4 for bf16 rows (5.66 / 5.05 / 5.76 TB/s, 7.58 at K = 131072; rings 5 and 6 spill at two waves per
+    // SIMD).  Everything else that was built and measured on the way -- register rings of depth 1-6 in the general kernel
+    // below, an LDS-DMA ring (global_load ... lds) of 2-6 stages, a 32-lanes-per-row bf16 kernel -- is recorded in DESIGN 4.1 /
+    // 4.6 with its numbers; the variants and their HCM_BANK_VARIANT / HCM_BANK_ROWS switches were removed in r05.
+    {   // the helper returns (and clears) the launch status itself: HCM_CHECK_LAUNCH below would see hipSuccess
+      const int rc = hcm::bank_pass_lean_launch(kBf16 ? 1 : 0, kBf16 ? 4 : 2, bank1, bank2, bank3, idx, x1, x2, x3, B, K1, R,
+                                                scale2, ws.part_m, ws.part_s, ws.part_acc, ws.l0, stream);
+      if (rc != 0) { span.stop(); return rc; }
     }
-#undef HCM_LAUNCH_GLDS
-#undef HCM_LAUNCH_PASS
     span.stop();
     HCM_CHECK_LAUNCH();
     bank_finish_kernel<T, 128><<<B, kWG, (size_t)nch * 6 * sizeof(float), st>>>(

@@ -282,13 +282,12 @@ int launch(const float* x, const float* w, float* y, int N, int C, int K, int H,
 int dispatch(const float* x, const float* w, float* y, int N, int C, int K, int H, int W, bool flip, hipStream_t st,
              float* stat_part = nullptr, const float* stat_shift = nullptr) {
   if (N <= 0 || C != K || !x || !w || !y || H % 4 != 0) return (int)hipErrorInvalidValue;
-  static const bool hybrid = !(getenv("HCM_CONV_HYBRID") && getenv("HCM_CONV_HYBRID")[0] == '0');
   // 4-row bands (4 waves): 8-row bands with 8 waves halve the workgroup count and the weight re-reads, but the
   // kernel gets slower (36ch: 14.6 -> 19.5 us) and so does the step (654 -> 642 samples/s)
-  if (W == 64 && C > 16 && C <= 18 && hybrid) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
+  if (W == 64 && C > 16 && C <= 18) return launch<5, 1, 64, 4, 2>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
   if (W == 64 && C > 16 && C <= 20) return launch<5, 2, 64, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
   // (a padded 32-channel instance for HRNet-w32's first branch was measured: 436 vs 441 samples/s with MIOpen -- not kept)
-  if (W == 32 && C > 32 && C <= 36 && hybrid) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
+  if (W == 32 && C > 32 && C <= 36) return launch<9, 2, 32, 4, 4>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
   if (W == 32 && C > 32 && C <= 36) return launch<9, 3, 32, 4, 0>(x, w, y, N, C, K, H, flip, st, stat_part, stat_shift);
   return (int)hipErrorInvalidValue;
 }

@@ -877,12 +877,11 @@ int hcm_three_interpolate_contract(int b, int c, int m, int n, const float* poin
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || c <= 0 || n <= 0) return b < 0 || c < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
   // source rows in LDS when a useful block of channels of all m points fits (m <= 8960 points at 4 channels) and there
-  // is enough work per workgroup to pay for the fill; HCM_THREE_INTERP=1 forces the gather kernel
-  static const int ti_variant = getenv("HCM_THREE_INTERP") ? atoi(getenv("HCM_THREE_INTERP")) : 0;
+  // is enough work per workgroup to pay for the fill; the gather kernel otherwise
   int cbl = m > 0 ? (int)((140 * 1024) / ((size_t)m * sizeof(float))) & ~3 : 0;
   if (cbl > 32) cbl = 32;
   if (cbl > ((c + 3) & ~3)) cbl = (c + 3) & ~3;
-  if (ti_variant != 1 && cbl >= 4 && n >= 2048) {
+  if (cbl >= 4 && n >= 2048) {
     const int nblk = (c + cbl - 1) / cbl;
     // positions per workgroup: all of them unless that leaves the GPU short of workgroups (fill cost ~ m positions)
     int nsplit = 1;
@@ -924,9 +923,8 @@ int hcm_ball_query_contract(int b, int n, int m, float radius, int nsample, cons
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || m <= 0 || nsample <= 0) return b < 0 || m < 0 || nsample < 0 ? (int)hipErrorInvalidValue : 0;
   // the cloud fits LDS (every level of Pointnet2MSG: n <= 4096 points = 64 KB): one WAVE per centre, lanes over the points
-  static const int bq_variant = getenv("HCM_BALL_QUERY") ? atoi(getenv("HCM_BALL_QUERY")) : 0;      // 1 = thread per centre
   const size_t cloud_lds = (size_t)((n + 127) & ~127) * sizeof(float4);
-  if (bq_variant != 1 && n > 0 && cloud_lds <= 72 * 1024) {          // two workgroups per CU
+  if (n > 0 && cloud_lds <= 72 * 1024) {          // two workgroups per CU
     const void* fw = contract == HCM_CONTRACT_FMA ? reinterpret_cast<const void*>(ball_query_wave_kernel<true>)
                                                   : reinterpret_cast<const void*>(ball_query_wave_kernel<false>);
     hipError_t e2 = hipFuncSetAttribute(fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cloud_lds);
@@ -968,9 +966,8 @@ int hcm_three_nn_contract(int b, int n, int m, const float* unknown, const float
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || n <= 0) return b < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
   // few unknowns (the feature-propagation levels: b x n <= 2^17 ... 2^19): split each scan across 16 lanes; many
-  // (pts2depth: 2 M unknowns) -> a thread per two unknowns keeps every SIMD busy.  HCM_THREE_NN = 1 / 2 forces one of them.
-  static const int nn_variant = getenv("HCM_THREE_NN") ? atoi(getenv("HCM_THREE_NN")) : 0;
-  if (nn_variant == 2 || (nn_variant != 1 && (long long)b * n <= (1ll << 19) && m >= 16)) {
+  // (pts2depth: 2 M unknowns) -> a thread per two unknowns keeps every SIMD busy.
+  if ((long long)b * n <= (1ll << 19) && m >= 16) {
     dim3 gs((n + (kT / 16) * kNU - 1) / ((kT / 16) * kNU), b);
     if (contract == HCM_CONTRACT_FMA)
       three_nn_split_kernel<true><<<gs, kT, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
@@ -1017,9 +1014,8 @@ int hcm_furthest_point_sampling_contract(int b, int n, int m, const float* datas
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || n <= 0 || m <= 0) return b < 0 || n < 0 || m < 0 ? (int)hipErrorInvalidValue : 0;
   const int bs = opt_n_threads(n);   // the reference's block size: defines the tie-break order only
-  static const int pt_env = getenv("HCM_FPS_THREADS") ? atoi(getenv("HCM_FPS_THREADS")) : 512;
   int threads = bs < 64 ? 64 : bs;
-  if (threads > pt_env && pt_env >= 64) threads = pt_env;
+  if (threads > 512) threads = 512;       // 512 threads x 8 points at n = 4096: the round's serial chain is shortest there (r04)
   const int per = (n + threads - 1) / threads;
   int log2bs = 0;
   while ((1 << log2bs) < bs) ++log2bs;

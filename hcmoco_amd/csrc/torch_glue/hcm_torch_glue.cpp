@@ -227,17 +227,13 @@ ConvKey key_of(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
 
 // hcm_conv3x3_forward / _backward_data (csrc/conv.hip) serve the 3x3 stride-1 convolutions of the two
 // high-resolution branches (18ch@64-wide, 36ch@32-wide: 14 us against MIOpen's 25 / 21 us); everything else
-// stays on MIOpen.  HCM_CONV_KERNEL=0 keeps every layer there.
+// stays on MIOpen.
 bool own_conv(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
-  static const bool on = !(getenv("HCM_CONV_KERNEL") && getenv("HCM_CONV_KERNEL")[0] == '0');
-  return on && stride == 1 && pad == 1 && w.size(2) == 3 && w.size(3) == 3 &&
+  return stride == 1 && pad == 1 && w.size(2) == 3 && w.size(3) == 3 &&
          hcm_conv3x3_supported((int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3)) == 1;
 }
 
-bool stats_in_conv() {
-  static const bool on = !(getenv("HCM_CONV_STATS") && getenv("HCM_CONV_STATS")[0] == '0');
-  return on;
-}
+bool stats_in_conv() { return true; }
 
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
@@ -432,16 +428,14 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
 // MIOpen's five-launch path: 3x3 with at most 48 channels (25 / 22 us against 49 / 38 us) and the 1x1
 // convolutions of the fuse layers (9-11 us against 25-47 us) and their 3x3 stride-2 convolutions (14-23 us
 // against 27-37 us); two launches, deterministic.  Everything
-// else stays on MIOpen.  HCM_WGRAD_KERNEL=0 keeps every layer there.
+// else stays on MIOpen.
 int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no; 3 / 1: kernel size at stride 1; 2: 3x3 at stride 2
-  static const bool on = [] { const char* e = getenv("HCM_WGRAD_KERNEL"); return !(e && e[0] == '0'); }();
-  static const int64_t maxc = [] { const char* e = getenv("HCM_WGRAD_MAXC"); return e ? (int64_t)atoi(e) : (int64_t)48; }();
-  static const int64_t max1 = [] { const char* e = getenv("HCM_WGRAD_MAX1X1"); return e ? (int64_t)atoi(e) : (int64_t)160; }();
+  constexpr int64_t maxc = 48, max1 = 160;
   // the 3-channel stem convolution (3 -> 64, stride 2, 128x128 output) falls on the kernel's generic,
   // non-constant-folded instantiation: 279 us per call against MIOpen's ~60 us (r02 profile)
-  static const int64_t minc = [] { const char* e = getenv("HCM_WGRAD_MINC"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+  constexpr int64_t minc = 8;
   const bool det = g_deterministic.load(std::memory_order_relaxed);
-  if (!(on || det) || (g.size(3) & 3) != 0 || (!det && w.size(1) < minc)) return 0;
+  if ((g.size(3) & 3) != 0 || (!det && w.size(1) < minc)) return 0;
   const int64_t mc = det ? (int64_t)1 << 30 : maxc, m1 = det ? (int64_t)1 << 30 : max1;
   const bool same = g.size(2) == x.size(2) && g.size(3) == x.size(3);
   const bool half = 2 * g.size(2) == x.size(2) && 2 * g.size(3) == x.size(3);
@@ -450,7 +444,7 @@ int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no
     // wide 1x1 layers on maps far larger than an HRNet branch -- the shared MLPs of PointNet++ on [B, C, npoint, nsample]
     // ball tensors (64 / 128 channels, 16 K - 131 K positions per image) -- run one or two map rows per unit here
     // (0.8-1.5 ms, 2 TB/s); MIOpen's implicit GEMM is faster on them: HRNetPN 468 -> 480 samples/s (r03)
-    static const int64_t maxpix = [] { const char* e = getenv("HCM_WGRAD_MAX1X1_PIXELS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    constexpr int64_t maxpix = 4096;
     if (!det && std::max(w.size(0), w.size(1)) > maxc && g.size(2) * g.size(3) > maxpix) return 0;
     return 1;
   }
@@ -848,8 +842,7 @@ void flush_wgrad_reductions(hipStream_t st) {
 
 // true: the layer's partial sums are parked and its reduction is queued on stream `st` (the current stream)
 bool defer_own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g, float* dw, hipStream_t st) {
-  static const bool on = !(getenv("HCM_WGRAD_DEFER_REDUCE") && getenv("HCM_WGRAD_DEFER_REDUCE")[0] == '0');
-  const int ks = on ? own_wgrad(x, w, g) : 0;
+  const int ks = own_wgrad(x, w, g);
   if (ks == 0) return false;
   const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)g.size(2), W = (int)g.size(3);
   const size_t need = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W)

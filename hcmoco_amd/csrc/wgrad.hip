@@ -244,14 +244,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(ReduceBatch b)
 // (MT, NTW, waves across N) per K: few N tiles per workgroup where K is small (more workgroups across
 // N, fewer and smaller partials), at most ~24 tiles (96 accumulator registers) per wave
 bool pick_tiles_default(int mt, int& ntw, int& wn_max);
-// HCM_WGRAD_WN<mt>=<waves across N> overrides the table below (tuning sweeps, tools/bench_wgrad.py)
-bool pick_tiles(int mt, int& ntw, int& wn_max) {
-  if (!pick_tiles_default(mt, ntw, wn_max)) return false;
-  char name[32];
-  snprintf(name, sizeof(name), "HCM_WGRAD_WN%d", mt);
-  if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= 1 && v <= 8) wn_max = v; }
-  return true;
-}
+bool pick_tiles(int mt, int& ntw, int& wn_max) { return pick_tiles_default(mt, ntw, wn_max); }
 bool pick_tiles_default(int mt, int& ntw, int& wn_max) {
   wn_max = 4;
   switch (mt) {
@@ -294,16 +287,14 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g)
   for (;;) {
     g.dstride = rb * W + 4;
     size_t bytes = ((size_t)g.cmax * (st * rb + 2) * (st * W + 8) + (size_t)(K + 1) * g.dstride) * 4;
-    static const size_t cap = (size_t)(getenv("HCM_WGRAD_LDS_KB") ? atoi(getenv("HCM_WGRAD_LDS_KB")) : 48) * 1024;
-    static const size_t cap_wide = getenv("HCM_WGRAD_LDS_KB_WIDE") ? (size_t)atoi(getenv("HCM_WGRAD_LDS_KB_WIDE")) * 1024 : cap;
-    if (bytes <= (g.mt >= 5 ? cap_wide : cap) || rb == 1) break;
+    constexpr size_t cap = 48 * 1024;
+    if (bytes <= cap || rb == 1) break;
     rb = (rb + 1) / 2;
   }
   g.rb = rb;
   g.rblocks = (H + rb - 1) / rb;
   g.units = N * g.rblocks;
-  static const int waves_wide = getenv("HCM_WGRAD_WAVES_WIDE") ? atoi(getenv("HCM_WGRAD_WAVES_WIDE")) : 8;
-  int wp = (g.mt >= 5 ? waves_wide : 8) / wn;
+  int wp = 8 / wn;
   if (wp > rb) wp = rb;
   if (wp < 1) wp = 1;
   g.wp = wp;
@@ -316,10 +307,8 @@ bool make_wgeo(int N, int C, int K, int H, int W, int taps, int st, WgradGeo& g)
   // 1024 and two waves across N make the ISOLATED kernel faster than MIOpen's five launches (72ch@16x16: 28 -> 21.7 us
   // vs 30.8; 144ch@8x8 27.7 vs 28.7), but routing those layers here is SLOWER in the step (625 vs 632 samples/s:
   // 512-thread workgroups with 30-50 KB of LDS crowd out the other encoder's stream) -- the defaults stay as in r01
-  // and the wide layers stay on MIOpen; HCM_WGRAD_WANT_WIDE / HCM_WGRAD_WN<mt> / HCM_WGRAD_LDS_KB keep the sweep runnable
-  static const int target = getenv("HCM_WGRAD_WANT") ? atoi(getenv("HCM_WGRAD_WANT")) : 1024;
-  static const int target_wide = getenv("HCM_WGRAD_WANT_WIDE") ? atoi(getenv("HCM_WGRAD_WANT_WIDE")) : 1024;
-  int want = (g.mt >= 5 ? target_wide : target) / g.ngroups;
+  // and the wide layers stay on MIOpen (the sweep's switches were removed in r05; DESIGN 4.6 keeps the record)
+  int want = 1024 / g.ngroups;
   if (want < 1) want = 1;
   if (want > g.units) want = g.units;
   g.per = (g.units + want - 1) / want;

@@ -676,66 +676,11 @@ def bn_act_supported(x):
             and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[1] <= 65535)
 
 
-class _BnAct(torch.autograd.Function):
-    """Training-mode BatchNorm2d [+ residual] [+ ReLU] (official_hrnet.py:40-105 block tails).
-    forward: hcm_bn_act_forward (stats + apply); backward: hcm_bn_act_backward (reduce + apply)."""
-
-    @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu):
-        if not bn_act_supported(x):
-            raise RuntimeError('hcmoco_amd.bn_act needs fp32 NCHW-contiguous ROCm maps with H*W % 4 == 0 '
-                               '(no CPU fallback exists)')
-        N, Cc, H, W = x.shape
-        HW = H * W
-        if residual is not None and (residual.shape != x.shape or not residual.is_contiguous()
-                                     or residual.dtype != torch.float32):
-            residual = residual.to(torch.float32).expand_as(x).contiguous()
-        y = torch.empty_like(x)
-        stats = torch.empty(_bn_stats_floats(N, Cc, HW), dtype=torch.float32, device=x.device)
-        check(_lib.lib().hcm_bn_act_forward(
-            x.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(), bias.data_ptr(),
-            None if running_mean is None else running_mean.data_ptr(),
-            None if running_var is None else running_var.data_ptr(),
-            float(momentum), float(eps), int(relu), N, Cc, HW, y.data_ptr(), stats.data_ptr(), _stream()),
-            'hcm_bn_act_forward')
-        ctx.relu, ctx.has_res = bool(relu), residual is not None
-        if relu:
-            ctx.save_for_backward(x, weight, stats, y)
-        else:
-            ctx.save_for_backward(x, weight, stats)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        if ctx.relu:
-            x, weight, stats, y = ctx.saved_tensors
-        else:
-            (x, weight, stats), y = ctx.saved_tensors, None
-        N, Cc, H, W = x.shape
-        if not g.is_contiguous():
-            g = g.contiguous()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dz = torch.empty_like(x) if ctx.relu else None
-        gstats = torch.empty(stats.numel(), dtype=torch.float32, device=x.device)
-        check(_lib.lib().hcm_bn_act_backward(
-            g.data_ptr(), None, x.data_ptr(), None if y is None else y.data_ptr(), weight.data_ptr(), stats.data_ptr(),
-            int(ctx.relu), N, Cc, H * W, None if dz is None else dz.data_ptr(),
-            None if dx is None else dx.data_ptr(), gstats.data_ptr(), _stream()), 'hcm_bn_act_backward')
-        dres = (dz if ctx.relu else g) if ctx.has_res else None
-        return dx, dres, gstats[:Cc], gstats[Cc:2 * Cc], None, None, None, None, None
-
-
-_BN_GLUE = os.environ.get('HCM_BN_GLUE', '1') != '0'
-
-
 def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
     """relu?(batch_norm(x; batch statistics) + residual?) with the running statistics updated in place.
-    Runs as a C++ autograd node (csrc/torch_glue, torch.ops.hcmoco.bn_act) over hcm_bn_act_*;
-    HCM_BN_GLUE=0 selects the Python autograd.Function over the same two C entry points."""
-    if _BN_GLUE:
-        return _lib.torch_glue().bn_act(x, residual, weight, bias, running_mean, running_var,
-                                        float(momentum), float(eps), bool(relu))
-    return _BnAct.apply(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
+    Runs as a C++ autograd node (csrc/torch_glue, torch.ops.hcmoco.bn_act) over hcm_bn_act_*."""
+    return _lib.torch_glue().bn_act(x, residual, weight, bias, running_mean, running_var,
+                                    float(momentum), float(eps), bool(relu))
 
 
 # --------------------------------------------------------------------------- #
@@ -1030,7 +975,7 @@ class _Stage2Section(torch.autograd.Function):
             # bank update, which only has to come after the NCE pass has read the rows.  Nothing in between depends on
             # the other ranks, so a rank that arrives late costs the others nothing until then.
             allp, pending = gather(f)                                     # [B*W, 3F+2], rank-major
-            if pending is not None and (tape is not None or os.environ.get('HCM_SYNC_GATHER', '0') != '0'):
+            if pending is not None and tape is not None:
                 pending.wait()
                 pending = None
             all_x = [allp[:, i * F:(i + 1) * F] for i in range(3)]
@@ -1151,7 +1096,7 @@ class _Stage2SectionPN(torch.autograd.Function):
         pending = None
         if gather is not None:
             allp, pending = gather(f)
-            if pending is not None and (tape is not None or os.environ.get('HCM_SYNC_GATHER', '0') != '0'):
+            if pending is not None and tape is not None:
                 pending.wait()
                 pending = None
             all_x = [allp[:, i * F:(i + 1) * F] for i in range(3)]

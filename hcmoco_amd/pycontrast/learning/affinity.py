@@ -41,14 +41,7 @@ def pin_to_gpu_node(device_index, mode=None):
     mode = os.environ.get('HCM_PIN_NUMA', 'node') if mode is None else mode
     if mode in ('0', 'off', 'none') or not hasattr(os, 'sched_setaffinity'):
         return None
-    forced = os.environ.get('HCM_PIN_NUMA_FORCE_NODE')          # experiments: bind to this node instead of the GPU's
     info = gpu_node(device_index)
-    if forced is not None:
-        try:
-            cpus = _parse_cpulist(open('/sys/devices/system/node/node%d/cpulist' % int(forced)).read())
-            info = (int(forced), cpus)
-        except (OSError, ValueError):
-            return None
     if info is None:
         return None
     node, cpus = info

@@ -61,7 +61,7 @@ class ContrastTrainer(BaseTrainer):
             model.defer_projection = True
             # ... and, when it can, the heads too: the whole serial section becomes one autograd node
             if (getattr(self.engine, 'supports_section', None) is not None and hasattr(model, 'defer_heads')
-                    and self.device.type == 'cuda' and os.environ.get('HCM_FUSED_SECTION', '1') != '0'
+                    and self.device.type == 'cuda' and getattr(args, 'fused_section', True)
                     and getattr(args, 'grad_sync', 'auto') != 'ddp' and not getattr(args, 'channels_last', False)
                     and self.engine.supports_section(model)):      # (the section kernels read NCHW branch maps)
                 model.defer_heads = True
@@ -70,8 +70,8 @@ class ContrastTrainer(BaseTrainer):
             # the loss section read NCHW
             from ..networks import hrnet as _hrnet
             if self.device.type == 'cuda' and (_hrnet.CONV_GLUE or _hrnet.ENCODER_PROGRAM or _hrnet.FUSED_BN):
-                raise ValueError('channels_last needs the stock ATen encoders: HCM_CONV_GLUE=0 HCM_ENCODER_PROGRAM=0 '
-                                 'HCM_FUSED_BN=0 (the encoder runtime and the loss section are NCHW)')
+                raise ValueError('channels_last needs the stock ATen encoders (networks.hrnet.CONV_GLUE / ENCODER_PROGRAM / '
+                                 'FUSED_BN = False): the encoder runtime and the loss section are NCHW')
             model.to(memory_format=torch.channels_last)
         if isinstance(model_ema, torch.nn.Module):
             model_ema.to(self.device)
@@ -87,7 +87,7 @@ class ContrastTrainer(BaseTrainer):
         if sync == 'auto':           # ROCm: own bucketed reduction (see below); CPU: DistributedDataParallel
             sync = 'overlap' if self.device.type == 'cuda' else 'ddp'
         deferred = (self.device.type == 'cuda' and sync != 'ddp'
-                    and os.environ.get('HCM_ASYNC_WGRAD', '1') != '0')
+                    and getattr(args, 'async_wgrad', True))      # False: the plain-autograd twin of the parity tests
         if deferred:
             # Deferred weight gradients (csrc/torch_glue): helper threads issue the encoders' reverse loops
             # and the MIOpen backward-weights calls while the autograd thread walks on.  The contract --
@@ -97,8 +97,7 @@ class ContrastTrainer(BaseTrainer):
             # buffers, launched chunk by chunk while the reverse loops are still running.
             from ... import _lib
             self.async_wgrad = _lib.torch_glue()
-            self.async_wgrad.set_wgrad_stream(os.environ.get('HCM_WGRAD_STREAM', '0') != '0',
-                                              int(os.environ.get('HCM_WGRAD_BATCH', '16')))
+            self.async_wgrad.set_wgrad_stream(False, 16)
         if multi and sync in ('flat', 'overlap'):
             from .grad_sync import GradSync, broadcast_model
             broadcast_model(model)
@@ -108,7 +107,7 @@ class ContrastTrainer(BaseTrainer):
                 glue = _lib.torch_glue()
             self.grad_sync = GradSync(model, [p for g in optimizer.param_groups for p in g['params']], mode=sync,
                                       chunks=int(os.environ.get('HCM_GRAD_CHUNKS', '4')), glue=glue)
-        if (deferred and os.environ.get('HCM_FLAT_SGD', '1') != '0' and isinstance(optimizer, torch.optim.SGD)):
+        if deferred and getattr(args, 'flat_sgd', True) and isinstance(optimizer, torch.optim.SGD):
             # one update launch per encoder instead of ~40 per step (learning/flat_sgd.py); checkpoints keep the
             # reference's per-parameter layout
             from .flat_sgd import FlatParamSGD

@@ -205,10 +205,9 @@ class GradSync(object):
             if self._comm is None:
                 # The event waits in front of the collectives go onto the trainer's own stream: it has nothing else to do
                 # until the join, and RCCL's stream picks the chunks up from there.  r02 gave them a stream of their
-                # own (HCM_GRAD_COMM_STREAM=1): a fifth active stream on four hardware queues made two of them share a
-                # queue, and that alone was most of the 1-rank cost of the N>1 path (665 vs 689 of 691 samples/s, r03).
-                self._comm = (torch.cuda.Stream(device=dev) if os.environ.get('HCM_GRAD_COMM_STREAM', '0') != '0'
-                              else torch.cuda.current_stream(dev))
+                # own: a fifth active stream on four hardware queues made two of them share a queue, and that alone was
+                # most of the 1-rank cost of the N>1 path (665 vs 689 of 691 samples/s, r03).
+                self._comm = torch.cuda.current_stream(dev)
             live = []
             for enc in self.encoders:
                 n = int(self.glue.grad_chunk_count(enc.grad_tag)) if enc.last_program is not None else 0

@@ -33,7 +33,7 @@ def main(argv=None, engine=None):
 def main_worker(gpu, ngpus_per_node, args, engine=None):
     trainer = ContrastTrainer(args, engine=engine)
     trainer.init_ddp_environment(gpu, ngpus_per_node)
-    args.channels_last = os.environ.get('HCMOCO_CHANNELS_LAST', '0') == '1'
+    args.channels_last = bool(getattr(args, 'channels_last', False))
 
     model, model_ema = build_model(args)
 

@@ -51,7 +51,8 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # Set by a trainer whose loss engine also computes the pooling + heads inside its fused loss section
         # (engine.section, csrc/section.hip): ``return_fm`` then returns ``f = None`` next to the raw branch maps.
         self.defer_heads = False
-        # The three encoders are independent until the heads.  HCM_TWO_STREAMS is a bit mask:
+        # The three encoders are independent until the heads.  ``two_streams`` (an attribute; tests and the quiet first step
+        # set it to 0) is a bit mask:
         #   1            SemGCN on a side HIP stream, issued first: its single-workgroup kernels
         #                (3.5 ms per step, one CU) run underneath the HRNets instead of in line;
         #   2            encoder2 on a second side stream (small HRNet kernels overlap; when it runs as a
@@ -61,7 +62,7 @@ class CMC3HRNetSGCNSingleHead(nn.Module):
         # caller's stream right behind encoder1, underneath encoder2's tail; a stream of their own is one more active
         # stream for four hardware queues to share (697-699 -> 699-702 samples/s, alternating runs on one box).
         # Backward follows automatically: autograd replays every node on its forward stream.
-        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '2'))
+        self.two_streams = 2
         self._side_streams = {}
         # torch.bfloat16: the two HRNets run under bf16 autocast (module path: stock MIOpen bf16 convolutions, batch
         # norm with fp32 statistics and parameters); their maps come back as fp32.  Set by the trainer from
@@ -192,7 +193,8 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         sgcn_dim = 128
         self.encoder3 = create_sgcn(opt.skeleton_meta_name, sgcn_dim, 4)
         self.head1 = nn.Sequential(nn.Linear(dim_in, feat_dim), Normalize(2))
-        self.two_streams = int(os.environ.get('HCM_TWO_STREAMS', '7'))
+        self.two_streams = 7          # bit 0: SemGCN, bit 1: the cloud branch, bit 2: the cloud's geometry on streams of their own
+        self.trace_streams = False    # tools/probes/hrnetpn_streams.py: record when each branch starts / ends on the GPU
         self._side_streams = {}
         self.head2 = nn.Sequential(nn.Linear(self.pn_dim, feat_dim), Normalize(2))
         self.head3 = nn.Sequential(nn.Linear(sgcn_dim, feat_dim), Normalize(2))
@@ -260,10 +262,8 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
         pixels the nearest resize throws away: at 256^2 -> 64^2 it keeps one pixel in sixteen, so three_nn, three_interpolate
         and their backward run on 4096 pixels per image instead of 65 536 and the [B, 128, 256, 256] map (1 GB at B = 32) is
         never written.  Every kept pixel is computed exactly as in the full map (three_nn / three_interpolate are
-        per-pixel), and the discarded pixels carry exact-zero gradients in the full flow.  HCM_PTS2DEPTH_FULL=1 takes
-        the two-step route."""
-        if os.environ.get('HCM_PTS2DEPTH_FULL', '0') != '0':
-            return F.interpolate(cls.pts2depth(sampled_pts, pts, feat, h, w), size=(oh, ow))
+        per-pixel), and the discarded pixels carry exact-zero gradients in the full flow (tests/test_pointnet2_gpu.py compares
+        with the two-step route)."""
         keep = cls.kept_pixels(h, w, oh, ow, pts.device)
         out = cls.pts2depth(sampled_pts, pts.index_select(2, keep), feat, oh, ow)
         return out
@@ -307,7 +307,7 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
                     _feat3 = self.encoder3(s)
             # r04: the GEOMETRY of the cloud branch (back-projection, the four FPS levels, eight ball queries, the three_nn of
             # the four FP levels and of pts2depth) depends on the depth input alone.  It goes first, on a stream of its own
-            # (bit 2 of HCM_TWO_STREAMS): 40 launches of serial, low-occupancy kernels (an FPS level is 32 workgroups
+            # (bit 2 of ``two_streams``): 40 launches of serial, low-occupancy kernels (an FPS level is 32 workgroups
             # walking a chain of rounds) that run underneath the HRNet instead of in front of the cloud branch's MLPs.
             plan = None
             if side_geo is not None:
@@ -329,9 +329,8 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             # branch is ~700 launches issued from Python.  With the geometry on its own stream the HRNet goes first: the FPS
             # levels then run underneath its kernels (61.4 vs 62.1 ms per synchronised step; with the geometry inside the
             # cloud branch the order made no difference, 63.0 vs 63.4: whichever branch is issued second finishes last).
-            # HCM_PN_ORDER=cloud_first / hrnet_first forces one.
-            first = os.environ.get('HCM_PN_ORDER', 'hrnet_first' if plan is not None else 'cloud_first') == 'hrnet_first'
-            trace = os.environ.get('HCM_TRACE_STREAMS', '0') != '0'      # probe: when each branch starts / ends on the GPU
+            first = plan is not None
+            trace = self.trace_streams
             if trace:
                 ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 'h0', 'h1', 'p0', 'p1')}
                 ev['t0'].record(main)

@@ -14,13 +14,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 BN_MOMENTUM = 0.01                                           # official_hrnet.py:23
-FUSED_BN = os.environ.get('HCM_FUSED_BN', '1') != '0'        # hcm_bn_act_* on the GPU (0: stock ops)
-CONV_GLUE = os.environ.get('HCM_CONV_GLUE', '1') != '0'      # torch.ops.hcmoco.conv2d (0: ATen)
-ENCODER_PROGRAM = os.environ.get('HCM_ENCODER_PROGRAM', '1') != '0'   # whole encoder as one C++-executed program
+# Module attributes, not environment switches (r05): the parity tests flip them to build the plain-ATen / module-path
+# twin of a model inside one process (tests/test_glue_gpu.py, test_trainer_gpu.py, test_exact_gpu.py).
+FUSED_BN = True          # hcm_bn_act_* on the GPU (False: stock ops)
+CONV_GLUE = True         # torch.ops.hcmoco.conv2d (False: ATen)
+ENCODER_PROGRAM = True   # whole encoder as one C++-executed program
 # HRNet branch i on HIP stream i of the encoder.  Off: measured 530 vs 572 samples/s -- the ~300 cross-stream
 # event waits per pass cost more than the extra overlap buys (134 ms/step with GPU_MAX_HW_QUEUES=8).
-BRANCH_STREAMS = os.environ.get('HCM_BRANCH_STREAMS', '0') != '0'
-FUSE_UPSAMPLE_ADD = os.environ.get('HCM_FUSE_UPSAMPLE_ADD', '1') != '0'   # fuse-layer terms as one instruction
+BRANCH_STREAMS = False
+FUSE_UPSAMPLE_ADD = True  # fuse-layer terms as one instruction
 
 
 def bn_act_supported(x):

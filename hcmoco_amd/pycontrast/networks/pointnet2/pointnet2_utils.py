@@ -17,10 +17,9 @@ from .... import pointnet2_hip as pointnet2
 
 # backward of the gather-type ops: 'planned' (deterministic ranked LDS rounds, csrc/scatter.hip), 'lds' (r02: LDS float
 # atomics) or 'atomic' (the reference's global atomics, *_grad_wrapper)
-SCATTER_BACKWARD = os.environ.get('HCM_PN2_BACKWARD', 'planned')
-# Resolved ONCE, next to the mode: the narrow-channel shortcut below applies only when the mode was left at its
-# default and reproducibility was not asked for; an explicit HCM_PN2_BACKWARD=planned means planned for every shape.
-_NARROW_SHORTCUT = 'HCM_PN2_BACKWARD' not in os.environ and os.environ.get('HCM_DETERMINISTIC', '0') == '0'
+SCATTER_BACKWARD = 'planned'          # module attribute (tests compare the three forms)
+# Resolved ONCE: the narrow-channel shortcut below applies unless reproducibility was asked for
+_NARROW_SHORTCUT = os.environ.get('HCM_DETERMINISTIC', '0') == '0'
 
 
 def _scatter_backward(grad_out, idx, coef, m, div, legacy):

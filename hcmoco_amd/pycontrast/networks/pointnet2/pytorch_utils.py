@@ -6,7 +6,7 @@ import os
 import torch
 import torch.nn as nn
 
-FUSED = os.environ.get('HCM_FUSED_BN', '1') != '0' and os.environ.get('HCM_CONV_GLUE', '1') != '0'
+FUSED = True      # module attribute: tests flip it to get the stock-op twin of a layer
 
 
 class _BN(nn.Sequential):

@@ -54,7 +54,7 @@ def graph_index(adj):
     return [row_ptr, cols.to(torch.int32), csc_ptr, order.to(torch.int32), rows.to(torch.int32)]
 
 
-_FUSED = os.environ.get('HCM_SGCN_FUSED', '1') != '0'      # A/B switch for measurements
+_FUSED = True      # module attribute (tests compare against the eager modules through _fusable)
 
 
 def _fusable(x, cout):

@@ -40,7 +40,7 @@ def _run(mode, steps=3):
     args = bench.make_args(32, 1024, 4096, 256, 'coco17', 'nccl', tempfile.mkdtemp(), steps + 1)
     args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
     plain = mode == 'plain'
-    os.environ['HCM_ASYNC_WGRAD'] = '0' if plain else '1'
+    args.async_wgrad = not plain          # plain: no deferred weight gradients, no encoder programs (plain autograd)
     hrnet.ENCODER_PROGRAM = not plain
     if mode == 'rccl1':
         args.grad_sync = 'overlap'
@@ -69,7 +69,6 @@ def _run(mode, steps=3):
         glue.set_async_wgrad(False)
         glue.set_grad_chunks(0)
         glue.set_deterministic(False)
-        os.environ.pop('HCM_ASYNC_WGRAD', None)
         if dist.is_initialized():
             dist.destroy_process_group()
     return losses, params, banks, first, launched

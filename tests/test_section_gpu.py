@@ -459,7 +459,7 @@ def test_section_draws_its_own_negatives_and_pixels_and_counts_launches():
 
 
 def test_channels_last_is_refused_with_the_encoder_runtime():
-    """--channels_last / HCMOCO_CHANNELS_LAST=1 was an r01 experiment for stock ATen encoders; the encoder runtime and the
+    """args.channels_last was an r01 experiment for stock ATen encoders; the encoder runtime and the
     section kernels are NCHW, so the trainer says so instead of failing inside the first convolution."""
     import tempfile
     import bench

@@ -26,8 +26,7 @@ def _run(plain, steps=2):
     dev = torch.device('cuda:0')
     args = bench.make_args(8, 1024, 4096, 128, 'coco17', 'nccl', tempfile.mkdtemp(), steps + 1)
     args.rank, args.world_size, args.local_rank, args.gpu, args.channels_last = 0, 1, 0, 0, False
-    old = os.environ.get('HCM_ASYNC_WGRAD')
-    os.environ['HCM_ASYNC_WGRAD'] = '0' if plain else '1'
+    args.async_wgrad = not plain          # plain: no deferred weight gradients, no encoder programs (plain autograd)
     hrnet.ENCODER_PROGRAM = not plain
     try:
         tr = ContrastTrainer(args)
@@ -47,10 +46,6 @@ def _run(plain, steps=2):
     finally:
         hrnet.ENCODER_PROGRAM = True
         _lib.torch_glue().set_async_wgrad(False)
-        if old is None:
-            os.environ.pop('HCM_ASYNC_WGRAD', None)
-        else:
-            os.environ['HCM_ASYNC_WGRAD'] = old
     return losses, params, banks
 
 

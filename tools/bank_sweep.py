@@ -1,6 +1,6 @@
 """The bank pass over the regimes that matter: n_data x K x storage type x kernel variant.
 
-    python tools/bank_sweep.py time OUT.json      every configuration in its own subprocess (HCM_BANK_VARIANT is read
+    python tools/bank_sweep.py time OUT.json      every configuration in its own subprocess (the library's state is read
                                                   once per process): mean duration of the PASS kernel (hipEvents around
                                                   it, hcm_prof_*) back to back, and 'cold' -- a 1 GiB fill between two
                                                   launches pushes the banks out of the 256 MiB Infinity Cache, which is
@@ -81,13 +81,10 @@ def main():
     for n in NS:
         for K in KS:
             for dtype in ('fp32', 'bf16'):
-                # (name, HCM_BANK_VARIANT, HCM_BANK_ROWS): register ring of depth 3 / 4, LDS-DMA ring of 2 / 4 stages,
-                # 256 (r02) or 512 rows per workgroup; the library's default is the first entry
-                # r04: lean = csrc/bank_lean.hip (ring 2 fp32 / ring 4 bf16), the defaults; reg* = the general kernel of bank.hip
-                variants = {'fp32': (('lean2_r512', 32, 512), ('reg3_r512', 3, 512), ('lean2_r256', 32, 256), ('glds2_r256', 12, 256)),
-                            'bf16': (('lean4_r512', 34, 512), ('reg6w2_r512', 26, 512), ('reg4_r512', 4, 512), ('glds4_r256', 14, 256))}[dtype]
-                for name, var, nrows in variants:
-                    env = dict(os.environ, HCM_BANK_VARIANT=str(var), HCM_BANK_ROWS=str(nrows))
+                # r05: ONE kernel per dtype is left (csrc/bank_lean.hip, ring 2 fp32 / ring 4 bf16, 512 rows per workgroup); the
+                # variants r03 / r04 swept here (general kernel rings, LDS-DMA rings, 256 rows) are in profiles/r0{3,4}_bank_pass_sweep.json
+                for name in ({'fp32': 'lean2_r512', 'bf16': 'lean4_r512'}[dtype],):
+                    env = dict(os.environ)
                     res = subprocess.run([sys.executable, os.path.abspath(__file__), 'worker', str(n), str(K), dtype],
                                          capture_output=True, text=True, env=env, timeout=600)
                     line = [l for l in res.stdout.splitlines() if l.startswith('{')]

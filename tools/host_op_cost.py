@@ -1,5 +1,5 @@
-"""Host enqueue cost per BatchNorm+ReLU layer (forward, backward): stock ops (MIOpen) vs the Python
-autograd.Function over hcm_bn_act_* vs the C++ autograd node (torch.ops.hcmoco.bn_act)."""
+"""Host enqueue cost per BatchNorm+ReLU layer (forward, backward): stock ops (MIOpen) vs the C++ autograd node
+(torch.ops.hcmoco.bn_act); r01 also measured a Python autograd.Function over the same entry points (deleted in r05)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn as nn, torch.nn.functional as F
@@ -18,7 +18,6 @@ def chain(layer):
 
 variants = {
     'stock': lambda x: F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, 0.1, 1e-5), inplace=True),
-    'python-node': lambda x: hip_ops._BnAct.apply(x, None, *args, True),
     'c++-node': lambda x: hip_ops._lib.torch_glue().bn_act(x, None, *args, True),
 }
 for name, layer in variants.items():

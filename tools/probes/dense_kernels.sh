@@ -1,5 +1,5 @@
 # Average durations of the dense-loss kernels (prep / table, stats, grad) from a kernel trace of a short bench run.
-# usage: [HCM_DENSE_TABLE=0|1] dense_kernels.sh
+# usage: dense_kernels.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/dk
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dk -- python $R/bench.py --steps 10 --warmup 5 --no_cpu_baseline --no_check > /dev/null 2>&1

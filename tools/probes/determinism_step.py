@@ -1,6 +1,6 @@
 """Which parameter tensors differ bit-wise between two identical runs of N training steps in ONE process
 (same seed, same data, fresh model/optimizer/banks each time)?  Run on the GPU box:
-    python tools/probes/determinism_step.py [steps]            (HCM_WGRAD_MAXC / HCM_WGRAD_MAX1X1 select the dW kernels)"""
+    python tools/probes/determinism_step.py [steps]            (HCM_DETERMINISTIC=1 sends every dW to the fixed-order kernels)"""
 import os
 import sys
 import tempfile

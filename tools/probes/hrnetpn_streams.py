@@ -1,10 +1,9 @@
 """When the HRNet and the cloud branch of the HRNetPN model run on the GPU relative to each other (un-profiled, HIP events
-on their own streams; HCM_TRACE_STREAMS=1 in networks/build_backbone.py).  usage: [HCM_PN_ORDER=hrnet_first] hrnetpn_streams.py"""
+on their own streams; ``net.trace_streams = True`` in networks/build_backbone.py).  usage: hrnetpn_streams.py"""
 import os
 import sys
 import tempfile
 import time
-os.environ['HCM_TRACE_STREAMS'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
@@ -17,6 +16,7 @@ tr = ContrastTrainer(args)
 tr.device = dev
 model, contrast, opt, data = bench.build(args, tr, dev)
 net = tr.unwrap(model)
+net.trace_streams = True
 it = iter(data)
 for _ in range(8):
     tr.train_step(next(it), model, contrast, opt, stage2=True)
@@ -34,5 +34,5 @@ for _ in range(20):
     for k, v in row.items():
         acc[k] = acc.get(k, 0.0) + v
     n += 1
-print('order %s, HCM_TWO_STREAMS=%s (ms after the forward began on the GPU; synchronised steps):' % (os.environ.get('HCM_PN_ORDER', 'default (HRNet first when the geometry has its own stream)'), os.environ.get('HCM_TWO_STREAMS', 'default')),
+print('two_streams = %d (ms after the forward began on the GPU; synchronised steps):' % net.two_streams,
       {k: round(v / n, 2) for k, v in acc.items()})

@@ -1,9 +1,10 @@
-# FETCH_SIZE / WRITE_SIZE of the bank pass for one HCM_BANK_VARIANT (separate --pmc passes).  usage: pmc_bank_variant.sh <variant> [n_data] [K] [dtype]
+# FETCH_SIZE / WRITE_SIZE of the bank pass (separate --pmc passes).  usage: pmc_bank_variant.sh [n_data] [K] [dtype]
+# (r04 took a kernel variant as first argument; the variants were removed in r05)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-V=$1; N=${2:-1048576}; K=${3:-16384}; DT=${4:-fp32}
+N=${1:-1048576}; K=${2:-16384}; DT=${3:-fp32}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmcv; HCM_BANK_VARIANT=$V timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcv -- python $R/tools/bank_sweep.py pmc $N $K $DT > /dev/null 2>&1
+  rm -rf /tmp/pmcv; timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcv -- python $R/tools/bank_sweep.py pmc $N $K $DT > /dev/null 2>&1
   python - $c $(find /tmp/pmcv -name '*counter_collection.csv' | head -1) <<'PY'
 import csv, sys
 from collections import defaultdict
