@@ -240,6 +240,7 @@ class FailSafe(object):
         self.phase, self.t_phase = 'start', time.monotonic()
         self.comm = {}
         self.lock = threading.Lock()
+        self.store_lock = threading.Lock()      # one TCPStore client, two threads
         self.printed = False
         self.store = None
         self.armed = world > 1
@@ -299,11 +300,13 @@ class FailSafe(object):
                 t_end = time.monotonic() + 3.0
                 while time.monotonic() < t_end and not self.printed:
                     try:
-                        hit = [k for k in ('hcm_bench_error/%d' % r_ for r_ in range(1, self.world)) if self.store.check([k])]
+                        with self.store_lock:
+                            hit = [k for k in ('hcm_bench_error/%d' % r_ for r_ in range(1, self.world)) if self.store.check([k])]
+                            note = self.store.get(hit[0]).decode(errors='replace') if hit else None
                     except Exception:         # noqa: BLE001
                         break
                     if hit:
-                        msg = '%s: %s || rank 0 then saw: %s' % (hit[0], self.store.get(hit[0]).decode(errors='replace'), msg)
+                        msg = '%s: %s || rank 0 then saw: %s' % (hit[0], note, msg)
                         break
                     time.sleep(0.1)
             self.emit(msg)
@@ -332,9 +335,11 @@ class FailSafe(object):
             if self.store is not None:
                 try:
                     keys = ['hcm_bench_error/%d' % r_ for r_ in range(1, self.world)]
-                    hit = [k for k in keys if self.store.check([k])]
+                    with self.store_lock:
+                        hit = [k for k in keys if self.store.check([k])]
+                        note = self.store.get(hit[0]).decode(errors='replace') if hit else None
                     if hit:
-                        self.emit('%s: %s' % (hit[0], self.store.get(hit[0]).decode(errors='replace')))
+                        self.emit('%s: %s' % (hit[0], note))
                         os._exit(3)
                 except Exception:             # noqa: BLE001 -- store gone: the launcher's SIGTERM follows
                     pass
