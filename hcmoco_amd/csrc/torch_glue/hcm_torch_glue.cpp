@@ -235,7 +235,18 @@ bool own_conv(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
 
 bool stats_in_conv() { return true; }
 
+// TEMPORARY A/B (r05): 1x1 convolutions on ball tensors as batched library GEMMs on the NCHW tensors as they lie
+bool gemm_conv1x1(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
+  static const bool ab = [] { const char* e = getenv("HCM_AB_GEMM_CONV"); return e && e[0] == '1'; }();
+  return ab && stride == 1 && pad == 0 && w.size(2) == 1 && w.size(3) == 1 && x.size(2) * x.size(3) > 4096;
+}
+
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
+  if (gemm_conv1x1(x, w, stride, pad)) {
+    at::AutoGradMode no_grad(false);
+    const int64_t N = x.size(0), C = x.size(1), K = w.size(0), H = x.size(2), W = x.size(3);
+    return at::matmul(w.view({K, C}), x.view({N, C, H * W})).view({N, K, H, W});
+  }
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
                   w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
                   w.is_contiguous(),
@@ -389,7 +400,11 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   miopenHandle_t h = thread_handle(k.dev, st);
   const float one = 1.f, zero = 0.f;
   ConvGrads o;
-  if (need_dx && own_conv(x, w, stride, pad)) {
+  if (need_dx && gemm_conv1x1(x, w, stride, pad)) {
+    at::AutoGradMode no_grad(false);
+    const int64_t N = x.size(0), C = x.size(1), K = w.size(0), H = x.size(2), W = x.size(3);
+    o.dx = at::matmul(w.view({K, C}).t(), g.view({N, K, H * W})).view({N, C, H, W});
+  } else if (need_dx && own_conv(x, w, stride, pad)) {
     o.dx = at::empty_like(x);
     check_rc(hcm_conv3x3_backward_data(g.data_ptr<float>(), w.data_ptr<float>(), o.dx.data_ptr<float>(), (int)x.size(0),
                                        (int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3), st),
@@ -1233,15 +1248,23 @@ struct PendingForward {
   std::mutex m; std::condition_variable cv; bool done = false; std::string error;
   ForwardResult result;
   Tensor x; std::vector<Tensor> params, buffers; std::vector<int64_t> prog, out_slots;
-  int64_t n_values = 0, tag = 0; double momentum = 0, eps = 0; bool grad = false;
+  int64_t n_values = 0, tag = 0; double momentum = 0, eps = 0; bool grad = false, node_at_wait = false;
+  std::vector<Tensor> outs;     // node_at_wait == false: the node was made on the helper thread, these are its outputs
   c10::hip::HIPStream stream = c10::hip::getDefaultHIPStream();
 };
 std::mutex g_pending_mutex;
 std::unordered_map<int64_t, std::shared_ptr<PendingForward>> g_pending;
 int64_t g_pending_next = 1;
 
+// node_at_wait: false -- the autograd node is made on the helper thread, right behind the launches (its sequence number is
+// that thread's: the engine picks it LAST among ready nodes).  That is the order the two-HRNet model wants: measured on one
+// box, alternating runs, r05: 704-707 samples/s with encoder2's node made here against 680-684 with it made at _wait (where
+// it outranks encoder1's and its reverse loop is queued first) -- a 3.5 % difference from the ORDER of two pushes;
+// true -- encoder_forward_wait makes it on the caller's thread, i.e. AFTER every node the caller made meanwhile (HRNetPN: the
+// HRNet's reverse loop then starts before autograd walks the cloud branch).
 int64_t encoder_forward_async(const Tensor& x, at::TensorList params, at::TensorList buffers, std::vector<int64_t> prog,
-                              std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps, int64_t tag) {
+                              std::vector<int64_t> out_slots, int64_t n_values, double momentum, double eps, int64_t tag,
+                              bool node_at_wait) {
   auto pend = std::make_shared<PendingForward>();
   int64_t id;
   {
@@ -1256,14 +1279,21 @@ int64_t encoder_forward_async(const Tensor& x, at::TensorList params, at::Tensor
   pend->out_slots = std::move(out_slots);
   pend->n_values = n_values; pend->momentum = momentum; pend->eps = eps; pend->tag = tag;
   pend->grad = at::GradMode::is_enabled();
+  pend->node_at_wait = node_at_wait;
   pend->stream = c10::hip::getCurrentHIPStream(x.get_device());
   worker_for(pend->stream).push([pend](Tensor*) mutable {
     ForwardResult r;
     std::string err;
     try {
-      at::AutoGradMode mode(false);           // raw launches only; the node is made by encoder_forward_wait
-      r = encoder_forward_compute(pend->x, at::TensorList(pend->params), at::TensorList(pend->buffers), pend->prog,
-                                  pend->out_slots, pend->n_values, pend->momentum, pend->eps, pend->tag);
+      if (pend->node_at_wait || !pend->grad) {
+        at::AutoGradMode mode(false);         // raw launches only; the node is made by encoder_forward_wait
+        r = encoder_forward_compute(pend->x, at::TensorList(pend->params), at::TensorList(pend->buffers), pend->prog,
+                                    pend->out_slots, pend->n_values, pend->momentum, pend->eps, pend->tag);
+      } else {
+        at::AutoGradMode mode(true);
+        pend->outs = EncoderFn::apply(pend->x, at::TensorList(pend->params), at::TensorList(pend->buffers), pend->prog,
+                                      pend->out_slots, pend->n_values, pend->momentum, pend->eps, pend->tag, (int64_t)0);
+      }
     } catch (const std::exception& e) { err = e.what(); }
     {
       std::lock_guard<std::mutex> lk(pend->m);
@@ -1288,6 +1318,7 @@ std::vector<Tensor> encoder_forward_wait(int64_t id) {
     pend->cv.wait(lk, [&] { return pend->done; });
   }
   TORCH_CHECK(pend->error.empty(), "hcmoco::encoder_forward_async failed: ", pend->error);
+  if (pend->grad && !pend->node_at_wait) return std::move(pend->outs);
   if (!pend->grad || !at::GradMode::is_enabled()) return std::move(pend->result.outs);
   {
     std::lock_guard<std::mutex> lk(g_precomputed_mutex);
@@ -1311,7 +1342,7 @@ TORCH_LIBRARY(hcmoco, m) {
   m.def("run_encoder(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
         "float momentum, float eps, int tag=0) -> Tensor[]", &run_encoder);
   m.def("encoder_forward_async(Tensor x, Tensor[] params, Tensor[] buffers, int[] program, int[] outputs, int n_values, "
-        "float momentum, float eps, int tag=0) -> int", &encoder_forward_async);
+        "float momentum, float eps, int tag=0, bool node_at_wait=False) -> int", &encoder_forward_async);
   m.def("set_grad_chunks(int n) -> ()", &set_grad_chunks);
   m.def("grad_chunk_count(int tag) -> int", &grad_chunk_count);
   m.def("grad_chunk_wait(int tag, int k) -> Tensor", &grad_chunk_wait);

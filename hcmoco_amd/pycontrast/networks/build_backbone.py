@@ -344,7 +344,7 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             if first:
                 if trace:
                     ev['h0'].record(main)
-                hr_pending = self.encoder1.forward_async(x1) if hasattr(self.encoder1, 'forward_async') else None
+                hr_pending = self.encoder1.forward_async(x1, node_at_wait=True) if hasattr(self.encoder1, 'forward_async') else None
                 if hr_pending is None:
                     _feat1 = self.encoder1(x1)
                     if trace:

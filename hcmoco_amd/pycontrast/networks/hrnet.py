@@ -438,14 +438,15 @@ class HighResolutionNet(nn.Module):
         return (x, pb.params, pb.buffers, pb.instr, outs, len(pb.shapes), self.bn1.momentum, self.bn1.eps,
                 self.grad_tag)
 
-    def forward_async(self, x):
+    def forward_async(self, x, node_at_wait=False):
         """Start the forward on the helper thread of the CURRENT stream (C++, no GIL); returns a handle
-        for forward_wait, or None when the module path has to run (then call forward)."""
+        for forward_wait, or None when the module path has to run (then call forward).  ``node_at_wait``: the autograd node
+        is made by ``forward_wait`` on the calling thread instead of on the helper thread (csrc/torch_glue)."""
         args = self._program_args(x)
         if args is None:
             return None
         self._count_batch()
-        return _glue_op('encoder_forward_async')(*args)
+        return _glue_op('encoder_forward_async')(*args, node_at_wait)
 
     @staticmethod
     def forward_wait(handle):
