@@ -235,18 +235,7 @@ bool own_conv(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
 
 bool stats_in_conv() { return true; }
 
-// TEMPORARY A/B (r05): 1x1 convolutions on ball tensors as batched library GEMMs on the NCHW tensors as they lie
-bool gemm_conv1x1(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
-  static const bool ab = [] { const char* e = getenv("HCM_AB_GEMM_CONV"); return e && e[0] == '1'; }();
-  return ab && stride == 1 && pad == 0 && w.size(2) == 1 && w.size(3) == 1 && x.size(2) * x.size(3) > 4096;
-}
-
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
-  if (gemm_conv1x1(x, w, stride, pad)) {
-    at::AutoGradMode no_grad(false);
-    const int64_t N = x.size(0), C = x.size(1), K = w.size(0), H = x.size(2), W = x.size(3);
-    return at::matmul(w.view({K, C}), x.view({N, C, H * W})).view({N, K, H, W});
-  }
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
                   w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
                   w.is_contiguous(),
@@ -400,11 +389,7 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   miopenHandle_t h = thread_handle(k.dev, st);
   const float one = 1.f, zero = 0.f;
   ConvGrads o;
-  if (need_dx && gemm_conv1x1(x, w, stride, pad)) {
-    at::AutoGradMode no_grad(false);
-    const int64_t N = x.size(0), C = x.size(1), K = w.size(0), H = x.size(2), W = x.size(3);
-    o.dx = at::matmul(w.view({K, C}).t(), g.view({N, K, H * W})).view({N, C, H, W});
-  } else if (need_dx && own_conv(x, w, stride, pad)) {
+  if (need_dx && own_conv(x, w, stride, pad)) {
     o.dx = at::empty_like(x);
     check_rc(hcm_conv3x3_backward_data(g.data_ptr<float>(), w.data_ptr<float>(), o.dx.data_ptr<float>(), (int)x.size(0),
                                        (int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3), st),
