@@ -135,7 +135,11 @@ class GradSync(object):
         came back non-zero -- a reduced value, hence the same decision on every rank.  In between, a rank whose local
         pattern shrinks contributes zeros (no collective needed), and a rank that suddenly has a gradient OUTSIDE the
         union raises the flag: that one gradient is dropped on that step (``.grad = None``, so no replica applies a
-        local-only update) and the union grows on the next."""
+        local-only update) and the union grows on the next.  Consequence, stated so nobody has to find it: at an
+        in-process switch that makes a parameter USED for the first time on every rank at once (stage 1 -> stage 2: the two
+        1x1 projections), every rank drops that parameter's first gradient, so an N-GPU run differs from the 1-GPU run by
+        that one update of those parameters; the released recipe switches stages between processes (``--pretrain``), where
+        the first step agrees on the full union."""
         local = tuple(p.grad is not None for p in group)
         cached = self._presence.get(key)
         if cached is not None and len(cached) != len(group):
