@@ -105,6 +105,11 @@ SIGNATURES = {
     'hcm_bn_relu_ballmax_stats_floats': (_sz, [_i] * 4),
     'hcm_bn_relu_ballmax_forward': (_i, [_p] * 5 + [_f, _f] + [_i] * 4 + [_p] * 5),
     'hcm_bn_relu_ballmax_backward': (_i, [_p] * 7 + [_i] * 4 + [_p] * 3),
+    'hcm_conv1x1_supported': (_i, [_i] * 3),
+    'hcm_conv1x1_forward': (_i, [_p] * 3 + [_i] * 4 + [_p]),
+    'hcm_conv1x1_backward_data': (_i, [_p] * 3 + [_i] * 4 + [_p]),
+    'hcm_conv1x1_ball_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
+    'hcm_conv1x1_ball_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_ball_project_stats_floats': (_sz, [_i] * 4),
     'hcm_ball_project_forward': (_i, [_p] * 7 + [_f, _f] + [_i] * 6 + [_p] * 3),
     'hcm_ball_project_backward': (_i, [_p] * 7 + [_i] * 6 + [_p] * 4),

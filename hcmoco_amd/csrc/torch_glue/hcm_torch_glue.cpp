@@ -235,7 +235,22 @@ bool own_conv(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
 
 bool stats_in_conv() { return true; }
 
+// hcm_conv1x1_forward / _backward_data (csrc/conv1x1.hip): the 1x1 convolutions of the PointNet++ shared MLPs on ball tensors
+// (maps far larger than an HRNet branch), on the tensors as they lie.
+bool own_conv1x1(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
+  return stride == 1 && pad == 0 && w.size(2) == 1 && w.size(3) == 1 && x.size(2) * x.size(3) > 4096 &&
+         hcm_conv1x1_supported((int)x.size(1), (int)w.size(0), (int)(x.size(2) * x.size(3))) == 1;
+}
+
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
+  if (x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && x.is_contiguous() && w.is_contiguous() &&
+      own_conv1x1(x, w, stride, pad)) {
+    Tensor y = at::empty({x.size(0), w.size(0), x.size(2), x.size(3)}, x.options());
+    check_rc(hcm_conv1x1_forward(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), (int)x.size(0), (int)x.size(1),
+                                 (int)w.size(0), (int)(x.size(2) * x.size(3)), current_stream(x)),
+             "hcm_conv1x1_forward");
+    return y;
+  }
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
                   w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
                   w.is_contiguous(),
@@ -389,7 +404,12 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
   miopenHandle_t h = thread_handle(k.dev, st);
   const float one = 1.f, zero = 0.f;
   ConvGrads o;
-  if (need_dx && own_conv(x, w, stride, pad)) {
+  if (need_dx && own_conv1x1(x, w, stride, pad)) {
+    o.dx = at::empty_like(x);
+    check_rc(hcm_conv1x1_backward_data(g.data_ptr<float>(), w.data_ptr<float>(), o.dx.data_ptr<float>(), (int)x.size(0),
+                                       (int)x.size(1), (int)w.size(0), (int)(x.size(2) * x.size(3)), st),
+             "hcm_conv1x1_backward_data");
+  } else if (need_dx && own_conv(x, w, stride, pad)) {
     o.dx = at::empty_like(x);
     check_rc(hcm_conv3x3_backward_data(g.data_ptr<float>(), w.data_ptr<float>(), o.dx.data_ptr<float>(), (int)x.size(0),
                                        (int)x.size(1), (int)w.size(0), (int)x.size(2), (int)x.size(3), st),
@@ -429,7 +449,7 @@ ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, i
 // convolutions of the fuse layers (9-11 us against 25-47 us) and their 3x3 stride-2 convolutions (14-23 us
 // against 27-37 us); two launches, deterministic.  Everything
 // else stays on MIOpen.
-int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no; 3 / 1: kernel size at stride 1; 2: 3x3 at stride 2
+int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no; 3 / 1: kernel size at stride 1; 2: 3x3 at stride 2; 4: 1x1 on ball tensors
   constexpr int64_t maxc = 48, max1 = 160;
   // the 3-channel stem convolution (3 -> 64, stride 2, 128x128 output) falls on the kernel's generic,
   // non-constant-folded instantiation: 279 us per call against MIOpen's ~60 us (r02 profile)
@@ -440,6 +460,12 @@ int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no
   const bool same = g.size(2) == x.size(2) && g.size(3) == x.size(3);
   const bool half = 2 * g.size(2) == x.size(2) && 2 * g.size(3) == x.size(3);
   if (same && w.size(2) == 3 && w.size(3) == 3 && w.size(0) <= mc && w.size(1) <= mc) return 3;
+  // 1x1 layers on maps far larger than an HRNet branch -- the shared MLPs of PointNet++ on [B, C, npoint, nsample] ball tensors
+  // (16 .. 256 channels, 8 K - 131 K positions per image): hcm_conv1x1_ball_wgrad (csrc/conv1x1.hip), on the NCHW tensors
+  // as they lie (MIOpen: two layout transposes + an NHWC implicit GEMM)
+  if (same && w.size(2) == 1 && w.size(3) == 1 && g.size(2) * g.size(3) > 4096 &&
+      hcm_conv1x1_ball_wgrad_workspace_bytes((int)x.size(0), (int)w.size(1), (int)w.size(0), (int)g.size(2), (int)g.size(3)) > 0)
+    return 4;
   if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= m1 && w.size(1) <= m1) {
     // wide 1x1 layers on maps far larger than an HRNet branch -- the shared MLPs of PointNet++ on [B, C, npoint, nsample]
     // ball tensors (64 / 128 channels, 16 K - 131 K positions per image) -- run one or two map rows per unit here
@@ -458,9 +484,11 @@ void run_wgrad(ConvPlan* p, const Tensor& g, const Tensor& x, void* dw, const Te
   if (const int ks = own_wgrad(x, w, g)) {
     // H, W: the OUTPUT map (= the input map at stride 1)
     const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)g.size(2), W = (int)g.size(3);
-    const auto bytes = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes : ks == 1 ? hcm_conv1x1_wgrad_workspace_bytes
-                                                                             : hcm_conv3x3s2_wgrad_workspace_bytes;
-    const auto run = ks == 3 ? hcm_conv3x3_wgrad : ks == 1 ? hcm_conv1x1_wgrad : hcm_conv3x3s2_wgrad;
+    const auto bytes = ks == 3   ? hcm_conv3x3_wgrad_workspace_bytes
+                       : ks == 1 ? hcm_conv1x1_wgrad_workspace_bytes
+                       : ks == 4 ? hcm_conv1x1_ball_wgrad_workspace_bytes
+                                 : hcm_conv3x3s2_wgrad_workspace_bytes;
+    const auto run = ks == 3 ? hcm_conv3x3_wgrad : ks == 1 ? hcm_conv1x1_wgrad : ks == 4 ? hcm_conv1x1_ball_wgrad : hcm_conv3x3s2_wgrad;
     const size_t need = bytes(N, C, K, H, W);
     if (need > 0) {
       Tensor local;

@@ -215,6 +215,59 @@ def ball_project(P, Q, idx, gamma, beta, running_mean=None, running_var=None, mo
     return _BallProject.apply(P, Q, idx, gamma, beta, running_mean, running_var, momentum, eps, relu)
 
 
+class _PointProject(torch.autograd.Function):
+    """P[b] = W src[b] for W [K, C], src [B, C, N] -> [B, K, N] on csrc/conv1x1.hip (hcm_conv1x1_forward / _backward_data /
+    hcm_conv1x1_ball_wgrad): the source-point projection of ``Conv2d.forward_grouped``.  Its weight gradient is a [K x C] output
+    with a reduction over all B * N points -- as a library GEMM a handful of workgroups walking 0.5 M columns each (0.4 ms
+    per call in profiles/r05_hrnetpn_timeline.txt); the ball kernel splits the points over the chip and sums the partial
+    blocks in fixed order."""
+
+    @staticmethod
+    def forward(ctx, W, src):
+        W, src = W.contiguous(), src.contiguous()
+        B, Cs, N = src.shape
+        K = W.shape[0]
+        out = torch.empty(B, K, N, dtype=torch.float32, device=src.device)
+        check(_lib.lib().hcm_conv1x1_forward(_f(src, 'point_project'), _f(W, 'point_project'), _f(out, 'point_project'), B, Cs, K,
+                                             N, _stream()), 'hcm_conv1x1_forward')
+        ctx.save_for_backward(W, src)
+        return out
+
+    @staticmethod
+    def backward(ctx, dP):
+        W, src = ctx.saved_tensors
+        B, Cs, N = src.shape
+        K = W.shape[0]
+        dP = dP.contiguous()
+        L = _lib.lib()
+        dW = dsrc = None
+        if ctx.needs_input_grad[1]:
+            dsrc = torch.empty_like(src)
+            check(L.hcm_conv1x1_backward_data(_f(dP, 'point_project'), _f(W, 'point_project'), _f(dsrc, 'point_project'), B, Cs, K,
+                                              N, _stream()), 'hcm_conv1x1_backward_data')
+        if ctx.needs_input_grad[0]:
+            need = int(L.hcm_conv1x1_ball_wgrad_workspace_bytes(B, Cs, K, N, 1))
+            ws = torch.empty(need // 4, dtype=torch.float32, device=src.device)
+            dW = torch.empty_like(W)
+            check(L.hcm_conv1x1_ball_wgrad(_f(src, 'point_project'), _f(dP, 'point_project'), B, Cs, K, N, 1, _f(dW, 'point_project'),
+                                           _f(ws, 'point_project'), need, _stream()), 'hcm_conv1x1_ball_wgrad')
+        return dW, dsrc
+
+
+def point_project_supported(K, Cs, N):
+    """Shapes ``point_project`` takes: K and C multiples of 16 (the caller pads the source channels), N a multiple of 256."""
+    return K % 16 == 0 and Cs % 16 == 0 and N % 256 == 0 and N > 0
+
+
+def point_project(W, src):
+    """W [K, C] applied to every point of src [B, C, N] (fp32, ROCm) -> [B, K, N]; see ``_PointProject``."""
+    if not (W.is_cuda and src.is_cuda and W.dtype == src.dtype == torch.float32):
+        raise RuntimeError('hcmoco_amd.point_project needs fp32 ROCm tensors (no CPU fallback exists)')
+    if W.dim() != 2 or src.dim() != 3 or W.shape[1] != src.shape[1] or not point_project_supported(W.shape[0], src.shape[1], src.shape[2]):
+        raise ValueError('point_project: unsupported shapes W %s src %s' % (tuple(W.shape), tuple(src.shape)))
+    return _PointProject.apply(W, src)
+
+
 class _BallMax(torch.autograd.Function):
     """max over the last axis with ATen max_pool2d's tie rule (first index); hcm_rowmax_*."""
 

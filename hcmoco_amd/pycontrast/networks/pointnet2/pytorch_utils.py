@@ -5,6 +5,7 @@ import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 FUSED = True      # module attribute: tests flip it to get the stock-op twin of a layer
 
@@ -58,10 +59,16 @@ class _ConvBNAct(nn.Sequential):
         from .... import pointnet2_hip
         bn = self.bn.bn
         W = self.conv.weight.view(self.conv.weight.shape[0], -1)            # [C1, 3 + C], xyz columns first
-        src = xyz.transpose(1, 2)
-        if features is not None:
-            src = torch.cat([src, features], dim=1)
-        P = torch.matmul(W, src)                                             # [B, C1, N]
+        parts = [xyz.transpose(1, 2)] + ([features] if features is not None else [])
+        cs = sum(t.shape[1] for t in parts)
+        pad = -cs % 16
+        if pointnet2_hip.point_project_supported(W.shape[0], cs + pad, xyz.shape[1]):
+            # csrc/conv1x1.hip takes channel counts in multiples of 16: zero channels against zero weight columns (exact)
+            if pad:
+                parts.append(xyz.new_zeros(xyz.shape[0], pad, xyz.shape[1]))
+            P = pointnet2_hip.point_project(F.pad(W, (0, pad)), torch.cat(parts, dim=1))     # [B, C1, N]
+        else:
+            P = torch.matmul(W, torch.cat(parts, dim=1) if len(parts) > 1 else parts[0])
         Q = torch.matmul(W[:, :3], new_xyz.transpose(1, 2))                  # [B, C1, np]
         bn.num_batches_tracked.add_(1)
         return pointnet2_hip.ball_project(P, Q, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,

@@ -411,6 +411,22 @@ int hcm_bn_act_forward_pre(const float* x, const float* residual, const float* g
                            float* running_mean, float* running_var, float momentum, float eps, int relu,
                            int N, int C, int HW, float* y, float* stats, const float* partial_sums, int nslots,
                            hcm_stream_t stream);
+/* 1x1 convolutions of the PointNet++ shared MLPs on ball tensors (r05; reference: networks/pointnet2/pytorch_utils.py:5-33,
+ * nn.Conv2d(kernel_size=1, bias=False)).  x [N, C, P], w [K, C] (nn.Conv2d.weight viewed as a matrix), z [N, K, P], P = the
+ * positions of one image (npoint * nsample), fp32, contiguous.  forward: z = w x per image; backward_data: dx = w^T dz.
+ * Exact fp32 MFMA on the tensors as they lie (no LDS, no layout change).  hcm_conv1x1_supported: C % 4 == 0, K % 4 == 0,
+ * P % 64 == 0; anything else returns hipErrorInvalidValue and the caller keeps its library path.
+ * hcm_conv1x1_ball_wgrad: dw [K, C] = sum over n, p of dy[n][k][p] x[n][c][p] (same argument order as hcm_conv1x1_wgrad below:
+ * H * W = P); fp32 MFMA over the positions as they lie, per-workgroup partials in the workspace, summed in fixed order
+ * (deterministic).  Needs K % 16 == 0, C % 16 == 0, P % 256 == 0: _workspace_bytes returns 0 for anything else and the
+ * caller keeps hcm_conv1x1_wgrad / its library path. */
+int hcm_conv1x1_supported(int C, int K, int P);
+int hcm_conv1x1_forward(const float* x, const float* w, float* z, int N, int C, int K, int P, hcm_stream_t stream);
+int hcm_conv1x1_backward_data(const float* dz, const float* w, float* dx, int N, int C, int K, int P, hcm_stream_t stream);
+size_t hcm_conv1x1_ball_wgrad_workspace_bytes(int N, int C, int K, int H, int W);
+int hcm_conv1x1_ball_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
+                           void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+
 /* BatchNorm2d (training mode) + ReLU + max over the ball in one piece (r05): the last layer of a PointNet++ SharedMLP
  * followed by F.max_pool2d(y, [1, nsample]) (networks/pointnet2/pointnet2_modules.py:44-55, pytorch_utils.py:5-33 of the
  * reference).  z [N, C, np, ns] fp32 contiguous (the 1x1 convolution's output); y = relu(bn(z)) is never written:
