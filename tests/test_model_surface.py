@@ -84,13 +84,17 @@ def check_backward_against_fixture(gb, model, device, tol_full=2e-3, tol_proj=5e
     c1 = torch.randn(aux['linear_merge1'].shape, generator=gc) * 0.05
     c2 = torch.randn(aux['linear_merge2'].shape, generator=gc) * 0.05
     assert torch.equal(cf, gb['cf']) and torch.equal(c3, gb['c3'])
-    loss = ((f * cf.to(device)).sum() + (f3 * c3.to(device)).sum() + (aux['linear_merge1'] * c1.to(device)).sum()
-            + (aux['linear_merge2'] * c2.to(device)).sum())
+    terms = [f * cf.to(device), f3 * c3.to(device), aux['linear_merge1'] * c1.to(device), aux['linear_merge2'] * c2.to(device)]
+    loss = terms[0].sum() + terms[1].sum() + terms[2].sum() + terms[3].sum()
     loss.backward()
     if device.type == 'cuda':
         torch.cuda.synchronize()
     loss = loss.detach()
-    assert abs(float(loss) - float(gb["loss"])) <= 1e-4 * abs(float(gb['loss'])) + 1e-4, (float(loss), float(gb['loss']))
+    # the loss (64.2 for coco_reduce) is what is left of 1.5e5 of |terms| (two 128-channel maps of |x| ~ 1e2 against random
+    # cotangents): 1e-6 of that mass -- the maps themselves are compared at 1e-4 / 5e-5 -- plus 1e-4 of the value.  (One fp32
+    # ulp at the mass is 9e-3; MIOpen's Find picks its algorithms by timing, so the GPU value moves by that from run to run.)
+    mass = float(sum(t.detach().abs().sum() for t in terms))
+    assert abs(float(loss) - float(gb["loss"])) <= 1e-4 * abs(float(gb['loss'])) + 1e-6 * mass, (float(loss), float(gb['loss']), mass)
 
     def rel(a, b):
         return float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
