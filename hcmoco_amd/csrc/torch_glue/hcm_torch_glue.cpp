@@ -237,8 +237,12 @@ bool stats_in_conv() { return true; }
 
 // hcm_conv1x1_forward / _backward_data (csrc/conv1x1.hip): the 1x1 convolutions of the PointNet++ shared MLPs on ball tensors
 // (maps far larger than an HRNet branch), on the tensors as they lie.
+// A ball tensor is tall -- npoint / nsample = 8 .. 256 -- where an HRNet branch is square: the encoders' own 1x1 layers (80 x 80
+// maps at a 320 crop) stay where they were tuned.
+bool ball_shaped(int64_t H, int64_t W) { return H * W > 4096 && H >= 8 * W; }
+
 bool own_conv1x1(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
-  return stride == 1 && pad == 0 && w.size(2) == 1 && w.size(3) == 1 && x.size(2) * x.size(3) > 4096 &&
+  return stride == 1 && pad == 0 && w.size(2) == 1 && w.size(3) == 1 && ball_shaped(x.size(2), x.size(3)) &&
          hcm_conv1x1_supported((int)x.size(1), (int)w.size(0), (int)(x.size(2) * x.size(3))) == 1;
 }
 
@@ -463,7 +467,7 @@ int own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g) {      // 0: no
   // 1x1 layers on maps far larger than an HRNet branch -- the shared MLPs of PointNet++ on [B, C, npoint, nsample] ball tensors
   // (16 .. 256 channels, 8 K - 131 K positions per image): hcm_conv1x1_ball_wgrad (csrc/conv1x1.hip), on the NCHW tensors
   // as they lie (MIOpen: two layout transposes + an NHWC implicit GEMM)
-  if (same && w.size(2) == 1 && w.size(3) == 1 && g.size(2) * g.size(3) > 4096 &&
+  if (same && w.size(2) == 1 && w.size(3) == 1 && ball_shaped(g.size(2), g.size(3)) &&
       hcm_conv1x1_ball_wgrad_workspace_bytes((int)x.size(0), (int)w.size(1), (int)w.size(0), (int)g.size(2), (int)g.size(3)) > 0)
     return 4;
   if (same && w.size(2) == 1 && w.size(3) == 1 && w.size(0) <= m1 && w.size(1) <= m1) {
@@ -871,7 +875,7 @@ void flush_wgrad_reductions(hipStream_t st) {
 // true: the layer's partial sums are parked and its reduction is queued on stream `st` (the current stream)
 bool defer_own_wgrad(const Tensor& x, const Tensor& w, const Tensor& g, float* dw, hipStream_t st) {
   const int ks = own_wgrad(x, w, g);
-  if (ks == 0) return false;
+  if (ks == 0 || ks == 4) return false;          // 4: the ball kernel keeps its own partials (run_wgrad)
   const int N = (int)x.size(0), C = (int)x.size(1), K = (int)w.size(0), H = (int)g.size(2), W = (int)g.size(3);
   const size_t need = ks == 3 ? hcm_conv3x3_wgrad_workspace_bytes(N, C, K, H, W)
                     : ks == 1 ? hcm_conv1x1_wgrad_workspace_bytes(N, C, K, H, W) : hcm_conv3x3s2_wgrad_workspace_bytes(N, C, K, H, W);

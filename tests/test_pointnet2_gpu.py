@@ -660,7 +660,7 @@ def test_point_project_matches_matmul_and_runs_on_conv1x1_hip():
         ref = torch.matmul(Wd, sd)
         ref.backward(cot.double())
         for got, want in ((out, ref), (W.grad, Wd.grad), (src.grad, sd.grad)):
-            assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+            assert float((got.detach().double() - want.detach()).abs().max()) <= 2e-5 * float(want.detach().abs().max())
     with pytest.raises(ValueError):
         pointnet2_hip.point_project(torch.randn(16, 9, device=dev), torch.randn(2, 9, 512, device=dev))
     with pytest.raises(RuntimeError):
