@@ -232,7 +232,7 @@ class FailSafe(object):
       * a phase that makes no progress for ``limit`` seconds (a mis-wired rank: the peers sit in a collective) -- chosen
         BELOW the process group's own timeout (120 s), whose RCCL watchdog aborts the process without unwinding Python."""
     PG_TIMEOUT_S = 120
-    STALL_S = {'default': 100.0, 'build': 400.0, 'first steps': 400.0}
+    STALL_S = {'default': 100.0, 'build': 400.0, 'first steps': 400.0, 'warmup': 400.0}   # --no_check: the cold start is in warmup
 
     def __init__(self, rank, world, header):
         import threading
@@ -528,6 +528,7 @@ def run(a, rank, world, local, fs):
     fs.enter('warmup')
     for _ in range(a.warmup):
         trainer.train_step(next(it), model, contrast, opt, stage2=True)
+        fs.t_phase = time.monotonic()         # progress
     ranks_seen = None
     if dist.is_initialized():
         # the first multi-GPU run must be able to say WHY it scales as it does: exposed communication per step from HIP
