@@ -301,8 +301,27 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             side_g = self._side(0, x.device) if self.two_streams & 1 else None
             side_geo = self._side(2, x.device) if self.two_streams & 4 else None
             side_pn.wait_stream(main)
+            trace = self.trace_streams
+            if trace:
+                ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 'h0', 'h1', 'p0', 'p1')}
+                ev['t0'].record(main)
+            # r05: the HRNet's forward goes to the C++ helper thread of the caller's stream (encoder_forward_async) FIRST -- the
+            # geometry's ~40 Python-issued launches and the cloud branch's ~700 are issued while that thread issues the
+            # program's ~360 -- and is collected BEHIND the cloud branch: encoder_forward_wait makes the program's autograd
+            # node on this thread at that point, i.e. AFTER every node of the cloud branch, so the engine -- which runs the
+            # ready node that was created last -- starts the HRNet's reverse loop (one push to its helper thread) before it
+            # walks the cloud branch's ~700 nodes instead of after them (r04: the HRNet queue idle for the first ~15 ms of
+            # backward).
+            hr_pending = None
+            early = side_geo is not None and hasattr(self.encoder1, 'forward_async')
+            inputs_ready = torch.cuda.Event()          # the side streams wait for the inputs, not for the HRNet launches
+            inputs_ready.record(main)                  # that the helper thread is about to queue behind them
+            if early:
+                if trace:
+                    ev['h0'].record(main)
+                hr_pending = self.encoder1.forward_async(x1, node_at_wait=True)
             if side_g is not None:
-                side_g.wait_stream(main)
+                side_g.wait_event(inputs_ready)
                 with torch.cuda.stream(side_g):
                     _feat3 = self.encoder3(s)
             # r04: the GEOMETRY of the cloud branch (back-projection, the four FPS levels, eight ball queries, the three_nn of
@@ -311,7 +330,7 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
             # walking a chain of rounds) that run underneath the HRNet instead of in front of the cloud branch's MLPs.
             plan = None
             if side_geo is not None:
-                side_geo.wait_stream(main)
+                side_geo.wait_event(inputs_ready)
                 with torch.cuda.stream(side_geo):
                     from .pointnet2.pointnet2_modules import PointnetFPModule
                     sample_pn, full_pn, _ = self.depth2pts(x2, depth_mask, grid_xy, original_h, original_w, mean)
@@ -325,23 +344,13 @@ class CMC3HRNetSGCNPN2SingleHead(nn.Module):
                         plan.extra['map_ready'] = plan.mark(True)
                     plan.share(side_pn)
                     plan.share(main)
-            # Issue order (r04).  The HRNet is one compiled program whose launches a C++ loop issues in ~2 ms; the cloud
-            # branch is ~700 launches issued from Python.  With the geometry on its own stream the HRNet goes first: the FPS
-            # levels then run underneath its kernels (61.4 vs 62.1 ms per synchronised step; with the geometry inside the
-            # cloud branch the order made no difference, 63.0 vs 63.4: whichever branch is issued second finishes last).
+            # Issue order.  The HRNet is one compiled program whose launches a C++ loop issues in ~2 ms; the cloud branch is
+            # ~700 launches issued from Python.  r04: with the geometry on its own stream the HRNet goes before the cloud
+            # branch (61.4 vs 62.1 ms per synchronised step).  r05: and before the geometry too, from its helper thread -- the
+            # profiled step had both encoder queues idle for 5.7 ms while Python issued the geometry's ~150 small kernels:
+            # same-box A/B 660.8 / 660.2 vs 649.6 samples/s (a cold 625 aside).
             first = plan is not None
-            trace = self.trace_streams
-            if trace:
-                ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 'h0', 'h1', 'p0', 'p1')}
-                ev['t0'].record(main)
-            # r05: the HRNet's forward goes to the C++ helper thread of the caller's stream (encoder_forward_async) and is
-            # collected BEHIND the cloud branch: (i) its ~360 launches and the cloud branch's ~700 Python-issued launches are
-            # issued by two threads at once, (ii) encoder_forward_wait makes the program's autograd node on this thread at
-            # that point, i.e. AFTER every node of the cloud branch, so the engine -- which runs the ready node that was
-            # created last -- starts the HRNet's reverse loop (one push to its helper thread) before it walks the cloud
-            # branch's ~700 nodes instead of after them (r04: the HRNet queue idle for the first ~15 ms of backward).
-            hr_pending = None
-            if first:
+            if first and hr_pending is None:
                 if trace:
                     ev['h0'].record(main)
                 hr_pending = self.encoder1.forward_async(x1, node_at_wait=True) if hasattr(self.encoder1, 'forward_async') else None
