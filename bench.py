@@ -49,7 +49,7 @@ MFMA_BF16_PEAK_TFS = 2500.0    # dense bf16 MFMA peak
 
 
 def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, sampled=1, arch='HRNet', width=18,
-              bank_dtype='fp32', fmap_dtype='fp32', encoder_dtype='fp32'):
+              bank_dtype='fp32', fmap_dtype='fp32', encoder_dtype='fp32', wgrad_stream=8):
     from hcmoco_amd.pycontrast.options.train_options import TrainOptions
     argv = ['--method', 'CMCJointsPri3DRGBD2S', '--modal', 'RGBD2S', '--arch', arch, '--width', str(width),
             '--bank_dtype', bank_dtype, '--fmap_dtype', fmap_dtype, '--encoder_dtype', encoder_dtype,
@@ -59,7 +59,7 @@ def make_args(batch_global, nce_k, n_data, size, skeleton, backend, tmp, steps, 
             '--learning_rate', '0.03', '--dist-backend', backend, '--synthetic',
             '--synthetic_n_data', str(n_data), '--synthetic_size', str(size), '--synthetic_steps', str(steps),
             '--model_path', tmp, '--tb_path', tmp, '--seed', '0', '--print_freq', '1000000',
-            '--sampled_projection', str(sampled)]
+            '--sampled_projection', str(sampled), '--wgrad_stream', str(wgrad_stream)]
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -406,6 +406,8 @@ def main():
                          'batch-norm statistics / master weights / loss section); not the headline config')
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
+    ap.add_argument('--wgrad_stream', type=int, default=8,
+                    help='layers per hand-over of the encoders\' library weight gradients to their side stream (0: in line)')
     ap.add_argument('--fault', type=str, default=None, help=argparse.SUPPRESS)      # tests: "rank:step:exit|raise|hang"
     ap.add_argument('--backend', type=str, default='nccl',
                     help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '
@@ -494,7 +496,8 @@ def run(a, rank, world, local, fs):
     B = a.batch_per_gpu
     args = make_args(B * world, a.nce_k, a.n_data, a.size, a.skeleton, a.backend, tempfile.mkdtemp(),
                      a.steps + a.warmup + 2, sampled=a.sampled_projection, arch=a.arch, width=a.width,
-                     bank_dtype=a.bank_dtype, fmap_dtype=a.fmap_dtype, encoder_dtype=a.encoder_dtype)
+                     bank_dtype=a.bank_dtype, fmap_dtype=a.fmap_dtype, encoder_dtype=a.encoder_dtype,
+                     wgrad_stream=a.wgrad_stream)
     args.rank, args.world_size, args.local_rank, args.gpu = rank, world, local, dev.index
     args.channels_last = bool(a.channels_last)
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
@@ -750,6 +753,7 @@ def run(a, rank, world, local, fs):
                        'batch_per_gpu': B, 'global_batch': B * world, 'nce_k': a.nce_k, 'n_data': a.n_data,
                        'samples_per_image': 400, 'feat_dim': D, 'parallelism': 'dp%d' % world,
                        'channels_last': bool(a.channels_last), 'sampled_projection': bool(a.sampled_projection),
+                       'wgrad_stream': int(a.wgrad_stream),
                        'grad_collectives_per_step': (trainer.grad_sync.launched if trainer.grad_sync is not None
                                                      else (None if world > 1 else 0)),
                        'backend': a.backend if (world > 1 or forced) else None,

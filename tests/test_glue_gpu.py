@@ -197,7 +197,7 @@ def test_deferred_weight_gradients_equal_inline_ones():
     _grads_agree(grads[1], grads[0])
 
 
-def _hrnet_run(net, x, state, program, deferred=False, use_async=False, branch_streams=False):
+def _hrnet_run(net, x, state, program, deferred=False, use_async=False, branch_streams=False, wgrad_stream=0):
     from hcmoco_amd import _lib
     from hcmoco_amd.pycontrast.networks import hrnet
     ops = _lib.torch_glue()
@@ -207,6 +207,7 @@ def _hrnet_run(net, x, state, program, deferred=False, use_async=False, branch_s
     hrnet.BRANCH_STREAMS = branch_streams       # branch i of every HighResolutionModule on stream i
     net._programs.clear()
     ops.set_async_wgrad(deferred)
+    ops.set_wgrad_stream(wgrad_stream > 0, max(wgrad_stream, 1))   # library weight gradients on a side stream, n per hand-over
     try:
         if use_async:
             side = torch.cuda.Stream()
@@ -222,6 +223,7 @@ def _hrnet_run(net, x, state, program, deferred=False, use_async=False, branch_s
         ops.wgrad_join()
     finally:
         ops.set_async_wgrad(False)
+        ops.set_wgrad_stream(False, 16)
         hrnet.ENCODER_PROGRAM = True
         hrnet.BRANCH_STREAMS = False
         net._programs.clear()
@@ -256,7 +258,7 @@ def test_encoder_program_equals_module_path():
     state = {k: v.clone() for k, v in small.state_dict().items()}
     ref = _hrnet_run(small, x, state, program=False)
     for kwargs in (dict(), dict(deferred=True), dict(deferred=True, use_async=True),
-                   dict(deferred=True, use_async=True, branch_streams=True)):
+                   dict(deferred=True, use_async=True, branch_streams=True), dict(deferred=True, use_async=True, wgrad_stream=4)):
         got = _hrnet_run(small, x, state, program=True, **kwargs)
         for a, b in zip(got[0], ref[0]):
             _close(a, b, 1e-4)
@@ -273,6 +275,12 @@ def test_encoder_program_equals_module_path():
     for a, b in zip(got[0], ref[0]):
         _close(a, b, 1e-3)
     _grads_agree(got[1], ref[1])
+    # the trainer's default since r05: the library weight gradients on a side stream, 8 (and 3: ragged batches) layers per
+    # hand-over -- the same kernels on the same operands, so the gradients equal the in-line ones up to MIOpen's atomics
+    for n in (8, 3):
+        side = _hrnet_run(net, xi, state, program=True, deferred=True, use_async=True, wgrad_stream=n)
+        _grads_agree(side[1], ref[1])
+        _grads_agree(side[1], got[1], min_cos=0.99999)
     # an input size whose coarsest maps are 7x7 (H*W % 4 != 0) must take the module path, not fail
     y = net(torch.randn(2, 3, 224, 224, device=dev))
     assert [t.shape[-1] for t in y] == [56, 28, 14, 7]

@@ -77,11 +77,15 @@ def test_fused_semgcn_layer_is_the_path_under_test(skel):
     assert any('bnact' in k or 'bn_' in k for k in names), names
 
 
-@pytest.mark.parametrize('skel', ['mpii', 'coco_reduce'])
-def test_default_runtime_backward_matches_reference(golden, skel):
+@pytest.mark.parametrize('skel,wgrad_stream', [('mpii', 8), ('coco_reduce', 8), ('mpii', 0)])
+def test_default_runtime_backward_matches_reference(golden, skel, wgrad_stream):
     """d loss / d skeleton, every SemGCN / head / projection gradient in full, and norm + random projection of every
-    encoder parameter's gradient, against the reference's CPU backward."""
+    encoder parameter's gradient, against the reference's CPU backward -- with the encoder programs' library weight
+    gradients on their side stream, 8 layers per hand-over (the trainer's default, --wgrad_stream) and in line."""
+    from hcmoco_amd import _lib
     report = {}
+    glue = _lib.torch_glue()
+    glue.set_wgrad_stream(wgrad_stream > 0, max(wgrad_stream, 1))
     try:
         # per parameter 3e-2 (the smallest gradients -- BatchNorm biases of the deep layers, 1e-4 of the largest norm,
         # each a sum of thousands of cancelling terms -- sit at ~1e-2 in fp32 with another summation order); median and
@@ -89,5 +93,7 @@ def test_default_runtime_backward_matches_reference(golden, skel):
         check_backward_against_fixture(golden('model_bwd_hrnet_w18_' + skel), _model(skel).train(), dev(), tol_proj=3e-2,
                                        report=report)
     finally:
+        glue.wgrad_join()
+        glue.set_wgrad_stream(False, 16)
         print(skel, {k: v for k, v in report.items() if k != 'table'},
               [(round(t[0], 5), t[1]) for t in report.get('table', [])[:6]])
