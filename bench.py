@@ -407,7 +407,7 @@ def main():
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--wgrad_stream', type=int, default=8,
-                    help='layers per hand-over of the encoders\' library weight gradients to their side stream (0: in line)')
+                    help='layers per hand-over of the encoders\' weight gradients to their side stream (0: in line)')
     ap.add_argument('--fault', type=str, default=None, help=argparse.SUPPRESS)      # tests: "rank:step:exit|raise|hang"
     ap.add_argument('--backend', type=str, default='nccl',
                     help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '

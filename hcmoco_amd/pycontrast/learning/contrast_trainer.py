@@ -97,7 +97,7 @@ class ContrastTrainer(BaseTrainer):
             # buffers, launched chunk by chunk while the reverse loops are still running.
             from ... import _lib
             self.async_wgrad = _lib.torch_glue()
-            # r05: the library weight gradients of the encoder programs on a side stream, 8 layers per hand-over: the
+            # r05: the weight gradients of the encoder programs on a side stream, 8 layers per hand-over: the
             # reverse chain of each encoder is what the step waits for, its dW kernels are not on it (same-box A/B:
             # HRNet x 2 704.7 / 705.4 -> 749.7 samples/s, HRNetPN 674 / 678 -> 707; batches of 16 / 32: 743 / 744)
             n = int(getattr(args, 'wgrad_stream', 8))

@@ -106,8 +106,8 @@ BASE_FLAGS = [
                                      help='1: apply merge_all_res + the 1x1 feature-map projection only at the '
                                           'pixels the losses sample (same math, SURVEY 8f-1); 0: full maps')),
     (('--wgrad_stream',), dict(type=_I, default=8,
-                               help='n > 0: the encoder programs hand the weight gradients that go to the library '
-                                    '(MIOpen, five launches each) to a side stream, n layers at a time, so that the reverse '
+                               help='n > 0: the encoder programs hand their weight gradients (own kernels '
+                                    'and MIOpen\'s five-launch path alike) to a side stream, n layers at a time, so that the reverse '
                                     'chain dx -> BatchNorm -> dx is not queued behind them (csrc/torch_glue); 0: in line')),
     (('--grad_sync',), dict(type=_S, default='auto', choices=['auto', 'ddp', 'flat', 'overlap'],
                             help='N>1 gradient averaging: ddp = DistributedDataParallel; overlap = in-place RCCL '

@@ -207,7 +207,7 @@ def _hrnet_run(net, x, state, program, deferred=False, use_async=False, branch_s
     hrnet.BRANCH_STREAMS = branch_streams       # branch i of every HighResolutionModule on stream i
     net._programs.clear()
     ops.set_async_wgrad(deferred)
-    ops.set_wgrad_stream(wgrad_stream > 0, max(wgrad_stream, 1))   # library weight gradients on a side stream, n per hand-over
+    ops.set_wgrad_stream(wgrad_stream > 0, max(wgrad_stream, 1))   # weight gradients on a side stream, n per hand-over
     try:
         if use_async:
             side = torch.cuda.Stream()
@@ -275,7 +275,7 @@ def test_encoder_program_equals_module_path():
     for a, b in zip(got[0], ref[0]):
         _close(a, b, 1e-3)
     _grads_agree(got[1], ref[1])
-    # the trainer's default since r05: the library weight gradients on a side stream, 8 (and 3: ragged batches) layers per
+    # the trainer's default since r05: the weight gradients on a side stream, 8 (and 3: ragged batches) layers per
     # hand-over -- the same kernels on the same operands; every run re-builds the program (MIOpen's Find may pick other
     # algorithms, a few ReLU masks flip), so the two agree like two runs of one mode do: cosine 0.999 per parameter
     for n in (8, 3):
