@@ -129,9 +129,24 @@ __global__ __launch_bounds__(256) void wgrad1x1_ball_kernel(const float* __restr
   extern __shared__ float red[];                       // [4 waves][KT*CT*4][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int np = lane & 15, g = lane >> 4;
+  // Workgroup id -> (chunk of positions, block of dW).  The blocks of one chunk read the same rows of X / dZ again: they get
+  // ids 8 apart -- dispatched back to back onto the SAME XCD (ids go round-robin over the 8 XCDs), so the second reader
+  // finds the rows in that XCD's L2 (r05_conv1x1_pmc.json: 1.33x the algorithmic bytes fetched with the blocks a whole
+  // grid dimension apart, 64 -> 128 channels).
+  const int nblocks = gridDim.y, chunks = gridDim.x;
+  const int id = blockIdx.y * chunks + blockIdx.x;                 // linear dispatch order
+  int chunk, blk;
+  if ((chunks & 7) == 0) {
+    const int group = id / (8 * nblocks), r = id - group * (8 * nblocks);
+    blk = r >> 3;
+    chunk = group * 8 + (r & 7);
+  } else {
+    blk = blockIdx.y;
+    chunk = blockIdx.x;
+  }
   const int per_image = P / (4 * L);
-  const int n = blockIdx.x / per_image, run = blockIdx.x - n * per_image;
-  const int k0 = (blockIdx.y / cblocks) * (16 * KT), c0 = (blockIdx.y % cblocks) * (16 * CT);
+  const int n = chunk / per_image, run = chunk - n * per_image;
+  const int k0 = (blk / cblocks) * (16 * KT), c0 = (blk % cblocks) * (16 * CT);
   const size_t pw = (size_t)run * 4 * L + (size_t)wave * L + 4 * g;
   const float* a_ptr = DZ + ((size_t)n * K + k0 + np) * P + pw;
   const float* b_ptr = X + ((size_t)n * C + c0 + np) * P + pw;
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_ball_kernel(const float* __restr
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[(wave * (KT * CT * 4) + (kt * CT + ct) * 4 + q) * 64 + lane] = acc[kt][ct][q];
   __syncthreads();
-  float* out = partial + (size_t)blockIdx.x * K * C;
+  float* out = partial + (size_t)chunk * K * C;
   for (int e = threadIdx.x; e < KT * CT * 4 * 64; e += 256) {
     const float v = (red[e] + red[KT * CT * 256 + e]) + (red[2 * KT * CT * 256 + e] + red[3 * KT * CT * 256 + e]);
     const int l = e & 63, t = e >> 6, q = t & 3, ct = (t >> 2) % CT, kt = (t >> 2) / CT;

@@ -21,7 +21,10 @@ def timeit(fn, n=20):
 
 p = lambda t: CT.c_void_p(t.data_ptr())
 B = int(os.environ.get('B', 32))
-for C, K, npnt, ns in [(16, 32, 4096, 16), (32, 64, 4096, 32), (64, 128, 1024, 16), (64, 128, 1024, 32), (128, 256, 256, 32)]:
+SHAPES = [(16, 32, 4096, 16), (32, 64, 4096, 32), (64, 128, 1024, 16), (64, 128, 1024, 32), (128, 256, 256, 32)]
+if 'ONLY' in os.environ:                      # tools/probes/pmc_conv1x1.sh: one layer under the counters
+    SHAPES = [SHAPES[int(os.environ['ONLY'])]]
+for C, K, npnt, ns in SHAPES:
     P = npnt * ns
     x = torch.randn(B, C, npnt, ns, device=dev); dy = torch.randn(B, K, npnt, ns, device=dev); w = torch.randn(K, C, 1, 1, device=dev)
     z, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
