@@ -111,8 +111,8 @@ SIGNATURES = {
     'hcm_conv1x1_ball_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
     'hcm_conv1x1_ball_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_ball_project_stats_floats': (_sz, [_i] * 4),
-    'hcm_ball_project_forward': (_i, [_p] * 7 + [_f, _f] + [_i] * 6 + [_p] * 3),
-    'hcm_ball_project_backward': (_i, [_p] * 7 + [_i] * 6 + [_p] * 4),
+    'hcm_ball_project_forward': (_i, [_p] * 8 + [_f, _f] + [_i] * 6 + [_p] * 3),
+    'hcm_ball_project_backward': (_i, [_p] * 8 + [_i] * 6 + [_p] * 4),
     'hcm_rowmax_forward': (_i, [_p, C.c_longlong, _i, _p, _p, _p]),
     'hcm_rowmax_backward': (_i, [_p, _p, C.c_longlong, _i, _p, _p]),
     'hcm_heads_forward': (_i, [Branches, Branches, _p] + [_i] * 5 + [_p] * 11 + [_i, _p, _p]),
@@ -142,7 +142,7 @@ for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]
 
 _lib = None
-ABI_VERSION = 4       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
+ABI_VERSION = 5       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
 
 
 def build(verbose=False):

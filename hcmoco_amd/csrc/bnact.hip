@@ -65,6 +65,9 @@ __device__ __forceinline__ void block_sum2(float& a, float& b) {
   b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
 }
 
+// ReLU that keeps a NaN (ATen's relu / clamp_min propagate it; fmaxf(NaN, 0) = 0 would hide a diverged layer)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 // Merge the per-slice partials of channel c (slice order, one lane per slice).
 __device__ __forceinline__ void merge_partials(const float* part, const Geo& g, int c, float& p1, float& p2) {
   const int lane = threadIdx.x & 63;
@@ -131,18 +134,20 @@ __global__ __launch_bounds__(kBT) void bn_apply_kernel(
     }
   }
   const float sc = gamma[c] * invstd;
-  const float sh = fmaf(-mean, sc, beta[c]);
+  const float bt = beta[c];
   const int beg = s * g.per, end = min(g.M, beg + g.per);
 #pragma unroll 4
   for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
     const size_t o = elem_offset(g, c, f);
     const float4 v = *reinterpret_cast<const float4*>(x + o);
-    float4 r = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
+    // (x - mean) * (gamma invstd) + beta, ATen's order: the subtraction is exact near the mean, where x * sc + (beta - mean sc)
+    // keeps eps * |mean| / std of round-off in the normalised value (r06; 8 such layers in a row in the PointNet++ FP chain)
+    float4 r = make_float4(fmaf(v.x - mean, sc, bt), fmaf(v.y - mean, sc, bt), fmaf(v.z - mean, sc, bt), fmaf(v.w - mean, sc, bt));
     if (RES) {
       const float4 q = *reinterpret_cast<const float4*>(res + o);
       r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
     }
-    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    if (RELU) { r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w); }
     *reinterpret_cast<float4*>(y + o) = r;
   }
 }
@@ -265,8 +270,19 @@ __global__ __launch_bounds__(1024) void bn_small_fwd_kernel(
   block_sum2_n(s1, s2);
   const float invM = 1.f / (float)g.M;
   const float m1 = s1 * invM;
-  const float var = fmaxf(fmaf(-m1, m1, s2 * invM), 0.f);
   const float mean = k + m1;
+  // the channel sits in registers: second pass for the variance (sum (x - mean)^2, no E[x^2] - E[x]^2 cancellation);
+  // the first-order correction term (sum (x - mean))^2 / M removes what the rounding of `mean` leaves (r06)
+  float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!ok[i]) continue;
+    const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+    q1 += (a + b) + (cc + d);
+    q2 = fmaf(a, a, q2); q2 = fmaf(b, b, q2); q2 = fmaf(cc, cc, q2); q2 = fmaf(d, d, q2);
+  }
+  block_sum2_n(q1, q2);
+  const float var = fmaxf((q2 - q1 * q1 * invM) * invM, 0.f);
   const float invstd = 1.f / sqrtf(var + eps);
   if (threadIdx.x == 0) {
     stats[c] = mean;
@@ -278,16 +294,17 @@ __global__ __launch_bounds__(1024) void bn_small_fwd_kernel(
     }
   }
   const float sc = gamma[c] * invstd;
-  const float sh = fmaf(-mean, sc, beta[c]);
+  const float bt = beta[c];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (!ok[i]) continue;
-    float4 r = make_float4(fmaf(v[i].x, sc, sh), fmaf(v[i].y, sc, sh), fmaf(v[i].z, sc, sh), fmaf(v[i].w, sc, sh));
+    float4 r = make_float4(fmaf(v[i].x - mean, sc, bt), fmaf(v[i].y - mean, sc, bt), fmaf(v[i].z - mean, sc, bt),
+                           fmaf(v[i].w - mean, sc, bt));
     if (RES) {
       const float4 q = *reinterpret_cast<const float4*>(res + o[i]);
       r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
     }
-    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    if (RELU) { r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w); }
     *reinterpret_cast<float4*>(y + o[i]) = r;
   }
 }
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(kBT) void bn_relu_ballmax_kernel(
     }
   }
   const float sc = gamma[c] * invstd;
-  const float sh = fmaf(-mean, sc, beta[c]);
+  const float bt = beta[c];
   constexpr int ns = 4 * L;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
   for (int f0 = beg; f0 < end; f0 += kVec) {
@@ -406,20 +423,22 @@ __global__ __launch_bounds__(kBT) void bn_relu_ballmax_kernel(
     const int n = ok ? (g.shift >= 0 ? (f >> g.shift) : (f / g.HW)) : 0;
     const int w = f - n * g.HW;                    // offset inside the (n, c) plane
     if (ok) v = *reinterpret_cast<const float4*>(x + ((size_t)n * g.C + c) * (size_t)g.HW + w);
-    const float y0 = fmaxf(fmaf(v.x, sc, sh), 0.f), y1 = fmaxf(fmaf(v.y, sc, sh), 0.f);
-    const float y2 = fmaxf(fmaf(v.z, sc, sh), 0.f), y3 = fmaxf(fmaf(v.w, sc, sh), 0.f);
+    const float y0 = relu_nan(fmaf(v.x - mean, sc, bt)), y1 = relu_nan(fmaf(v.y - mean, sc, bt));
+    const float y2 = relu_nan(fmaf(v.z - mean, sc, bt)), y3 = relu_nan(fmaf(v.w - mean, sc, bt));
     const int j0 = w & (ns - 1);
     float bv = y0, bz = v.x;
     int bj = j0;
-    if (y1 > bv) { bv = y1; bz = v.y; bj = j0 + 1; }
-    if (y2 > bv) { bv = y2; bz = v.z; bj = j0 + 2; }
-    if (y3 > bv) { bv = y3; bz = v.w; bj = j0 + 3; }
+    // ATen's max_pool2d: a later value wins if it is larger OR NaN while the running maximum is not (a NaN sticks)
+    if (y1 > bv || (y1 != y1 && bv == bv)) { bv = y1; bz = v.y; bj = j0 + 1; }
+    if (y2 > bv || (y2 != y2 && bv == bv)) { bv = y2; bz = v.z; bj = j0 + 2; }
+    if (y3 > bv || (y3 != y3 && bv == bv)) { bv = y3; bz = v.w; bj = j0 + 3; }
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) {        // the L lanes of a row are adjacent and aligned
       const float ov = __shfl_xor(bv, off);
       const float oz = __shfl_xor(bz, off);
       const int oj = __shfl_xor(bj, off);
-      const bool take = ov > bv || (ov == bv && oj < bj);
+      const bool onan = ov != ov, bnan = bv != bv;
+      const bool take = (onan && !bnan) || (onan == bnan && (ov > bv || ((ov == bv || onan) && oj < bj)));
       bv = take ? ov : bv; bz = take ? oz : bz; bj = take ? oj : bj;
     }
     if (ok && (threadIdx.x & (L - 1)) == 0) {
@@ -501,38 +520,65 @@ __global__ __launch_bounds__(kBT) void ballmax_bwd_apply_kernel(
 
 
 // ---------------------------------------------------------------------------------------------
-// First layer of a PointNet++ SharedMLP without the grouped tensor (r05).  QueryAndGroup builds x[b, :, i, j] =
-// [xyz[idx] - centre_i ; features[idx]] ([B, 3 + C, npoint, nsample], up to 415 MB) and the first 1x1 convolution
-// multiplies it by W (networks/pointnet2/pointnet2_utils.py:231-268, pytorch_utils.py:5-33 of the reference).  The
-// convolution commutes with the gather:  W x[b, :, i, j] = P[b, :, idx[b, i, j]] - Q[b, :, i]  with
-// P = W [xyz ; features] ([B, C1, N]: nsample x fewer products, a library GEMM on the host side) and Q = W_xyz centre.
-// These kernels take z = P[idx] - Q as an implicit tensor: statistics and normalisation read it through the gather
-// (P's row of one (b, c) is N floats: cache resident), the backward hands dz out once for the planned scatter into dP
-// and row-sums it into dQ.  Neither x nor z nor their gradients exist in memory.
+// First layer of a PointNet++ SharedMLP without the grouped tensor (r05; arithmetic restated in r06).  QueryAndGroup builds
+// x[b, :, i, j] = [xyz[idx] - centre_i ; features[idx]] ([B, 3 + C, npoint, nsample], up to 415 MB) and the first 1x1
+// convolution multiplies it by W = [W_xyz | W_f] (networks/pointnet2/pointnet2_utils.py:231-268, pytorch_utils.py:5-33 of the
+// reference).  The FEATURE half of the convolution commutes with the gather:  W_f features[idx] = P[b, :, idx[b, i, j]] with
+// P = W_f features ([B, C1, N]: nsample x fewer products, hcm_conv1x1_forward on the host side).  The COORDINATE half is
+// evaluated here from the relative offsets D[b, :, i, j] = xyz[idx] - centre_i ([B, 3, np, ns], the reference's own
+// grouped_xyz, 3 channels: geometry, computed ahead of the feature path):
+//     z[b, c, i, j] = P[b, c, idx[b, i, j]] + W_xyz[c, :] . D[b, :, i, j].
+// r05 also commuted the coordinate half (z = P'[idx] - Q, P' = W [xyz ; features], Q = W_xyz centre): a difference of two
+// O(|xyz|) numbers whose value is O(radius) -- 40 x the round-off of the reference's subtract-then-multiply for 2.5 cm balls in
+// a 1 m cloud, 50 x the reference's own fp32 error on the first level's output (tests/test_pn_reference_gpu.py, r06).
+// These kernels take z as that implicit tensor: statistics and normalisation read it through the gather (P's row of one
+// (b, c) is N floats: cache resident) plus three coalesced reads of D; the backward hands dz out once for the planned scatter
+// into dP and reduces dW_xyz[c, :] = sum dz D in the same pass.  Neither x nor z nor their gradients exist in memory.
 // ---------------------------------------------------------------------------------------------
 struct BallGeo {
   int N, np, ns;      // source points, centres, ball size
 };
 
-__device__ __forceinline__ float4 ball_z(const float* __restrict__ Prow, float qv, const int* __restrict__ idx, size_t o) {
-  const int4 id = *reinterpret_cast<const int4*>(idx + o);
-  return make_float4(Prow[id.x] - qv, Prow[id.y] - qv, Prow[id.z] - qv, Prow[id.w] - qv);
+// z of four consecutive ball members of (n, c): o = n * HW + w indexes idx, Dn = D + n * 3 * HW
+template <bool HASP>
+__device__ __forceinline__ float4 ball_z(const float* __restrict__ Prow, const int* __restrict__ idx, size_t o,
+                                         const float* __restrict__ Dn, int HW, int w, float w0, float w1, float w2) {
+  const float4 d0 = *reinterpret_cast<const float4*>(Dn + w);
+  const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)HW + w);
+  const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)HW + w);
+  float4 z = make_float4(fmaf(w2, d2.x, fmaf(w1, d1.x, w0 * d0.x)), fmaf(w2, d2.y, fmaf(w1, d1.y, w0 * d0.y)),
+                         fmaf(w2, d2.z, fmaf(w1, d1.z, w0 * d0.z)), fmaf(w2, d2.w, fmaf(w1, d1.w, w0 * d0.w)));
+  if (HASP) {
+    const int4 id = *reinterpret_cast<const int4*>(idx + o);
+    z.x += Prow[id.x]; z.y += Prow[id.y]; z.z += Prow[id.z]; z.w += Prow[id.w];
+  }
+  return z;
+}
+
+// z of the channel's very first element (the shift of the one-pass variance)
+template <bool HASP>
+__device__ __forceinline__ float ball_z0(const float* __restrict__ P, const int* __restrict__ idx, const float* __restrict__ D,
+                                         int c, int N, int HW, float w0, float w1, float w2) {
+  const float z = fmaf(w2, D[2 * (size_t)HW], fmaf(w1, D[(size_t)HW], w0 * D[0]));
+  return HASP ? z + P[(size_t)c * N + idx[0]] : z;
 }
 
 // slice sums of (z - k), (z - k)^2; k = z of the channel's first element.  Geo g describes [B, C, np * ns].
-__global__ __launch_bounds__(kBT) void ball_stats_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                         const int* __restrict__ idx, Geo g, BallGeo bg,
-                                                         float* __restrict__ part) {
+template <bool HASP>
+__global__ __launch_bounds__(kBT) void ball_stats_kernel(const float* __restrict__ P, const float* __restrict__ D,
+                                                         const float* __restrict__ Wxyz, const int* __restrict__ idx, Geo g,
+                                                         BallGeo bg, float* __restrict__ part) {
   const int c = blockIdx.x, s = blockIdx.y;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
-  const float k = P[(size_t)c * bg.N + idx[0]] - Q[(size_t)c * bg.np];
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  const float k = ball_z0<HASP>(P, idx, D, c, bg.N, g.HW, w0, w1, w2);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll 2
   for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
     const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
     const int w = f - n * g.HW;
-    const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
-                            (size_t)n * g.HW + w);
+    const float4 v = ball_z<HASP>(HASP ? P + ((size_t)n * g.C + c) * bg.N : nullptr, idx, (size_t)n * g.HW + w,
+                                  D + (size_t)n * 3 * g.HW, g.HW, w, w0, w1, w2);
     const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
     s1 += (a + b) + (cc + d);
     s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(cc, cc, s2); s2 = fmaf(d, d, s2);
@@ -544,15 +590,17 @@ __global__ __launch_bounds__(kBT) void ball_stats_kernel(const float* __restrict
   }
 }
 
-template <bool RELU>
+template <bool RELU, bool HASP>
 __global__ __launch_bounds__(kBT) void ball_apply_kernel(
-    const float* __restrict__ P, const float* __restrict__ Q, const int* __restrict__ idx, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ part, Geo g, BallGeo bg, float eps, float momentum,
-    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
+    const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ Wxyz, const int* __restrict__ idx,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, Geo g, BallGeo bg,
+    float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats,
+    float* __restrict__ y) {
   const int c = blockIdx.x, s = blockIdx.y;
   float p1, p2;
   merge_partials(part, g, c, p1, p2);
-  const float k = P[(size_t)c * bg.N + idx[0]] - Q[(size_t)c * bg.np];
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  const float k = ball_z0<HASP>(P, idx, D, c, bg.N, g.HW, w0, w1, w2);
   const float invM = 1.f / (float)g.M;
   const float m1 = p1 * invM;
   const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
@@ -568,27 +616,30 @@ __global__ __launch_bounds__(kBT) void ball_apply_kernel(
     }
   }
   const float sc = gamma[c] * invstd;
-  const float sh = fmaf(-mean, sc, beta[c]);
+  const float bt = beta[c];
   const int beg = s * g.per, end = min(g.M, beg + g.per);
 #pragma unroll 2
   for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
     const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
     const int w = f - n * g.HW;
-    const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
-                            (size_t)n * g.HW + w);
-    float4 r = make_float4(fmaf(v.x, sc, sh), fmaf(v.y, sc, sh), fmaf(v.z, sc, sh), fmaf(v.w, sc, sh));
-    if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    const float4 v = ball_z<HASP>(HASP ? P + ((size_t)n * g.C + c) * bg.N : nullptr, idx, (size_t)n * g.HW + w,
+                                  D + (size_t)n * 3 * g.HW, g.HW, w, w0, w1, w2);
+    // (z - mean) first: exact where z is close to the mean, no eps * |mean| / std left in the normalised value
+    float4 r = make_float4(fmaf(v.x - mean, sc, bt), fmaf(v.y - mean, sc, bt), fmaf(v.z - mean, sc, bt), fmaf(v.w - mean, sc, bt));
+    if (RELU) { r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w); }
     *reinterpret_cast<float4*>(y + ((size_t)n * g.C + c) * (size_t)g.HW + w) = r;
   }
 }
 
-template <bool RELU>
+template <bool RELU, bool HASP>
 __global__ __launch_bounds__(kBT) void ball_bwd_reduce_kernel(
-    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ Q,
-    const int* __restrict__ idx, const float* __restrict__ stats, Geo g, BallGeo bg, float* __restrict__ part) {
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
+    const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ stats, Geo g, BallGeo bg,
+    float* __restrict__ part) {
   const int c = blockIdx.x, s = blockIdx.y;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
   const float mean = stats[c];
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll 2
   for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
@@ -601,8 +652,8 @@ __global__ __launch_bounds__(kBT) void ball_bwd_reduce_kernel(
       d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
       d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
     }
-    const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
-                            (size_t)n * g.HW + w);
+    const float4 v = ball_z<HASP>(HASP ? P + ((size_t)n * g.C + c) * bg.N : nullptr, idx, (size_t)n * g.HW + w,
+                                  D + (size_t)n * 3 * g.HW, g.HW, w, w0, w1, w2);
     s1 += (d.x + d.y) + (d.z + d.w);
     s2 = fmaf(d.x, v.x - mean, s2); s2 = fmaf(d.y, v.y - mean, s2);
     s2 = fmaf(d.z, v.z - mean, s2); s2 = fmaf(d.w, v.w - mean, s2);
@@ -614,13 +665,13 @@ __global__ __launch_bounds__(kBT) void ball_bwd_reduce_kernel(
   }
 }
 
-// dz (for the scatter into dP) and dQ[b, c, i] = - sum_j dz[b, c, i, j] (L = ns / 4 adjacent lanes hold a ball)
-template <bool RELU, int L>
+// dz (for the scatter into dP) and this slice's share of dW_xyz[c, :] = sum dz D  ->  wpart[s][c][3]
+template <bool RELU, bool HASP>
 __global__ __launch_bounds__(kBT) void ball_bwd_apply_kernel(
-    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ Q,
-    const int* __restrict__ idx, const float* __restrict__ gamma, const float* __restrict__ stats,
-    const float* __restrict__ part, Geo g, BallGeo bg, float* __restrict__ gstats, float* __restrict__ dz,
-    float* __restrict__ dQ) {
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
+    const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ gamma,
+    const float* __restrict__ stats, const float* __restrict__ part, Geo g, BallGeo bg, float* __restrict__ gstats,
+    float* __restrict__ dz, float* __restrict__ wpart) {
   const int c = blockIdx.x, s = blockIdx.y;
   float p1, p2;
   merge_partials(part, g, c, p1, p2);
@@ -629,39 +680,56 @@ __global__ __launch_bounds__(kBT) void ball_bwd_apply_kernel(
     gstats[c] = p2 * invstd;     // d gamma
     gstats[g.C + c] = p1;        // d beta
   }
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
   const float invM = 1.f / (float)g.M;
   const float a = gamma[c] * invstd;
   const float b = p1 * invM;
   const float q = p2 * invstd * invstd * invM;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
-  for (int f0 = beg; f0 < end; f0 += kVec) {
-    const int f = f0 + threadIdx.x * 4;
-    const bool ok = f < end;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    int n = 0, w = 0;
-    if (ok) {
-      n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
-      w = f - n * g.HW;
-      const size_t o = ((size_t)n * g.C + c) * (size_t)g.HW + w;
-      float4 d = *reinterpret_cast<const float4*>(dy + o);
-      if (RELU) {
-        const float4 out = *reinterpret_cast<const float4*>(y + o);
-        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
-      }
-      const float4 v = ball_z(P + ((size_t)n * g.C + c) * bg.N, Q[((size_t)n * g.C + c) * bg.np + w / bg.ns], idx,
-                              (size_t)n * g.HW + w);
-      r.x = a * (d.x - b - (v.x - mean) * q);
-      r.y = a * (d.y - b - (v.y - mean) * q);
-      r.z = a * (d.z - b - (v.z - mean) * q);
-      r.w = a * (d.w - b - (v.w - mean) * q);
-      *reinterpret_cast<float4*>(dz + o) = r;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll 2
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const size_t o = ((size_t)n * g.C + c) * (size_t)g.HW + w;
+    float4 d = *reinterpret_cast<const float4*>(dy + o);
+    if (RELU) {
+      const float4 out = *reinterpret_cast<const float4*>(y + o);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
     }
-    float rs = (r.x + r.y) + (r.z + r.w);
-#pragma unroll
-    for (int off = 1; off < L; off <<= 1) rs += __shfl_xor(rs, off);
-    if (ok && (threadIdx.x & (L - 1)) == 0) dQ[((size_t)n * g.C + c) * bg.np + w / bg.ns] = -rs;
+    const float* Dn = D + (size_t)n * 3 * g.HW;
+    const float4 v = ball_z<HASP>(HASP ? P + ((size_t)n * g.C + c) * bg.N : nullptr, idx, (size_t)n * g.HW + w, Dn, g.HW, w,
+                                  w0, w1, w2);
+    float4 r;
+    r.x = a * (d.x - b - (v.x - mean) * q);
+    r.y = a * (d.y - b - (v.y - mean) * q);
+    r.z = a * (d.z - b - (v.z - mean) * q);
+    r.w = a * (d.w - b - (v.w - mean) * q);
+    *reinterpret_cast<float4*>(dz + o) = r;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn + w);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW + w);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW + w);
+    t0 = fmaf(r.x, d0.x, t0); t0 = fmaf(r.y, d0.y, t0); t0 = fmaf(r.z, d0.z, t0); t0 = fmaf(r.w, d0.w, t0);
+    t1 = fmaf(r.x, d1.x, t1); t1 = fmaf(r.y, d1.y, t1); t1 = fmaf(r.z, d1.z, t1); t1 = fmaf(r.w, d1.w, t1);
+    t2 = fmaf(r.x, d2.x, t2); t2 = fmaf(r.y, d2.y, t2); t2 = fmaf(r.z, d2.z, t2); t2 = fmaf(r.w, d2.w, t2);
   }
+  __shared__ float sh3[3][kBT / 64];
+  t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+  if ((threadIdx.x & 63) == 0) { sh3[0][threadIdx.x >> 6] = t0; sh3[1][threadIdx.x >> 6] = t1; sh3[2][threadIdx.x >> 6] = t2; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    wpart[((size_t)s * g.C + c) * 3 + threadIdx.x] =
+        (sh3[threadIdx.x][0] + sh3[threadIdx.x][1]) + (sh3[threadIdx.x][2] + sh3[threadIdx.x][3]);
+}
+
+// dW_xyz[c, d] = sum over the slices, in slice order (one thread per (c, d))
+__global__ void ball_wxyz_merge_kernel(const float* __restrict__ wpart, int C, int split, float* __restrict__ dW) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * C) return;
+  float acc = 0.f;
+  for (int s = 0; s < split; ++s) acc += wpart[(size_t)s * 3 * C + t];
+  dW[t] = acc;
 }
 
 bool bad_ball(int N, int C, int np, int ns) {
@@ -838,13 +906,13 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
 size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns) {
   if (bad_ball(B, C, np, ns)) return 0;
   const Geo g = make_geo(B, C, np * ns);
-  return (size_t)(2 + 2 * g.split) * (size_t)C;
+  return (size_t)(2 + 5 * g.split) * (size_t)C;     // [2C results][2 split C partial sums][3 split C dW_xyz partials]
 }
 
-int hcm_ball_project_forward(const float* P, const float* Q, const int32_t* idx, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float momentum, float eps, int relu, int B, int C,
-                             int N, int np, int ns, float* y, float* stats, hcm_stream_t stream) {
-  if (bad_ball(B, C, np, ns) || N <= 0 || !P || !Q || !idx || !gamma || !beta || !y || !stats ||
+int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, const int32_t* idx, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                             int B, int C, int N, int np, int ns, float* y, float* stats, hcm_stream_t stream) {
+  if (bad_ball(B, C, np, ns) || (P && (N <= 0 || !idx)) || !D || !Wxyz || !gamma || !beta || !y || !stats ||
       (running_mean == nullptr) != (running_var == nullptr))
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(B, C, np * ns);
@@ -852,42 +920,44 @@ int hcm_ball_project_forward(const float* P, const float* Q, const int32_t* idx,
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(C, g.split);
   float* part = stats + 2 * (size_t)C;
-  ball_stats_kernel<<<grid, kBT, 0, st>>>(P, Q, idx, g, bg, part);
-  HCM_CHECK_LAUNCH();
-  if (relu) ball_apply_kernel<true><<<grid, kBT, 0, st>>>(P, Q, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
-                                                          running_var, stats, y);
-  else ball_apply_kernel<false><<<grid, kBT, 0, st>>>(P, Q, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
-                                                      running_var, stats, y);
+#define HCM_BALL_FWD(R, HP)                                                                                          \
+  do {                                                                                                               \
+    ball_stats_kernel<HP><<<grid, kBT, 0, st>>>(P, D, Wxyz, idx, g, bg, part);                                      \
+    HCM_CHECK_LAUNCH();                                                                                              \
+    ball_apply_kernel<R, HP><<<grid, kBT, 0, st>>>(P, D, Wxyz, idx, gamma, beta, part, g, bg, eps, momentum,        \
+                                                   running_mean, running_var, stats, y);                             \
+  } while (0)
+  if (relu) { if (P) HCM_BALL_FWD(true, true); else HCM_BALL_FWD(true, false); }
+  else      { if (P) HCM_BALL_FWD(false, true); else HCM_BALL_FWD(false, false); }
+#undef HCM_BALL_FWD
   HCM_CHECK_LAUNCH();
   return 0;
 }
 
-int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* Q, const int32_t* idx,
-                              const float* gamma, const float* stats, int relu, int B, int C, int N, int np, int ns,
-                              float* dz, float* dQ, float* gstats, hcm_stream_t stream) {
-  if (bad_ball(B, C, np, ns) || N <= 0 || !dy || (relu && !y) || !P || !Q || !idx || !gamma || !stats || !dz || !dQ || !gstats)
+int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* D, const float* Wxyz,
+                              const int32_t* idx, const float* gamma, const float* stats, int relu, int B, int C, int N,
+                              int np, int ns, float* dz, float* dWxyz, float* gstats, hcm_stream_t stream) {
+  if (bad_ball(B, C, np, ns) || !dy || (relu && !y) || (P && (N <= 0 || !idx)) || !D || !Wxyz || !gamma || !stats || !dz ||
+      !dWxyz || !gstats)
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(B, C, np * ns);
   const BallGeo bg = {N, np, ns};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(C, g.split);
   float* part = gstats + 2 * (size_t)C;
-  if (relu) ball_bwd_reduce_kernel<true><<<grid, kBT, 0, st>>>(dy, y, P, Q, idx, stats, g, bg, part);
-  else ball_bwd_reduce_kernel<false><<<grid, kBT, 0, st>>>(dy, y, P, Q, idx, stats, g, bg, part);
-  HCM_CHECK_LAUNCH();
-#define HCM_BALL_BWD(R, LL) \
-  ball_bwd_apply_kernel<R, LL><<<grid, kBT, 0, st>>>(dy, y, P, Q, idx, gamma, stats, part, g, bg, gstats, dz, dQ)
-#define HCM_BALL_BWD_L(R)                    \
-  switch (ns) {                              \
-    case 4: HCM_BALL_BWD(R, 1); break;       \
-    case 8: HCM_BALL_BWD(R, 2); break;       \
-    case 16: HCM_BALL_BWD(R, 4); break;      \
-    case 32: HCM_BALL_BWD(R, 8); break;      \
-    default: HCM_BALL_BWD(R, 16); break;     \
-  }
-  if (relu) { HCM_BALL_BWD_L(true) } else { HCM_BALL_BWD_L(false) }
-#undef HCM_BALL_BWD_L
+  float* wpart = part + 2 * (size_t)g.split * C;
+#define HCM_BALL_BWD(R, HP)                                                                                          \
+  do {                                                                                                               \
+    ball_bwd_reduce_kernel<R, HP><<<grid, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);                \
+    HCM_CHECK_LAUNCH();                                                                                              \
+    ball_bwd_apply_kernel<R, HP><<<grid, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, g, bg, gstats,   \
+                                                       dz, wpart);                                                   \
+  } while (0)
+  if (relu) { if (P) HCM_BALL_BWD(true, true); else HCM_BALL_BWD(true, false); }
+  else      { if (P) HCM_BALL_BWD(false, true); else HCM_BALL_BWD(false, false); }
 #undef HCM_BALL_BWD
+  HCM_CHECK_LAUNCH();
+  ball_wxyz_merge_kernel<<<(3 * C + 255) / 256, 256, 0, st>>>(wpart, C, g.split, dWxyz);
   HCM_CHECK_LAUNCH();
   return 0;
 }

@@ -104,6 +104,12 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
 LDS_SCATTER_MAX_TARGETS = 140 * 1024 // 4
 
 
+def deterministic():
+    """HCM_DETERMINISTIC=1: no path with floating-point atomics may be taken silently."""
+    import os
+    return os.environ.get('HCM_DETERMINISTIC', '0') != '0'
+
+
 def scatter_add_lds(grad_out, idx, coef, m, div=1):
     """grad_points[b,c,j] = sum_{q: idx[b,q]==j} coef[b,q] * grad_out[b,c,q//div]  -> [B, C, m]."""
     B, Cc, qsrc = grad_out.shape
@@ -159,60 +165,83 @@ def scatter_add_planned(grad_out, idx, coef, m, div=1):
 
 
 class _BallProject(torch.autograd.Function):
-    """y = relu?(batchnorm(P[b, :, idx[b, i, j]] - Q[b, :, i])) -> [B, C, np, ns]: the first SharedMLP layer on the implicit
-    grouped tensor (hcm_ball_project_*, csrc/bnact.hip).  Backward returns dP (planned scatter of dz, deterministic), dQ,
-    dgamma, dbeta."""
+    """y = relu?(batchnorm(P[b, :, idx[b, i, j]] + Wxyz D[b, :, i, j])) -> [B, C, np, ns]: the first SharedMLP layer on the
+    implicit grouped tensor (hcm_ball_project_*, csrc/bnact.hip).  Backward returns dP (planned scatter of dz,
+    deterministic), dWxyz, dgamma, dbeta; the offsets D carry no gradient."""
 
     @staticmethod
-    def forward(ctx, P, Q, idx, gamma, beta, running_mean, running_var, momentum, eps, relu):
-        for t in (P, Q, gamma, beta):
+    def forward(ctx, P, D, Wxyz, idx, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        for t in (D, Wxyz, gamma, beta) + (() if P is None else (P,)):
             if not t.is_cuda or t.dtype != torch.float32:
                 raise RuntimeError('hcmoco_amd.ball_project needs fp32 ROCm tensors (no CPU fallback exists)')
-        P, Q, idx = P.contiguous(), Q.contiguous(), idx.contiguous()
-        B, Cc, N = P.shape
-        _, npnt, ns = idx.shape
+        D, Wxyz, idx = D.contiguous(), Wxyz.contiguous(), idx.contiguous()
+        B, three, npnt, ns = D.shape
+        Cc = Wxyz.shape[0]
+        N = 0
+        if P is not None:
+            P = P.contiguous()
+            N = P.shape[2]
         L = _lib.lib()
         nf = int(L.hcm_ball_project_stats_floats(B, Cc, npnt, ns))
-        if nf == 0 or Q.shape != (B, Cc, npnt):
-            raise ValueError('ball_project: unsupported shape P %s Q %s idx %s' % (tuple(P.shape), tuple(Q.shape), tuple(idx.shape)))
-        y = torch.empty(B, Cc, npnt, ns, dtype=torch.float32, device=P.device)
-        stats = torch.empty(nf, dtype=torch.float32, device=P.device)
+        if (nf == 0 or three != 3 or tuple(Wxyz.shape) != (Cc, 3) or tuple(idx.shape) != (B, npnt, ns)
+                or (P is not None and tuple(P.shape[:2]) != (B, Cc))):
+            raise ValueError('ball_project: unsupported shape P %s D %s Wxyz %s idx %s' % (
+                None if P is None else tuple(P.shape), tuple(D.shape), tuple(Wxyz.shape), tuple(idx.shape)))
+        y = torch.empty(B, Cc, npnt, ns, dtype=torch.float32, device=D.device)
+        stats = torch.empty(nf, dtype=torch.float32, device=D.device)
         rm = C.c_void_p(0) if running_mean is None else _f(running_mean, 'ball_project')
         rv = C.c_void_p(0) if running_var is None else _f(running_var, 'ball_project')
-        check(L.hcm_ball_project_forward(_f(P, 'ball_project'), _f(Q, 'ball_project'), _i(idx, 'ball_project'),
+        pp = C.c_void_p(0) if P is None else _f(P, 'ball_project')
+        check(L.hcm_ball_project_forward(pp, _f(D, 'ball_project'), _f(Wxyz, 'ball_project'), _i(idx, 'ball_project'),
                                          _f(gamma, 'ball_project'), _f(beta, 'ball_project'), rm, rv, float(momentum),
                                          float(eps), int(bool(relu)), B, Cc, N, npnt, ns, _f(y, 'ball_project'),
                                          _f(stats, 'ball_project'), _stream()), 'hcm_ball_project_forward')
-        ctx.save_for_backward(P, Q, gamma, stats, y)
-        ctx.idx, ctx.relu = idx, bool(relu)          # the same tensor OBJECT: the scatter plan is cached on it
+        ctx.save_for_backward(D, Wxyz, gamma, stats, y, *(() if P is None else (P,)))
+        ctx.idx, ctx.relu, ctx.has_p = idx, bool(relu), P is not None   # the same idx OBJECT: the scatter plan is cached on it
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        P, Q, gamma, stats, y = ctx.saved_tensors
+        D, Wxyz, gamma, stats, y = ctx.saved_tensors[:5]
+        P = ctx.saved_tensors[5] if ctx.has_p else None
         idx = ctx.idx
-        B, Cc, N = P.shape
-        _, npnt, ns = idx.shape
+        B, _, npnt, ns = D.shape
+        Cc = Wxyz.shape[0]
+        N = P.shape[2] if P is not None else 0
         dy = dy.contiguous()
         dz = torch.empty_like(y)
-        dQ = torch.empty_like(Q)
+        dW = torch.empty_like(Wxyz)
         gstats = torch.empty_like(stats)
-        check(_lib.lib().hcm_ball_project_backward(_f(dy, 'ball_project'), _f(y, 'ball_project'), _f(P, 'ball_project'),
-                                                   _f(Q, 'ball_project'), _i(idx, 'ball_project'), _f(gamma, 'ball_project'),
+        pp = C.c_void_p(0) if P is None else _f(P, 'ball_project')
+        check(_lib.lib().hcm_ball_project_backward(_f(dy, 'ball_project'), _f(y, 'ball_project'), pp, _f(D, 'ball_project'),
+                                                   _f(Wxyz, 'ball_project'), _i(idx, 'ball_project'), _f(gamma, 'ball_project'),
                                                    _f(stats, 'ball_project'), int(ctx.relu), B, Cc, N, npnt, ns,
-                                                   _f(dz, 'ball_project'), _f(dQ, 'ball_project'), _f(gstats, 'ball_project'),
+                                                   _f(dz, 'ball_project'), _f(dW, 'ball_project'), _f(gstats, 'ball_project'),
                                                    _stream()), 'hcm_ball_project_backward')
-        if N <= LDS_SCATTER_MAX_TARGETS:
-            dP = scatter_add_planned(dz.view(B, Cc, npnt * ns), idx, None, N, 1)
-        else:                                   # a target axis too long for LDS: ATen's scatter (atomics)
-            dP = torch.zeros_like(P).scatter_add_(2, idx.view(B, 1, -1).long().expand(B, Cc, -1), dz.view(B, Cc, -1))
-        return dP, dQ, None, gstats[:Cc], gstats[Cc:2 * Cc], None, None, None, None, None
+        dP = None
+        if P is not None and ctx.needs_input_grad[0]:
+            if N <= LDS_SCATTER_MAX_TARGETS:
+                dP = scatter_add_planned(dz.view(B, Cc, npnt * ns), idx, None, N, 1)
+            elif deterministic():
+                raise RuntimeError('ball_project backward: %d source points exceed the planned scatter (%d) and '
+                                   'HCM_DETERMINISTIC forbids the atomic fallback' % (N, LDS_SCATTER_MAX_TARGETS))
+            else:                                   # a target axis too long for LDS: ATen's scatter (atomics)
+                dP = torch.zeros_like(P).scatter_add_(2, idx.view(B, 1, -1).long().expand(B, Cc, -1), dz.view(B, Cc, -1))
+        return dP, None, dW, None, gstats[:Cc], gstats[Cc:2 * Cc], None, None, None, None, None
 
 
-def ball_project(P, Q, idx, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True):
+def ball_project(P, D, Wxyz, idx, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True):
     """The first conv -> BatchNorm2d -> ReLU of a PointNet++ SharedMLP applied to the grouped tensor WITHOUT building it:
-    P [B, C1, N] = W [xyz ; features], Q [B, C1, np] = W_xyz centres, idx [B, np, ns] the ball members."""
-    return _BallProject.apply(P, Q, idx, gamma, beta, running_mean, running_var, momentum, eps, relu)
+    P [B, C1, N] = W_f features (or None), D [B, 3, np, ns] = xyz[idx] - centre (``ball_offsets``), Wxyz [C1, 3], idx
+    [B, np, ns] the ball members."""
+    if D.requires_grad:
+        raise RuntimeError('ball_project: the coordinates carry no gradient on this path (detach D)')
+    return _BallProject.apply(P, D, Wxyz, idx, gamma, beta, running_mean, running_var, momentum, eps, relu)
+
+
+def ball_project_supported(B, Cc, npnt, ns):
+    """Shapes the hcm_ball_project_* kernels take (ball of 4..64 members, npoint a multiple of 4)."""
+    return int(_lib.lib().hcm_ball_project_stats_floats(B, Cc, npnt, ns)) != 0
 
 
 class _PointProject(torch.autograd.Function):

@@ -24,34 +24,60 @@ class PointnetSAModuleMSG(nn.Module):
                 spec[0] += 3
             self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
 
+    @staticmethod
+    def ball_offsets(xyz_t, new_xyz, idx):
+        """xyz[idx] - centre -> [B, 3, np, ns]: QueryAndGroup's grouped_xyz (pointnet2_utils.py:251-253 of the reference),
+        the same gather-then-subtract, so the same fp32 values.  No autograd: the clouds carry no gradient."""
+        with torch.no_grad():
+            return pointnet2_utils.grouping_operation(xyz_t, idx).sub_(new_xyz.transpose(1, 2).unsqueeze(-1))
+
+    def _offsets_wanted(self, xyz):
+        """The scales whose first layer runs on the implicit grouped tensor need the relative offsets of their balls."""
+        return [self.npoint is not None and g.use_xyz and len(mlp) > 1 and g.nsample in (4, 8, 16, 32, 64)
+                and self.npoint % 4 == 0 and pt_utils.first_layer_fusable(mlp, xyz)
+                for g, mlp in zip(self.groupers, self.mlps)]
+
     def geometry(self, xyz, new_xyz=None):
-        """The feature-independent half of forward: FPS picks -> centres, ball indices of every scale."""
+        """The feature-independent half of forward: FPS picks -> centres, ball indices of every scale and (for the
+        scales that take the fused first layer) the members' offsets from their centre."""
+        xyz_t = None
         if new_xyz is None and self.npoint is not None:
             picks = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
+            xyz_t = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_t, picks).transpose(1, 2).contiguous()
         idx = [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) if self.npoint is not None else None
                for g in self.groupers]
-        return new_xyz, idx
+        offsets = [None] * len(idx)
+        for i, want in enumerate(self._offsets_wanted(xyz)):
+            if want and new_xyz.shape[1] % 4 == 0:
+                xyz_t = xyz.transpose(1, 2).contiguous() if xyz_t is None else xyz_t
+                offsets[i] = self.ball_offsets(xyz_t, new_xyz, idx[i])
+        return new_xyz, idx, offsets
 
     def forward(self, xyz, features=None, new_xyz=None, geometry=None):
         """``geometry``: the (new_xyz, idx per scale) pair of ``self.geometry(xyz)`` when it was computed ahead."""
         if geometry is not None:
-            new_xyz, ball_idx = geometry
+            new_xyz, ball_idx, ball_off = geometry
         else:
             ball_idx = [None] * len(self.groupers)
+            ball_off = [None] * len(self.groupers)
             if new_xyz is None and self.npoint is not None:
                 picks = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
                 new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
         outs = []
-        for grouper, mlp, bidx in zip(self.groupers, self.mlps, ball_idx):
+        # the centre count is the CALLER's when new_xyz / geometry is handed in: gate on it, not on self.npoint (ADVICE r05)
+        centres = new_xyz.shape[1] if new_xyz is not None else 0
+        wanted = self._offsets_wanted(xyz)
+        for grouper, mlp, bidx, off, want in zip(self.groupers, self.mlps, ball_idx, ball_off, wanted):
             layers = list(mlp)
-            fuse_first = (self.npoint is not None and grouper.use_xyz and len(layers) > 1 and grouper.nsample in (4, 8, 16, 32, 64)
-                          and self.npoint % 4 == 0 and pt_utils.first_layer_fusable(mlp, xyz))
+            fuse_first = want and centres % 4 == 0
             if fuse_first and bidx is None:
                 bidx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            if fuse_first and off is None:
+                off = self.ball_offsets(xyz.transpose(1, 2).contiguous(), new_xyz, bidx)
             if fuse_first:
                 # r05: the first layer on the IMPLICIT grouped tensor -- [B, 3 + C, npoint, nsample] is never built
-                x = layers[0].forward_grouped(xyz, new_xyz, features, bidx)
+                x = layers[0].forward_grouped(off, features, bidx)
                 mlp = layers[1:]
             else:
                 x = grouper(xyz, new_xyz, features, idx=bidx)               # (B, C, npoint, nsample)

@@ -49,30 +49,30 @@ class _ConvBNAct(nn.Sequential):
         return super().forward(x)
 
 
-    def forward_grouped(self, xyz, new_xyz, features, idx):
-        """This layer applied to QueryAndGroup's output [xyz[idx] - centre ; features[idx]] without building it (r05): a 1x1
-        convolution commutes with the gather, so the N source points are projected once -- P = W [xyz ; features], a GEMM
-        nsample times smaller than the convolution over the grouped tensor --, the centres contribute Q = W_xyz centre, and
-        normalisation + ReLU read z = P[idx] - Q through the gather (``pointnet2_hip.ball_project``).  xyz [B, N, 3],
-        new_xyz [B, np, 3], features [B, C, N] or None, idx [B, np, ns] -> [B, C1, np, ns].
+    def forward_grouped(self, offsets, features, idx):
+        """This layer applied to QueryAndGroup's output [xyz[idx] - centre ; features[idx]] without building it (r05): the
+        FEATURE half of a 1x1 convolution commutes with the gather, so the N source points are projected once -- P = W_f
+        features, a GEMM nsample times smaller than the convolution over the grouped tensor -- and normalisation + ReLU
+        read z = P[idx] + W_xyz offsets through the gather (``pointnet2_hip.ball_project``).  The COORDINATE half is
+        evaluated on the relative offsets themselves (``offsets`` [B, 3, np, ns] = xyz[idx] - centre, the reference's
+        grouped_xyz: geometry, made ahead of the feature path): r05 commuted it too (P' = W [xyz ; features] minus
+        Q = W_xyz centre), which subtracts two numbers of the cloud's extent to get one of the ball's radius -- 40 x the
+        reference's round-off on the 2.5 cm balls (r06, tests/test_pn_reference_gpu.py).
+        features [B, C, N] or None, idx [B, np, ns] -> [B, C1, np, ns].
         Reference: pointnet2_utils.py:231-268 + pytorch_utils.py:5-33."""
         from .... import pointnet2_hip
         bn = self.bn.bn
         W = self.conv.weight.view(self.conv.weight.shape[0], -1)            # [C1, 3 + C], xyz columns first
-        parts = [xyz.transpose(1, 2)] + ([features] if features is not None else [])
-        cs = sum(t.shape[1] for t in parts)
-        pad = -cs % 16
-        if pointnet2_hip.point_project_supported(W.shape[0], cs + pad, xyz.shape[1]):
-            # csrc/conv1x1.hip takes channel counts in multiples of 16: zero channels against zero weight columns (exact)
-            if pad:
-                parts.append(xyz.new_zeros(xyz.shape[0], pad, xyz.shape[1]))
-            P = pointnet2_hip.point_project(F.pad(W, (0, pad)), torch.cat(parts, dim=1))     # [B, C1, N]
-        else:
-            P = torch.matmul(W, torch.cat(parts, dim=1) if len(parts) > 1 else parts[0])
-        Q = torch.matmul(W[:, :3], new_xyz.transpose(1, 2))                  # [B, C1, np]
+        P = None
+        if features is not None:
+            Wf = W[:, 3:].contiguous()
+            if pointnet2_hip.point_project_supported(Wf.shape[0], Wf.shape[1], features.shape[2]):
+                P = pointnet2_hip.point_project(Wf, features)               # [B, C1, N] on csrc/conv1x1.hip
+            else:
+                P = torch.matmul(Wf, features)
         bn.num_batches_tracked.add_(1)
-        return pointnet2_hip.ball_project(P, Q, idx, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
-                                          bn.eps, hasattr(self, 'activation'))
+        return pointnet2_hip.ball_project(P, offsets, W[:, :3], idx, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                          bn.momentum, bn.eps, hasattr(self, 'activation'))
 
     def forward_ballmax(self, x):
         """relu(bn(conv(x))).max(-1) for x [B, C, npoint, nsample] as ONE autograd node (torch.ops.hcmoco.conv_bn_relu_ballmax,

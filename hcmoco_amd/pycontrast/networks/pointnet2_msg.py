@@ -97,9 +97,9 @@ class GeometryPlan:
             torch.cuda.current_stream().wait_event(ev)
 
     def tensors(self):
-        for new_xyz, idx in self.sa:
+        for new_xyz, idx, offsets in self.sa:
             yield new_xyz
-            for t in idx:
+            for t in list(idx) + list(offsets):
                 if t is not None:
                     yield t
         for idx, weight in self.fp:

@@ -28,8 +28,10 @@ typedef void* hcm_stream_t; /* hipStream_t */
 /* 2 (round 3): hcm_sgc_forward/backward take a workspace, the PointNet++ index/distance ops default to the
  * FMA arithmetic contract, new loss-section entry points.  3 (round 4): hcm_project_rows* added (row 8 on the matrix
  * cores); nothing removed.  4 (round 5): hcm_bn_relu_ballmax_*, hcm_ball_project_* (PointNet++ set abstraction without the
- * grouped tensors); nothing removed.  A library and a caller must agree on this number. */
-#define HCM_ABI_VERSION 4
+ * grouped tensors); nothing removed.  5 (round 6): hcm_ball_project_* take the relative offsets D and W_xyz instead of Q = W_xyz
+ * centre (signature change: the coordinate half is no longer a difference of two projections).  A library and a caller must
+ * agree on this number. */
+#define HCM_ABI_VERSION 5
 int hcm_abi_version(void);
 /* hipGetErrorString() for a value returned by any entry point. */
 const char* hcm_error_string(int err);
@@ -444,24 +446,30 @@ int hcm_bn_relu_ballmax_forward(const float* z, const float* gamma, const float*
 int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int32_t* arg, const float* zsel,
                                  const float* z, const float* gamma, const float* stats, int N, int C, int np, int ns,
                                  float* dz, float* gstats, hcm_stream_t stream);
-/* First layer of a PointNet++ SharedMLP WITHOUT the grouped tensor (r05).  QueryAndGroup + the first 1x1 convolution
- * (networks/pointnet2/pointnet2_utils.py:231-268, pytorch_utils.py:5-33 of the reference) compute, for ball i of image b and
- * its j-th member n = idx[b, i, j],  z[b, :, i, j] = W [xyz_n - centre_i ; features_n] = P[b, :, n] - Q[b, :, i]  with
- * P = W [xyz ; features] [B, C, N] and Q = W_xyz centre [B, C, np] (two small GEMMs, the caller's).  These entry points take
- * z as that implicit tensor:
+/* First layer of a PointNet++ SharedMLP WITHOUT the grouped tensor (r05; coordinate half restated in r06, ABI 5).
+ * QueryAndGroup + the first 1x1 convolution (networks/pointnet2/pointnet2_utils.py:231-268, pytorch_utils.py:5-33 of the
+ * reference) compute, for ball i of image b and its j-th member n = idx[b, i, j],
+ *     z[b, :, i, j] = W [xyz_n - centre_i ; features_n] = W_xyz (xyz_n - centre_i) + W_f features_n
+ *                   = Wxyz D[b, :, i, j] + P[b, :, n]
+ * with D [B, 3, np, ns] = the reference's grouped_xyz (relative offsets: geometry, no features) and P = W_f features
+ * [B, C, N] (hcm_conv1x1_forward, the caller's).  ABI 4 also commuted the coordinate half (P' = W [xyz ; features],
+ * Q = W_xyz centre, z = P'[n] - Q[i]): a difference of two O(|xyz|) numbers worth O(radius), 40 x the reference's round-off on
+ * 2.5 cm balls.  These entry points take z as that implicit tensor:
  *   forward : y [B, C, np, ns] = relu?(batchnorm(z)) with batch statistics over all B * np * ns members (running statistics
  *             updated like hcm_bn_act_forward); stats: hcm_ball_project_stats_floats(B, C, np, ns) floats.
  *   backward: dy [B, C, np, ns] (and y, for the ReLU mask) -> dz [B, C, np, ns] = d loss / d z (the caller scatters it into
- *             dP[b, c, idx], hcm_scatter_add_planned), dQ [B, C, np] = - sum_j dz, gstats = [dgamma C][dbeta C][scratch] (same
- *             size as stats).
+ *             dP[b, c, idx], hcm_scatter_add_planned), dWxyz [C, 3] = sum_{b,i,j} dz D, gstats = [dgamma C][dbeta C][scratch]
+ *             (same size as stats).  No gradient w.r.t. the coordinates (the reference's clouds carry none either:
+ *             networks/build_backbone.py:379-445 builds them under no autograd-tracked input).
+ * P may be NULL (no point features: the first SA level, z = Wxyz D; idx and N are then unused).  Wxyz [C, 3] row-major.
  * idx [B, np, ns] int32 in [0, N); ns in {4, 8, 16, 32, 64}, np % 4 == 0.  Deterministic. */
 size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns);
-int hcm_ball_project_forward(const float* P, const float* Q, const int32_t* idx, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float momentum, float eps, int relu, int B, int C,
-                             int N, int np, int ns, float* y, float* stats, hcm_stream_t stream);
-int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* Q, const int32_t* idx,
-                              const float* gamma, const float* stats, int relu, int B, int C, int N, int np, int ns,
-                              float* dz, float* dQ, float* gstats, hcm_stream_t stream);
+int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, const int32_t* idx, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                             int B, int C, int N, int np, int ns, float* y, float* stats, hcm_stream_t stream);
+int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* D, const float* Wxyz,
+                              const int32_t* idx, const float* gamma, const float* stats, int relu, int B, int C, int N,
+                              int np, int ns, float* dz, float* dWxyz, float* gstats, hcm_stream_t stream);
 /* Same, with the partial-sum scratch in its own buffer (hcm_bn_act_stats_floats - 2C floats): `gstats`
  * is then exactly [dgamma C][dbeta C], so a caller can lay every parameter gradient of a network out in
  * one dense buffer (what the encoder runtime hands to RCCL in place, csrc/torch_glue). */

@@ -439,15 +439,228 @@ def gen_model_bwd():
 
 
 def gen_model_pn():
-    """HRNetPN arch: state_dict keys/shapes only (its forward needs the CUDA point ops)."""
+    """HRNetPN arch: state_dict keys/shapes (forward / backward: gen_pointnet2_msg, gen_model_pn_fwd, gen_model_pn_bwd)."""
     from networks.build_backbone import build_model
-    opt = argparse.Namespace(modal='RGBD2S', arch='HRNetPN', jigsaw=False, head='linear', feat_dim=128,
-                             in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
-                             skeleton_meta_name='mpii', IN_Pretrain=None, depth_Pretrain=None, mem='bank')
-    model, _ = build_model(opt)
+    model, _ = build_model(pn_opt())
     sd = model.state_dict()
     npz('model_hrnetpn_w18_keys', keys=np.array(list(sd.keys())), shapes=np.array([str(list(v.shape)) for v in sd.values()]),
         n_params=sum(p.numel() for p in model.parameters()))
+
+
+# --------------------------------------------------------------------------- #
+# 7b. the PointNet++ MODULE layer and the HRNetPN encoder (VERDICT r05 row a18)
+#     networks/pointnet2/pointnet2_modules.py:19-55 (SA-MSG forward), pytorch_utils.py:5-33 (SharedMLP),
+#     networks/pointnet2_msg.py:79-95, networks/build_backbone.py:379-455 (depth2pts / pts2depth), :457-514 (forward)
+#     The reference's Python modules run UNMODIFIED; the nine ``pointnet2_cuda.*_wrapper`` entry points they call are
+#     bound to oracle/pointnet2_shim.py -- the C restatement of the reference's kernels (FMA contract = the reference's
+#     nvcc -O2 build), itself pinned against those kernels compiled for gfx950 (oracle/_ref, tests/test_pointnet2_ref_gpu.py).
+# --------------------------------------------------------------------------- #
+def pn_opt(skel='mpii'):
+    return argparse.Namespace(modal='RGBD2S', arch='HRNetPN', jigsaw=False, head='linear', feat_dim=128,
+                              in_channel_list=[3, 3], linear_feat_map=1, width=18, pool_method='mean',
+                              skeleton_meta_name=skel, IN_Pretrain=None, depth_Pretrain=None, mem='bank')
+
+
+def bind_point_ops():
+    """``pointnet2_cuda`` := oracle/pointnet2_shim (CPU, FMA contract) inside the reference's pointnet2_utils, and the
+    ``torch.cuda.{Int,Float}Tensor`` constructors the reference allocates its outputs with := their CPU twins
+    (pointnet2_utils.py:25-26, 55, 67, 94-95, 128, 146, 172, 190, 218)."""
+    repo = os.path.dirname(os.path.dirname(OUT))
+    if repo not in sys.path:
+        sys.path.append(repo)
+    from oracle import pointnet2_shim, pointnet2_oracle
+    pointnet2_oracle.set_contract('fma')
+    torch.cuda.IntTensor = torch.IntTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+    from networks.pointnet2 import pointnet2_utils as ref_utils
+    ref_utils.pointnet2 = pointnet2_shim
+    return ref_utils
+
+
+def surface_cloud(B, N, seed):
+    """A depth-camera-like cloud in metres: a smooth surface over [-0.5, 0.5] x [-1, 1] with 1 cm noise, one third of
+    the points exact duplicates (depth2pts samples pixels WITH replacement, build_backbone.py:427) -- level-1 balls of
+    2.5 cm hold a handful of points (padded groups), 12.5 cm balls overflow their 32 slots."""
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(B, N, 2, generator=g) * torch.tensor([1.0, 2.0]) - torch.tensor([0.5, 1.0])
+    z = 0.2 * torch.sin(3 * xy[..., 0]) * torch.cos(2 * xy[..., 1]) + 0.01 * torch.randn(B, N, generator=g)
+    pts = torch.cat([xy, z.unsqueeze(-1)], -1)
+    src = torch.randint(0, N, (B, N // 3), generator=g)
+    for b in range(B):
+        pts[b, :N // 3] = pts[b, src[b]]
+    return pts.contiguous()
+
+
+def grad_summary(named_params, full_below=0, full_prefixes=()):
+    """names / L2 norms / projections on name-keyed random vectors (seed crc32(name) + 1, as gen_model_bwd), and the
+    gradient itself for small tensors or the given prefixes."""
+    import zlib
+    names, norms, dots, full = [], [], [], {}
+    for k, p_ in named_params:
+        assert p_.grad is not None, k
+        gg = torch.Generator().manual_seed((zlib.crc32(k.encode()) + 1) & 0x7fffffff)
+        r = torch.randn(p_.shape, generator=gg)
+        names.append(k)
+        norms.append(float(p_.grad.double().norm()))
+        dots.append(float((p_.grad.double() * r.double()).sum()))
+        if p_.numel() <= full_below or k.startswith(tuple(full_prefixes)):
+            full['g:' + k] = p_.grad
+    return dict(names=np.array(names), norms=np.array(norms), dots=np.array(dots), **full)
+
+
+def gen_pointnet2_msg():
+    """The reference's ``Pointnet2MSG(input_channels=0)`` (4 SA-MSG levels, 4 FP levels) on a 2 x 4096-point cloud with
+    name-keyed deterministic weights: forward in eval and train mode (per-level centres and features, the output), and
+    the reference's backward in train mode for a seeded cotangent (every parameter gradient as norm + projection, small
+    ones in full)."""
+    bind_point_ops()
+    from networks.pointnet2_msg import Pointnet2MSG
+    net = Pointnet2MSG(input_channels=0)
+    net.load_state_dict(deterministic_fill(net.state_dict()))
+    cloud = surface_cloud(2, 4096, 21)
+    arrays = dict(cloud=cloud, keys=np.array(list(net.state_dict().keys())))
+    levels = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: levels.append(out)) for m in net.SA_modules]
+    for mode in ('eval', 'train'):
+        getattr(net, mode)()
+        del levels[:]
+        with torch.no_grad():
+            out = net(cloud)
+        gp = torch.Generator().manual_seed(31)
+        proj = torch.randn(out.shape, generator=gp)
+        arrays.update({mode + '_out_slice': out[:, ::2, ::32], mode + '_out_norm': out.double().norm(),
+                       mode + '_out_dot': (out.double() * proj.double()).sum()})
+        for k, (xyz_k, feat_k) in enumerate(levels):
+            arrays['%s_l%d_xyz' % (mode, k + 1)] = xyz_k if k else xyz_k[:, ::16]      # FPS picks, chained through the levels
+            arrays['%s_l%d_feat_slice' % (mode, k + 1)] = feat_k[:, ::4, ::max(1, feat_k.shape[2] // 64)]
+            arrays['%s_l%d_feat_norm' % (mode, k + 1)] = feat_k.double().norm()
+    for h_ in hooks:
+        h_.remove()
+    # backward, train mode (running statistics of the eval/train passes above are irrelevant to batch-stat BN)
+    net.load_state_dict(deterministic_fill(net.state_dict()))
+    net.train()
+    out = net(cloud)
+    gc = torch.Generator().manual_seed(33)
+    cot = torch.randn(out.shape, generator=gc) * 0.1
+    loss = (out * cot).sum()
+    loss.backward()
+    arrays.update(loss=loss.detach(), **grad_summary(net.named_parameters(), full_below=2048))
+    sd = net.state_dict()
+    arrays['bn_running_mean_after'] = sd['SA_modules.0.mlps.0.layer0.bn.bn.running_mean']
+    arrays['bn_running_var_after'] = sd['SA_modules.0.mlps.0.layer0.bn.bn.running_var']
+    npz('pointnet2_msg', **arrays)
+
+
+def pn_inputs(*a, **k):
+    """Seeded HRNetPN inputs: tests/golden/pn_inputs.py (shared with the tests, which re-create them instead of loading
+    1.5 MB of noise)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('pn_inputs', os.path.join(OUT, 'pn_inputs.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.pn_inputs(*a, **k)
+
+
+class capture_multinomial(object):
+    """Record what ``Tensor.multinomial`` returns inside the reference's depth2pts (build_backbone.py:427)."""
+
+    def __enter__(self):
+        self.drawn = []
+        self.orig = torch.Tensor.multinomial
+        cap = self
+
+        def wrapped(t, *a, **k):
+            r = cap.orig(t, *a, **k)
+            cap.drawn.append(r.clone())
+            return r
+        torch.Tensor.multinomial = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.multinomial = self.orig
+
+
+def replay_multinomial(ind):
+    """Make the next ``Tensor.multinomial`` calls return the recorded draw (the second forward sees the same cloud)."""
+    class _R(object):
+        def __enter__(self_):
+            self_.orig = torch.Tensor.multinomial
+            torch.Tensor.multinomial = lambda t, *a, **k: ind.clone()
+
+        def __exit__(self_, *exc):
+            torch.Tensor.multinomial = self_.orig
+    return _R()
+
+
+def gen_model_pn_fwd():
+    """The reference's ``CMC3HRNetSGCNPN2SingleHead`` (HRNet-w18 + Pointnet2MSG + SemGCN, build_backbone.py:305-514)
+    forward with ``return_fm=True`` in eval and train mode: B = 3 at 64 x 64, the third sample without depth (its cloud is
+    all zeros, :399-443).  The pixel draw of depth2pts is recorded (``ind``) and replayed for the second mode."""
+    bind_point_ops()
+    from networks.build_backbone import build_model
+    model, _ = build_model(pn_opt())
+    model.load_state_dict(deterministic_fill(model.state_dict()))
+    x, s, mask, grid_xy, oh, ow, mean = pn_inputs(3, 64, 16, 41, empty=(2,))
+    arrays = dict(x=x, s=s, depth_mask=mask, grid_xy=grid_xy, original_h=oh, original_w=ow, mean=mean)
+    ind = None
+    for mode in ('eval', 'train'):
+        getattr(model, mode)()
+        torch.manual_seed(43)
+        with torch.no_grad():
+            if ind is None:
+                with capture_multinomial() as cap:
+                    f1, f2, f3, f, aux = model(x, s, mask, grid_xy, oh, ow, mean, return_fm=True)
+                assert len(cap.drawn) == 1
+                ind = cap.drawn[0]
+                x1, x2 = torch.split(x, [3, 3], dim=1)
+                with replay_multinomial(ind):
+                    sample, full, _ = model.depth2pts(x2, mask, grid_xy, oh, ow, mean)
+                arrays.update(ind=ind.int(), cloud_sample_slice=sample[:, :, ::8], cloud_sample_sum=sample.double().sum(),
+                              cloud_full_slice=full[:, :, ::8], cloud_full_sum=full.double().sum())
+            else:
+                with replay_multinomial(ind):
+                    f1, f2, f3, f, aux = model(x, s, mask, grid_xy, oh, ow, mean, return_fm=True)
+        assert f2.shape == (3, 128, 4096) and aux['linear_merge2'].shape == (3, 128, 16, 16), (f2.shape, aux['linear_merge2'].shape)
+        arrays.update({mode + '_f': f, mode + '_feat3': f3, mode + '_feat2_slice': f2[:, ::2, ::32],
+                       mode + '_feat2_norm': f2.double().norm(),
+                       mode + '_lm1_slice': aux['linear_merge1'][:, :8, ::5, ::5],
+                       mode + '_lm2': aux['linear_merge2'][:, ::2],
+                       mode + '_feat1_3': f1[3]})
+    npz('model_hrnetpn_w18_mpii', **arrays)
+
+
+def gen_model_pn_bwd():
+    """The reference HRNetPN model's backward on CPU, train mode: B = 4 at 128 x 128 (gen_model_bwd's reason: the
+    coarsest HRNet branch must normalise over more than 8 values), sample 1 without depth.  Loss = <f, cf> + <feat3, c3>
+    + <lm1, c1> + <lm2, c2> with seeded cotangents.  Stored: the inputs that are not re-creatable from a seed alone
+    (the pixel draw), d loss / d skeleton, norm + projection of every parameter gradient, and the gradients of the
+    PointNet++ encoder's small tensors, encoder2_linear, the heads and the SemGCN in full."""
+    bind_point_ops()
+    from networks.build_backbone import build_model
+    model, _ = build_model(pn_opt())
+    model.load_state_dict(deterministic_fill(model.state_dict()))
+    model.train()
+    x, s, mask, grid_xy, oh, ow, mean = pn_inputs(4, 128, 16, 47, empty=(1,))
+    s.requires_grad_(True)
+    torch.manual_seed(49)
+    with capture_multinomial() as cap:
+        f1, f2, f3, f, aux = model(x, s, mask, grid_xy, oh, ow, mean, return_fm=True)
+    assert len(cap.drawn) == 1
+    gc = torch.Generator().manual_seed(53)
+    cf = torch.randn(f.shape, generator=gc)
+    c3 = torch.randn(f3.shape, generator=gc) * 0.1
+    c1 = torch.randn(aux['linear_merge1'].shape, generator=gc) * 0.05
+    c2 = torch.randn(aux['linear_merge2'].shape, generator=gc) * 0.05
+    terms = [f * cf, f3 * c3, aux['linear_merge1'] * c1, aux['linear_merge2'] * c2]
+    loss = terms[0].sum() + terms[1].sum() + terms[2].sum() + terms[3].sum()
+    loss.backward()
+    arrays = dict(ind=cap.drawn[0].int(), s=s.detach(), cf=cf, c3=c3, loss=loss.detach(), grad_s=s.grad,
+                  mass=sum(t.detach().abs().sum() for t in terms), x_checksum=x.double().sum(), mean=mean,
+                  lm2_slice=aux['linear_merge2'].detach()[:, ::4, ::3, ::3], f=f.detach())
+    full = tuple(k for k, p_ in model.named_parameters()
+                 if not k.startswith('encoder1.') and (not k.startswith('encoder2.') or p_.numel() <= 2048))
+    arrays.update(grad_summary(model.named_parameters(), full_prefixes=full))
+    npz('model_bwd_hrnetpn_w18_mpii', **arrays)
 
 
 # --------------------------------------------------------------------------- #
@@ -906,7 +1119,8 @@ if __name__ == '__main__':
     only = set(sys.argv[1:])
     sys.argv = sys.argv[:1]
     gens = dict(alias=gen_alias, bank=gen_bank, moco=gen_moco, dense=gen_dense, joint=gen_joint,
-                scl=gen_scl, model=gen_model, model_bwd=gen_model_bwd, model_pn=gen_model_pn, options=gen_options, trace=gen_trace,
+                scl=gen_scl, model=gen_model, model_bwd=gen_model_bwd, model_pn=gen_model_pn, pointnet2_msg=gen_pointnet2_msg, model_pn_fwd=gen_model_pn_fwd,
+                model_pn_bwd=gen_model_pn_bwd, options=gen_options, trace=gen_trace,
                 trace_moco=gen_trace_moco, dataset=gen_dataset)
     for name, fn in gens.items():
         if not only or name in only:

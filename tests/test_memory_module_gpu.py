@@ -34,7 +34,7 @@ def test_forward_api_contract_vs_golden(golden):
     assert len(out) == 7 and out[-1].dtype == torch.long and int(out[-1].abs().sum()) == 0
     for p in range(6):
         assert out[p].shape == (g['B'], g['K'] + 1)
-        assert torch.allclose(out[p].cpu(), g['logits%d' % p], atol=2e-5)
+        assert torch.allclose(out[p].cpu(), g['logits%d' % p], atol=1e-5)
     for i in (1, 2, 3):
         assert torch.allclose(getattr(mem, 'memory_%d' % i).cpu(), g['bank1_%d' % i], rtol=1e-6, atol=1e-7)
     # backward runs AFTER the in-place update and must still use the rows the logits were made from
@@ -96,8 +96,8 @@ def test_build_mem_and_moco_module(golden):
         q1 = g['s%d_q1' % s].to(d).requires_grad_(True)
         l1, l2, lab = moco(q1, g['s%d_k1' % s].to(d), g['s%d_q2' % s].to(d), g['s%d_k2' % s].to(d),
                            all_k1=g['s%d_all_k1' % s].to(d), all_k2=g['s%d_all_k2' % s].to(d))
-        assert torch.allclose(l1.cpu(), g['s%d_logits1' % s], atol=2e-5)
-        assert torch.allclose(l2.cpu(), g['s%d_logits2' % s], atol=2e-5)
+        assert torch.allclose(l1.cpu(), g['s%d_logits1' % s], atol=1e-5)
+        assert torch.allclose(l2.cpu(), g['s%d_logits2' % s], atol=1e-5)
         assert moco.index == g['s%d_index' % s]
         assert torch.equal(moco.memory_1.cpu(), g['s%d_queue_1' % s])
         # d logits / d q through the library GEMM backward

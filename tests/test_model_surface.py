@@ -99,12 +99,22 @@ def check_backward_against_fixture(gb, model, device, tol_full=2e-3, tol_proj=5e
     def rel(a, b):
         return float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
+    e = rel(s.grad, gb['grad_s'])
+    assert e < tol_full, ('grad_s', e)
+    worst = compare_param_grads(gb, model.named_parameters(), tol_full, tol_proj, report)
+    worst['full'] = max(worst['full'], e)
+    if report is not None:
+        report.update(worst)
+    return worst
+
+
+def compare_param_grads(gb, named_params, tol_full, tol_proj, report=None):
+    """Every parameter's ``.grad`` against a fixture written by gen_golden.py's ``grad_summary`` / ``gen_model_bwd``:
+    ``names`` / ``norms`` / ``dots`` (projection on the name-keyed random vector, seed crc32(name) + 1) for all of them,
+    ``g:<name>`` in full for some.  Shared by the HRNet and the PointNet++ / HRNetPN (row a18) checks."""
     worst = {'full': 0.0, 'norm': 0.0, 'dot': 0.0}
     table = []
-    e = rel(s.grad, gb['grad_s'])
-    worst['full'] = max(worst['full'], e)
-    assert e < tol_full, ('grad_s', e)
-    params = dict(model.named_parameters())
+    params = dict(named_params)
     names = [str(k) for k in gb['names']]
     assert names == list(params.keys())
     scale = max(float(v) for v in gb['norms'])

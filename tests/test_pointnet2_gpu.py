@@ -497,18 +497,24 @@ def test_sa_module_takes_the_fused_ballmax_path():
 
 
 @pytest.mark.parametrize('B,C,C1,N,npnt,ns,radius', [(3, 0, 16, 512, 128, 16, 0.15), (2, 13, 32, 256, 64, 32, 0.3),
-                                                      (2, 5, 8, 64, 16, 4, 0.2), (32, 96, 64, 4096, 1024, 16, 0.125)])
+                                                      (2, 5, 8, 64, 16, 4, 0.2), (32, 96, 64, 4096, 1024, 16, 0.125),
+                                                      (4, 0, 16, 4096, 4096, 16, 0.025), (4, 0, 32, 4096, 4096, 32, 0.125)])
 def test_first_layer_on_the_implicit_grouped_tensor(B, C, C1, N, npnt, ns, radius):
-    """r05: QueryAndGroup + the first conv -> BatchNorm2d -> ReLU WITHOUT the grouped tensor (Conv2d.forward_grouped:
-    P = W [xyz ; features], Q = W_xyz centre, hcm_ball_project_* on z = P[idx] - Q) against the module path that builds
+    """r05 / r06: QueryAndGroup + the first conv -> BatchNorm2d -> ReLU WITHOUT the grouped tensor (Conv2d.forward_grouped:
+    P = W_f features, hcm_ball_project_* on z = P[idx] + W_xyz (xyz[idx] - centre)) against the module path that builds
     [B, 3 + C, npoint, nsample] (reference: pointnet2_utils.py:231-268, pytorch_utils.py:5-33): output, gradients of the
-    features and of every parameter, running statistics.  The backward is bit-reproducible (planned scatter)."""
+    features and of every parameter, running statistics.  The backward is bit-reproducible (planned scatter).
+    r06: ACCURACY against the same layer in float64 -- the fused path may not be less accurate than the module path (the r05
+    form z = W [xyz ; f][idx] - W_xyz centre lost 40 x on 2.5 cm balls in a unit cloud: the last two cases, the first SA
+    level's shapes)."""
     from hcmoco_amd.pycontrast.networks.pointnet2 import pointnet2_utils as U, pytorch_utils as pt_utils
+    from hcmoco_amd.pycontrast.networks.pointnet2.pointnet2_modules import PointnetSAModuleMSG
     dev = torch.device('cuda:0')
     torch.manual_seed(N + ns)
-    xyz = torch.rand(B, N, 3, device=dev)
+    xyz = torch.rand(B, N, 3, device=dev) * 2 - 1
     picks = U.furthest_point_sample(xyz, npnt)
-    new_xyz = U.gather_operation(xyz.transpose(1, 2).contiguous(), picks).transpose(1, 2).contiguous()
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    new_xyz = U.gather_operation(xyz_t, picks).transpose(1, 2).contiguous()
     idx = U.ball_query(radius, ns, xyz, new_xyz)
     feats = torch.randn(B, C, N, device=dev) if C else None
     layer = pt_utils.Conv2d(3 + C, C1, bn=True).to(dev).train()
@@ -524,7 +530,7 @@ def test_first_layer_on_the_implicit_grouped_tensor(B, C, C1, N, npnt, ns, radiu
         layer.zero_grad(set_to_none=True)
         f = feats.clone().requires_grad_() if C else None
         if mode == 'fused':
-            y = layer.forward_grouped(xyz, new_xyz, f, idx)
+            y = layer.forward_grouped(PointnetSAModuleMSG.ball_offsets(xyz_t, new_xyz, idx), f, idx)
         else:
             y = layer(grouper(xyz, new_xyz, f, idx=idx))
         y.backward(gy)
@@ -537,13 +543,26 @@ def test_first_layer_on_the_implicit_grouped_tensor(B, C, C1, N, npnt, ns, radiu
     a, a2, m = res['fused'][0], res['fused'][1], res['module'][0]
     assert torch.equal(a[0], a2[0]) and (a[1] is None or torch.equal(a[1], a2[1]))
     assert all(torch.equal(a[2][n], a2[2][n]) for n in a[2])
-    assert (a[0] - m[0]).abs().max().item() <= 2e-5 * m[0].abs().max().item(), (a[0] - m[0]).abs().max().item()
+    # float64 truth of the same layer on the same (fp32) grouped values: gather, subtract in fp32 like the reference, then fp64
+    gi = idx.long().reshape(B, 1, npnt * ns)
+    gx = (torch.gather(xyz_t, 2, gi.expand(B, 3, -1)).view(B, 3, npnt, ns) - new_xyz.transpose(1, 2).unsqueeze(-1)).double()
     if C:
-        assert rel(a[1], m[1]) < 2e-4, rel(a[1], m[1])
+        gx = torch.cat([gx, torch.gather(feats, 2, gi.expand(B, C, -1)).view(B, C, npnt, ns).double()], 1)
+    z = torch.einsum('kc,bcij->bkij', state['conv.weight'].view(C1, -1).double(), gx)
+    mu, var = z.mean((0, 2, 3), keepdim=True), z.var((0, 2, 3), unbiased=False, keepdim=True)
+    y64 = torch.relu((z - mu) / torch.sqrt(var + layer.bn.bn.eps) * state['bn.bn.weight'].double().view(1, -1, 1, 1)
+                     + state['bn.bn.bias'].double().view(1, -1, 1, 1))
+    top = float(y64.abs().max())
+    e_fused, e_module = float((a[0].double() - y64).abs().max()), float((m[0].double() - y64).abs().max())
+    print('first layer vs float64: fused %.3g  module %.3g  (of max %.3g)' % (e_fused, e_module, top))
+    assert e_fused <= 3 * e_module + 5e-7 * top, (e_fused, e_module, top)
+    assert (a[0] - m[0]).abs().max().item() <= 5e-6 * m[0].abs().max().item(), (a[0] - m[0]).abs().max().item()
+    if C:
+        assert rel(a[1], m[1]) < 1e-4, rel(a[1], m[1])
     for n, gb in m[2].items():
-        assert rel(a[2][n], gb) < 5e-4, (n, rel(a[2][n], gb))
+        assert rel(a[2][n], gb) < 1e-4, (n, rel(a[2][n], gb))
     for n, bb in m[3].items():
-        assert torch.allclose(a[3][n].float(), bb.float(), rtol=1e-4, atol=1e-6), n
+        assert torch.allclose(a[3][n].float(), bb.float(), rtol=1e-5, atol=1e-6), n
 
 
 @pytest.mark.parametrize('N,C,K,H,W', [(2, 16, 32, 128, 16), (3, 32, 64, 64, 32), (2, 64, 128, 32, 16), (2, 256, 512, 16, 16),

@@ -126,7 +126,7 @@ class CheckingEngine(object):
             _, want = self.oracle.fmap_sampled([c(m) for m in branches1], [c(m) for m in branches2], p1, p2, c(feat3),
                                                c(depth_mask), c(joints2d), c(joints_vis), c(use_depth), c(use_rgb),
                                                num_samples, temperature, sample_ind=c(sample_ind), keep=c(keep))
-        assert torch.allclose(c(meters), want, rtol=2e-4, atol=2e-5), (meters, want)
+        assert torch.allclose(c(meters), want, rtol=1e-5, atol=1e-6), (meters, want)
         self.calls['fmap'] += 1
         return total, meters
 

@@ -8,9 +8,8 @@ the nine feature-map meters and the gradients of the feature-map losses w.r.t. t
 projection weights and the SemGCN output (reference data flow: merge_all_res + full-resolution projection,
 networks/build_backbone.py:243-254, :290-300; losses learning/contrast_trainer.py:954-980).
 
-Tolerances (fp32): losses 1e-5 relative, bank gradients 1e-4 relative L2, feature-map meters 2e-4 relative (the
-projection sums 270 terms in another order than torch's convolution), feature-map gradients 5e-4 relative L2, bank
-update 1e-6 absolute.  bf16 (config 5): bank rows are compared in the rows' own rounding (update to 1 bf16 ulp), the
+Tolerances (fp32) = SURVEY 8d's parity gate: losses and feature-map meters 1e-5 relative, bank and feature-map gradients
+1e-4 relative L2 (r06: were 2e-4 / 5e-4; measured on the bench configuration 3.8e-7 / 3.8e-6), bank update 1e-6 absolute.  bf16 (config 5): bank rows are compared in the rows' own rounding (update to 1 bf16 ulp), the
 bf16 feature-map contractions to 1e-2 on the meters and 2e-2 relative L2 on the gradients against the fp32 oracle."""
 import os
 import sys
