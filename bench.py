@@ -402,8 +402,11 @@ def main():
     ap.add_argument('--fmap_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
                     help='bf16 = BASELINE config 5 feature-map GEMMs; not the headline config')
     ap.add_argument('--encoder_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
-                    help='bf16 = BASELINE config 5 mixed precision (bf16 encoder convolutions under autocast, fp32 '
-                         'batch-norm statistics / master weights / loss section); not the headline config')
+                    help='bf16 = bf16 encoder convolutions under autocast (fp32 batch-norm statistics / master weights / loss '
+                         'section).  CORRECT, NOT ACCELERATED: it takes the stock module path instead of the encoder '
+                         'programs and is SLOWER than fp32 (465.6 vs 739.4 samples/s, profiles/r05_secondary_configs.log); '
+                         'BASELINE config 5 as SURVEY 8d words it is --bank_dtype bf16 --fmap_dtype bf16.  Not the headline '
+                         'config')
     ap.add_argument('--sampled_projection', type=int, default=1,
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--wgrad_stream', type=int, default=8,
@@ -442,7 +445,7 @@ def main():
               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'higher_is_better': True, 'scaling': 'weak',
               'vs_baseline': None, 'data': 'synthetic'}
     fs = FailSafe(rank, world, header)
-    fs.comm.update(world_size=world, rank=rank, backend=a.backend,
+    fs.comm.update(world_size=world, rank=rank, backend=a.backend, failsafe_armed=fs.armed,
                    hsa_enable_ipc_mode_legacy={'value': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
                                                'source': 'inherited' if hsa_ipc_inherited is not None else 'set by bench.py'})
     try:
@@ -543,6 +546,7 @@ def run(a, rank, world, local, fs):
         fs.comm['ranks_seen'] = ranks_seen
         if trainer.grad_sync is not None:
             trainer.grad_sync.wait_events = []
+            trainer.grad_sync.ready_events = []
         hip_ops.GATHER_WAIT_EVENTS = []
     hip_ops.prof_enable(True)
     if world > 1:
@@ -582,8 +586,20 @@ def run(a, rank, world, local, fs):
                 'note': 'HIP events on the trainer stream around work.wait() of the gradient all-reduces (after backward '
                         'returned) and around the wait for the packed feature/index all-gather in front of the bank '
                         'update: the time the stream stands still for communication that compute did not cover'})
+        # when is the LAST gradient chunk of a step ready on each rank, counted from the end of the previous step's collectives
+        # (a point every rank passes together)?  max - min over the ranks = what the early ranks spend waiting inside the
+        # all-reduce for the late one: an under-scaling curve can be read from the line without another run.
+        rd = trainer.grad_sync.ready_events if trainer.grad_sync is not None else None
+        mine = torch.tensor([mean_ms(rd) if rd else -1.0], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(t.item()), 4) for t in every]
+        have = [v for v in per_rank if v >= 0]
+        comm.update({'chunk_ready_ms_per_rank': per_rank if have else None,
+                     'chunk_ready_skew_ms': round(max(have) - min(have), 4) if len(have) == world else None})
         if trainer.grad_sync is not None:
             trainer.grad_sync.wait_events = None
+            trainer.grad_sync.ready_events = None
         hip_ops.GATHER_WAIT_EVENTS = None
     kern_ms, kern_n = hip_ops.prof_read()
     secondary_raw = {tag: hip_ops.prof_read(tag) for tag in ('dense_stats', 'dense_grad', 'scl_stats', 'scl_grad',
@@ -609,6 +625,31 @@ def run(a, rank, world, local, fs):
         sgc_idle = {tag: hip_ops.prof_read(tag) for tag in ('sgc_fwd', 'sgc_bwd')}
         hip_ops.prof_enable(False)
         for p_ in layer.parameters():
+            p_.grad = None
+    # BASELINE config 4: the PointNet++ kernels' rooflines.  Inside the step the cloud branch shares the
+    # device with two more busy streams (event spans there include queueing, like the SemGCN's above), so the encoder is run
+    # ALONE after the timed region: the model's own Pointnet2MSG at the step's shapes ([B, 4096, 3] clouds back-projected from a
+    # batch of the synthetic source), forward + backward, 1 + 3 passes; every launcher adds its algorithmic work to its tag.
+    pn_idle = {}
+    if rank == 0 and a.arch == 'HRNetPN':
+        net_pn = trainer.unwrap(model)
+        batch_pn = data.pool[0]
+        with torch.no_grad():
+            sample_pn, _, _ = net_pn.depth2pts(batch_pn[0][:, 3:].float(), batch_pn[7], batch_pn[12], int(batch_pn[13][0]),
+                                               int(batch_pn[14][0]), batch_pn[15])
+        cloud_pn = sample_pn.transpose(1, 2).contiguous()
+        torch.cuda.synchronize()
+        for it_ in range(4):
+            if it_ == 1:
+                torch.cuda.synchronize()
+                hip_ops.prof_enable(True)
+            net_pn.encoder2(cloud_pn).sum().backward()
+            torch.cuda.synchronize()
+        for tag in ('conv1x1_fwd', 'conv1x1_dx', 'conv1x1_dw', 'ball_fwd', 'ball_bwd', 'ballmax_fwd', 'ballmax_bwd', 'fps',
+                    'three_nn', 'ball_query'):
+            pn_idle[tag] = hip_ops.prof_read(tag) + (hip_ops.prof_read_work(tag),)
+        hip_ops.prof_enable(False)
+        for p_ in net_pn.encoder2.parameters():
             p_.grad = None
     kept_per_step = float(sum(int(b[6].sum()) for b in data.pool)) / len(data.pool)    # images with depth: B' of the dense loss
     tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -727,9 +768,21 @@ def run(a, rank, world, local, fs):
                                   'launches_timed': n})
             elif kind == 'mfma':
                 ach = work / (avg * 1e-3) / 1e12
-                secondary.append({'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak,
-                                  'unit': 'TFLOP/s', 'frac': round(ach / mfma_peak, 4), 'flops_per_launch': int(work),
-                                  'avg_launch_ms': round(avg, 5), 'launches_timed': n})
+                entry = {'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak,
+                         'unit': 'TFLOP/s', 'frac': round(ach / mfma_peak, 4), 'flops_per_launch': int(work),
+                         'avg_launch_ms': round(avg, 5), 'launches_timed': n}
+                if a.fmap_dtype == 'fp32':
+                    # what the fp32 instantiation really issues: every fp32 operand is split into two bf16 pieces and
+                    # a product is 3 (dense) / 4 (SCL) v_mfma_f32_16x16x32_bf16 terms with fp32 accumulation; `frac` prices the
+                    # ALGORITHMIC flops against the fp32-input MFMA rate an exact fp32 contraction would be bound by
+                    terms = 4 if tag.startswith('scl') else 3
+                    entry.update({'arith': 'fp32-accurate split-bf16: %d bf16 MFMA terms per product, fp32 accumulate '
+                                           '(error vs float64 4e-6..6e-6, profiles/r05_split_bf16_error_study.txt)' % terms,
+                                  'issued_tflops': round(ach * terms, 2),
+                                  'frac_of_bf16_mfma_peak_issued': round(ach * terms / MFMA_BF16_PEAK_TFS, 4),
+                                  'note': 'VALU / latency bound, not MFMA bound: matrix pipes busy 7 % of wave cycles '
+                                          '(profiles/r05_strip_mfma_pmc_fp32.json)'})
+                secondary.append(entry)
             else:
                 ach = work / (avg * 1e-3) / 1e9
                 secondary.append({'kernel': name, 'bound': 'latency', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
@@ -737,6 +790,34 @@ def run(a, rank, world, local, fs):
                                   'avg_launch_ms': round(avg, 5), 'launches_timed': n,
                                   'timed': 'idle GPU after the timed region (kernel time; agrees with rocprofv3)',
                                   'span_ms_inside_the_step_incl_queueing': in_step})
+        # config 4: sum(work) / sum(time) per PointNet++ kernel over every shape it was launched at (3 passes of the encoder)
+        PN_SPEC = [('conv1x1_fwd', 'conv1x1_kernel forward (SharedMLP 1x1 convolutions + the source-point projection, fp32 MFMA)', 'mfma'),
+                   ('conv1x1_dx', 'conv1x1_kernel data gradient', 'mfma'),
+                   ('conv1x1_dw', 'wgrad1x1_ball_kernel + wgrad1x1_reduce_kernel (weight gradient)', 'mfma'),
+                   ('ball_fwd', 'ball_stats_kernel + ball_apply_kernel (first SharedMLP layer on the implicit grouped tensor)', 'hbm'),
+                   ('ball_bwd', 'ball_bwd_reduce_kernel + ball_bwd_apply_kernel (+ dW_xyz merge)', 'hbm'),
+                   ('ballmax_fwd', 'bn_stats_kernel + bn_relu_ballmax_kernel (last layer: BatchNorm + ReLU + max over the ball)', 'hbm'),
+                   ('ballmax_bwd', 'ballmax_bwd_reduce_kernel + ballmax_bwd_apply_kernel', 'hbm'),
+                   ('fps', 'fps_kernel (furthest point sampling, 4 levels)', 'pairs'),
+                   ('three_nn', 'three_nn_split_kernel (FP levels)', 'pairs'),
+                   ('ball_query', 'ball_query_wave_kernel (8 scales; early exit: b m n is an upper bound on its work)', 'pairs')]
+        for tag, name, kind in PN_SPEC:
+            ms, n, work = pn_idle.get(tag, (0.0, 0, 0.0))
+            if not n or not ms:
+                continue
+            rate = work / (ms * 1e-3)
+            common = {'kernel': name, 'avg_launch_ms': round(ms / n, 5), 'launches_timed': n,
+                      'timed': 'cloud encoder alone on the idle GPU after the timed region, all shapes of one step summed'}
+            if kind == 'mfma':
+                secondary.append(dict(common, bound='mfma', achieved=round(rate / 1e12, 2), peak=MFMA_F32_PEAK_TFS, unit='TFLOP/s',
+                                      frac=round(rate / 1e12 / MFMA_F32_PEAK_TFS, 4), flops_timed=int(work)))
+            elif kind == 'hbm':
+                secondary.append(dict(common, bound='hbm', achieved=round(rate / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                                      frac=round(rate / 1e9 / HBM_PEAK_GBS, 4), bytes_timed=int(work)))
+            else:       # rows 12 / 13 / 16 as distance evaluations per second against the fp32 vector peak (9 flop each)
+                peak = MFMA_F32_PEAK_TFS * 1e12 / 9.0
+                secondary.append(dict(common, bound='valu', achieved=round(rate / 1e9, 2), peak=round(peak / 1e9, 1),
+                                      unit='G distance evaluations/s', frac=round(rate / peak, 4), pairs_timed=int(work)))
         out = {
             'metric': 'pretrain samples/sec (RGB+depth+kpt triples) HRNet-w18',
             'value': round(B * world * a.steps / dt, 3), 'unit': 'samples/s',
@@ -768,6 +849,10 @@ def run(a, rank, world, local, fs):
                          'traffic': traffic, 'traffic_source': traffic_src, 'bytes_per_launch': bytes_per_launch,
                          'avg_launch_ms': round(avg_ms, 5), 'launches_timed': kern_n},
         }
+        if a.encoder_dtype == 'bf16':
+            out['config']['note'] = ('--encoder_dtype bf16 is correct but not accelerated: stock module path instead of the '
+                                     'encoder programs, slower than fp32 (465.6 vs 739.4 samples/s in r05); the encoders are '
+                                     'outside SURVEY 8 (2.1 #9)')
         out['roofline_secondary'] = secondary
         out['comm'] = comm
         if records_path is not None:

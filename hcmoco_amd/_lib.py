@@ -132,6 +132,7 @@ SIGNATURES = {
     'hcm_prof_enable': (_i, [_i]),
     'hcm_prof_read': (_i, [_p, _p]),
     'hcm_prof_read_tag': (_i, [_i, _p, _p]),
+    'hcm_prof_read_work': (_i, [_i, _p]),
 }
 
 SIGNATURES['hcm_dense_soft_nce_coords_bf16'] = SIGNATURES['hcm_dense_soft_nce_coords']

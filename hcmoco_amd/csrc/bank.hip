@@ -650,11 +650,12 @@ inline FusedWs carve(void* ws, int B, int K1, int D) {
 
 // ---- optional in-library timing of selected kernels (bench.py roofline objects) ----------------
 // The only process-global state of the library; off by default; mutex-protected.
-constexpr int kProfTags = 12;
+constexpr int kProfTags = HCM_PROF_NTAGS;
 struct ProfState {
   std::mutex mu;
   bool on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[kProfTags];
+  double work[kProfTags] = {};
 };
 ProfState& prof() {
   static ProfState p;
@@ -664,11 +665,12 @@ ProfState& prof() {
 }  // namespace
 
 namespace hcm {
-ProfSpan::ProfSpan(int tag_, hipStream_t s) : st(s), tag(tag_) {
+ProfSpan::ProfSpan(int tag_, hipStream_t s, double work) : st(s), tag(tag_) {
   bool on;
   {
     std::lock_guard<std::mutex> lk(prof().mu);
     on = prof().on && tag >= 0 && tag < kProfTags && prof().spans[tag].size() < 65536;
+    if (on) prof().work[tag] += work;
   }
   if (on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
     hipEventRecord(e0, st);
@@ -866,6 +868,7 @@ int hcm_prof_enable(int enable) {
     }
     v.clear();
   }
+  for (auto& w : prof().work) w = 0.0;
   prof().on = enable != 0;
   return 0;
 }
@@ -890,6 +893,13 @@ int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host) {
   }
   if (total_ms_host) *total_ms_host = total;
   if (launches_host) *launches_host = n;
+  return 0;
+}
+
+int hcm_prof_read_work(int tag, double* work_host) {
+  if (tag < 0 || tag >= kProfTags || !work_host) return (int)hipErrorInvalidValue;
+  std::lock_guard<std::mutex> lk(prof().mu);
+  *work_host = prof().work[tag];
   return 0;
 }
 

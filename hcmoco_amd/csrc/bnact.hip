@@ -860,6 +860,8 @@ int hcm_bn_relu_ballmax_forward(const float* z, const float* gamma, const float*
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(C, g.split);
   float* part = stats + 2 * (size_t)C;
+  const double M = (double)N * C * np * ns;
+  hcm::ProfSpan span(HCM_PROF_BALLMAX_FWD, st, 4.0 * (2.0 * M + 3.0 * M / ns));     // z twice; out, arg, zsel written
   bn_stats_kernel<<<grid, kBT, 0, st>>>(z, g, part);
   HCM_CHECK_LAUNCH();
 #define HCM_BALLMAX(LL)                                                                                              \
@@ -885,6 +887,8 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
   const Geo g = make_geo(N, C, np * ns), gr = make_geo(N, C, np);
   hipStream_t st = (hipStream_t)stream;
   float* part = gstats + 2 * (size_t)C;
+  const double M = (double)N * C * np * ns;
+  hcm::ProfSpan span(HCM_PROF_BALLMAX_BWD, st, 4.0 * (2.0 * M + 6.0 * M / ns));     // z read, dz written; the [N, C, np] tensors twice
   ballmax_bwd_reduce_kernel<<<dim3(C, gr.split), kBT, 0, st>>>(dout, out, zsel, stats, gr, part);
   HCM_CHECK_LAUNCH();
   const dim3 grid(C, g.split);
@@ -920,6 +924,9 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(C, g.split);
   float* part = stats + 2 * (size_t)C;
+  // algorithmic bytes: y written once; idx, D and P each read once per pass (P's rows and D are re-read per channel out of L2)
+  const double uniq = (double)B * np * ns * (P ? 4.0 : 3.0) + (P ? (double)B * C * N : 0.0);
+  hcm::ProfSpan span(HCM_PROF_BALL_FWD, st, 4.0 * ((double)B * C * np * ns + 2.0 * uniq));
 #define HCM_BALL_FWD(R, HP)                                                                                          \
   do {                                                                                                               \
     ball_stats_kernel<HP><<<grid, kBT, 0, st>>>(P, D, Wxyz, idx, g, bg, part);                                      \
@@ -946,6 +953,8 @@ int hcm_ball_project_backward(const float* dy, const float* y, const float* P, c
   const dim3 grid(C, g.split);
   float* part = gstats + 2 * (size_t)C;
   float* wpart = part + 2 * (size_t)g.split * C;
+  const double uniq = (double)B * np * ns * (P ? 4.0 : 3.0) + (P ? (double)B * C * N : 0.0);
+  hcm::ProfSpan span(HCM_PROF_BALL_BWD, st, 4.0 * (5.0 * (double)B * C * np * ns + 2.0 * uniq));   // dy, y twice; dz written
 #define HCM_BALL_BWD(R, HP)                                                                                          \
   do {                                                                                                               \
     ball_bwd_reduce_kernel<R, HP><<<grid, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);                \

@@ -235,14 +235,14 @@ bool ball_wgrad_geo(int N, int C, int K, int P, BallWgradGeo& g) {
 }
 
 template <int KT, int CT>
-void ball_wgrad_launch(const float* x, const float* dz, float* partial, int C, int K, int P, const BallWgradGeo& g, hipStream_t st) {
+int ball_wgrad_launch(const float* x, const float* dz, float* partial, int C, int K, int P, const BallWgradGeo& g, hipStream_t st) {
   const size_t lds = (size_t)4 * KT * CT * 256 * sizeof(float);
-  static const bool once = [&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_ball_kernel<KT, CT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  }();
-  (void)once;
+  // the attribute is per DEVICE: set on every launch (as rowproj.hip / pointnet2.hip do), not once per process
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_ball_kernel<KT, CT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
   wgrad1x1_ball_kernel<KT, CT><<<dim3(g.chunks, g.kblocks * g.cblocks), 256, lds, st>>>(x, dz, partial, C, K, P, g.L, g.cblocks);
+  return 0;
 }
 
 }  // namespace
@@ -263,15 +263,18 @@ int hcm_conv1x1_ball_wgrad(const float* x, const float* dy, int N, int C, int K,
   hipStream_t st = (hipStream_t)stream;
   float* partial = static_cast<float*>(workspace);
   const int P = H * W;
-  if (g.kt == 4 && g.ct == 4) ball_wgrad_launch<4, 4>(x, dy, partial, C, K, P, g, st);
-  else if (g.kt == 4 && g.ct == 2) ball_wgrad_launch<4, 2>(x, dy, partial, C, K, P, g, st);
-  else if (g.kt == 4) ball_wgrad_launch<4, 1>(x, dy, partial, C, K, P, g, st);
-  else if (g.kt == 2 && g.ct == 4) ball_wgrad_launch<2, 4>(x, dy, partial, C, K, P, g, st);
-  else if (g.kt == 2 && g.ct == 2) ball_wgrad_launch<2, 2>(x, dy, partial, C, K, P, g, st);
-  else if (g.kt == 2) ball_wgrad_launch<2, 1>(x, dy, partial, C, K, P, g, st);
-  else if (g.ct == 4) ball_wgrad_launch<1, 4>(x, dy, partial, C, K, P, g, st);
-  else if (g.ct == 2) ball_wgrad_launch<1, 2>(x, dy, partial, C, K, P, g, st);
-  else ball_wgrad_launch<1, 1>(x, dy, partial, C, K, P, g, st);
+  hcm::ProfSpan span(HCM_PROF_CONV1X1_DW, st, 2.0 * N * (double)C * K * P);
+  int rc;
+  if (g.kt == 4 && g.ct == 4) rc = ball_wgrad_launch<4, 4>(x, dy, partial, C, K, P, g, st);
+  else if (g.kt == 4 && g.ct == 2) rc = ball_wgrad_launch<4, 2>(x, dy, partial, C, K, P, g, st);
+  else if (g.kt == 4) rc = ball_wgrad_launch<4, 1>(x, dy, partial, C, K, P, g, st);
+  else if (g.kt == 2 && g.ct == 4) rc = ball_wgrad_launch<2, 4>(x, dy, partial, C, K, P, g, st);
+  else if (g.kt == 2 && g.ct == 2) rc = ball_wgrad_launch<2, 2>(x, dy, partial, C, K, P, g, st);
+  else if (g.kt == 2) rc = ball_wgrad_launch<2, 1>(x, dy, partial, C, K, P, g, st);
+  else if (g.ct == 4) rc = ball_wgrad_launch<1, 4>(x, dy, partial, C, K, P, g, st);
+  else if (g.ct == 2) rc = ball_wgrad_launch<1, 2>(x, dy, partial, C, K, P, g, st);
+  else rc = ball_wgrad_launch<1, 1>(x, dy, partial, C, K, P, g, st);
+  if (rc != 0) return rc;
   HCM_CHECK_LAUNCH();
   wgrad1x1_reduce_kernel<<<(K * C + 63) / 64, 256, 0, st>>>(partial, dw, K * C, g.chunks);
   HCM_CHECK_LAUNCH();
@@ -284,11 +287,13 @@ int hcm_conv1x1_supported(int C, int K, int P) {
 
 int hcm_conv1x1_forward(const float* x, const float* w, float* z, int N, int C, int K, int P, hcm_stream_t stream) {
   if (!x || !w || !z || N <= 0 || !hcm_conv1x1_supported(C, K, P)) return (int)hipErrorInvalidValue;
+  hcm::ProfSpan span(HCM_PROF_CONV1X1_FWD, (hipStream_t)stream, 2.0 * N * (double)C * K * P);
   return launch<false>(x, w, z, N, K, C, C, P, (hipStream_t)stream);
 }
 
 int hcm_conv1x1_backward_data(const float* dz, const float* w, float* dx, int N, int C, int K, int P, hcm_stream_t stream) {
   if (!dz || !w || !dx || N <= 0 || !hcm_conv1x1_supported(C, K, P)) return (int)hipErrorInvalidValue;
+  hcm::ProfSpan span(HCM_PROF_CONV1X1_DX, (hipStream_t)stream, 2.0 * N * (double)C * K * P);
   return launch<true>(dz, w, dx, N, C, K, C, P, (hipStream_t)stream);
 }
 

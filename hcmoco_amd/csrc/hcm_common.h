@@ -22,7 +22,10 @@ struct ProfSpan {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t st;
   int tag;
-  ProfSpan(int tag, hipStream_t s);
+  // work: what this launch does in the tag's unit (flops, bytes or distance evaluations), summed per tag next to the time:
+  // kernels that are launched at many shapes (the PointNet++ layers) still give ONE achieved rate, sum(work) / sum(time)
+  ProfSpan(int tag, hipStream_t s, double work = 0.0);
+  ~ProfSpan() { stop(); }
   void stop();
 };
 

@@ -922,6 +922,7 @@ int hcm_ball_query_contract(int b, int n, int m, float radius, int nsample, cons
                             const float* xyz, int* idx, int contract, hcm_stream_t stream) {
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || m <= 0 || nsample <= 0) return b < 0 || m < 0 || nsample < 0 ? (int)hipErrorInvalidValue : 0;
+  hcm::ProfSpan span(HCM_PROF_BALL_QUERY, (hipStream_t)stream, (double)b * m * (double)n);
   // the cloud fits LDS (every level of Pointnet2MSG: n <= 4096 points = 64 KB): one WAVE per centre, lanes over the points
   const size_t cloud_lds = (size_t)((n + 127) & ~127) * sizeof(float4);
   if (n > 0 && cloud_lds <= 72 * 1024) {          // two workgroups per CU
@@ -965,6 +966,7 @@ int hcm_three_nn_contract(int b, int n, int m, const float* unknown, const float
                           int* idx, int contract, hcm_stream_t stream) {
   if (contract != HCM_CONTRACT_FMA && contract != HCM_CONTRACT_IEEE) return (int)hipErrorInvalidValue;
   if (b <= 0 || n <= 0) return b < 0 || n < 0 ? (int)hipErrorInvalidValue : 0;
+  hcm::ProfSpan span(HCM_PROF_THREE_NN, (hipStream_t)stream, (double)b * n * (double)m);
   // few unknowns (the feature-propagation levels: b x n <= 2^17 ... 2^19): split each scan across 16 lanes; many
   // (pts2depth: 2 M unknowns) -> a thread per two unknowns keeps every SIMD busy.
   if ((long long)b * n <= (1ll << 19) && m >= 16) {
@@ -1022,6 +1024,7 @@ int hcm_furthest_point_sampling_contract(int b, int n, int m, const float* datas
   const size_t lds = (size_t)n * 3 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const bool fma = contract == HCM_CONTRACT_FMA;
+  hcm::ProfSpan span(HCM_PROF_FPS, st, (double)b * m * (double)n);
 #define HCM_FPS1(P, F)                                                                      \
   do {                                                                                      \
     hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<P, F>),                     \

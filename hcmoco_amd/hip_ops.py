@@ -134,8 +134,13 @@ class _BankNCEFused(torch.autograd.Function):
                                               [x1.contiguous(), x2.contiguous(), x3.contiguous()],
                                               T, use_depth, use_rgb)
         ctx.save_for_backward(*gx)
-        ctx.mark_non_differentiable(accs)
-        return losses.sum(), losses.detach().clone(), accs
+        # the six losses are METERS: marked non-differentiable so that the copies the trainer's running averages hold across
+        # steps carry no grad_fn -- a meter with a grad_fn keeps this node, and through it the whole step's graph down to the
+        # parameters' AccumulateGrad nodes, alive into the next step (r05: "AccumulateGrad node's stream does not match"
+        # in the stage-1 loop: the nodes of the quiet first step were re-used when a side stream produced the gradient)
+        meters = losses.clone()
+        ctx.mark_non_differentiable(meters, accs)
+        return losses.sum(), meters, accs
 
     @staticmethod
     def backward(ctx, g_total, g_losses, g_accs):
@@ -179,7 +184,9 @@ def prof_enable(on):
 
 
 PROF_TAGS = {'bank_pass': 0, 'dense_stats': 1, 'dense_grad': 2, 'scl_stats': 3, 'scl_grad': 4, 'sgc_fwd': 5,
-             'sgc_bwd': 6, 'row8_fwd': 7, 'row8_dw': 8, 'row8_bwd': 9, 'joint': 10}
+             'sgc_bwd': 6, 'row8_fwd': 7, 'row8_dw': 8, 'row8_bwd': 9, 'joint': 10,
+             'conv1x1_fwd': 11, 'conv1x1_dx': 12, 'conv1x1_dw': 13, 'ball_fwd': 14, 'ball_bwd': 15, 'ballmax_fwd': 16,
+             'ballmax_bwd': 17, 'fps': 18, 'three_nn': 19, 'ball_query': 20}
 
 
 def prof_read(tag='bank_pass'):
@@ -187,6 +194,13 @@ def prof_read(tag='bank_pass'):
     total, n = C.c_double(0.0), C.c_int64(0)
     check(_lib.lib().hcm_prof_read_tag(PROF_TAGS[tag], C.byref(total), C.byref(n)), 'hcm_prof_read_tag')
     return float(total.value), int(n.value)
+
+
+def prof_read_work(tag):
+    """Algorithmic work (flops, bytes or distance evaluations, see include/hcmoco_hip.h) the tagged launches stated."""
+    w = C.c_double(0.0)
+    check(_lib.lib().hcm_prof_read_work(PROF_TAGS[tag], C.byref(w)), 'hcm_prof_read_work')
+    return float(w.value)
 
 
 # --------------------------------------------------------------------------- #
@@ -392,7 +406,9 @@ class _FmapLosses(torch.autograd.Function):
         ctx.save_for_backward(g1, g2, gfeat3 if gfeat3 is not None else torch.empty(0, device=dev))
         ctx.has_g3 = gfeat3 is not None
         total = out[0] + out[1] + out[4] + out[5] + out[8]
-        return total, out.detach().clone()
+        meters = out.clone()
+        ctx.mark_non_differentiable(meters)      # see _BankNCEFused.forward
+        return total, meters
 
     @staticmethod
     def backward(ctx, g_total, g_out):

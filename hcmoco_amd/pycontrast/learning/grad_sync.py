@@ -26,7 +26,9 @@ not filled yet.  ``GradSync`` keeps the overlap and drops the hooks:
 * ``optimizer.step()`` is ordered behind all of it by ``work.wait()`` on the caller's stream.
 
 ``mode='flat'`` keeps the single-bucket behaviour (one all-reduce after the join) for comparison;
-both modes produce bit-identical parameters (tests/test_plumbing_cpu.py, world_size 2 over gloo).
+both modes produce bit-identical parameters with two ranks and parameters equal to round-off with eight (a ring adds the
+eight contributions of an element in an order that depends on the element's position in the buffer, and the modes cut the
+buffers differently; tests/test_plumbing_cpu.py, world_size 2 and 8 over gloo).
 
 Not synchronised, unlike DDP's default ``broadcast_buffers=True``: BatchNorm running statistics stay
 per-replica.  They never enter a training-mode forward, and rank 0 writes the checkpoint from its
@@ -93,6 +95,10 @@ class GradSync(object):
         # bench.py sets this to a list: every reduce() then appends a HIP event pair around the waits below -- the time the
         # trainer's stream stands still for collectives that backward did not cover (exposed communication)
         self.wait_events = None
+        # bench.py (N > 1): (end of the previous step's collectives, this step's LAST encoder chunk ready) event pairs -- how long
+        # into a step this rank's gradients are complete; max - min over the ranks is what the fast ranks wait inside RCCL
+        self.ready_events = None
+        self._last_end = None
         self._comm = None
         # several chunks in one RCCL launch (nccl only: gloo's coalescing manager has no all-reduce fast path)
         self.coalesce = self.avg and os.environ.get('HCM_GRAD_COALESCE', '1') != '0'
@@ -224,6 +230,11 @@ class GradSync(object):
                     works.extend(self._launch_group(pieces))
             for enc, _ in live:
                 handled.update(id(p) for p in enc.last_program.params)
+            if self.ready_events is not None and live:
+                ready = torch.cuda.Event(enable_timing=True)
+                ready.record(self._comm)          # behind the stream-wait on the last chunk's event
+                if self._last_end is not None:
+                    self.ready_events.append((self._last_end, ready))
         if join is not None:
             join()
         if self.mode == 'flat':
@@ -259,6 +270,7 @@ class GradSync(object):
         if timed:
             ev[1].record()
             self.wait_events.append(ev)
+            self._last_end = ev[1]
         # the reduced flag goes to the host without a sync; it is read at the top of the next reduce()
         if carrier.is_cuda:
             if self._flag_pinned is None:            # one pinned word for the life of the object (a pinned allocation per

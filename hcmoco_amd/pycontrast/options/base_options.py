@@ -109,14 +109,27 @@ BASE_FLAGS = [
                                help='n > 0: the encoder programs hand their weight gradients (own kernels '
                                     'and MIOpen\'s five-launch path alike) to a side stream, n layers at a time, so that the reverse '
                                     'chain dx -> BatchNorm -> dx is not queued behind them (csrc/torch_glue); 0: in line')),
+    # escape hatches of the ROCm runtime (reachable from the CLI, not only from test code).  All default to on;
+    # 0 gives the plain-autograd twin the parity tests compare with (tests/test_trainer_gpu.py, tests/test_section_gpu.py)
+    (('--fused_section',), dict(type=_I, default=1,
+                                help='1: pooling, heads, all-gather, bank NCE + update, pixel sampling, sampled projection and '
+                                     'the three feature-map losses as ONE autograd node (csrc/section.hip); 0: module by module')),
+    (('--async_wgrad',), dict(type=_I, default=1,
+                              help='1: the encoder programs\' reverse loops and weight gradients are issued by helper threads '
+                                   'while the autograd thread walks on (csrc/torch_glue); 0: everything on the autograd thread')),
+    (('--flat_sgd',), dict(type=_I, default=1,
+                           help='1: one SGD launch per encoder over its flat parameter buffer (learning/flat_sgd.py; '
+                                'checkpoints keep the per-parameter layout); 0: torch.optim.SGD as it is')),
     (('--grad_sync',), dict(type=_S, default='auto', choices=['auto', 'ddp', 'flat', 'overlap'],
                             help='N>1 gradient averaging: ddp = DistributedDataParallel; overlap = in-place RCCL '
                                  'all-reduces of the encoders\' flat gradient buffers, launched chunk by chunk while '
                                  'backward is still running (learning/grad_sync.py); flat = ONE all-reduce after '
                                  'backward; auto = overlap on ROCm, ddp on CPU')),
     (('--fmap_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
-                             help='arithmetic of the dense / SCL feature-map contractions: fp32 MFMA (the reference\'s '
-                                  'arithmetic) or bf16 MFMA with fp32 accumulation (BASELINE config 5)')),
+                             help='arithmetic of the dense / SCL feature-map contractions: fp32 = fp32-ACCURATE products on the '
+                                  'bf16 matrix cores (operands split into two bf16 pieces, 3 / 4 MFMA terms per product, fp32 '
+                                  'accumulation; 4e-6..6e-6 of float64, inside the 1e-5 / 1e-4 parity gate) or bf16 = operands '
+                                  'rounded to bf16, fp32 accumulation (BASELINE config 5)')),
     (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
                              help='storage type of the memory banks (bf16: BASELINE config 5)')),
     (('--encoder_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],

@@ -635,9 +635,24 @@ int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2, 
 #define HCM_PROF_ROW8_DW 8      /* proj_dw_partial + proj_dw_reduce of hcm_project_rows_dw     */
 #define HCM_PROF_ROW8_BWD 9     /* branch_grad_t_kernel of hcm_project_rows_backward           */
 #define HCM_PROF_JOINT 10       /* the kernels of hcm_joint_nce                                */
+/* BASELINE config 4 (HRNetPN): the PointNet++ kernels, launched at many shapes per step -- each launch adds its own
+ * algorithmic work to the tag (hcm_prof_read_work), so sum(work) / sum(time) is ONE achieved rate per kernel (r06). */
+#define HCM_PROF_CONV1X1_FWD 11   /* conv1x1_kernel of hcm_conv1x1_forward: flops 2 N C K P                          */
+#define HCM_PROF_CONV1X1_DX 12    /* conv1x1_kernel of hcm_conv1x1_backward_data: flops 2 N C K P                    */
+#define HCM_PROF_CONV1X1_DW 13    /* wgrad1x1_ball_kernel + reduce of hcm_conv1x1_ball_wgrad: flops 2 N C K P        */
+#define HCM_PROF_BALL_FWD 14      /* ball_stats + ball_apply of hcm_ball_project_forward: bytes                      */
+#define HCM_PROF_BALL_BWD 15      /* ball_bwd_reduce + ball_bwd_apply (+ merge) of hcm_ball_project_backward: bytes  */
+#define HCM_PROF_BALLMAX_FWD 16   /* bn_stats + bn_relu_ballmax of hcm_bn_relu_ballmax_forward: bytes                */
+#define HCM_PROF_BALLMAX_BWD 17   /* ballmax_bwd_reduce + ballmax_bwd_apply of hcm_bn_relu_ballmax_backward: bytes   */
+#define HCM_PROF_FPS 18           /* fps kernels of hcm_furthest_point_sampling*: distance evaluations b m n          */
+#define HCM_PROF_THREE_NN 19      /* three_nn kernels of hcm_three_nn*: distance evaluations b n m                    */
+#define HCM_PROF_BALL_QUERY 20    /* ball_query kernel of hcm_ball_query*: distance evaluations b m n (upper bound)   */
+#define HCM_PROF_NTAGS 24
 int hcm_prof_enable(int enable);
 int hcm_prof_read(double* total_ms_host, int64_t* launches_host);
 int hcm_prof_read_tag(int tag, double* total_ms_host, int64_t* launches_host);
+/* the work the tag's launches added since hcm_prof_enable(1) (0 for tags whose launchers state none) */
+int hcm_prof_read_work(int tag, double* work_host);
 
 /* Direct 3x3 convolution, stride 1, pad 1, fp32 NCHW, for the BasicBlocks of the two high-resolution HRNet
  * branches (reference: networks/official_hrnet.py:40-70 `conv3x3` -> nn.Conv2d(bias=False); replaces the

@@ -58,3 +58,28 @@ def test_bench_under_torchrun_still_works():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16
+
+
+def test_four_ranks_on_one_gpu_control_flow():
+    """First-run readiness of the N > 2 job: four ranks share cuda:0 over gloo at a small size; what
+    is W-dependent in the control flow -- rendez-vous of four, packed all-gather of four slices, chunked gradient
+    all-reduces with the presence agreement, the fail-safe watcher, the per-rank chunk-ready times and their skew -- runs
+    exactly as it will with four devices (RCCL itself needs one device per rank: the driver's job)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--backend', 'gloo',
+                          '--batch_per_gpu', '4', '--size', '64', '--nce_k', '1024', '--n_data', '4096', '--steps', '2',
+                          '--warmup', '1', '--no_cpu_baseline', '--no_check'],
+                         capture_output=True, text=True, env=_clean_env(), timeout=1100)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith('{"metric"') and sum(l.startswith('{"metric"') for l in lines) == 1
+    out = json.loads(lines[-1])
+    assert out['n_gpus'] == 4 and out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp4'
+    assert out['value'] > 0 and out['config']['final_loss'] == out['config']['final_loss']
+    comm = out['comm']
+    assert comm['ranks_seen'] == 4 and comm['world_size'] == 4 and comm['failsafe_armed'] is True
+    assert comm['launches'] == 9 and comm['steps_measured'] == 2
+    assert out['config']['grad_collectives_per_step'] == 9
+    # one timed step has a predecessor inside the timed region (the first one's reference point is the warm-up's end)
+    per_rank = comm['chunk_ready_ms_per_rank']
+    assert per_rank is not None and len(per_rank) == 4 and all(v > 0 for v in per_rank), per_rank
+    assert comm['chunk_ready_skew_ms'] is not None and 0 <= comm['chunk_ready_skew_ms'] <= max(per_rank)

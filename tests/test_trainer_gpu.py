@@ -158,10 +158,16 @@ def test_stage1_loop_on_the_hip_engine_through_main(_pg_env):
     """BASELINE config 1's method (CMCRGBD2S, learning/contrast_trainer.py:532-640) on the MI355X through the
     real entry point: two steps with use_depth AND use_rgb masks (the `both_*` row-selection regime), the fused
     bank kernel's losses / accuracies / d/dx / momentum update checked against the oracle at every step."""
+    import warnings
     from hcmoco_amd.pycontrast import main_contrast
     eng = CheckingEngine()
-    outs, trainer, model, contrast = main_contrast.main(_main_args('CMCRGBD2S', []), engine=eng)
-    torch.cuda.synchronize()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        outs, trainer, model, contrast = main_contrast.main(_main_args('CMCRGBD2S', []), engine=eng)
+        torch.cuda.synchronize()
+    # r05's GPU run warned "The AccumulateGrad node's stream does not match ..." here: the six loss meters carried a grad_fn
+    # and the running averages kept step 1's graph (made on one stream, the quiet first step) alive into step 2 (side streams)
+    assert not [str(w.message)[:120] for w in caught if 'AccumulateGrad' in str(w.message)]
     assert trainer.device.type == 'cuda' and trainer.args.mem == 'bank'
     assert len(outs) == 6 and all(v == v for v in outs)
     assert eng.calls['bank'] == 2 and eng.calls['grad'] == 6 and eng.calls['regimes'] == {(True, True)}
