@@ -36,12 +36,20 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
   for (int i = 0; i < PB; ++i) {
     const int p0 = ((blockIdx.x * PB + i) * 4 + wave) * 64;
     const bool active = p0 < P;                        // P is a multiple of 64
-    const float* x = X + (size_t)blockIdx.z * R * P + (active ? p0 : 0) + np;
+    // r06: ONE 16-byte load per lane and k-step.  A sum over channels does not care which position an MFMA row stands for, as
+    // long as the store agrees: lane (np, g) loads X[c0 + g][p0 + 4 pi(np) .. + 3] and feeds element j to MFMA number j, so row
+    // np of MFMA j is position p0 + 4 pi(np) + j.  With pi(r) = 4 (r mod 4) + r div 4 (a 4 x 4 transpose of the row index) the
+    // accumulator register q of lane (np, g) in MFMA j is Z[m0 + np][p0 + 16 q + 4 g + j]: the four MFMAs' registers q are four
+    // CONSECUTIVE positions, one 16-byte store, and the four g lanes of a channel row write 64 contiguous bytes -- the store
+    // pattern of r05 -- while a load instruction now covers 4 rows x 256 contiguous bytes (r05: four 4-byte loads per lane and
+    // k-step, 64-byte pieces; profiles/r05_conv1x1_sq_counters.txt: waves parked on memory 47 % of their cycles).
+    const int perm = 4 * (np & 3) + (np >> 2);
+    const float* x = X + (size_t)blockIdx.z * R * P + (active ? p0 : 0) + 4 * perm;
     v4f acc[4][MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[j][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
     for (int rc = 0; rc < R; rc += RC) {
       const int rows = min(RC, R - rc);
       if (R > RC || i == 0) {
@@ -59,35 +67,45 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
       }
       if (active) {
         const float* xr = x + (size_t)(rc + g) * P;
-        float xv[4], xn[4];
+        // kPF k-steps in flight (a k-step is 4 MT MFMAs = 128 MT issue cycles per wave; HBM answers in a few thousand)
+        constexpr int kPF = MT >= 4 ? 3 : 6;
+        v4f xq[kPF];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xv[t] = xr[16 * t];
-        for (int r0 = 0; r0 < rows; r0 += 4) {
-          const bool more = r0 + 4 < rows;
+        for (int u = 0; u < kPF; ++u)
+          xq[u] = 4 * u < rows ? *reinterpret_cast<const v4f*>(xr + (size_t)(4 * u) * P) : (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int r0 = 0; r0 < rows; r0 += 4 * kPF) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) xn[t] = more ? xr[(size_t)(r0 + 4) * P + 16 * t] : 0.f;
-          float wv[MT];
+          for (int u = 0; u < kPF; ++u) {
+            const int r1 = r0 + 4 * u;                       // this k-step; its successor kPF steps ahead is requested first
+            if (r1 < rows) {
+              const v4f xv = xq[u];
+              const int rn = r1 + 4 * kPF;
+              if (rn < rows) xq[u] = *reinterpret_cast<const v4f*>(xr + (size_t)rn * P);
+              float wv[MT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wv[mt] = Ws[(r0 + g) * (16 * MT) + np * MT + mt];
+              for (int mt = 0; mt < MT; ++mt) wv[mt] = Ws[(r1 + g) * (16 * MT) + np * MT + mt];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t], wv[mt], acc[t][mt], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) xv[t] = xn[t];
+              for (int mt = 0; mt < MT; ++mt) {
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], wv[mt], acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], wv[mt], acc[1][mt], 0, 0, 0);
+                acc[2][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], wv[mt], acc[2][mt], 0, 0, 0);
+                acc[3][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], wv[mt], acc[3][mt], 0, 0, 0);
+              }
+            }
+          }
         }
       }
     }
     if (active) {
-      // acc[t][mt][q] = Z[m0 + 16 mt + np][p0 + 16 t + 4 g + q]
+      // acc[j][mt][q] = Z[m0 + 16 mt + np][p0 + 16 q + 4 g + j]
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + np;
         if (m < M) {
           float* z = Z + ((size_t)blockIdx.z * M + m) * P + p0 + 4 * g;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) *reinterpret_cast<v4f*>(z + 16 * t) = acc[t][mt];
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<v4f*>(z + 16 * q) = (v4f){acc[0][mt][q], acc[1][mt][q], acc[2][mt][q], acc[3][mt][q]};
         }
       }
     }

@@ -20,6 +20,13 @@ def pytest_configure(config):
     from oracle import pointnet2_oracle
     if not os.path.exists(pointnet2_oracle._SO):
         pointnet2_oracle.build()
+    # The GPU box's host has 128 cores / 256 threads: torch then runs every small CPU op of the ORACLE (a gather of
+    # 131 K rows, a 128-long dot product per row) across 256 OpenMP threads, and the fork-join cost is 10-20 x the work
+    # (r06: the K = 65536 oracle check took 50 s there, 3.7 s on the 8-core build container).  16 threads, like the
+    # checker subprocess of bench.py.  Host-side arithmetic is unaffected (same ops, fewer workers).
+    import torch
+    if (os.cpu_count() or 1) > 32 and 'OMP_NUM_THREADS' not in os.environ:
+        torch.set_num_threads(16)
 
 
 @pytest.fixture(scope='session', autouse=True)

@@ -80,10 +80,10 @@ def test_hrnetpn_forward_matches_reference(golden):
         print('error / bound (1 = the gate):', report)
 
 
-@pytest.mark.parametrize('wgrad_stream,two_streams', [(8, 7), (0, 7), (8, 0)])
+@pytest.mark.parametrize('wgrad_stream,two_streams', [(8, 7), (0, 0)])
 def test_hrnetpn_backward_matches_reference(golden, wgrad_stream, two_streams):
-    """Default placement (cloud branch, SemGCN and geometry on side streams, weight gradients 8 layers per hand-over), the
-    same with in-line weight gradients, and everything on the caller's stream."""
+    """Default placement (cloud branch, SemGCN and geometry on side streams, weight gradients 8 layers per hand-over) and
+    everything on the caller's stream with in-line weight gradients."""
     from hcmoco_amd import _lib
     report = {}
     glue = _lib.torch_glue()
