@@ -123,6 +123,8 @@ SIGNATURES = {
     'hcm_branch_grad': (_i, [_p] * 4 + [_i] * 3 + [Branches, Branches, _p, _i, _p, _i] + [_p] * 5),
     'hcm_section_total': (_i, [_p, _p, _p, _p]),
     'hcm_project_rows': (_i, [Branches, Branches, _i, _p] + [_i] * 3 + [_p] * 8),
+    'hcm_project_rows_nhwc_floats': (_sz, [Branches, Branches, _i, _i]),
+    'hcm_project_rows_cl': (_i, [Branches, Branches, _i, _p] + [_i] * 3 + [_p] * 8 + [_sz, _p]),
     'hcm_project_rows_dw_workspace_bytes': (_sz, [_i, _i]),
     'hcm_project_rows_dw': (_i, [_p] * 3 + [_i] * 4 + [_p] * 5 + [_sz, _p]),
     'hcm_project_rows_backward_workspace_bytes': (_sz, [_i, _i, _i, Branches]),

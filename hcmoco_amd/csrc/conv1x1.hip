@@ -10,6 +10,7 @@
 // Z[m0 + np][p0 + 4 g .. + 3] (one 16-byte store).  No transposes, LDS only for the weights; every activation byte is read once
 // per 64-channel output block and written once.  A wave owns 64 positions x 16 MT output channels, a workgroup 4 waves = 256
 // positions; grid = (position blocks, output-channel blocks, images).  Exact fp32 (an fmaf chain per output element).
+#include <cstdlib>
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
 
@@ -32,19 +33,31 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
   const int np = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * (16 * MT);
   // a workgroup walks PB consecutive blocks of 256 positions: the channel rows of a ball tensor lie 32 .. 512 KB apart, so a
-  // block touches R + M distant pieces of memory, and staying on them for PB KB each (and staging W once) is what pays
-  for (int i = 0; i < PB; ++i) {
-    const int p0 = ((blockIdx.x * PB + i) * 4 + wave) * 64;
+  // block touches R + M distant pieces of memory, and staying on them for PB KB each (and staging W once) is what pays.
+  //
+  // r06: ONE 16-byte load per lane and k-step.  A sum over channels does not care which position an MFMA row stands for, as
+  // long as the store agrees: lane (np, g) loads X[c0 + g][p0 + 4 np .. + 3] (16 consecutive lanes = 256 contiguous bytes of one
+  // channel row) and feeds element j to MFMA number j, so row np of MFMA j is position p0 + 4 np + j, and accumulator register
+  // q of lane (np, g) in MFMA j is Z[m0 + np][p0 + 16 g + 4 q + j]: the four MFMAs' registers q are four CONSECUTIVE
+  // positions = one 16-byte store.  (r05: four 4-byte loads per lane and k-step.  A first r06 form permuted np so that the
+  // g lanes of a row stored 64 contiguous bytes: its loads then put the four lanes of a quad 64 bytes apart and ran 7-25 %
+  // SLOWER than r05 -- profiles/r06_conv1x1_layers.txt; consecutive lanes of a store are different channel rows anyway.)
+  // The k-steps of ALL the workgroup's blocks form one software pipeline (R <= 128, R % 16 == 0: every layer of Pointnet2MSG):
+  // a block of 64 positions x 32 channels is only 8 k-steps, and with three waves per SIMD the load latency at the head of
+  // each block was most of a block's time (r05: 0.35-0.6 of the HBM / MFMA floors).
+  const bool flat = R <= RC && (R & 15) == 0;
+  const int nblk = PB;
+  auto pos0 = [&](int i) { return ((blockIdx.x * PB + i) * 4 + wave) * 64; };
+  constexpr int kPF = 4;
+  v4f xq[kPF];
+  const float* xb = X + (size_t)blockIdx.z * R * P + 4 * np + (size_t)g * P;        // + p0 + row * P
+  if (flat && pos0(0) < P) {
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) xq[u] = *reinterpret_cast<const v4f*>(xb + pos0(0) + (size_t)(4 * u) * P);
+  }
+  for (int i = 0; i < nblk; ++i) {
+    const int p0 = pos0(i);
     const bool active = p0 < P;                        // P is a multiple of 64
-    // r06: ONE 16-byte load per lane and k-step.  A sum over channels does not care which position an MFMA row stands for, as
-    // long as the store agrees: lane (np, g) loads X[c0 + g][p0 + 4 pi(np) .. + 3] and feeds element j to MFMA number j, so row
-    // np of MFMA j is position p0 + 4 pi(np) + j.  With pi(r) = 4 (r mod 4) + r div 4 (a 4 x 4 transpose of the row index) the
-    // accumulator register q of lane (np, g) in MFMA j is Z[m0 + np][p0 + 16 q + 4 g + j]: the four MFMAs' registers q are four
-    // CONSECUTIVE positions, one 16-byte store, and the four g lanes of a channel row write 64 contiguous bytes -- the store
-    // pattern of r05 -- while a load instruction now covers 4 rows x 256 contiguous bytes (r05: four 4-byte loads per lane and
-    // k-step, 64-byte pieces; profiles/r05_conv1x1_sq_counters.txt: waves parked on memory 47 % of their cycles).
-    const int perm = 4 * (np & 3) + (np >> 2);
-    const float* x = X + (size_t)blockIdx.z * R * P + (active ? p0 : 0) + 4 * perm;
     v4f acc[4][MT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -65,47 +78,48 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
         }
         __syncthreads();
       }
-      if (active) {
-        const float* xr = x + (size_t)(rc + g) * P;
-        // kPF k-steps in flight (a k-step is 4 MT MFMAs = 128 MT issue cycles per wave; HBM answers in a few thousand)
-        constexpr int kPF = MT >= 4 ? 3 : 6;
-        v4f xq[kPF];
+      if (!active) continue;
+      const float* xr = xb + p0 + (size_t)rc * P;
+      if (!flat) {
 #pragma unroll
         for (int u = 0; u < kPF; ++u)
           xq[u] = 4 * u < rows ? *reinterpret_cast<const v4f*>(xr + (size_t)(4 * u) * P) : (v4f){0.f, 0.f, 0.f, 0.f};
-        for (int r0 = 0; r0 < rows; r0 += 4 * kPF) {
+      }
+      const int pn = pos0(i + 1);
+      const bool next = flat && i + 1 < nblk && pn < P;
+      for (int r0 = 0; r0 < rows; r0 += 4 * kPF) {
 #pragma unroll
-          for (int u = 0; u < kPF; ++u) {
-            const int r1 = r0 + 4 * u;                       // this k-step; its successor kPF steps ahead is requested first
-            if (r1 < rows) {
-              const v4f xv = xq[u];
-              const int rn = r1 + 4 * kPF;
-              if (rn < rows) xq[u] = *reinterpret_cast<const v4f*>(xr + (size_t)rn * P);
-              float wv[MT];
+        for (int u = 0; u < kPF; ++u) {
+          const int r1 = r0 + 4 * u;                       // this k-step; the one kPF steps ahead is requested before its MFMAs
+          if (r1 < rows) {
+            const v4f xv = xq[u];
+            const int rn = r1 + 4 * kPF;
+            if (rn < rows) xq[u] = *reinterpret_cast<const v4f*>(xr + (size_t)rn * P);
+            else if (next) xq[u] = *reinterpret_cast<const v4f*>(xb + pn + (size_t)(rn - rows) * P);   // head of the next block
+            float wv[MT];
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) wv[mt] = Ws[(r1 + g) * (16 * MT) + np * MT + mt];
+            for (int mt = 0; mt < MT; ++mt) wv[mt] = Ws[(r1 + g) * (16 * MT) + np * MT + mt];
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], wv[mt], acc[0][mt], 0, 0, 0);
-                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], wv[mt], acc[1][mt], 0, 0, 0);
-                acc[2][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], wv[mt], acc[2][mt], 0, 0, 0);
-                acc[3][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], wv[mt], acc[3][mt], 0, 0, 0);
-              }
+            for (int mt = 0; mt < MT; ++mt) {
+              acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], wv[mt], acc[0][mt], 0, 0, 0);
+              acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], wv[mt], acc[1][mt], 0, 0, 0);
+              acc[2][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], wv[mt], acc[2][mt], 0, 0, 0);
+              acc[3][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], wv[mt], acc[3][mt], 0, 0, 0);
             }
           }
         }
       }
     }
     if (active) {
-      // acc[j][mt][q] = Z[m0 + 16 mt + np][p0 + 16 q + 4 g + j]
+      // acc[j][mt][q] = Z[m0 + 16 mt + np][p0 + 16 g + 4 q + j]
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + np;
         if (m < M) {
-          float* z = Z + ((size_t)blockIdx.z * M + m) * P + p0 + 4 * g;
+          float* z = Z + ((size_t)blockIdx.z * M + m) * P + p0 + 16 * g;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<v4f*>(z + 16 * q) = (v4f){acc[0][mt][q], acc[1][mt][q], acc[2][mt][q], acc[3][mt][q]};
+            *reinterpret_cast<v4f*>(z + 4 * q) = (v4f){acc[0][mt][q], acc[1][mt][q], acc[2][mt][q], acc[3][mt][q]};
         }
       }
     }
@@ -119,7 +133,8 @@ int launch(const float* X, const float* W, float* Z, int N, int M, int R, int Cw
   // and one for the narrow outputs (M <= 32: little W to stage, and the short workgroups balance better -- 32 -> 64 data
   // gradient at 131 K positions 327 us against 397 us, tools/bench_conv1x1.py)
   int PB = 1;
-  if (R <= 128 && M > 32)
+  static const int narrow_pb = [] { const char* v = getenv("HCM_CONV1X1_NARROW_PB"); return v ? atoi(v) : 0; }();   // r06 probe
+  if (R <= 128 && (M > 32 || narrow_pb))
     while (PB < 8 && (long long)((P + 512 * PB - 1) / (512 * PB)) * mblocks * N >= 2048) PB *= 2;
   const int pb = (P + 256 * PB - 1) / (256 * PB);
   if (M <= 16) conv1x1_kernel<1, TRANS><<<dim3(pb, 1, N), 256, 0, st>>>(X, W, Z, M, R, Cw, P, PB);

@@ -51,6 +51,42 @@ constexpr int kPW = 512;     // forward workgroup: 8 waves, wave w owns output c
 constexpr int kSR = 32;      // rows per LDS tile: two 16-row MFMA tiles = two independent accumulator chains per wave
 constexpr int kF = 128;      // projected channels (the loss kernels' C)
 
+// ---- channels-last copies of the branch maps the forward kernel gathers from global memory (r06; north_star's "coalesced
+// reads of the modality feature maps", SURVEY 8f-1: "channels-last so each gather is one line").  The HRNet writes NCHW: the C_i
+// values of one sampled pixel lie H_i W_i * 4 bytes apart (16 KB for the finest branch at 256 x 256), so a tap of a row costs
+// C_i 4-byte accesses to C_i different cache lines (r04 counters: 7.9 L1 accesses per line requested from L2).  This kernel
+// writes [B, H_i W_i, C_i] next to the NCHW map -- 64-pixel tiles through LDS, 256-byte runs in, fully contiguous runs out --
+// for the branches that are NOT staged in LDS (the two finest at 256 x 256: 14 MB per modality), one launch for all of them;
+// project_rows_kernel then reads ONE contiguous run of C_i floats per tap.
+struct TJobs {
+  const float* src[8];
+  float* dst[8];
+  int C[8], HW[8], first[9];     // job k owns blocks [first[k], first[k + 1]): (image, 64-pixel tile) pairs
+};
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(TJobs j, int njobs) {
+  extern __shared__ float tl[];                   // [C][65]
+  int k = 0;
+  while (k + 1 < njobs && (int)blockIdx.x >= j.first[k + 1]) ++k;
+  const float* src = sel8(j.src, k);
+  float* dst = sel8(j.dst, k);
+  const int C = sel8(j.C, k), HW = sel8(j.HW, k);
+  int fk = 0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) fk = t == k ? j.first[t] : fk;
+  const int tiles = (HW + 63) >> 6, blk = blockIdx.x - fk;
+  const int b = blk / tiles, q0 = (blk - b * tiles) << 6, nq = min(64, HW - q0);
+  for (int e = threadIdx.x; e < C * 64; e += 256) {
+    const int c = e >> 6, q = e & 63;
+    if (q < nq) tl[c * 65 + q] = src[((size_t)b * C + c) * HW + q0 + q];
+  }
+  __syncthreads();
+  float* out = dst + ((size_t)b * HW + q0) * C;
+  for (int e = threadIdx.x; e < nq * C; e += 256) {
+    const int q = e / C, c = e - q * C;
+    out[e] = tl[c * 65 + q];
+  }
+}
+
 // one channel of one row from a branch: a plain gather (finest branch) or the 4-tap bilinear stencil
 struct RowTaps {
   int o00, o01, o10, o11;
@@ -65,7 +101,7 @@ __device__ __forceinline__ float tap4(const float* __restrict__ xc, const RowTap
 // (stride * i + g) mod 32 takes 32 different values for i < 16, g < 2.
 template <int KS>
 __global__ __launch_bounds__(kPW) void project_rows_kernel(
-    Maps8 e, int B, const int64_t* __restrict__ pix, int R, int Ctot, const float* __restrict__ Wp1,
+    Maps8 e, Maps8T et, int B, const int64_t* __restrict__ pix, int R, int Ctot, const float* __restrict__ Wp1,
     const float* __restrict__ bp1, const float* __restrict__ Wp2, const float* __restrict__ bp2,
     float* __restrict__ xs, int ld, float* __restrict__ rows, float* __restrict__ grows, int per, int off2, int off3) {
   constexpr int XS = 4 * KS + 2;
@@ -174,12 +210,16 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
           const int k = (cg >= gend[0]) + (cg >= gend[1]) + (cg >= gend[2]);
           const int i = sel4(gid, k), c = cg - (k == 0 ? 0 : sel4(gend, k - 1));
           const int C = sel4(e.C, i), hw = sel4(e.H, i) * sel4(e.W, i);
-          const float* x = sel8(e.p, m * 4 + i) + ((int64_t)b * C + c) * hw;
           const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i][0]);
           wv[u] = *reinterpret_cast<const float4*>(&s_tw[lr][i][0]);
-          rv[u][0] = x[o.x];
+          // channels-last copy present (r06): consecutive threads = consecutive channels = consecutive addresses, one
+          // contiguous run of C floats per tap; otherwise the NCHW plane walk (one word per line)
+          const float* xt = sel8(et.t, m * 4 + i);
+          const float* x = xt != nullptr ? xt + (int64_t)b * hw * C + c : sel8(e.p, m * 4 + i) + ((int64_t)b * C + c) * hw;
+          const int st = xt != nullptr ? C : 1;
+          rv[u][0] = x[o.x * st];
           rv[u][1] = rv[u][2] = rv[u][3] = 0.f;
-          if (i != 0) { rv[u][1] = x[o.y]; rv[u][2] = x[o.z]; rv[u][3] = x[o.w]; }     // the finest branch is one word
+          if (i != 0) { rv[u][1] = x[o.y * st]; rv[u][2] = x[o.z * st]; rv[u][3] = x[o.w * st]; }     // the finest branch is one word
           dst[u] = lr * XS + sel4(gcol, k) + c;
         }
 #pragma unroll
@@ -699,17 +739,71 @@ int dw_chunks(int B) {
   return 128;                     // x 2 modalities = one workgroup per CU of an MI355X
 }
 
+// LDS budget of the forward kernel: the tile, then branch 3, then branch 2 if they fit in 160 KiB.  -> floats used, or -1
+template <int KS>
+int lds_plan(const int (&C)[4], const int (&H)[4], const int (&W)[4], int* off2, int* off3) {
+  constexpr int XS = 4 * KS + 2;
+  const int cap = (160 * 1024 - 4096) / 4;            // 3.2 KB of static LDS: the stencil table
+  int used = kSR * XS;
+  *off2 = -1; *off3 = -1;
+  if (kSR * XS > cap) return -1;
+  const int n3 = C[3] * ((H[3] * W[3]) | 1), n2 = C[2] * ((H[2] * W[2]) | 1);
+  if (used + n3 <= cap) { *off3 = used; used += n3; }
+  if (used + n2 <= cap) { *off2 = used; used += n2; }
+  return used;
+}
+
+// floats of channels-last workspace the forward wants for ONE modality (the branches it gathers from global memory)
+size_t nhwc_floats_one(const int (&C)[4], const int (&H)[4], const int (&W)[4], int B, int Ctot) {
+  int off2, off3, used;
+  if (Ctot + 1 <= 4 * 68) used = lds_plan<68>(C, H, W, &off2, &off3);
+  else if (Ctot + 1 <= 4 * 121) used = lds_plan<121>(C, H, W, &off2, &off3);
+  else used = lds_plan<181>(C, H, W, &off2, &off3);
+  if (used < 0) return 0;
+  size_t n = 0;
+  for (int i = 0; i < 4; ++i)
+    if (!((i == 2 && off2 >= 0) || (i == 3 && off3 >= 0))) n += (size_t)B * C[i] * H[i] * W[i];
+  return n;
+}
+
 template <int KS>
 int launch_project(const Maps8& e, int nmod, int B, const int64_t* pix, int R, int Ctot, const float* Wp1, const float* bp1,
-                   const float* Wp2, const float* bp2, float* xs, int ld, float* rows, float* grows, hipStream_t s) {
-  constexpr int XS = 4 * KS + 2;
-  // LDS budget: the tile, then branch 3, then branch 2 if they fit in 160 KiB
-  const int cap = (160 * 1024 - 4096) / 4;            // 3.2 KB of static LDS: the stencil table
-  int used = kSR * XS, off2 = -1, off3 = -1;
-  const int n3 = e.C[3] * ((e.H[3] * e.W[3]) | 1), n2 = e.C[2] * ((e.H[2] * e.W[2]) | 1);
-  if (used + n3 <= cap) { off3 = used; used += n3; }
-  if (used + n2 <= cap) { off2 = used; used += n2; }
-  if (kSR * XS > cap) return (int)hipErrorInvalidValue;
+                   const float* Wp2, const float* bp2, float* xs, int ld, float* rows, float* grows, float* nhwc_ws,
+                   hipStream_t s) {
+  int off2, off3;
+  int used = lds_plan<KS>(e.C, e.H, e.W, &off2, &off3);
+  if (used < 0) return (int)hipErrorInvalidValue;
+  // ---- channels-last copies of the branches that stay in global memory (workspace given = the caller wants them)
+  Maps8T et;
+  for (int k = 0; k < 8; ++k) et.t[k] = nullptr;
+  if (nhwc_ws != nullptr) {
+    TJobs j;
+    int nj = 0, blocks = 0, cmax = 0;
+    float* wp = nhwc_ws;
+    for (int m = 0; m < nmod; ++m)
+      for (int i = 0; i < 4; ++i) {
+        if ((i == 2 && off2 >= 0) || (i == 3 && off3 >= 0)) continue;
+        const int hw = e.H[i] * e.W[i];
+        j.src[nj] = e.p[m * 4 + i]; j.dst[nj] = wp; j.C[nj] = e.C[i]; j.HW[nj] = hw; j.first[nj] = blocks;
+        et.t[m * 4 + i] = wp;
+        wp += (size_t)B * e.C[i] * hw;
+        blocks += B * ((hw + 63) / 64);
+        cmax = e.C[i] > cmax ? e.C[i] : cmax;
+        ++nj;
+      }
+    for (int k = nj; k < 8; ++k) { j.src[k] = nullptr; j.dst[k] = nullptr; j.C[k] = 0; j.HW[k] = 0; }
+    for (int k = nj; k <= 8; ++k) j.first[k] = blocks;
+    if (nj > 0) {
+      const size_t tb = (size_t)cmax * 65 * sizeof(float);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(nchw_to_nhwc_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
+      if (e2 != hipSuccess) return (int)e2;
+      hcm::ProfSpan tspan(HCM_PROF_ROW8_NHWC, s, 8.0 * (double)(wp - nhwc_ws));      // every float read once, written once
+      nchw_to_nhwc_kernel<<<blocks, 256, tb, s>>>(j, nj);
+      tspan.stop();
+      HCM_CHECK_LAUNCH();
+    }
+  }
   // rows per workgroup: fewest (rounds over the CUs) x (tiles per workgroup + the staging prologue)
   const int cus = num_cus();
   int best = 1;
@@ -726,7 +820,7 @@ int launch_project(const Maps8& e, int nmod, int B, const int64_t* pix, int R, i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (err != hipSuccess) return (int)err;
   hcm::ProfSpan span(HCM_PROF_ROW8_FWD, s);
-  project_rows_kernel<KS><<<dim3(best, B, nmod), kPW, bytes, s>>>(e, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows,
+  project_rows_kernel<KS><<<dim3(best, B, nmod), kPW, bytes, s>>>(e, et, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows,
                                                              per, off2, off3);
   span.stop();
   HCM_CHECK_LAUNCH();
@@ -743,9 +837,21 @@ int hcm_debug_row8_timing(unsigned long long* buf) {
 }
 #endif
 
+size_t hcm_project_rows_nhwc_floats(hcm_branches enc1, hcm_branches enc2, int B, int Ctot) {
+  if (B <= 0 || !branches_ok(enc1, Ctot)) return 0;
+  return (absent(enc2) ? 1 : 2) * nhwc_floats_one(enc1.C, enc1.H, enc1.W, B, Ctot);
+}
+
 int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
                      const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
                      float* grows, hcm_stream_t stream) {
+  return hcm_project_rows_cl(enc1, enc2, B, pix, R, Ctot, F, Wp1, bp1, Wp2, bp2, xs, rows, grows, nullptr, 0, stream);
+}
+
+int hcm_project_rows_cl(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
+                        const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
+                        float* grows, float* nhwc_ws, size_t nhwc_floats, hcm_stream_t stream) {
+  if (nhwc_ws != nullptr && nhwc_floats < hcm_project_rows_nhwc_floats(enc1, enc2, B, Ctot)) return (int)hipErrorInvalidValue;
   const int nmod = absent(enc2) ? 1 : 2;          // absent: rows[1] / xs[1] / grows[1] are left to the caller
   if (B <= 0 || R <= 0 || F != kF || pix == nullptr || rows == nullptr || !branches_ok(enc1, Ctot) ||
       (nmod == 2 && !branches_ok(enc2, Ctot)))
@@ -756,9 +862,9 @@ int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t*
   const Maps8 e = pack8(enc1, nmod == 2 ? enc2 : enc1);
   hipStream_t s = (hipStream_t)stream;
   // HRNet-w18 / w32 / w48: 270 / 480 / 720 channels + the bias column
-  if (Ctot + 1 <= 4 * 68) return launch_project<68>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
-  if (Ctot + 1 <= 4 * 121) return launch_project<121>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
-  if (Ctot + 1 <= 4 * 181) return launch_project<181>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, s);
+  if (Ctot + 1 <= 4 * 68) return launch_project<68>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, nhwc_ws, s);
+  if (Ctot + 1 <= 4 * 121) return launch_project<121>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, nhwc_ws, s);
+  if (Ctot + 1 <= 4 * 181) return launch_project<181>(e, nmod, B, pix, R, Ctot, Wp1, bp1, Wp2, bp2, xs, ld, rows, grows, nhwc_ws, s);
   return (int)hipErrorInvalidValue;
 }
 

@@ -12,6 +12,9 @@ struct Maps8 {
   const float* p[8];
   int C[4], H[4], W[4];
 };
+struct Maps8T {
+  const float* t[8];      // channels-last copies [B, H W, C] of (modality, branch) maps, or NULL (csrc/rowproj.hip, r06)
+};
 struct Maps8Out {
   float* p[8];
   int C[4], H[4], W[4];

@@ -186,7 +186,7 @@ def prof_enable(on):
 PROF_TAGS = {'bank_pass': 0, 'dense_stats': 1, 'dense_grad': 2, 'scl_stats': 3, 'scl_grad': 4, 'sgc_fwd': 5,
              'sgc_bwd': 6, 'row8_fwd': 7, 'row8_dw': 8, 'row8_bwd': 9, 'joint': 10,
              'conv1x1_fwd': 11, 'conv1x1_dx': 12, 'conv1x1_dw': 13, 'ball_fwd': 14, 'ball_bwd': 15, 'ballmax_fwd': 16,
-             'ballmax_bwd': 17, 'fps': 18, 'three_nn': 19, 'ball_query': 20}
+             'ballmax_bwd': 17, 'fps': 18, 'three_nn': 19, 'ball_query': 20, 'row8_nhwc': 21}
 
 
 def prof_read(tag='bank_pass'):
@@ -861,10 +861,16 @@ def branch_grad(dxs, dpooled, scale, pix, shapes, dWpad=None, F=128, keep=None, 
     return g1, g2, dWp1, dbp1, dWp2, dbp2
 
 
-def project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, save=True, zero_grows=True):
+ROW8_CHANNELS_LAST = True      # module attribute: the forward reads channels-last copies of the branches it gathers (r06)
+
+
+def project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, save=True, zero_grows=True, channels_last=None):
     """(rows [2,B*R,128], xs [2,B*R,ld] or None, grows [2,B*R,128] zero-filled or None): merge_all_res + the 1x1
     projections (build_backbone.py:243-254, :290-300) at the pixels ``pix`` for both modalities in ONE launch on the fp32
-    matrix cores (csrc/rowproj.hip).  ``save``: keep the sampled rows ``xs`` for the weight gradient."""
+    matrix cores (csrc/rowproj.hip).  ``save``: keep the sampled rows ``xs`` for the weight gradient.
+    ``channels_last`` (default ROW8_CHANNELS_LAST): hcm_project_rows_cl -- the branch maps that are gathered from global
+    memory are first copied [B, H W, C] (one launch), so that a stencil tap is one contiguous run of C floats instead of C
+    words on C cache lines; same results bit for bit."""
     B, R = pix.shape
     Ctot = sum(m.shape[1] for m in maps1)
     F = Wp1.shape[0]
@@ -879,10 +885,18 @@ def project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, save=True, zero_grows=Tr
     d = lambda t: _dev(t, torch.float32, 'project_rows')
     w2 = C.c_void_p(0) if maps2 is None else d(Wp2.reshape(F, Ctot))
     b2 = C.c_void_p(0) if maps2 is None else d(bp2)
-    check(_lib.lib().hcm_project_rows(
-        _branches(maps1, 'project_rows'), _branches(maps2, 'project_rows'), B, _dev(pix, torch.int64, 'project_rows'), R,
+    br1, br2 = _branches(maps1, 'project_rows'), _branches(maps2, 'project_rows')
+    L = _lib.lib()
+    ws, nws = None, 0
+    if ROW8_CHANNELS_LAST if channels_last is None else channels_last:
+        nws = int(L.hcm_project_rows_nhwc_floats(br1, br2, B, Ctot))
+        if nws:
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+    check(L.hcm_project_rows_cl(
+        br1, br2, B, _dev(pix, torch.int64, 'project_rows'), R,
         Ctot, F, d(Wp1.reshape(F, Ctot)), d(bp1), w2, b2, _opt(xs, torch.float32, 'project_rows'),
-        d(rows), _opt(grows, torch.float32, 'project_rows'), _stream()), 'hcm_project_rows')
+        d(rows), _opt(grows, torch.float32, 'project_rows'), C.c_void_p(0) if ws is None else C.c_void_p(ws.data_ptr()),
+        nws, _stream()), 'hcm_project_rows_cl')
     return rows, xs, grows
 
 

@@ -329,6 +329,16 @@ int hcm_branch_grad(const float* dxs, const float* dpooled, const float* scale, 
 int hcm_project_rows(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
                      const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
                      float* grows, hcm_stream_t stream);
+/* Same, reading the branch maps it gathers from global memory CHANNELS-LAST (r06; north_star: "coalesced HBM reads of the
+ * modality feature maps", SURVEY 8f-1: "channels-last so each gather is one line"; producer networks/build_backbone.py:247-254,
+ * :290-300).  The HRNet writes NCHW, where the C_i values of a sampled pixel lie H_i W_i floats apart; with a workspace of
+ * hcm_project_rows_nhwc_floats(...) floats the entry point first writes [B, H_i W_i, C_i] copies of the branches that are not
+ * staged whole in LDS (one launch, 64-pixel tiles through LDS) and the row kernel reads ONE contiguous run of C_i floats per
+ * stencil tap.  nhwc_ws NULL = hcm_project_rows.  Same results bit for bit (the same values enter the same sums). */
+size_t hcm_project_rows_nhwc_floats(hcm_branches enc1, hcm_branches enc2, int B, int Ctot);
+int hcm_project_rows_cl(hcm_branches enc1, hcm_branches enc2, int B, const int64_t* pix, int R, int Ctot, int F,
+                        const float* Wp1, const float* bp1, const float* Wp2, const float* bp2, float* xs, float* rows,
+                        float* grows, float* nhwc_ws, size_t nhwc_floats, hcm_stream_t stream);
 /* d[W | b] = (*scale) * grows^T xs per modality -> dWp [F, Ctot], dbp [F]: MFMA partials over 128 row chunks, summed in
  * chunk order (deterministic).  workspace: hcm_project_rows_dw_workspace_bytes(B, Ctot). */
 size_t hcm_project_rows_dw_workspace_bytes(int B, int Ctot);
@@ -647,6 +657,7 @@ int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2, 
 #define HCM_PROF_FPS 18           /* fps kernels of hcm_furthest_point_sampling*: distance evaluations b m n          */
 #define HCM_PROF_THREE_NN 19      /* three_nn kernels of hcm_three_nn*: distance evaluations b n m                    */
 #define HCM_PROF_BALL_QUERY 20    /* ball_query kernel of hcm_ball_query*: distance evaluations b m n (upper bound)   */
+#define HCM_PROF_ROW8_NHWC 21     /* nchw_to_nhwc_kernel of hcm_project_rows_cl: bytes (read + written)              */
 #define HCM_PROF_NTAGS 24
 int hcm_prof_enable(int enable);
 int hcm_prof_read(double* total_ms_host, int64_t* launches_host);
