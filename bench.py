@@ -411,6 +411,7 @@ def main():
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--wgrad_stream', type=int, default=8,
                     help='layers per hand-over of the encoders\' weight gradients to their side stream (0: in line)')
+    ap.add_argument('--row8_channels_last', type=int, default=1, help=argparse.SUPPRESS)   # A/B of hcm_project_rows_cl (r06)
     ap.add_argument('--fault', type=str, default=None, help=argparse.SUPPRESS)      # tests: "rank:step:exit|raise|hang"
     ap.add_argument('--backend', type=str, default='nccl',
                     help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '
@@ -510,6 +511,7 @@ def run(a, rank, world, local, fs):
         from hcmoco_amd.pycontrast.learning.engine import RecordingEngine
         recorder = RecordingEngine(a.fmap_dtype)
         recorder.armed = False
+    hip_ops.ROW8_CHANNELS_LAST = bool(a.row8_channels_last)
     trainer = ContrastTrainer(args, engine=recorder)                         # HIP loss engine
     trainer.device = dev
     model, contrast, opt, data = build(args, trainer, dev)
@@ -603,7 +605,9 @@ def run(a, rank, world, local, fs):
         hip_ops.GATHER_WAIT_EVENTS = None
     kern_ms, kern_n = hip_ops.prof_read()
     secondary_raw = {tag: hip_ops.prof_read(tag) for tag in ('dense_stats', 'dense_grad', 'scl_stats', 'scl_grad',
-                                                               'sgc_fwd', 'sgc_bwd', 'row8_fwd', 'row8_dw', 'row8_bwd', 'joint')}
+                                                               'sgc_fwd', 'sgc_bwd', 'row8_fwd', 'row8_dw', 'row8_bwd', 'joint',
+                                                               'row8_nhwc')}
+    row8_nhwc_bytes = hip_ops.prof_read_work('row8_nhwc') / max(secondary_raw['row8_nhwc'][1], 1)
     hip_ops.prof_enable(False)
     # The SemGCN runs on a side stream next to two encoder streams: a hipEvent pair around its launches inside the step
     # spans queueing behind them, not kernel time (r02: 0.0696 ms reported against 14.8 us of kernels in rocprofv3).
@@ -739,6 +743,8 @@ def run(a, rank, world, local, fs):
                 ('scl_grad', 'strip_kernel<Scl, grad> + chunk merge', 'mfma', 2 * scl_gemm),
                 ('row8_fwd', 'project_rows_kernel (merge_all_res + 1x1 projection at the sampled pixels, fp32 MFMA)', 'mfma+bytes',
                  (row8_fwd_flops, row8_fwd_bytes)),
+                ('row8_nhwc', 'nchw_to_nhwc_kernel (channels-last copies of the branches project_rows gathers from global memory)',
+                 'hbm', row8_nhwc_bytes),
                 ('row8_dw', 'proj_dw_partial + proj_dw_reduce (d[W | b] = grows^T xs, fp32 MFMA)', 'mfma+bytes',
                  (row8_dw_flops, row8_dw_bytes)),
                 ('row8_bwd', 'branch_grad_t_kernel (branch-map gradients W_i^T (S_i^T grows) + pooling gradient, fp32 MFMA)',
@@ -783,6 +789,11 @@ def run(a, rank, world, local, fs):
                                   'note': 'VALU / latency bound, not MFMA bound: matrix pipes busy 7 % of wave cycles '
                                           '(profiles/r05_strip_mfma_pmc_fp32.json)'})
                 secondary.append(entry)
+            elif kind == 'hbm':
+                ach = work / (avg * 1e-3) / 1e9
+                secondary.append({'kernel': name, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                                  'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'bytes_per_launch': int(work),
+                                  'avg_launch_ms': round(avg, 5), 'launches_timed': n})
             else:
                 ach = work / (avg * 1e-3) / 1e9
                 secondary.append({'kernel': name, 'bound': 'latency', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,

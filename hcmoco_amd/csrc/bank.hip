@@ -677,6 +677,12 @@ ProfSpan::ProfSpan(int tag_, hipStream_t s, double work) : st(s), tag(tag_) {
   else
     e0 = nullptr;
 }
+void ProfSpan::add_work(double work) {
+  if (e0 != nullptr) {
+    std::lock_guard<std::mutex> lk(prof().mu);
+    prof().work[tag] += work;
+  }
+}
 void ProfSpan::stop() {
   if (e0 != nullptr) {
     hipEventRecord(e1, st);

@@ -10,7 +10,6 @@
 // Z[m0 + np][p0 + 4 g .. + 3] (one 16-byte store).  No transposes, LDS only for the weights; every activation byte is read once
 // per 64-channel output block and written once.  A wave owns 64 positions x 16 MT output channels, a workgroup 4 waves = 256
 // positions; grid = (position blocks, output-channel blocks, images).  Exact fp32 (an fmaf chain per output element).
-#include <cstdlib>
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
 
@@ -24,6 +23,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // The MFMA runs transposed -- A = a 16-position tile of X^T, B = 16 channels of W^T -- so that a lane's four accumulator
 // registers are four CONSECUTIVE positions of one output channel: one 16-byte store per (channel tile, position tile)
 // instead of four 4-byte ones (the forward pass writes twice what it reads).
+// r06, measured and NOT adopted (profiles/r06_conv1x1_layers.txt): 16-byte activation loads with a permuted-position operand
+// (one load per lane and k-step instead of four; the weight gradient's trick).  (a) np permuted so that the store pattern below is
+// kept, prefetch 3-6 k-steps deep: forward 416 -> 446 us at 32 -> 64 / P = 131072, 311 -> 337 at 64 -> 128 / P = 32768, data
+// gradient 337 -> 430; (b) identity permutation (256 contiguous bytes per row and instruction), the k-steps of all of a
+// workgroup's position blocks as ONE software pipeline: 596 / 379 / 283 us forward.  Both slower on all five layers: the layer
+// is bound by moving 1.6 GB (one third read, two thirds written) through rows that lie 64 - 512 KB apart, not by the number of
+// load instructions.  (c) the r05 access pattern with three k-steps in flight instead of one: 442 / 306 / 242 us, inside the
+// run-to-run spread of r05's 416 / 311 / 249.  The r05 form stays.
 template <int MT, bool TRANS>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                       float* __restrict__ Z, int M, int R, int Cw, int P, int PB) {
@@ -33,36 +40,16 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
   const int np = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * (16 * MT);
   // a workgroup walks PB consecutive blocks of 256 positions: the channel rows of a ball tensor lie 32 .. 512 KB apart, so a
-  // block touches R + M distant pieces of memory, and staying on them for PB KB each (and staging W once) is what pays.
-  //
-  // r06: ONE 16-byte load per lane and k-step.  A sum over channels does not care which position an MFMA row stands for, as
-  // long as the store agrees: lane (np, g) loads X[c0 + g][p0 + 4 np .. + 3] (16 consecutive lanes = 256 contiguous bytes of one
-  // channel row) and feeds element j to MFMA number j, so row np of MFMA j is position p0 + 4 np + j, and accumulator register
-  // q of lane (np, g) in MFMA j is Z[m0 + np][p0 + 16 g + 4 q + j]: the four MFMAs' registers q are four CONSECUTIVE
-  // positions = one 16-byte store.  (r05: four 4-byte loads per lane and k-step.  A first r06 form permuted np so that the
-  // g lanes of a row stored 64 contiguous bytes: its loads then put the four lanes of a quad 64 bytes apart and ran 7-25 %
-  // SLOWER than r05 -- profiles/r06_conv1x1_layers.txt; consecutive lanes of a store are different channel rows anyway.)
-  // The k-steps of ALL the workgroup's blocks form one software pipeline (R <= 128, R % 16 == 0: every layer of Pointnet2MSG):
-  // a block of 64 positions x 32 channels is only 8 k-steps, and with three waves per SIMD the load latency at the head of
-  // each block was most of a block's time (r05: 0.35-0.6 of the HBM / MFMA floors).
-  const bool flat = R <= RC && (R & 15) == 0;
-  const int nblk = PB;
-  auto pos0 = [&](int i) { return ((blockIdx.x * PB + i) * 4 + wave) * 64; };
-  constexpr int kPF = 4;
-  v4f xq[kPF];
-  const float* xb = X + (size_t)blockIdx.z * R * P + 4 * np + (size_t)g * P;        // + p0 + row * P
-  if (flat && pos0(0) < P) {
-#pragma unroll
-    for (int u = 0; u < kPF; ++u) xq[u] = *reinterpret_cast<const v4f*>(xb + pos0(0) + (size_t)(4 * u) * P);
-  }
-  for (int i = 0; i < nblk; ++i) {
-    const int p0 = pos0(i);
+  // block touches R + M distant pieces of memory, and staying on them for PB KB each (and staging W once) is what pays
+  for (int i = 0; i < PB; ++i) {
+    const int p0 = ((blockIdx.x * PB + i) * 4 + wave) * 64;
     const bool active = p0 < P;                        // P is a multiple of 64
+    const float* x = X + (size_t)blockIdx.z * R * P + (active ? p0 : 0) + np;
     v4f acc[4][MT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[j][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
     for (int rc = 0; rc < R; rc += RC) {
       const int rows = min(RC, R - rc);
       if (R > RC || i == 0) {
@@ -78,48 +65,37 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
         }
         __syncthreads();
       }
-      if (!active) continue;
-      const float* xr = xb + p0 + (size_t)rc * P;
-      if (!flat) {
+      if (active) {
+        const float* xr = x + (size_t)(rc + g) * P;
+        float xv[4], xn[4];
 #pragma unroll
-        for (int u = 0; u < kPF; ++u)
-          xq[u] = 4 * u < rows ? *reinterpret_cast<const v4f*>(xr + (size_t)(4 * u) * P) : (v4f){0.f, 0.f, 0.f, 0.f};
-      }
-      const int pn = pos0(i + 1);
-      const bool next = flat && i + 1 < nblk && pn < P;
-      for (int r0 = 0; r0 < rows; r0 += 4 * kPF) {
+        for (int t = 0; t < 4; ++t) xv[t] = xr[16 * t];
+        for (int r0 = 0; r0 < rows; r0 += 4) {
+          const bool more = r0 + 4 < rows;
 #pragma unroll
-        for (int u = 0; u < kPF; ++u) {
-          const int r1 = r0 + 4 * u;                       // this k-step; the one kPF steps ahead is requested before its MFMAs
-          if (r1 < rows) {
-            const v4f xv = xq[u];
-            const int rn = r1 + 4 * kPF;
-            if (rn < rows) xq[u] = *reinterpret_cast<const v4f*>(xr + (size_t)rn * P);
-            else if (next) xq[u] = *reinterpret_cast<const v4f*>(xb + pn + (size_t)(rn - rows) * P);   // head of the next block
-            float wv[MT];
+          for (int t = 0; t < 4; ++t) xn[t] = more ? xr[(size_t)(r0 + 4) * P + 16 * t] : 0.f;
+          float wv[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) wv[mt] = Ws[(r1 + g) * (16 * MT) + np * MT + mt];
+          for (int mt = 0; mt < MT; ++mt) wv[mt] = Ws[(r0 + g) * (16 * MT) + np * MT + mt];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], wv[mt], acc[0][mt], 0, 0, 0);
-              acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], wv[mt], acc[1][mt], 0, 0, 0);
-              acc[2][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], wv[mt], acc[2][mt], 0, 0, 0);
-              acc[3][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], wv[mt], acc[3][mt], 0, 0, 0);
-            }
-          }
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t], wv[mt], acc[t][mt], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) xv[t] = xn[t];
         }
       }
     }
     if (active) {
-      // acc[j][mt][q] = Z[m0 + 16 mt + np][p0 + 16 g + 4 q + j]
+      // acc[t][mt][q] = Z[m0 + 16 mt + np][p0 + 16 t + 4 g + q]
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + 16 * mt + np;
         if (m < M) {
-          float* z = Z + ((size_t)blockIdx.z * M + m) * P + p0 + 16 * g;
+          float* z = Z + ((size_t)blockIdx.z * M + m) * P + p0 + 4 * g;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<v4f*>(z + 4 * q) = (v4f){acc[0][mt][q], acc[1][mt][q], acc[2][mt][q], acc[3][mt][q]};
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<v4f*>(z + 16 * t) = acc[t][mt];
         }
       }
     }
@@ -133,8 +109,7 @@ int launch(const float* X, const float* W, float* Z, int N, int M, int R, int Cw
   // and one for the narrow outputs (M <= 32: little W to stage, and the short workgroups balance better -- 32 -> 64 data
   // gradient at 131 K positions 327 us against 397 us, tools/bench_conv1x1.py)
   int PB = 1;
-  static const int narrow_pb = [] { const char* v = getenv("HCM_CONV1X1_NARROW_PB"); return v ? atoi(v) : 0; }();   // r06 probe
-  if (R <= 128 && (M > 32 || narrow_pb))
+  if (R <= 128 && M > 32)
     while (PB < 8 && (long long)((P + 512 * PB - 1) / (512 * PB)) * mblocks * N >= 2048) PB *= 2;
   const int pb = (P + 256 * PB - 1) / (256 * PB);
   if (M <= 16) conv1x1_kernel<1, TRANS><<<dim3(pb, 1, N), 256, 0, st>>>(X, W, Z, M, R, Cw, P, PB);

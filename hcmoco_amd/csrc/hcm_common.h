@@ -26,6 +26,7 @@ struct ProfSpan {
   // kernels that are launched at many shapes (the PointNet++ layers) still give ONE achieved rate, sum(work) / sum(time)
   ProfSpan(int tag, hipStream_t s, double work = 0.0);
   ~ProfSpan() { stop(); }
+  void add_work(double work);      // more work for this span's tag (a span around several launches)
   void stop();
 };
 

@@ -56,25 +56,13 @@ constexpr int kF = 128;      // projected channels (the loss kernels' C)
 // values of one sampled pixel lie H_i W_i * 4 bytes apart (16 KB for the finest branch at 256 x 256), so a tap of a row costs
 // C_i 4-byte accesses to C_i different cache lines (r04 counters: 7.9 L1 accesses per line requested from L2).  This kernel
 // writes [B, H_i W_i, C_i] next to the NCHW map -- 64-pixel tiles through LDS, 256-byte runs in, fully contiguous runs out --
-// for the branches that are NOT staged in LDS (the two finest at 256 x 256: 14 MB per modality), one launch for all of them;
+// for the branches that are NOT staged in LDS (the two finest at 256 x 256: 14 MB per modality), one launch per map;
 // project_rows_kernel then reads ONE contiguous run of C_i floats per tap.
-struct TJobs {
-  const float* src[8];
-  float* dst[8];
-  int C[8], HW[8], first[9];     // job k owns blocks [first[k], first[k + 1]): (image, 64-pixel tile) pairs
-};
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(TJobs j, int njobs) {
+// one map: [B, C, HW] -> [B, HW, C]; a workgroup owns one (image, 64-pixel tile)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
   extern __shared__ float tl[];                   // [C][65]
-  int k = 0;
-  while (k + 1 < njobs && (int)blockIdx.x >= j.first[k + 1]) ++k;
-  const float* src = sel8(j.src, k);
-  float* dst = sel8(j.dst, k);
-  const int C = sel8(j.C, k), HW = sel8(j.HW, k);
-  int fk = 0;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) fk = t == k ? j.first[t] : fk;
-  const int tiles = (HW + 63) >> 6, blk = blockIdx.x - fk;
-  const int b = blk / tiles, q0 = (blk - b * tiles) << 6, nq = min(64, HW - q0);
+  const int tiles = (HW + 63) >> 6;
+  const int b = blockIdx.x / tiles, q0 = (blockIdx.x - b * tiles) << 6, nq = min(64, HW - q0);
   for (int e = threadIdx.x; e < C * 64; e += 256) {
     const int c = e >> 6, q = e & 63;
     if (q < nq) tl[c * 65 + q] = src[((size_t)b * C + c) * HW + q0 + q];
@@ -777,32 +765,25 @@ int launch_project(const Maps8& e, int nmod, int B, const int64_t* pix, int R, i
   Maps8T et;
   for (int k = 0; k < 8; ++k) et.t[k] = nullptr;
   if (nhwc_ws != nullptr) {
-    TJobs j;
-    int nj = 0, blocks = 0, cmax = 0;
     float* wp = nhwc_ws;
+    hcm::ProfSpan tspan(HCM_PROF_ROW8_NHWC, s);
+    double moved = 0.0;
     for (int m = 0; m < nmod; ++m)
       for (int i = 0; i < 4; ++i) {
         if ((i == 2 && off2 >= 0) || (i == 3 && off3 >= 0)) continue;
         const int hw = e.H[i] * e.W[i];
-        j.src[nj] = e.p[m * 4 + i]; j.dst[nj] = wp; j.C[nj] = e.C[i]; j.HW[nj] = hw; j.first[nj] = blocks;
+        const size_t tb = (size_t)e.C[i] * 65 * sizeof(float);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(nchw_to_nhwc_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
+        if (e2 != hipSuccess) return (int)e2;
+        nchw_to_nhwc_kernel<<<B * ((hw + 63) / 64), 256, tb, s>>>(e.p[m * 4 + i], wp, e.C[i], hw);
+        HCM_CHECK_LAUNCH();
         et.t[m * 4 + i] = wp;
         wp += (size_t)B * e.C[i] * hw;
-        blocks += B * ((hw + 63) / 64);
-        cmax = e.C[i] > cmax ? e.C[i] : cmax;
-        ++nj;
+        moved += 8.0 * (double)B * e.C[i] * hw;          // every float read once, written once
       }
-    for (int k = nj; k < 8; ++k) { j.src[k] = nullptr; j.dst[k] = nullptr; j.C[k] = 0; j.HW[k] = 0; }
-    for (int k = nj; k <= 8; ++k) j.first[k] = blocks;
-    if (nj > 0) {
-      const size_t tb = (size_t)cmax * 65 * sizeof(float);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(nchw_to_nhwc_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
-      if (e2 != hipSuccess) return (int)e2;
-      hcm::ProfSpan tspan(HCM_PROF_ROW8_NHWC, s, 8.0 * (double)(wp - nhwc_ws));      // every float read once, written once
-      nchw_to_nhwc_kernel<<<blocks, 256, tb, s>>>(j, nj);
-      tspan.stop();
-      HCM_CHECK_LAUNCH();
-    }
+    tspan.add_work(moved);
+    tspan.stop();
   }
   // rows per workgroup: fewest (rounds over the CUs) x (tiles per workgroup + the staging prologue)
   const int cus = num_cus();
