@@ -411,7 +411,7 @@ def main():
                     help='project the feature maps only at the sampled pixels (SURVEY 8f-1)')
     ap.add_argument('--wgrad_stream', type=int, default=8,
                     help='layers per hand-over of the encoders\' weight gradients to their side stream (0: in line)')
-    ap.add_argument('--row8_channels_last', type=int, default=1, help=argparse.SUPPRESS)   # A/B of hcm_project_rows_cl (r06)
+    ap.add_argument('--row8_channels_last', type=int, default=0, help=argparse.SUPPRESS)   # A/B of hcm_project_rows_cl (r06)
     ap.add_argument('--fault', type=str, default=None, help=argparse.SUPPRESS)      # tests: "rank:step:exit|raise|hang"
     ap.add_argument('--backend', type=str, default='nccl',
                     help='process-group backend; nccl (= RCCL over xGMI) is the product, gloo only lets the '

@@ -1,6 +1,11 @@
 // Device-side helpers shared by the gfx950 kernels of libhcmoco_hip.so.
 // CDNA4 only: 64-lane wavefronts, DPP row = 16 lanes.
 #pragma once
+// gfx950 ONLY: the kernels use CDNA4 instructions without a fallback -- ds_read_b64_tr_b16, v_mfma_f32_16x16x32_bf16,
+// 160 KB of LDS per workgroup -- and are tuned for 256 CUs / wave64.  A build for another target must fail here, not at run time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "hcmoco_amd/csrc targets gfx950 (MI355X, CDNA4) only: build with --offload-arch=gfx950 (csrc/Makefile ARCH)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

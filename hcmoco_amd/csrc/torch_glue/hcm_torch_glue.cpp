@@ -247,18 +247,19 @@ bool own_conv1x1(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) 
 }
 
 Tensor conv_forward_raw(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad) {
-  if (x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && x.is_contiguous() && w.is_contiguous() &&
-      own_conv1x1(x, w, stride, pad)) {
+  // the shape / device / dtype contract FIRST: own_conv1x1 indexes w.size(2), w.size(3) and hcm_conv1x1_forward trusts
+  // w.size(1) == x.size(1) (a weight of another channel count read out of bounds on the fast path)
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
+                  w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
+                  w.is_contiguous(),
+              "hcmoco::conv2d needs contiguous fp32 ROCm tensors x [N,C,H,W], w [K,C,R,S] (groups = dilation = 1, no bias)");
+  if (own_conv1x1(x, w, stride, pad)) {
     Tensor y = at::empty({x.size(0), w.size(0), x.size(2), x.size(3)}, x.options());
     check_rc(hcm_conv1x1_forward(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), (int)x.size(0), (int)x.size(1),
                                  (int)w.size(0), (int)(x.size(2) * x.size(3)), current_stream(x)),
              "hcm_conv1x1_forward");
     return y;
   }
-  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() &&
-                  w.scalar_type() == at::kFloat && w.dim() == 4 && w.size(1) == x.size(1) && x.is_contiguous() &&
-                  w.is_contiguous(),
-              "hcmoco::conv2d needs contiguous fp32 ROCm tensors x [N,C,H,W], w [K,C,R,S] (groups = dilation = 1, no bias)");
   if (own_conv(x, w, stride, pad)) {
     Tensor y = at::empty({x.size(0), w.size(0), x.size(2), x.size(3)}, x.options());
     check_rc(hcm_conv3x3_forward(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), (int)x.size(0),
@@ -402,6 +403,10 @@ struct ConvGrads { Tensor dx, dw; };
 // g must be contiguous.
 ConvGrads conv_backward_raw(const Tensor& g, const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, bool need_dx,
                             bool need_dw) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 4 && w.is_cuda() && w.scalar_type() == at::kFloat &&
+                  w.dim() == 4 && w.size(1) == x.size(1) && g.is_cuda() && g.scalar_type() == at::kFloat && g.dim() == 4 &&
+                  g.size(0) == x.size(0) && g.size(1) == w.size(0),
+              "hcmoco::conv2d backward: fp32 ROCm tensors g [N,K,Ho,Wo], x [N,C,H,W], w [K,C,R,S] expected");
   const ConvKey k = key_of(x, w, stride, pad);
   ConvPlan* p = get_plan(k);
   hipStream_t st = (hipStream_t)current_stream(x);
@@ -1354,6 +1359,15 @@ std::vector<Tensor> encoder_forward_wait(int64_t id) {
     std::lock_guard<std::mutex> lk(g_precomputed_mutex);
     g_precomputed[id] = std::move(pend->result);
   }
+  // EncoderFn::forward takes the entry out again; if apply() throws before it gets there (argument checks of the autograd
+  // machinery), the parked tape -- every saved activation of an HRNet forward -- must not stay in the map
+  struct Unpark {
+    int64_t id;
+    ~Unpark() {
+      std::lock_guard<std::mutex> lk(g_precomputed_mutex);
+      g_precomputed.erase(id);
+    }
+  } unpark{id};
   // the node remembers the stream that is current while it is made: backward replays on the forward's stream
   c10::hip::HIPStreamGuard guard(pend->stream);
   return EncoderFn::apply(pend->x, at::TensorList(pend->params), at::TensorList(pend->buffers), std::move(pend->prog),

@@ -861,14 +861,19 @@ def branch_grad(dxs, dpooled, scale, pix, shapes, dWpad=None, F=128, keep=None, 
     return g1, g2, dWp1, dbp1, dWp2, dbp2
 
 
-ROW8_CHANNELS_LAST = True      # module attribute: the forward reads channels-last copies of the branches it gathers (r06)
+# module attribute: the forward reads channels-last copies of the branches it gathers (hcm_project_rows_cl, r06).  Built,
+# bit-identical, measured -- and OFF: project_rows_kernel 99 -> 82.5 us at the bench size, the four copy launches 36.5 us, net
+# +20 us per step and no change in samples/s (750.7 / 752.3 on vs 752.3 / 752.1 off, same box, alternating;
+# profiles/r06_row8_channels_last.txt).  The producer writes NCHW (the encoder runtime's kernels are per-channel), so the
+# coalesced read has to be paid for with a transposing pass that costs more than the scattered one it replaces.
+ROW8_CHANNELS_LAST = False
 
 
 def project_rows(maps1, maps2, pix, Wp1, bp1, Wp2, bp2, save=True, zero_grows=True, channels_last=None):
     """(rows [2,B*R,128], xs [2,B*R,ld] or None, grows [2,B*R,128] zero-filled or None): merge_all_res + the 1x1
     projections (build_backbone.py:243-254, :290-300) at the pixels ``pix`` for both modalities in ONE launch on the fp32
     matrix cores (csrc/rowproj.hip).  ``save``: keep the sampled rows ``xs`` for the weight gradient.
-    ``channels_last`` (default ROW8_CHANNELS_LAST): hcm_project_rows_cl -- the branch maps that are gathered from global
+    ``channels_last`` (default ROW8_CHANNELS_LAST = False, see there): hcm_project_rows_cl -- the branch maps that are gathered from global
     memory are first copied [B, H W, C] (one launch), so that a stencil tap is one contiguous run of C floats instead of C
     words on C cache lines; same results bit for bit."""
     B, R = pix.shape

@@ -8,6 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hcmoco_amd import hip_ops
+hip_ops.ROW8_CHANNELS_LAST = os.environ.get('ROW8_CL', '0') == '1'      # r06: hcm_project_rows_cl under the counters
 
 crop = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
