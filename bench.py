@@ -399,7 +399,7 @@ def main():
     ap.add_argument('--width', type=int, default=18, choices=[18, 32, 48])
     ap.add_argument('--bank_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
                     help='bf16 = BASELINE config 5 bank storage; not the headline config')
-    ap.add_argument('--fmap_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
+    ap.add_argument('--fmap_dtype', type=str, default='fp32', choices=['fp32', 'bf16', 'fp32_exact'],
                     help='bf16 = BASELINE config 5 feature-map GEMMs; not the headline config')
     ap.add_argument('--encoder_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
                     help='bf16 = bf16 encoder convolutions under autocast (fp32 batch-norm statistics / master weights / loss '
@@ -777,13 +777,15 @@ def run(a, rank, world, local, fs):
                 entry = {'kernel': name, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak,
                          'unit': 'TFLOP/s', 'frac': round(ach / mfma_peak, 4), 'flops_per_launch': int(work),
                          'avg_launch_ms': round(avg, 5), 'launches_timed': n}
-                if a.fmap_dtype == 'fp32':
+                if a.fmap_dtype in ('fp32', 'fp32_exact'):
                     # what the fp32 instantiation really issues: every fp32 operand is split into two bf16 pieces and
                     # a product is 3 (dense) / 4 (SCL) v_mfma_f32_16x16x32_bf16 terms with fp32 accumulation; `frac` prices the
                     # ALGORITHMIC flops against the fp32-input MFMA rate an exact fp32 contraction would be bound by
-                    terms = 4 if tag.startswith('scl') else 3
-                    entry.update({'arith': 'fp32-accurate split-bf16: %d bf16 MFMA terms per product, fp32 accumulate '
-                                           '(error vs float64 4e-6..6e-6, profiles/r05_split_bf16_error_study.txt)' % terms,
+                    terms = 9 if a.fmap_dtype == 'fp32_exact' else (4 if tag.startswith('scl') else 3)
+                    entry.update({'arith': ('exact-product fp32: three bf16 pieces per operand, all 9 MFMA terms, fp32 accumulate'
+                                            if terms == 9 else
+                                            'fp32-accurate split-bf16: %d bf16 MFMA terms per product, fp32 accumulate '
+                                            '(error vs float64 4e-6..6e-6, profiles/r05_split_bf16_error_study.txt)' % terms),
                                   'issued_tflops': round(ach * terms, 2),
                                   'frac_of_bf16_mfma_peak_issued': round(ach * terms / MFMA_BF16_PEAK_TFS, 4),
                                   'note': 'VALU / latency bound, not MFMA bound: matrix pipes busy 7 % of wave cycles '

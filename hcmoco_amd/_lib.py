@@ -139,6 +139,8 @@ SIGNATURES = {
 
 SIGNATURES['hcm_dense_soft_nce_coords_bf16'] = SIGNATURES['hcm_dense_soft_nce_coords']
 SIGNATURES['hcm_scl_bf16'] = SIGNATURES['hcm_scl']
+SIGNATURES['hcm_dense_soft_nce_coords_exact'] = SIGNATURES['hcm_dense_soft_nce_coords']
+SIGNATURES['hcm_scl_exact'] = SIGNATURES['hcm_scl']
 
 for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits_fwd', 'hcm_bank_logits_bwd',
               'hcm_bank_update', 'hcm_bank_update_checked'):

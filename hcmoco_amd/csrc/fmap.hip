@@ -187,8 +187,13 @@ __device__ unsigned long long* g_strip_dbg = nullptr;
 #else
 #define HCM_TS(k) do {} while (0)
 #endif
-template <class Policy, bool GRAD, bool BF16, bool BND>
+// EXACT (r06, `--fmap_dtype fp32_exact`; ADVICE r05: a true-fp32 contraction must stay selectable): every operand is split into
+// THREE bf16 pieces, x = hi + mid + lo EXACTLY (3 x 8 significand bits), and all nine piece products -- each exact in the fp32
+// accumulator -- are issued, smallest first: the contraction is an fp32 dot product whose only rounding is the accumulator's, the
+// class of v_mfma_f32_16x16x4_f32.  3 x the matrix work of the default (9 terms against 3), not a speed mode.
+template <class Policy, bool GRAD, bool BF16, bool BND, bool EXACT = false>
 __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
+  static_assert(!(BF16 && EXACT), "EXACT is a mode of the fp32 instantiation");
 #ifdef HCM_STRIP_TIMING
   unsigned long long tacc_[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long tlast_ = __builtin_amdgcn_s_memtime();
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   // in the instruction stream, independent accumulators, conflict-free LDS strides each changed nothing).  The pass is
   // bounded by (MFMA + VALU) instruction time: fewer VALU instructions per element is the only lever left in fp32.
   // BF16: the fp32 tile (operands rounded on their way into the MFMA).  Split: hi / mid planes, row-major [2][16][128] bf16 = 8 KB.
-  constexpr int kBufFloats = BF16 ? 16 * kKS : 8192 / 4;
-  constexpr int kT = Policy::kTerms;
+  constexpr int kBufFloats = BF16 ? 16 * kKS : (EXACT ? 12288 / 4 : 8192 / 4);      // EXACT: a third (lo) plane
+  constexpr int kT = EXACT ? 9 : Policy::kTerms;
   __shared__ __attribute__((aligned(16))) float sKb[3][kBufFloats];
   __shared__ int sMetaCb[3][16];
   __shared__ float sStatCb[3][16][3];
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   // A operand: lane (m = np, kslot = g) holds Q[row0+np][16j + 4g + e], j<8, e<4
   // (BF16: Q[row0+np][32j + 8g + e], j<4, e<8, rounded to bf16)
   // lane (m = np, kslot = g) holds Q[row0+np][32j + 8g + e], j<4, e<8, as bf16: rounded (BF16) or split into hi + mid
-  v8bf qh[4], qm[BF16 ? 1 : 4];
+  v8bf qh[4], qm[BF16 ? 1 : 4], ql[EXACT ? 4 : 1];
   {
     const int r = row0 + np;
 #pragma unroll
@@ -244,6 +249,8 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
       const v8f v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       qh[j] = __builtin_convertvector(v, v8bf);
       if constexpr (!BF16) qm[j] = __builtin_convertvector(v - __builtin_convertvector(qh[j], v8f), v8bf);
+      if constexpr (EXACT)
+        ql[j] = __builtin_convertvector((v - __builtin_convertvector(qh[j], v8f)) - __builtin_convertvector(qm[j], v8f), v8bf);
     }
   }
   // rows owned in the C layout: row0 + 4g + reg (stats pass: P = Q K^T) or row0 + np for every reg (grad pass: the
@@ -314,6 +321,9 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         const int o = rr * 256 + (((c4 >> 1) ^ rr) << 4) + ((c4 & 1) << 3);
         *reinterpret_cast<v4bf*>(base + o) = hi;
         *reinterpret_cast<v4bf*>(base + 4096 + o) = mid;
+        if constexpr (EXACT)
+          *reinterpret_cast<v4bf*>(base + 8192 + o) =
+              __builtin_convertvector((v - __builtin_convertvector(hi, v4f)) - __builtin_convertvector(mid, v4f), v4bf);
       }
     }
     if (threadIdx.x < 16) {
@@ -341,12 +351,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
       // split operands: the smallest terms go in first.  GRAD: A <-> B, the accumulator holds P^T, i.e. lane (np, g) reg q =
       // P[row0 + np][c0 + 4g + q]
       const char* base = reinterpret_cast<const char*>(sK);
-      v8bf kh[4], km[4];
+      v8bf kh[4], km[4], kl[EXACT ? 4 : 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int o = np * 256 + (((4 * j + g) ^ np) << 4);
         kh[j] = *reinterpret_cast<const v8bf*>(base + o);
         km[j] = *reinterpret_cast<const v8bf*>(base + 4096 + o);
+        if constexpr (EXACT) kl[j] = *reinterpret_cast<const v8bf*>(base + 8192 + o);
       }
       // term-major issue order: the four accumulators take turns, so no MFMA waits for the one before it (a dependent
       // v_mfma_f32_16x16x32_bf16 issues ~40 cycles after its producer, an independent one after ~17)
@@ -354,6 +365,13 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
   _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
       ap[j] = GRAD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(KB[j], QA[j], ap[j], 0, 0, 0)                           \
                    : __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA[j], KB[j], ap[j], 0, 0, 0)
+      if constexpr (EXACT) {                        // 2^-32, 2^-24, 2^-24, 2^-16, 2^-16 class terms first
+        HCM_TERM(ql, kl);
+        HCM_TERM(qm, kl);
+        HCM_TERM(ql, km);
+        HCM_TERM(qh, kl);
+        HCM_TERM(ql, kh);
+      }
       if constexpr (kT >= 4) { HCM_TERM(qm, km); }
       HCM_TERM(qh, km);
       HCM_TERM(qm, kh);
@@ -456,19 +474,31 @@ __global__ __launch_bounds__(kWG) void strip_kernel(StripArgs a, Policy pol) {
         const v4bf gh4 = __builtin_convertvector(gv, v4bf);
         const v4bf gm4 = __builtin_convertvector(gv - __builtin_convertvector(gh4, v4f), v4bf);
         const v4s gh = __builtin_bit_cast(v4s, gh4), gm = __builtin_bit_cast(v4s, gm4);
+        v4s gl = gh;
+        if constexpr (EXACT)
+          gl = __builtin_bit_cast(v4s, __builtin_convertvector((gv - __builtin_convertvector(gh4, v4f)) -
+                                                               __builtin_convertvector(gm4, v4f), v4bf));
         typedef v4s __attribute__((address_space(3))) * lds_v4s;
         const char* tb = reinterpret_cast<const char*>(sK);
         const int trow = 4 * g + (np >> 2), tq = np & 3;
-        v4s th[8], tm[8];
+        v4s th[8], tm[8], tl[EXACT ? 8 : 1];
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
           const int c4 = 4 * nt + tq;
           const int o = trow * 256 + (((c4 >> 1) ^ trow) << 4) + ((c4 & 1) << 3);
           th[nt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + o));
           tm[nt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 4096 + o));
+          if constexpr (EXACT) tl[nt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(tb + 8192 + o));
         }
 #define HCM_TERM2(GA, TB) \
   _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) dq[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(GA, TB[nt], dq[nt], 0, 0, 0)
+        if constexpr (EXACT) {
+          HCM_TERM2(gl, tl);
+          HCM_TERM2(gm, tl);
+          HCM_TERM2(gl, tm);
+          HCM_TERM2(gh, tl);
+          HCM_TERM2(gl, th);
+        }
         if constexpr (kT >= 4) { HCM_TERM2(gm, tm); }
         HCM_TERM2(gh, tm);
         HCM_TERM2(gm, th);
@@ -1379,7 +1409,7 @@ static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int
                       int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
                       int coord_w, const int32_t* keep, int S, float temperature, float* out4,
                       float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
-                      hcm_stream_t stream, bool bf16);
+                      hcm_stream_t stream, int mode);
 
 int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
                               int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
@@ -1387,7 +1417,7 @@ int hcm_dense_soft_nce_coords(const float* map1, const float* map2, hcm_strides4
                               float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
                               hcm_stream_t stream) {
   return dense_impl(map1, map2, st, B, C, h, w, sample_ind, coord_ind, coord_w, keep, S, temperature, out4, gmap1, gmap2,
-                    workspace, workspace_bytes, stream, false);
+                    workspace, workspace_bytes, stream, 0);
 }
 int hcm_dense_soft_nce_coords_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
                                    int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
@@ -1395,14 +1425,23 @@ int hcm_dense_soft_nce_coords_bf16(const float* map1, const float* map2, hcm_str
                                    float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
                                    hcm_stream_t stream) {
   return dense_impl(map1, map2, st, B, C, h, w, sample_ind, coord_ind, coord_w, keep, S, temperature, out4, gmap1, gmap2,
-                    workspace, workspace_bytes, stream, true);
+                    workspace, workspace_bytes, stream, 1);
+}
+int hcm_dense_soft_nce_coords_exact(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                                    int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                                    int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                                    float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                                    hcm_stream_t stream) {
+  return dense_impl(map1, map2, st, B, C, h, w, sample_ind, coord_ind, coord_w, keep, S, temperature, out4, gmap1, gmap2,
+                    workspace, workspace_bytes, stream, 2);
 }
 
 static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
                       int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
                       int coord_w, const int32_t* keep, int S, float temperature, float* out4,
                       float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
-                      hcm_stream_t stream, bool bf16) {
+                      hcm_stream_t stream, int mode) {
+  const bool bf16 = mode == 1, exact = mode == 2;      // 0: split-bf16 fp32 (default), 1: bf16 operands, 2: exact fp32 (r06)
   if (coord_ind == nullptr) { coord_ind = sample_ind; coord_w = w; }
   if (coord_w <= 0) return (int)hipErrorInvalidValue;
   if (C != kC || B <= 0 || S <= 0 || h <= 0 || w <= 0 || !(temperature > 0.f) || keep == nullptr)
@@ -1428,9 +1467,11 @@ static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int
     ProfSpan span(HCM_PROF_DENSE_STATS, s);
     if (a.bounded) {
       if (bf16) strip_kernel<DensePolicy, false, true, true><<<grid, kWG, 0, s>>>(a, pol);
+      else if (exact) strip_kernel<DensePolicy, false, false, true, true><<<grid, kWG, 0, s>>>(a, pol);
       else strip_kernel<DensePolicy, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
     } else {
       if (bf16) strip_kernel<DensePolicy, false, true, false><<<grid, kWG, 0, s>>>(a, pol);
+      else if (exact) strip_kernel<DensePolicy, false, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
       else strip_kernel<DensePolicy, false, false, false><<<grid, kWG, 0, s>>>(a, pol);
     }
     HCM_CHECK_LAUNCH();
@@ -1439,6 +1480,7 @@ static int dense_impl(const float* map1, const float* map2, hcm_strides4 st, int
   {
     ProfSpan span(HCM_PROF_DENSE_GRAD, s);
     if (bf16) strip_kernel<DensePolicy, true, true, false><<<grid, kWG, 0, s>>>(a, pol);
+    else if (exact) strip_kernel<DensePolicy, true, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
     else strip_kernel<DensePolicy, true, false, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     span.stop();
@@ -1459,27 +1501,35 @@ size_t hcm_scl_workspace_bytes(int B, int J, int C) {
 static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
                     const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
                     float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
-                    size_t workspace_bytes, hcm_stream_t stream, bool bf16);
+                    size_t workspace_bytes, hcm_stream_t stream, int mode);
 
 int hcm_scl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
             const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
             float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
             size_t workspace_bytes, hcm_stream_t stream) {
   return scl_impl(map1, map2, st, B, C, h, w, pix, use_depth, use_rgb, J, temperature, out1, gmap1, gmap2, workspace,
-                  workspace_bytes, stream, false);
+                  workspace_bytes, stream, 0);
 }
 int hcm_scl_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
                  const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
                  float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
                  size_t workspace_bytes, hcm_stream_t stream) {
   return scl_impl(map1, map2, st, B, C, h, w, pix, use_depth, use_rgb, J, temperature, out1, gmap1, gmap2, workspace,
-                  workspace_bytes, stream, true);
+                  workspace_bytes, stream, 1);
+}
+int hcm_scl_exact(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                  const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+                  float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+                  size_t workspace_bytes, hcm_stream_t stream) {
+  return scl_impl(map1, map2, st, B, C, h, w, pix, use_depth, use_rgb, J, temperature, out1, gmap1, gmap2, workspace,
+                  workspace_bytes, stream, 2);
 }
 
 static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
                     const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
                     float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
-                    size_t workspace_bytes, hcm_stream_t stream, bool bf16) {
+                    size_t workspace_bytes, hcm_stream_t stream, int mode) {
+  const bool bf16 = mode == 1, exact = mode == 2;      // 0: split-bf16 fp32 (default), 1: bf16 operands, 2: exact fp32 (r06)
   if (C != kC || B <= 0 || J <= 0 || J > 0xffff || h <= 0 || w <= 0 || !(temperature > 0.f) ||
       use_depth == nullptr)
     return (int)hipErrorInvalidValue;
@@ -1504,9 +1554,11 @@ static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B
     ProfSpan span(HCM_PROF_SCL_STATS, s);
     if (a.bounded) {
       if (bf16) strip_kernel<SclPolicy, false, true, true><<<grid, kWG, 0, s>>>(a, pol);
+      else if (exact) strip_kernel<SclPolicy, false, false, true, true><<<grid, kWG, 0, s>>>(a, pol);
       else strip_kernel<SclPolicy, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
     } else {
       if (bf16) strip_kernel<SclPolicy, false, true, false><<<grid, kWG, 0, s>>>(a, pol);
+      else if (exact) strip_kernel<SclPolicy, false, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
       else strip_kernel<SclPolicy, false, false, false><<<grid, kWG, 0, s>>>(a, pol);
     }
     HCM_CHECK_LAUNCH();
@@ -1519,6 +1571,7 @@ static int scl_impl(const float* map1, const float* map2, hcm_strides4 st, int B
   {
     ProfSpan span(HCM_PROF_SCL_GRAD, s);
     if (bf16) strip_kernel<SclPolicy, true, true, false><<<grid, kWG, 0, s>>>(a, pol);
+    else if (exact) strip_kernel<SclPolicy, true, false, false, true><<<grid, kWG, 0, s>>>(a, pol);
     else strip_kernel<SclPolicy, true, false, false><<<grid, kWG, 0, s>>>(a, pol);
     HCM_CHECK_LAUNCH();
     if (ws.nkc > 1) {

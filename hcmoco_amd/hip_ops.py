@@ -377,7 +377,7 @@ class _FmapLosses(torch.autograd.Function):
             S = sample_ind.shape[1]
             nb = L.hcm_dense_soft_nce_workspace_bytes(B, S, Cc)
             ws = _ws(nb, dev)
-            dense = L.hcm_dense_soft_nce_coords_bf16 if gemm_dtype == 'bf16' else L.hcm_dense_soft_nce_coords
+            dense = {'bf16': L.hcm_dense_soft_nce_coords_bf16, 'fp32_exact': L.hcm_dense_soft_nce_coords_exact}.get(gemm_dtype, L.hcm_dense_soft_nce_coords)
             check(dense(p1, p2, st, B, Cc, h, w,
                                               _dev(sample_ind, torch.int64, 'dense'),
                                               _opt(coord_ind, torch.int64, 'dense'), int(coord_w),
@@ -398,7 +398,7 @@ class _FmapLosses(torch.autograd.Function):
         if do_scl:
             nb = L.hcm_scl_workspace_bytes(B, J, Cc)
             ws = _ws(nb, dev)
-            scl = L.hcm_scl_bf16 if gemm_dtype == 'bf16' else L.hcm_scl
+            scl = {'bf16': L.hcm_scl_bf16, 'fp32_exact': L.hcm_scl_exact}.get(gemm_dtype, L.hcm_scl)
             check(scl(p1, p2, st, B, Cc, h, w, _dev(pix, torch.int64, 'scl'),
                             _dev(ud, torch.int32, 'scl'), _opt(ur, torch.int32, 'scl'), J, float(temperature),
                             C.c_void_p(out.data_ptr() + 32), pg1, pg2,
@@ -423,8 +423,8 @@ def fmap_losses(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth,
     ``coord_ind``/``coord_w``: pixel coordinates of the dense soft target when ``sample_ind`` is only
     a gather index (row mode, see ``fmap_losses_rows``).  ``gemm_dtype='bf16'``: the dense and SCL
     contractions on the bf16 matrix cores (BASELINE config 5; fp32 accumulation)."""
-    if gemm_dtype not in ('fp32', 'bf16'):
-        raise ValueError('gemm_dtype must be fp32 or bf16')
+    if gemm_dtype not in ('fp32', 'bf16', 'fp32_exact'):
+        raise ValueError('gemm_dtype must be fp32 (split-bf16, fp32-accurate), bf16 or fp32_exact')
     return _FmapLosses.apply(map1, map2, feat3, sample_ind, keep, pix, joints_vis, use_depth, use_rgb,
                              temperature, do_dense, do_joint, do_scl, coord_ind, coord_w, gemm_dtype)
 
@@ -966,7 +966,7 @@ def fmap_losses_on_rows(rows, grows, feat3, S, coord, w, keep, joints_vis, ud, u
     pg1, pg2 = C.c_void_p(grows[0].data_ptr()), C.c_void_p(grows[1].data_ptr())
     nb = L.hcm_dense_soft_nce_workspace_bytes(B, S, Cc)
     ws = _ws(nb, dev)
-    dense = L.hcm_dense_soft_nce_coords_bf16 if gemm_dtype == 'bf16' else L.hcm_dense_soft_nce_coords
+    dense = {'bf16': L.hcm_dense_soft_nce_coords_bf16, 'fp32_exact': L.hcm_dense_soft_nce_coords_exact}.get(gemm_dtype, L.hcm_dense_soft_nce_coords)
     check(dense(p1, p2, st, B, Cc, 1, R, _dev(gd, torch.int64, 'dense'), _dev(coord, torch.int64, 'dense'), int(w),
                 _dev(keep, torch.int32, 'dense'), S, float(temperature), C.c_void_p(out.data_ptr()), pg1, pg2,
                 C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_dense_soft_nce_coords')
@@ -980,7 +980,7 @@ def fmap_losses_on_rows(rows, grows, feat3, S, coord, w, keep, joints_vis, ud, u
                           C.c_void_p(ws.data_ptr()), nb, _stream()), 'hcm_joint_nce')
     nb = L.hcm_scl_workspace_bytes(B, J, Cc)
     ws = _ws(nb, dev)
-    scl = L.hcm_scl_bf16 if gemm_dtype == 'bf16' else L.hcm_scl
+    scl = {'bf16': L.hcm_scl_bf16, 'fp32_exact': L.hcm_scl_exact}.get(gemm_dtype, L.hcm_scl)
     udv = ud if ud is not None else torch.ones(B, dtype=torch.int32, device=dev)
     check(scl(p1, p2, st, B, Cc, 1, R, _dev(gj, torch.int64, 'scl'), _dev(udv, torch.int32, 'scl'),
               _opt(ur, torch.int32, 'scl'), J, float(temperature), C.c_void_p(out.data_ptr() + 32), pg1, pg2,

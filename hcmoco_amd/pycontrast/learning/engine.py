@@ -17,8 +17,8 @@ class HipLossEngine(object):
     def __init__(self, fmap_dtype='fp32'):
         """``fmap_dtype='bf16'`` (``--fmap_dtype bf16``, BASELINE config 5): the dense and SCL similarity /
         gradient contractions run on the bf16 matrix cores with fp32 accumulation."""
-        if fmap_dtype not in ('fp32', 'bf16'):
-            raise ValueError('fmap_dtype must be fp32 or bf16')
+        if fmap_dtype not in ('fp32', 'bf16', 'fp32_exact'):
+            raise ValueError('fmap_dtype must be fp32, bf16 or fp32_exact')
         self.fmap_dtype = fmap_dtype
 
     # ---- SURVEY 8a rows 1-4 -------------------------------------------------------------

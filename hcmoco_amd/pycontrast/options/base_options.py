@@ -125,11 +125,12 @@ BASE_FLAGS = [
                                  'all-reduces of the encoders\' flat gradient buffers, launched chunk by chunk while '
                                  'backward is still running (learning/grad_sync.py); flat = ONE all-reduce after '
                                  'backward; auto = overlap on ROCm, ddp on CPU')),
-    (('--fmap_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
+    (('--fmap_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16', 'fp32_exact'],
                              help='arithmetic of the dense / SCL feature-map contractions: fp32 = fp32-ACCURATE products on the '
                                   'bf16 matrix cores (operands split into two bf16 pieces, 3 / 4 MFMA terms per product, fp32 '
                                   'accumulation; 4e-6..6e-6 of float64, inside the 1e-5 / 1e-4 parity gate) or bf16 = operands '
-                                  'rounded to bf16, fp32 accumulation (BASELINE config 5)')),
+                                  'rounded to bf16, fp32 accumulation (BASELINE config 5); fp32_exact = three bf16 pieces per operand, all nine '
+                                  'piece products: an exact-product fp32 contraction at 3 x the matrix work (not a speed mode)')),
     (('--bank_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],
                              help='storage type of the memory banks (bf16: BASELINE config 5)')),
     (('--encoder_dtype',), dict(type=_S, default='fp32', choices=['fp32', 'bf16'],

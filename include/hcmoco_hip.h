@@ -194,6 +194,20 @@ int hcm_dense_soft_nce_coords_bf16(const float* map1, const float* map2, hcm_str
                                    int coord_w, const int32_t* keep, int S, float temperature, float* out4,
                                    float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
                                    hcm_stream_t stream);
+/* The same two losses with EXACT fp32 contractions (r06, `--fmap_dtype fp32_exact`): every operand split into three bf16 pieces
+ * (hi + mid + lo = x exactly), all nine piece products issued on the bf16 matrix cores with fp32 accumulation -- an fp32 dot
+ * product whose only rounding is the accumulator's.  The default entry points above use two pieces and 3 (dense) / 4 (SCL) terms
+ * (4e-6..6e-6 of float64 on the gradients, inside the 1e-5 / 1e-4 parity gate); this mode is 3 x their matrix work and exists so
+ * that a true-fp32 contraction stays selectable.  Same arguments. */
+int hcm_dense_soft_nce_coords_exact(const float* map1, const float* map2, hcm_strides4 st, int B, int C,
+                                    int h, int w, const int64_t* sample_ind, const int64_t* coord_ind,
+                                    int coord_w, const int32_t* keep, int S, float temperature, float* out4,
+                                    float* gmap1, float* gmap2, void* workspace, size_t workspace_bytes,
+                                    hcm_stream_t stream);
+int hcm_scl_exact(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
+                  const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
+                  float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,
+                  size_t workspace_bytes, hcm_stream_t stream);
 int hcm_scl_bf16(const float* map1, const float* map2, hcm_strides4 st, int B, int C, int h, int w,
                  const int64_t* pix, const int32_t* use_depth, const int32_t* use_rgb, int J,
                  float temperature, float* out1, float* gmap1, float* gmap2, void* workspace,

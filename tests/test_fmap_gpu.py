@@ -151,6 +151,38 @@ def test_all_three_vs_oracle(B, h, S, J):
     assert rel_l2(g3, j3) < GRAD_REL_L2
 
 
+def test_exact_fp32_mode_is_selectable_and_closer_to_float64():
+    """``gemm_dtype='fp32_exact'`` (r06; ADVICE r05: the default fp32 path is a split-bf16 contraction, a true-fp32 one must stay
+    selectable): three bf16 pieces per operand, all nine piece products.  Against the float64 oracle at the BASELINE shape
+    (B = 32, 64 x 64 maps, S = 400, J = 17) it must be at least as close as the default on every loss and gradient, and the
+    default must stay inside the SURVEY 8d gate.  Prints both."""
+    torch.manual_seed(77)
+    B, h, S, J, C, temp = 32, 64, 400, 17, 128, 0.07
+    m1, m2 = torch.randn(B, C, h, h), torch.randn(B, C, h, h)
+    f3 = torch.randn(B, J, C)
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[1] = False
+    ud = keep.clone().int()
+    ind = torch.randint(0, h * h, (B, S))
+    j2d = torch.rand(B, J, 2) * 4 * h
+    vis = (torch.rand(B, J) < 0.85).int()
+    vis[0, 0] = 1
+    pix = O.joint_pixels(j2d, h)
+    ld, ad, d1, d2 = O.dense_soft_nce(m1.double(), m2.double(), ind[keep], keep, temp, ud)
+    ls, s1, s2, _ = O.scl(m1.double(), m2.double(), j2d, temp, ud, None)
+    want_l = torch.cat([ld.double(), ls.double().reshape(1)])
+    err = {}
+    for mode in ('fp32', 'fp32_exact'):
+        total, met, g1, g2, _ = run(m1, m2, f3, ind, keep.int(), pix, vis, ud, None, temp, 'nchw', do_joint=False,
+                                    gemm_dtype=mode)
+        got_l = torch.cat([met[0:2].double(), met[8:9].double()])
+        err[mode] = (float(((got_l - want_l).abs() / want_l.abs()).max()), rel_l2(g1, d1 + s1), rel_l2(g2, d2 + s2))
+    print('loss rel / grad1 rel-L2 / grad2 rel-L2:', err)
+    assert err['fp32'][0] < LOSS_RTOL and max(err['fp32'][1:]) < GRAD_REL_L2
+    assert err['fp32_exact'][0] <= max(err['fp32'][0], 2e-7)
+    assert max(err['fp32_exact'][1:]) <= max(err['fp32'][1:]) and max(err['fp32_exact'][1:]) < 2e-6
+
+
 def test_determinism_bitwise():
     """Owner-computes scatter and fixed-order reductions: two runs are bit-identical."""
     torch.manual_seed(5)
