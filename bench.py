@@ -692,6 +692,18 @@ def run(a, rank, world, local, fs):
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (it cannot be read live);
         # reported only when the committed measurement was taken at this exact configuration
         traffic, traffic_src = None, None
+        for name in ('r06_bank_pass_pmc.json', 'r06_bank_pass_pmc_bf16_K131072.json'):      # this round's counters first
+            if traffic is not None:
+                break
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                c = pmc['config']
+                if ((c['B'], c['K'], c['n_data'], c['D']) == (B, a.nce_k, a.n_data, D)
+                        and c['dtype'] == ('bf16' if a.bank_dtype == 'bf16' else 'f32')
+                        and pmc['algorithmic_bytes_per_launch'] == bytes_per_launch):
+                    traffic, traffic_src = pmc['traffic_bytes_per_launch'], 'profiles/' + name
+            except (OSError, KeyError, ValueError):
+                pass
         for sweep_name in ('r04_bank_pass_sweep.json', 'r03_bank_pass_sweep.json'):
             if traffic is not None:
                 break

@@ -496,6 +496,37 @@ def test_sa_module_takes_the_fused_ballmax_path():
     assert not any('rowmax' in k for k in names), names
 
 
+def test_sa_module_with_caller_supplied_centres_falls_back_instead_of_raising():
+    """the fused first layer / ball-max gates looked at ``self.npoint`` while ``forward`` accepts the caller's
+    ``new_xyz`` (reference signature: pointnet2_modules.py:19).  30 centres (not a multiple of 4) must take the grouper path
+    and agree with the stock-op twin; 32 supplied centres take the fused path and agree too."""
+    from hcmoco_amd.pycontrast.networks.pointnet2 import pytorch_utils as pt_utils
+    from hcmoco_amd.pycontrast.networks.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.3], nsamples=[16], mlps=[[8, 16, 32]]).to(dev).train()
+    state = {k: v.clone() for k, v in sa.state_dict().items()}
+    xyz = torch.rand(2, 256, 3, device=dev)
+    feats = torch.randn(2, 8, 256, device=dev)
+    for ncentres in (30, 32):
+        centres = xyz[:, :ncentres].contiguous()
+        outs = {}
+        for fused in (True, False):
+            sa.load_state_dict(state)
+            old = pt_utils.FUSED
+            pt_utils.FUSED = fused
+            try:
+                f = feats.clone().requires_grad_()
+                nx, y = sa(xyz, f, new_xyz=centres)
+                y.square().sum().backward()
+            finally:
+                pt_utils.FUSED = old
+            assert nx.shape == (2, ncentres, 3) and y.shape == (2, 32, ncentres)
+            outs[fused] = (y.detach(), f.grad.clone())
+        assert torch.allclose(outs[True][0], outs[False][0], rtol=1e-4, atol=1e-5), ncentres
+        assert float((outs[True][1] - outs[False][1]).norm() / outs[False][1].norm()) < 1e-4, ncentres
+
+
 @pytest.mark.parametrize('B,C,C1,N,npnt,ns,radius', [(3, 0, 16, 512, 128, 16, 0.15), (2, 13, 32, 256, 64, 32, 0.3),
                                                       (2, 5, 8, 64, 16, 4, 0.2), (32, 96, 64, 4096, 1024, 16, 0.125),
                                                       (4, 0, 16, 4096, 4096, 16, 0.025), (4, 0, 32, 4096, 4096, 32, 0.125)])
