@@ -732,6 +732,203 @@ __global__ void ball_wxyz_merge_kernel(const float* __restrict__ wpart, int C, i
   dW[t] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The first SA level has NO point features (P == nullptr, z = W_xyz D): the two largest tensors of the network (y: 134 + 537 MB
+// at B = 32) and nothing to gather.  Two specialisations (r06):
+//
+// FORWARD, all channels per workgroup.  The (channel, slice) kernels above re-read D for every channel: C x 50 MB through L2 per
+// pass for a 50 MB tensor (C = 16 / 32), twice.  Here a workgroup owns a run of ball members, reads its D ONCE and loops over
+// the CC channels in registers: z is three FMAs.  ball_all_stats_kernel leaves per-block partial sums (2 CC accumulators per
+// thread, summed through LDS), ball_all_finish_kernel merges them in block order -> mean / invstd / running statistics,
+// ball_all_apply_kernel normalises and writes y: per pass D is read once, y written once = the algorithmic bytes.
+//
+// BACKWARD, one pass and no dz.  dz exists to be scattered into dP; without point features nothing needs it.  What is left --
+// dgamma, dbeta, dW_xyz -- are sums: with d = dy [y > 0], zc = z - mean,
+//     dbeta = S1 = sum d,   dgamma = invstd S2,  S2 = sum d zc,
+//     dW_xyz[c, k] = sum r D_k  with  r = a (d - b - q zc),  a = gamma invstd, b = S1 / M, q = S2 invstd^2 / M
+//                  = a (A_k - b B_k - q C_k),   A_k = sum d D_k,  B_k = sum D_k,  C_k = sum zc D_k
+// so ONE pass over (dy, y, D) accumulates S1, S2, A, C per channel (and B once), and a finish kernel combines them: 2 M floats
+// read instead of 4 M read + M written (ball_bwd_reduce + ball_bwd_apply), partial sums merged in slice order (deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int kAllBlocks = 1024;      // forward workgroups (partials merged by one block of the finish kernel)
+
+template <int CC>
+__global__ __launch_bounds__(kBT) void ball_all_stats_kernel(const float* __restrict__ D, const float* __restrict__ Wxyz,
+                                                             int HW, int total4, float* __restrict__ part) {
+  // total4 = B * HW / 4 float4 positions; position p -> image n = 4p / HW, offset w = 4p - n HW
+  __shared__ float red[2 * CC][kBT / 64];
+  __shared__ float4 wk[CC];                     // (w0, w1, w2, shift) per channel: LDS broadcast reads instead of 128 SGPRs
+  float s1[CC], s2[CC];
+  // shift of the one-pass variance: z of element 0 (any value near the mean does)
+  if (threadIdx.x < CC) {
+    const int c = threadIdx.x;
+    const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+    wk[c] = make_float4(w0, w1, w2, fmaf(w2, D[2 * (size_t)HW], fmaf(w1, D[(size_t)HW], w0 * D[0])));
+  }
+#pragma unroll
+  for (int c = 0; c < CC; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  __syncthreads();
+  for (int p = blockIdx.x * kBT + threadIdx.x; p < total4; p += gridDim.x * kBT) {
+    const int f = 4 * p, n = f / HW, w = f - n * HW;
+    const float* Dn = D + (size_t)n * 3 * HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)HW);
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const float4 q = wk[c];
+      const float a = fmaf(q.z, d2.x, fmaf(q.y, d1.x, q.x * d0.x)) - q.w, b = fmaf(q.z, d2.y, fmaf(q.y, d1.y, q.x * d0.y)) - q.w;
+      const float e = fmaf(q.z, d2.z, fmaf(q.y, d1.z, q.x * d0.z)) - q.w, h = fmaf(q.z, d2.w, fmaf(q.y, d1.w, q.x * d0.w)) - q.w;
+      s1[c] += (a + b) + (e + h);
+      s2[c] = fmaf(a, a, s2[c]); s2[c] = fmaf(b, b, s2[c]); s2[c] = fmaf(e, e, s2[c]); s2[c] = fmaf(h, h, s2[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CC; ++c) {
+    const float a = wave_sum(s1[c]), b = wave_sum(s2[c]);
+    if ((threadIdx.x & 63) == 0) { red[2 * c][threadIdx.x >> 6] = a; red[2 * c + 1][threadIdx.x >> 6] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * CC)
+    part[(size_t)blockIdx.x * 2 * CC + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// one block: partials [nblocks][2 C] in block order -> stats = [mean C][invstd C], running statistics
+__global__ void ball_all_finish_kernel(const float* __restrict__ part, int nblocks, int C, const float* __restrict__ D,
+                                       const float* __restrict__ Wxyz, int HW, float M, float eps, float momentum,
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float p1 = 0.f, p2 = 0.f;
+  for (int b = 0; b < nblocks; ++b) { p1 += part[(size_t)b * 2 * C + 2 * c]; p2 += part[(size_t)b * 2 * C + 2 * c + 1]; }
+  const float k = fmaf(Wxyz[3 * c + 2], D[2 * (size_t)HW], fmaf(Wxyz[3 * c + 1], D[(size_t)HW], Wxyz[3 * c] * D[0]));
+  const float invM = 1.f / M;
+  const float m1 = p1 * invM;
+  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+  const float mean = k + m1;
+  stats[c] = mean;
+  stats[C + c] = 1.f / sqrtf(var + eps);
+  if (rmean != nullptr) {
+    const float unbiased = M > 1.f ? var * (M / (M - 1.f)) : var;
+    rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+    rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+  }
+}
+
+template <int CC, bool RELU>
+__global__ __launch_bounds__(kBT) void ball_all_apply_kernel(const float* __restrict__ D, const float* __restrict__ Wxyz,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ stats, int HW, int total4,
+                                                             float* __restrict__ y) {
+  __shared__ float4 wk[CC];                     // (w0, w1, w2, mean)
+  __shared__ float2 sb[CC];                     // (gamma invstd, beta)
+  if (threadIdx.x < CC) {
+    const int c = threadIdx.x;
+    wk[c] = make_float4(Wxyz[3 * c], Wxyz[3 * c + 1], Wxyz[3 * c + 2], stats[c]);
+    sb[c] = make_float2(gamma[c] * stats[CC + c], beta[c]);
+  }
+  __syncthreads();
+  for (int p = blockIdx.x * kBT + threadIdx.x; p < total4; p += gridDim.x * kBT) {
+    const int f = 4 * p, n = f / HW, w = f - n * HW;
+    const float* Dn = D + (size_t)n * 3 * HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)HW);
+    float* yn = y + (size_t)n * CC * HW + w;
+#pragma unroll 8
+    for (int c = 0; c < CC; ++c) {
+      const float4 q = wk[c];
+      const float2 t = sb[c];
+      float4 r;
+      r.x = fmaf(fmaf(q.z, d2.x, fmaf(q.y, d1.x, q.x * d0.x)) - q.w, t.x, t.y);
+      r.y = fmaf(fmaf(q.z, d2.y, fmaf(q.y, d1.y, q.x * d0.y)) - q.w, t.x, t.y);
+      r.z = fmaf(fmaf(q.z, d2.z, fmaf(q.y, d1.z, q.x * d0.z)) - q.w, t.x, t.y);
+      r.w = fmaf(fmaf(q.z, d2.w, fmaf(q.y, d1.w, q.x * d0.w)) - q.w, t.x, t.y);
+      if (RELU) { r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w); }
+      *reinterpret_cast<float4*>(yn + (size_t)c * HW) = r;
+    }
+  }
+}
+
+// backward without point features: ONE pass, per (channel, slice) partial sums [S1, S2, A0..2, C0..2] (+ B0..2 by channel 0)
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void ball_bwd_nop_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ D, const float* __restrict__ Wxyz,
+                                                           const float* __restrict__ stats, Geo g, float* __restrict__ part8,
+                                                           float* __restrict__ partB) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  const float mean = stats[c];
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  float acc[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) acc[k] = 0.f;
+#pragma unroll 2
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const size_t o = ((size_t)n * g.C + c) * (size_t)g.HW + w;
+    float4 d = *reinterpret_cast<const float4*>(dy + o);
+    if (RELU) {
+      const float4 out = *reinterpret_cast<const float4*>(y + o);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+    }
+    const float* Dn = D + (size_t)n * 3 * g.HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
+    const float zx = fmaf(w2, d2.x, fmaf(w1, d1.x, w0 * d0.x)) - mean, zy = fmaf(w2, d2.y, fmaf(w1, d1.y, w0 * d0.y)) - mean;
+    const float zz = fmaf(w2, d2.z, fmaf(w1, d1.z, w0 * d0.z)) - mean, zw = fmaf(w2, d2.w, fmaf(w1, d1.w, w0 * d0.w)) - mean;
+    acc[0] += (d.x + d.y) + (d.z + d.w);
+    acc[1] = fmaf(d.x, zx, acc[1]); acc[1] = fmaf(d.y, zy, acc[1]); acc[1] = fmaf(d.z, zz, acc[1]); acc[1] = fmaf(d.w, zw, acc[1]);
+    acc[2] = fmaf(d.x, d0.x, acc[2]); acc[2] = fmaf(d.y, d0.y, acc[2]); acc[2] = fmaf(d.z, d0.z, acc[2]); acc[2] = fmaf(d.w, d0.w, acc[2]);
+    acc[3] = fmaf(d.x, d1.x, acc[3]); acc[3] = fmaf(d.y, d1.y, acc[3]); acc[3] = fmaf(d.z, d1.z, acc[3]); acc[3] = fmaf(d.w, d1.w, acc[3]);
+    acc[4] = fmaf(d.x, d2.x, acc[4]); acc[4] = fmaf(d.y, d2.y, acc[4]); acc[4] = fmaf(d.z, d2.z, acc[4]); acc[4] = fmaf(d.w, d2.w, acc[4]);
+    acc[5] = fmaf(zx, d0.x, acc[5]); acc[5] = fmaf(zy, d0.y, acc[5]); acc[5] = fmaf(zz, d0.z, acc[5]); acc[5] = fmaf(zw, d0.w, acc[5]);
+    acc[6] = fmaf(zx, d1.x, acc[6]); acc[6] = fmaf(zy, d1.y, acc[6]); acc[6] = fmaf(zz, d1.z, acc[6]); acc[6] = fmaf(zw, d1.w, acc[6]);
+    acc[7] = fmaf(zx, d2.x, acc[7]); acc[7] = fmaf(zy, d2.y, acc[7]); acc[7] = fmaf(zz, d2.z, acc[7]); acc[7] = fmaf(zw, d2.w, acc[7]);
+    if (c == 0) {          // block-uniform
+      acc[8] += (d0.x + d0.y) + (d0.z + d0.w);
+      acc[9] += (d1.x + d1.y) + (d1.z + d1.w);
+      acc[10] += (d2.x + d2.y) + (d2.z + d2.w);
+    }
+  }
+  __shared__ float red[11][kBT / 64];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float v = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8)
+    part8[((size_t)s * g.C + c) * 8 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (c == 0 && threadIdx.x >= 8 && threadIdx.x < 11)
+    partB[s * 3 + threadIdx.x - 8] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// one block, one thread per channel: slices in order -> dgamma, dbeta, dW_xyz
+__global__ void ball_bwd_nop_finish_kernel(const float* __restrict__ part8, const float* __restrict__ partB, int split, int C,
+                                           const float* __restrict__ gamma, const float* __restrict__ stats, float M,
+                                           float* __restrict__ gstats, float* __restrict__ dW) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bsum[3] = {0.f, 0.f, 0.f};
+  for (int s = 0; s < split; ++s) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] += part8[((size_t)s * C + c) * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bsum[k] += partB[s * 3 + k];
+  }
+  const float invstd = stats[C + c];
+  gstats[c] = t[1] * invstd;       // d gamma
+  gstats[C + c] = t[0];            // d beta
+  const float a = gamma[c] * invstd, b = t[0] / M, q = t[1] * invstd * invstd / M;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dW[3 * c + k] = a * (t[2 + k] - b * bsum[k] - q * t[5 + k]);
+}
+
 bool bad_ball(int N, int C, int np, int ns) {
   if (!(ns == 4 || ns == 8 || ns == 16 || ns == 32 || ns == 64) || np <= 0 || (np & 3) != 0) return true;
   return bad_shape(N, C, np * ns) || bad_shape(N, C, np);
@@ -910,7 +1107,13 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
 size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns) {
   if (bad_ball(B, C, np, ns)) return 0;
   const Geo g = make_geo(B, C, np * ns);
-  return (size_t)(2 + 5 * g.split) * (size_t)C;     // [2C results][2 split C partial sums][3 split C dW_xyz partials]
+  // [2C results][scratch]: with point features 2 split C partial sums + 3 split C dW_xyz partials; without (the all-channel
+  // forward / one-pass backward) kAllBlocks * 2C forward partials or split * (8C + 3) backward partials
+  size_t scratch = (size_t)5 * g.split * C;
+  const size_t fwd_all = (size_t)kAllBlocks * 2 * C, bwd_nop = (size_t)g.split * (8 * (size_t)C + 3);
+  if (fwd_all > scratch) scratch = fwd_all;
+  if (bwd_nop > scratch) scratch = bwd_nop;
+  return 2 * (size_t)C + scratch;
 }
 
 int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, const int32_t* idx, const float* gamma,
@@ -927,6 +1130,28 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
   // algorithmic bytes: y written once; idx, D and P each read once per pass (P's rows and D are re-read per channel out of L2)
   const double uniq = (double)B * np * ns * (P ? 4.0 : 3.0) + (P ? (double)B * C * N : 0.0);
   hcm::ProfSpan span(HCM_PROF_BALL_FWD, st, 4.0 * ((double)B * C * np * ns + 2.0 * uniq));
+  if (P == nullptr && (C == 16 || C == 32) && ((long long)B * g.HW) % 4 == 0) {
+    // no point features (first SA level): all channels per workgroup, D read once per pass
+    const int total4 = (int)(((long long)B * g.HW) / 4);
+    int blocks = (total4 + kBT - 1) / kBT;
+    if (blocks > kAllBlocks) blocks = kAllBlocks;
+    if (C == 16) ball_all_stats_kernel<16><<<blocks, kBT, 0, st>>>(D, Wxyz, g.HW, total4, part);
+    else ball_all_stats_kernel<32><<<blocks, kBT, 0, st>>>(D, Wxyz, g.HW, total4, part);
+    HCM_CHECK_LAUNCH();
+    ball_all_finish_kernel<<<1, 64, 0, st>>>(part, blocks, C, D, Wxyz, g.HW, (float)g.M, eps, momentum, running_mean, running_var,
+                                             stats);
+    HCM_CHECK_LAUNCH();
+    const int ablocks = (total4 + kBT - 1) / kBT < 4096 ? (total4 + kBT - 1) / kBT : 4096;
+    if (C == 16) {
+      if (relu) ball_all_apply_kernel<16, true><<<ablocks, kBT, 0, st>>>(D, Wxyz, gamma, beta, stats, g.HW, total4, y);
+      else ball_all_apply_kernel<16, false><<<ablocks, kBT, 0, st>>>(D, Wxyz, gamma, beta, stats, g.HW, total4, y);
+    } else {
+      if (relu) ball_all_apply_kernel<32, true><<<ablocks, kBT, 0, st>>>(D, Wxyz, gamma, beta, stats, g.HW, total4, y);
+      else ball_all_apply_kernel<32, false><<<ablocks, kBT, 0, st>>>(D, Wxyz, gamma, beta, stats, g.HW, total4, y);
+    }
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
 #define HCM_BALL_FWD(R, HP)                                                                                          \
   do {                                                                                                               \
     ball_stats_kernel<HP><<<grid, kBT, 0, st>>>(P, D, Wxyz, idx, g, bg, part);                                      \
@@ -944,7 +1169,7 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
 int hcm_ball_project_backward(const float* dy, const float* y, const float* P, const float* D, const float* Wxyz,
                               const int32_t* idx, const float* gamma, const float* stats, int relu, int B, int C, int N,
                               int np, int ns, float* dz, float* dWxyz, float* gstats, hcm_stream_t stream) {
-  if (bad_ball(B, C, np, ns) || !dy || (relu && !y) || (P && (N <= 0 || !idx)) || !D || !Wxyz || !gamma || !stats || !dz ||
+  if (bad_ball(B, C, np, ns) || !dy || (relu && !y) || (P && (N <= 0 || !idx || !dz)) || !D || !Wxyz || !gamma || !stats ||
       !dWxyz || !gstats)
     return (int)hipErrorInvalidValue;
   const Geo g = make_geo(B, C, np * ns);
@@ -954,6 +1179,18 @@ int hcm_ball_project_backward(const float* dy, const float* y, const float* P, c
   float* part = gstats + 2 * (size_t)C;
   float* wpart = part + 2 * (size_t)g.split * C;
   const double uniq = (double)B * np * ns * (P ? 4.0 : 3.0) + (P ? (double)B * C * N : 0.0);
+  if (P == nullptr && C <= 1024) {
+    // no point features: nobody needs dz (dz == NULL allowed) -- one pass over (dy, y, D), see ball_bwd_nop_kernel
+    hcm::ProfSpan span(HCM_PROF_BALL_BWD, st, 4.0 * (2.0 * (double)B * C * np * ns + uniq));       // dy, y once
+    float* part8 = gstats + 2 * (size_t)C;
+    float* partB = part8 + (size_t)g.split * C * 8;
+    if (relu) ball_bwd_nop_kernel<true><<<grid, kBT, 0, st>>>(dy, y, D, Wxyz, stats, g, part8, partB);
+    else ball_bwd_nop_kernel<false><<<grid, kBT, 0, st>>>(dy, y, D, Wxyz, stats, g, part8, partB);
+    HCM_CHECK_LAUNCH();
+    ball_bwd_nop_finish_kernel<<<1, 1024, 0, st>>>(part8, partB, g.split, C, gamma, stats, (float)g.M, gstats, dWxyz);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
   hcm::ProfSpan span(HCM_PROF_BALL_BWD, st, 4.0 * (5.0 * (double)B * C * np * ns + 2.0 * uniq));   // dy, y twice; dz written
 #define HCM_BALL_BWD(R, HP)                                                                                          \
   do {                                                                                                               \

@@ -209,14 +209,17 @@ class _BallProject(torch.autograd.Function):
         Cc = Wxyz.shape[0]
         N = P.shape[2] if P is not None else 0
         dy = dy.contiguous()
-        dz = torch.empty_like(y)
+        # without point features (the first SA level) nothing consumes dz: the entry point then makes ONE pass over (dy, y, D)
+        # and writes the parameter gradients only (the 134 / 537 MB dz tensors of that level are never allocated)
+        dz = torch.empty_like(y) if P is not None else None
         dW = torch.empty_like(Wxyz)
         gstats = torch.empty_like(stats)
         pp = C.c_void_p(0) if P is None else _f(P, 'ball_project')
         check(_lib.lib().hcm_ball_project_backward(_f(dy, 'ball_project'), _f(y, 'ball_project'), pp, _f(D, 'ball_project'),
                                                    _f(Wxyz, 'ball_project'), _i(idx, 'ball_project'), _f(gamma, 'ball_project'),
                                                    _f(stats, 'ball_project'), int(ctx.relu), B, Cc, N, npnt, ns,
-                                                   _f(dz, 'ball_project'), _f(dW, 'ball_project'), _f(gstats, 'ball_project'),
+                                                   C.c_void_p(0) if dz is None else _f(dz, 'ball_project'),
+                                                   _f(dW, 'ball_project'), _f(gstats, 'ball_project'),
                                                    _stream()), 'hcm_ball_project_backward')
         dP = None
         if P is not None and ctx.needs_input_grad[0]:

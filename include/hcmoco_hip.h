@@ -485,7 +485,9 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
  *             dP[b, c, idx], hcm_scatter_add_planned), dWxyz [C, 3] = sum_{b,i,j} dz D, gstats = [dgamma C][dbeta C][scratch]
  *             (same size as stats).  No gradient w.r.t. the coordinates (the reference's clouds carry none either:
  *             networks/build_backbone.py:379-445 builds them under no autograd-tracked input).
- * P may be NULL (no point features: the first SA level, z = Wxyz D; idx and N are then unused).  Wxyz [C, 3] row-major.
+ * P may be NULL (no point features: the first SA level, z = Wxyz D; idx and N are then unused, and so is dz -- nothing
+ * consumes it -- which may be NULL: the backward is then ONE pass over (dy, y, D), the forward reads D once per pass for all
+ * channels, C in {16, 32}).  Wxyz [C, 3] row-major.
  * idx [B, np, ns] int32 in [0, N); ns in {4, 8, 16, 32, 64}, np % 4 == 0.  Deterministic. */
 size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns);
 int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, const int32_t* idx, const float* gamma,
