@@ -750,7 +750,7 @@ __global__ void ball_wxyz_merge_kernel(const float* __restrict__ wpart, int C, i
 // so ONE pass over (dy, y, D) accumulates S1, S2, A, C per channel (and B once), and a finish kernel combines them: 2 M floats
 // read instead of 4 M read + M written (ball_bwd_reduce + ball_bwd_apply), partial sums merged in slice order (deterministic).
 // ---------------------------------------------------------------------------------------------
-constexpr int kAllBlocks = 1024;      // forward workgroups (partials merged by one block of the finish kernel)
+constexpr int kAllBlocks = 512;      // forward workgroups (partials merged by one block of the finish kernel)
 
 template <int CC>
 __global__ __launch_bounds__(kBT) void ball_all_stats_kernel(const float* __restrict__ D, const float* __restrict__ Wxyz,
@@ -794,23 +794,32 @@ __global__ __launch_bounds__(kBT) void ball_all_stats_kernel(const float* __rest
         (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// one block: partials [nblocks][2 C] in block order -> stats = [mean C][invstd C], running statistics
-__global__ void ball_all_finish_kernel(const float* __restrict__ part, int nblocks, int C, const float* __restrict__ D,
-                                       const float* __restrict__ Wxyz, int HW, float M, float eps, float momentum,
-                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats) {
-  const int c = threadIdx.x;
-  if (c >= C) return;
-  float p1 = 0.f, p2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) { p1 += part[(size_t)b * 2 * C + 2 * c]; p2 += part[(size_t)b * 2 * C + 2 * c + 1]; }
+// one workgroup (two waves) per channel: wave 0 merges the sum partials, wave 1 the square partials, each lane its blocks in
+// order, in DOUBLE (1024 partials added one after the other in fp32 cost 2e-6 of the mean offset: r06, first version), then a
+// fixed-order lane tree -> stats = [mean C][invstd C], running statistics
+__global__ __launch_bounds__(128) void ball_all_finish_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                              const float* __restrict__ D, const float* __restrict__ Wxyz, int HW,
+                                                              float M, float eps, float momentum, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, float* __restrict__ stats) {
+  __shared__ double sh[2];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, which = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int b = lane; b < nblocks; b += 64) acc += (double)part[(size_t)b * 2 * C + 2 * c + which];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) sh[which] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double invM = 1.0 / (double)M;
+  const double m1 = sh[0] * invM;
+  double var = sh[1] * invM - m1 * m1;
+  var = var > 0.0 ? var : 0.0;
   const float k = fmaf(Wxyz[3 * c + 2], D[2 * (size_t)HW], fmaf(Wxyz[3 * c + 1], D[(size_t)HW], Wxyz[3 * c] * D[0]));
-  const float invM = 1.f / M;
-  const float m1 = p1 * invM;
-  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
-  const float mean = k + m1;
+  const float mean = (float)((double)k + m1), varf = (float)var;
   stats[c] = mean;
-  stats[C + c] = 1.f / sqrtf(var + eps);
+  stats[C + c] = 1.f / sqrtf(varf + eps);
   if (rmean != nullptr) {
-    const float unbiased = M > 1.f ? var * (M / (M - 1.f)) : var;
+    const float unbiased = M > 1.f ? varf * (M / (M - 1.f)) : varf;
     rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
     rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
   }
@@ -914,19 +923,19 @@ __global__ void ball_bwd_nop_finish_kernel(const float* __restrict__ part8, cons
                                            float* __restrict__ gstats, float* __restrict__ dW) {
   const int c = threadIdx.x;
   if (c >= C) return;
-  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bsum[3] = {0.f, 0.f, 0.f};
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bsum[3] = {0, 0, 0};          // <= 64 slices, merged in slice order in double
   for (int s = 0; s < split; ++s) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] += part8[((size_t)s * C + c) * 8 + k];
+    for (int k = 0; k < 8; ++k) t[k] += (double)part8[((size_t)s * C + c) * 8 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) bsum[k] += partB[s * 3 + k];
+    for (int k = 0; k < 3; ++k) bsum[k] += (double)partB[s * 3 + k];
   }
-  const float invstd = stats[C + c];
-  gstats[c] = t[1] * invstd;       // d gamma
-  gstats[C + c] = t[0];            // d beta
-  const float a = gamma[c] * invstd, b = t[0] / M, q = t[1] * invstd * invstd / M;
+  const double invstd = (double)stats[C + c];
+  gstats[c] = (float)(t[1] * invstd);       // d gamma
+  gstats[C + c] = (float)t[0];              // d beta
+  const double a = (double)gamma[c] * invstd, b = t[0] / (double)M, q = t[1] * invstd * invstd / (double)M;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) dW[3 * c + k] = a * (t[2 + k] - b * bsum[k] - q * t[5 + k]);
+  for (int k = 0; k < 3; ++k) dW[3 * c + k] = (float)(a * (t[2 + k] - b * bsum[k] - q * t[5 + k]));
 }
 
 bool bad_ball(int N, int C, int np, int ns) {
@@ -1138,8 +1147,8 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
     if (C == 16) ball_all_stats_kernel<16><<<blocks, kBT, 0, st>>>(D, Wxyz, g.HW, total4, part);
     else ball_all_stats_kernel<32><<<blocks, kBT, 0, st>>>(D, Wxyz, g.HW, total4, part);
     HCM_CHECK_LAUNCH();
-    ball_all_finish_kernel<<<1, 64, 0, st>>>(part, blocks, C, D, Wxyz, g.HW, (float)g.M, eps, momentum, running_mean, running_var,
-                                             stats);
+    ball_all_finish_kernel<<<C, 128, 0, st>>>(part, blocks, C, D, Wxyz, g.HW, (float)g.M, eps, momentum, running_mean,
+                                              running_var, stats);
     HCM_CHECK_LAUNCH();
     const int ablocks = (total4 + kBT - 1) / kBT < 4096 ? (total4 + kBT - 1) / kBT : 4096;
     if (C == 16) {
