@@ -49,6 +49,19 @@ Geo make_geo(int N, int C, int HW) {
   return g;
 }
 
+// the same slicing for kernels whose workgroups own `group` channels each: ~1024 workgroups = (C / group) x split
+Geo make_geo_grouped(int N, int C, int HW, int group) {
+  Geo g = make_geo(N, C, HW);
+  int want = 1024 / ((C + group - 1) / group);
+  if (want < 1) want = 1;
+  if (want > kMaxSplit) want = kMaxSplit;
+  int per = (g.M + want - 1) / want;
+  per = ((per + kVec - 1) / kVec) * kVec;
+  g.per = per;
+  g.split = (g.M + per - 1) / per;
+  return g;
+}
+
 __device__ __forceinline__ size_t elem_offset(const Geo& g, int c, int f) {
   const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
   return ((size_t)n * g.C + c) * (size_t)g.HW + (size_t)(f - n * g.HW);
@@ -938,6 +951,249 @@ __global__ void ball_bwd_nop_finish_kernel(const float* __restrict__ part8, cons
   for (int k = 0; k < 3; ++k) dW[3 * c + k] = (float)(a * (t[2 + k] - b * bsum[k] - q * t[5 + k]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Levels 2-4 (point features present), sixteen channels per workgroup (r06).  The (channel, slice) kernels read idx and D
+// (16 bytes per ball member) once PER CHANNEL out of L2: 64-256 x the tensor per pass, and ran at 1.4-1.9 TB/s of their
+// algorithmic bytes (tools/probes/ball_levels.py).  Here a workgroup owns a slice of the members for kCH channels: idx and D
+// are read once per sixteen channels and the loop over the channels does the gather P[c][idx], three FMAs and the
+// normalisation.  Same slices, same partial-sum layout and merge order as the per-channel kernels.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCH = 16;
+
+__device__ __forceinline__ float4 ball_z_ch(const float* __restrict__ Prow, const int4& id, const float4& d0, const float4& d1,
+                                            const float4& d2, const float4& q) {
+  return make_float4(Prow[id.x] + fmaf(q.z, d2.x, fmaf(q.y, d1.x, q.x * d0.x)), Prow[id.y] + fmaf(q.z, d2.y, fmaf(q.y, d1.y, q.x * d0.y)),
+                     Prow[id.z] + fmaf(q.z, d2.z, fmaf(q.y, d1.z, q.x * d0.z)), Prow[id.w] + fmaf(q.z, d2.w, fmaf(q.y, d1.w, q.x * d0.w)));
+}
+
+// sum v over the workgroup for each of NV values held one per array slot; result for slot t valid in thread t (t < NV)
+template <int NV>
+__device__ __forceinline__ float block_sum_slots(float (&v)[NV], float (*red)[kBT / 64]) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float x = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = x;
+  }
+  __syncthreads();
+  const int t = threadIdx.x < NV ? threadIdx.x : 0;
+  return (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+}
+
+__global__ __launch_bounds__(kBT) void ball_stats_ch_kernel(const float* __restrict__ P, const float* __restrict__ D,
+                                                            const float* __restrict__ Wxyz, const int* __restrict__ idx, Geo g,
+                                                            BallGeo bg, float* __restrict__ part) {
+  __shared__ float4 wk[kCH];
+  __shared__ float red[2 * kCH][kBT / 64];
+  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  if (threadIdx.x < kCH) {
+    const int c = c0 + threadIdx.x;
+    const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+    wk[threadIdx.x] = make_float4(w0, w1, w2, P[(size_t)c * bg.N + idx[0]] + fmaf(w2, D[2 * (size_t)g.HW], fmaf(w1, D[(size_t)g.HW], w0 * D[0])));
+  }
+  __syncthreads();
+  float acc[2 * kCH];
+#pragma unroll
+  for (int k = 0; k < 2 * kCH; ++k) acc[k] = 0.f;
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
+    const float* Dn = D + (size_t)n * 3 * g.HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
+    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
+#pragma unroll
+    for (int c = 0; c < kCH; ++c) {
+      const float4 q = wk[c];
+      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
+      const float a = z.x - q.w, b = z.y - q.w, e = z.z - q.w, h = z.w - q.w;
+      acc[2 * c] += (a + b) + (e + h);
+      acc[2 * c + 1] = fmaf(a, a, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(b, b, acc[2 * c + 1]);
+      acc[2 * c + 1] = fmaf(e, e, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(h, h, acc[2 * c + 1]);
+    }
+  }
+  const float v = block_sum_slots<2 * kCH>(acc, red);
+  if (threadIdx.x < 2 * kCH)
+    part[(size_t)(2 * s + (threadIdx.x & 1)) * g.C + c0 + (threadIdx.x >> 1)] = v;
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void ball_apply_ch_kernel(
+    const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ Wxyz, const int* __restrict__ idx,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, Geo g, BallGeo bg,
+    float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats,
+    float* __restrict__ y) {
+  __shared__ float4 wk[kCH];                     // (w0, w1, w2, mean)
+  __shared__ float2 sb[kCH];                     // (gamma invstd, beta)
+  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
+  // statistics of the workgroup's channels: wave w merges channels w, w + 4, ... (slice order, one lane per slice)
+  for (int cl = threadIdx.x >> 6; cl < kCH; cl += kBT / 64) {
+    const int c = c0 + cl;
+    float p1, p2;
+    merge_partials(part, g, c, p1, p2);
+    if ((threadIdx.x & 63) == 0) {
+      const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+      const float k = P[(size_t)c * bg.N + idx[0]] + fmaf(w2, D[2 * (size_t)g.HW], fmaf(w1, D[(size_t)g.HW], w0 * D[0]));
+      const float invM = 1.f / (float)g.M;
+      const float m1 = p1 * invM;
+      const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+      const float mean = k + m1;
+      const float invstd = 1.f / sqrtf(var + eps);
+      wk[cl] = make_float4(w0, w1, w2, mean);
+      sb[cl] = make_float2(gamma[c] * invstd, beta[c]);
+      if (s == 0) {
+        stats[c] = mean;
+        stats[g.C + c] = invstd;
+        if (rmean != nullptr) {
+          const float unbiased = g.M > 1 ? var * ((float)g.M / (float)(g.M - 1)) : var;
+          rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+          rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
+    const float* Dn = D + (size_t)n * 3 * g.HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
+    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
+    float* yn = y + ((size_t)n * g.C + c0) * (size_t)g.HW + w;
+#pragma unroll 4
+    for (int c = 0; c < kCH; ++c) {
+      const float4 q = wk[c];
+      const float2 t = sb[c];
+      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
+      float4 r = make_float4(fmaf(z.x - q.w, t.x, t.y), fmaf(z.y - q.w, t.x, t.y), fmaf(z.z - q.w, t.x, t.y), fmaf(z.w - q.w, t.x, t.y));
+      if (RELU) { r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w); }
+      *reinterpret_cast<float4*>(yn + (size_t)c * g.HW) = r;
+    }
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void ball_bwd_reduce_ch_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
+    const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ stats, Geo g, BallGeo bg,
+    float* __restrict__ part) {
+  __shared__ float4 wk[kCH];                     // (w0, w1, w2, mean)
+  __shared__ float red[2 * kCH][kBT / 64];
+  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
+  if (threadIdx.x < kCH) {
+    const int c = c0 + threadIdx.x;
+    wk[threadIdx.x] = make_float4(Wxyz[3 * c], Wxyz[3 * c + 1], Wxyz[3 * c + 2], stats[c]);
+  }
+  __syncthreads();
+  float acc[2 * kCH];
+#pragma unroll
+  for (int k = 0; k < 2 * kCH; ++k) acc[k] = 0.f;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
+    const float* Dn = D + (size_t)n * 3 * g.HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
+    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
+    const size_t o = ((size_t)n * g.C + c0) * (size_t)g.HW + w;
+#pragma unroll 4
+    for (int c = 0; c < kCH; ++c) {
+      const float4 q = wk[c];
+      float4 d = *reinterpret_cast<const float4*>(dy + o + (size_t)c * g.HW);
+      if (RELU) {
+        const float4 out = *reinterpret_cast<const float4*>(y + o + (size_t)c * g.HW);
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
+      acc[2 * c] += (d.x + d.y) + (d.z + d.w);
+      acc[2 * c + 1] = fmaf(d.x, z.x - q.w, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(d.y, z.y - q.w, acc[2 * c + 1]);
+      acc[2 * c + 1] = fmaf(d.z, z.z - q.w, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(d.w, z.w - q.w, acc[2 * c + 1]);
+    }
+  }
+  const float v = block_sum_slots<2 * kCH>(acc, red);
+  if (threadIdx.x < 2 * kCH)
+    part[(size_t)(2 * s + (threadIdx.x & 1)) * g.C + c0 + (threadIdx.x >> 1)] = v;
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kBT) void ball_bwd_apply_ch_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
+    const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ gamma,
+    const float* __restrict__ stats, const float* __restrict__ part, Geo g, BallGeo bg, float* __restrict__ gstats,
+    float* __restrict__ dz, float* __restrict__ wpart) {
+  __shared__ float4 wk[kCH];                     // (w0, w1, w2, mean)
+  __shared__ float4 ab[kCH];                     // (a, b, q, -)
+  __shared__ float red[3 * kCH][kBT / 64];
+  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
+  const float invM = 1.f / (float)g.M;
+  for (int cl = threadIdx.x >> 6; cl < kCH; cl += kBT / 64) {
+    const int c = c0 + cl;
+    float p1, p2;
+    merge_partials(part, g, c, p1, p2);
+    if ((threadIdx.x & 63) == 0) {
+      const float mean = stats[c], invstd = stats[g.C + c];
+      wk[cl] = make_float4(Wxyz[3 * c], Wxyz[3 * c + 1], Wxyz[3 * c + 2], mean);
+      ab[cl] = make_float4(gamma[c] * invstd, p1 * invM, p2 * invstd * invstd * invM, 0.f);
+      if (s == 0) {
+        gstats[c] = p2 * invstd;     // d gamma
+        gstats[g.C + c] = p1;        // d beta
+      }
+    }
+  }
+  __syncthreads();
+  float t[3 * kCH];
+#pragma unroll
+  for (int k = 0; k < 3 * kCH; ++k) t[k] = 0.f;
+  const int beg = s * g.per, end = min(g.M, beg + g.per);
+  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
+    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
+    const int w = f - n * g.HW;
+    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
+    const float* Dn = D + (size_t)n * 3 * g.HW + w;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
+    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
+    const size_t o = ((size_t)n * g.C + c0) * (size_t)g.HW + w;
+#pragma unroll 2
+    for (int c = 0; c < kCH; ++c) {
+      const float4 q = wk[c], e = ab[c];
+      float4 d = *reinterpret_cast<const float4*>(dy + o + (size_t)c * g.HW);
+      if (RELU) {
+        const float4 out = *reinterpret_cast<const float4*>(y + o + (size_t)c * g.HW);
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
+      float4 r;
+      r.x = e.x * (d.x - e.y - (z.x - q.w) * e.z);
+      r.y = e.x * (d.y - e.y - (z.y - q.w) * e.z);
+      r.z = e.x * (d.z - e.y - (z.z - q.w) * e.z);
+      r.w = e.x * (d.w - e.y - (z.w - q.w) * e.z);
+      *reinterpret_cast<float4*>(dz + o + (size_t)c * g.HW) = r;
+      t[3 * c] = fmaf(r.x, d0.x, t[3 * c]); t[3 * c] = fmaf(r.y, d0.y, t[3 * c]);
+      t[3 * c] = fmaf(r.z, d0.z, t[3 * c]); t[3 * c] = fmaf(r.w, d0.w, t[3 * c]);
+      t[3 * c + 1] = fmaf(r.x, d1.x, t[3 * c + 1]); t[3 * c + 1] = fmaf(r.y, d1.y, t[3 * c + 1]);
+      t[3 * c + 1] = fmaf(r.z, d1.z, t[3 * c + 1]); t[3 * c + 1] = fmaf(r.w, d1.w, t[3 * c + 1]);
+      t[3 * c + 2] = fmaf(r.x, d2.x, t[3 * c + 2]); t[3 * c + 2] = fmaf(r.y, d2.y, t[3 * c + 2]);
+      t[3 * c + 2] = fmaf(r.z, d2.z, t[3 * c + 2]); t[3 * c + 2] = fmaf(r.w, d2.w, t[3 * c + 2]);
+    }
+  }
+  const float v = block_sum_slots<3 * kCH>(t, red);
+  if (threadIdx.x < 3 * kCH)                      // wpart[s][c][k], c0 + slot / 3, k = slot % 3
+    wpart[((size_t)s * g.C + c0) * 3 + threadIdx.x] = v;
+}
+
 bool bad_ball(int N, int C, int np, int ns) {
   if (!(ns == 4 || ns == 8 || ns == 16 || ns == 32 || ns == 64) || np <= 0 || (np & 3) != 0) return true;
   return bad_shape(N, C, np * ns) || bad_shape(N, C, np);
@@ -1116,9 +1372,10 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
 size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns) {
   if (bad_ball(B, C, np, ns)) return 0;
   const Geo g = make_geo(B, C, np * ns);
-  // [2C results][scratch]: with point features 2 split C partial sums + 3 split C dW_xyz partials; without (the all-channel
-  // forward / one-pass backward) kAllBlocks * 2C forward partials or split * (8C + 3) backward partials
-  size_t scratch = (size_t)5 * g.split * C;
+  // [2C results][scratch]: with point features 2 split C partial sums + 3 split C dW_xyz partials (split <= kMaxSplit: the
+  // sixteen-channel kernels slice finer than make_geo); without (the all-channel forward / one-pass backward) kAllBlocks * 2C
+  // forward partials or split * (8C + 3) backward partials
+  size_t scratch = (size_t)5 * kMaxSplit * C;
   const size_t fwd_all = (size_t)kAllBlocks * 2 * C, bwd_nop = (size_t)g.split * (8 * (size_t)C + 3);
   if (fwd_all > scratch) scratch = fwd_all;
   if (bwd_nop > scratch) scratch = bwd_nop;
@@ -1158,6 +1415,18 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
       if (relu) ball_all_apply_kernel<32, true><<<ablocks, kBT, 0, st>>>(D, Wxyz, gamma, beta, stats, g.HW, total4, y);
       else ball_all_apply_kernel<32, false><<<ablocks, kBT, 0, st>>>(D, Wxyz, gamma, beta, stats, g.HW, total4, y);
     }
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
+  if (P != nullptr && C % kCH == 0) {            // sixteen channels per workgroup: idx and D once per sixteen channels
+    const Geo g = make_geo_grouped(B, C, np * ns, kCH);
+    const dim3 gch(C / kCH, g.split);
+    ball_stats_ch_kernel<<<gch, kBT, 0, st>>>(P, D, Wxyz, idx, g, bg, part);
+    HCM_CHECK_LAUNCH();
+    if (relu) ball_apply_ch_kernel<true><<<gch, kBT, 0, st>>>(P, D, Wxyz, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
+                                                               running_var, stats, y);
+    else ball_apply_ch_kernel<false><<<gch, kBT, 0, st>>>(P, D, Wxyz, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
+                                                           running_var, stats, y);
     HCM_CHECK_LAUNCH();
     return 0;
   }
@@ -1201,6 +1470,20 @@ int hcm_ball_project_backward(const float* dy, const float* y, const float* P, c
     return 0;
   }
   hcm::ProfSpan span(HCM_PROF_BALL_BWD, st, 4.0 * (5.0 * (double)B * C * np * ns + 2.0 * uniq));   // dy, y twice; dz written
+  if (P != nullptr && C % kCH == 0) {
+    const Geo g = make_geo_grouped(B, C, np * ns, kCH);
+    float* wpart = part + 2 * (size_t)g.split * C;
+    const dim3 gch(C / kCH, g.split);
+    if (relu) ball_bwd_reduce_ch_kernel<true><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);
+    else ball_bwd_reduce_ch_kernel<false><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);
+    HCM_CHECK_LAUNCH();
+    if (relu) ball_bwd_apply_ch_kernel<true><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, g, bg, gstats, dz, wpart);
+    else ball_bwd_apply_ch_kernel<false><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, g, bg, gstats, dz, wpart);
+    HCM_CHECK_LAUNCH();
+    ball_wxyz_merge_kernel<<<(3 * C + 255) / 256, 256, 0, st>>>(wpart, C, g.split, dWxyz);
+    HCM_CHECK_LAUNCH();
+    return 0;
+  }
 #define HCM_BALL_BWD(R, HP)                                                                                          \
   do {                                                                                                               \
     ball_bwd_reduce_kernel<R, HP><<<grid, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);                \
