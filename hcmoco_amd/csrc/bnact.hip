@@ -49,19 +49,6 @@ Geo make_geo(int N, int C, int HW) {
   return g;
 }
 
-// the same slicing for kernels whose workgroups own `group` channels each: ~1024 workgroups = (C / group) x split
-Geo make_geo_grouped(int N, int C, int HW, int group) {
-  Geo g = make_geo(N, C, HW);
-  int want = 1024 / ((C + group - 1) / group);
-  if (want < 1) want = 1;
-  if (want > kMaxSplit) want = kMaxSplit;
-  int per = (g.M + want - 1) / want;
-  per = ((per + kVec - 1) / kVec) * kVec;
-  g.per = per;
-  g.split = (g.M + per - 1) / per;
-  return g;
-}
-
 __device__ __forceinline__ size_t elem_offset(const Geo& g, int c, int f) {
   const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
   return ((size_t)n * g.C + c) * (size_t)g.HW + (size_t)(f - n * g.HW);
@@ -952,247 +939,224 @@ __global__ void ball_bwd_nop_finish_kernel(const float* __restrict__ part8, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// Levels 2-4 (point features present), sixteen channels per workgroup (r06).  The (channel, slice) kernels read idx and D
-// (16 bytes per ball member) once PER CHANNEL out of L2: 64-256 x the tensor per pass, and ran at 1.4-1.9 TB/s of their
-// algorithmic bytes (tools/probes/ball_levels.py).  Here a workgroup owns a slice of the members for kCH channels: idx and D
-// are read once per sixteen channels and the loop over the channels does the gather P[c][idx], three FMAs and the
-// normalisation.  Same slices, same partial-sum layout and merge order as the per-channel kernels.
+// Levels 2-4 (point features present), the gathered row in LDS (r06).  tools/probes/ball_levels.py put the (channel, slice) kernels
+// at 1.4-1.9 TB/s of their algorithmic bytes.  Not the re-read of idx / D per channel (a sixteen-channels-per-workgroup form that
+// reads them once per sixteen channels was SLOWER: 210 / 400 us against 145 / 269 at level 2 -- its gathers leave the one-row
+// working set of a workgroup), but the gather itself: P[b, c, idx] is one 4-byte access per ball member through the texture
+// path, 64 different lines per wave instruction = 64 cycles, 67 M of them per pass at level 2 / ns = 32 = 0.11 ms on 256 CUs --
+// twice per direction.  A workgroup now owns (channel, image, sub-slice), copies the image's row of P (N floats <= 16 KB at every
+// level) into LDS with coalesced loads and gathers from THERE (64 lanes over 32 banks: a few cycles).  Partial sums per
+// (image, sub-slice) slot, merged slot by slot in order (lanes stride over the slots, fixed lane tree: deterministic).
 // ---------------------------------------------------------------------------------------------
-constexpr int kCH = 16;
-
-__device__ __forceinline__ float4 ball_z_ch(const float* __restrict__ Prow, const int4& id, const float4& d0, const float4& d1,
-                                            const float4& d2, const float4& q) {
-  return make_float4(Prow[id.x] + fmaf(q.z, d2.x, fmaf(q.y, d1.x, q.x * d0.x)), Prow[id.y] + fmaf(q.z, d2.y, fmaf(q.y, d1.y, q.x * d0.y)),
-                     Prow[id.z] + fmaf(q.z, d2.z, fmaf(q.y, d1.z, q.x * d0.z)), Prow[id.w] + fmaf(q.z, d2.w, fmaf(q.y, d1.w, q.x * d0.w)));
+struct RowGeo {
+  int C, HW, N, np, ns;   // channels, members per image (np * ns), source points
+  int B, sub, per;        // images, sub-slices per image, members per sub-slice (multiple of 4)
+  int M;                  // B * HW
+};
+RowGeo make_row_geo(int B, int C, int N, int np, int ns) {
+  RowGeo r;
+  r.C = C; r.HW = np * ns; r.N = N; r.np = np; r.ns = ns; r.B = B; r.M = B * r.HW;
+  // enough workgroups for the chip, at least 4 float4 per thread where the image allows it
+  int sub = 1;
+  while ((long long)C * B * sub < 2048 && r.HW / (sub * 2) >= kVec * 4) sub *= 2;
+  int per = (r.HW + sub - 1) / sub;
+  per = (per + 3) & ~3;
+  r.sub = (r.HW + per - 1) / per;
+  r.per = per;
+  return r;
+}
+__device__ __forceinline__ void stage_row(float* __restrict__ row, const float* __restrict__ src, int N) {
+  if ((N & 3) == 0) {
+    for (int e = threadIdx.x; e < (N >> 2); e += kBT) reinterpret_cast<float4*>(row)[e] = reinterpret_cast<const float4*>(src)[e];
+  } else {
+    for (int e = threadIdx.x; e < N; e += kBT) row[e] = src[e];
+  }
+}
+// merge the slot partials of channel c: lanes stride over the slots in order, then the fixed lane tree
+__device__ __forceinline__ void merge_slots(const float* part, int nslots, int C, int c, float& p1, float& p2) {
+  const int lane = threadIdx.x & 63;
+  p1 = 0.f; p2 = 0.f;
+  for (int sl = lane; sl < nslots; sl += 64) { p1 += part[(size_t)(2 * sl) * C + c]; p2 += part[(size_t)(2 * sl + 1) * C + c]; }
+  p1 = wave_sum(p1);
+  p2 = wave_sum(p2);
+}
+__device__ __forceinline__ float4 ball_z_row(const float* __restrict__ row, const int* __restrict__ idx, const float* __restrict__ Dn,
+                                              int HW, int w, float w0, float w1, float w2) {
+  const int4 id = *reinterpret_cast<const int4*>(idx + w);
+  const float4 d0 = *reinterpret_cast<const float4*>(Dn + w);
+  const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)HW + w);
+  const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)HW + w);
+  return make_float4(row[id.x] + fmaf(w2, d2.x, fmaf(w1, d1.x, w0 * d0.x)), row[id.y] + fmaf(w2, d2.y, fmaf(w1, d1.y, w0 * d0.y)),
+                     row[id.z] + fmaf(w2, d2.z, fmaf(w1, d1.z, w0 * d0.z)), row[id.w] + fmaf(w2, d2.w, fmaf(w1, d1.w, w0 * d0.w)));
+}
+// shift of the one-pass variance: z of the channel's first member (image 0)
+__device__ __forceinline__ float ball_k_row(const float* P, const int* idx, const float* D, int c, int N, int HW, float w0, float w1,
+                                            float w2) {
+  return P[(size_t)c * N + idx[0]] + fmaf(w2, D[2 * (size_t)HW], fmaf(w1, D[(size_t)HW], w0 * D[0]));
 }
 
-// sum v over the workgroup for each of NV values held one per array slot; result for slot t valid in thread t (t < NV)
-template <int NV>
-__device__ __forceinline__ float block_sum_slots(float (&v)[NV], float (*red)[kBT / 64]) {
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const float x = wave_sum(v[k]);
-    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = x;
-  }
+__global__ __launch_bounds__(kBT) void ball_stats_row_kernel(const float* __restrict__ P, const float* __restrict__ D,
+                                                             const float* __restrict__ Wxyz, const int* __restrict__ idx, RowGeo r,
+                                                             float* __restrict__ part) {
+  extern __shared__ float row[];
+  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  const float k = ball_k_row(P, idx, D, c, r.N, r.HW, w0, w1, w2);
   __syncthreads();
-  const int t = threadIdx.x < NV ? threadIdx.x : 0;
-  return (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
-}
-
-__global__ __launch_bounds__(kBT) void ball_stats_ch_kernel(const float* __restrict__ P, const float* __restrict__ D,
-                                                            const float* __restrict__ Wxyz, const int* __restrict__ idx, Geo g,
-                                                            BallGeo bg, float* __restrict__ part) {
-  __shared__ float4 wk[kCH];
-  __shared__ float red[2 * kCH][kBT / 64];
-  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
-  const int beg = s * g.per, end = min(g.M, beg + g.per);
-  if (threadIdx.x < kCH) {
-    const int c = c0 + threadIdx.x;
-    const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
-    wk[threadIdx.x] = make_float4(w0, w1, w2, P[(size_t)c * bg.N + idx[0]] + fmaf(w2, D[2 * (size_t)g.HW], fmaf(w1, D[(size_t)g.HW], w0 * D[0])));
+  const int beg = j * r.per, end = min(r.HW, beg + r.per);
+  const int* idn = idx + (size_t)n * r.HW;
+  const float* Dn = D + (size_t)n * 3 * r.HW;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+  for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
+    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
+    const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
+    s1 += (a + b) + (cc + d);
+    s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(cc, cc, s2); s2 = fmaf(d, d, s2);
   }
-  __syncthreads();
-  float acc[2 * kCH];
-#pragma unroll
-  for (int k = 0; k < 2 * kCH; ++k) acc[k] = 0.f;
-  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
-    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
-    const int w = f - n * g.HW;
-    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
-    const float* Dn = D + (size_t)n * 3 * g.HW + w;
-    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
-    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
-    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
-    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
-#pragma unroll
-    for (int c = 0; c < kCH; ++c) {
-      const float4 q = wk[c];
-      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
-      const float a = z.x - q.w, b = z.y - q.w, e = z.z - q.w, h = z.w - q.w;
-      acc[2 * c] += (a + b) + (e + h);
-      acc[2 * c + 1] = fmaf(a, a, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(b, b, acc[2 * c + 1]);
-      acc[2 * c + 1] = fmaf(e, e, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(h, h, acc[2 * c + 1]);
-    }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * blockIdx.y) * r.C + c] = s1;
+    part[(size_t)(2 * blockIdx.y + 1) * r.C + c] = s2;
   }
-  const float v = block_sum_slots<2 * kCH>(acc, red);
-  if (threadIdx.x < 2 * kCH)
-    part[(size_t)(2 * s + (threadIdx.x & 1)) * g.C + c0 + (threadIdx.x >> 1)] = v;
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(kBT) void ball_apply_ch_kernel(
+__global__ __launch_bounds__(kBT) void ball_apply_row_kernel(
     const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ Wxyz, const int* __restrict__ idx,
-    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, Geo g, BallGeo bg,
-    float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats,
-    float* __restrict__ y) {
-  __shared__ float4 wk[kCH];                     // (w0, w1, w2, mean)
-  __shared__ float2 sb[kCH];                     // (gamma invstd, beta)
-  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
-  // statistics of the workgroup's channels: wave w merges channels w, w + 4, ... (slice order, one lane per slice)
-  for (int cl = threadIdx.x >> 6; cl < kCH; cl += kBT / 64) {
-    const int c = c0 + cl;
-    float p1, p2;
-    merge_partials(part, g, c, p1, p2);
-    if ((threadIdx.x & 63) == 0) {
-      const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
-      const float k = P[(size_t)c * bg.N + idx[0]] + fmaf(w2, D[2 * (size_t)g.HW], fmaf(w1, D[(size_t)g.HW], w0 * D[0]));
-      const float invM = 1.f / (float)g.M;
-      const float m1 = p1 * invM;
-      const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
-      const float mean = k + m1;
-      const float invstd = 1.f / sqrtf(var + eps);
-      wk[cl] = make_float4(w0, w1, w2, mean);
-      sb[cl] = make_float2(gamma[c] * invstd, beta[c]);
-      if (s == 0) {
-        stats[c] = mean;
-        stats[g.C + c] = invstd;
-        if (rmean != nullptr) {
-          const float unbiased = g.M > 1 ? var * ((float)g.M / (float)(g.M - 1)) : var;
-          rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
-          rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
-        }
-      }
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, RowGeo r, float eps,
+    float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
+  extern __shared__ float row[];
+  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
+  float p1, p2;
+  merge_slots(part, r.B * r.sub, r.C, c, p1, p2);
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  const float k = ball_k_row(P, idx, D, c, r.N, r.HW, w0, w1, w2);
+  const float invM = 1.f / (float)r.M;
+  const float m1 = p1 * invM;
+  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+  const float mean = k + m1;
+  const float invstd = 1.f / sqrtf(var + eps);
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    stats[c] = mean;
+    stats[r.C + c] = invstd;
+    if (rmean != nullptr) {
+      const float unbiased = r.M > 1 ? var * ((float)r.M / (float)(r.M - 1)) : var;
+      rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
+      rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
     }
   }
+  const float sc = gamma[c] * invstd, bt = beta[c];
   __syncthreads();
-  const int beg = s * g.per, end = min(g.M, beg + g.per);
-  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
-    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
-    const int w = f - n * g.HW;
-    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
-    const float* Dn = D + (size_t)n * 3 * g.HW + w;
-    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
-    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
-    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
-    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
-    float* yn = y + ((size_t)n * g.C + c0) * (size_t)g.HW + w;
-#pragma unroll 4
-    for (int c = 0; c < kCH; ++c) {
-      const float4 q = wk[c];
-      const float2 t = sb[c];
-      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
-      float4 r = make_float4(fmaf(z.x - q.w, t.x, t.y), fmaf(z.y - q.w, t.x, t.y), fmaf(z.z - q.w, t.x, t.y), fmaf(z.w - q.w, t.x, t.y));
-      if (RELU) { r.x = relu_nan(r.x); r.y = relu_nan(r.y); r.z = relu_nan(r.z); r.w = relu_nan(r.w); }
-      *reinterpret_cast<float4*>(yn + (size_t)c * g.HW) = r;
-    }
+  const int beg = j * r.per, end = min(r.HW, beg + r.per);
+  const int* idn = idx + (size_t)n * r.HW;
+  const float* Dn = D + (size_t)n * 3 * r.HW;
+  float* yn = y + ((size_t)n * r.C + c) * (size_t)r.HW;
+#pragma unroll 2
+  for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
+    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
+    float4 o = make_float4(fmaf(v.x - mean, sc, bt), fmaf(v.y - mean, sc, bt), fmaf(v.z - mean, sc, bt), fmaf(v.w - mean, sc, bt));
+    if (RELU) { o.x = relu_nan(o.x); o.y = relu_nan(o.y); o.z = relu_nan(o.z); o.w = relu_nan(o.w); }
+    *reinterpret_cast<float4*>(yn + w) = o;
   }
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(kBT) void ball_bwd_reduce_ch_kernel(
+__global__ __launch_bounds__(kBT) void ball_bwd_reduce_row_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
-    const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ stats, Geo g, BallGeo bg,
+    const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ stats, RowGeo r,
     float* __restrict__ part) {
-  __shared__ float4 wk[kCH];                     // (w0, w1, w2, mean)
-  __shared__ float red[2 * kCH][kBT / 64];
-  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
-  if (threadIdx.x < kCH) {
-    const int c = c0 + threadIdx.x;
-    wk[threadIdx.x] = make_float4(Wxyz[3 * c], Wxyz[3 * c + 1], Wxyz[3 * c + 2], stats[c]);
-  }
+  extern __shared__ float row[];
+  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  const float mean = stats[c];
   __syncthreads();
-  float acc[2 * kCH];
-#pragma unroll
-  for (int k = 0; k < 2 * kCH; ++k) acc[k] = 0.f;
-  const int beg = s * g.per, end = min(g.M, beg + g.per);
-  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
-    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
-    const int w = f - n * g.HW;
-    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
-    const float* Dn = D + (size_t)n * 3 * g.HW + w;
-    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
-    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
-    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
-    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
-    const size_t o = ((size_t)n * g.C + c0) * (size_t)g.HW + w;
-#pragma unroll 4
-    for (int c = 0; c < kCH; ++c) {
-      const float4 q = wk[c];
-      float4 d = *reinterpret_cast<const float4*>(dy + o + (size_t)c * g.HW);
-      if (RELU) {
-        const float4 out = *reinterpret_cast<const float4*>(y + o + (size_t)c * g.HW);
-        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
-      }
-      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
-      acc[2 * c] += (d.x + d.y) + (d.z + d.w);
-      acc[2 * c + 1] = fmaf(d.x, z.x - q.w, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(d.y, z.y - q.w, acc[2 * c + 1]);
-      acc[2 * c + 1] = fmaf(d.z, z.z - q.w, acc[2 * c + 1]); acc[2 * c + 1] = fmaf(d.w, z.w - q.w, acc[2 * c + 1]);
+  const int beg = j * r.per, end = min(r.HW, beg + r.per);
+  const int* idn = idx + (size_t)n * r.HW;
+  const float* Dn = D + (size_t)n * 3 * r.HW;
+  const size_t o0 = ((size_t)n * r.C + c) * (size_t)r.HW;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+  for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
+    float4 d = *reinterpret_cast<const float4*>(dy + o0 + w);
+    if (RELU) {
+      const float4 out = *reinterpret_cast<const float4*>(y + o0 + w);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
     }
+    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
+    s1 += (d.x + d.y) + (d.z + d.w);
+    s2 = fmaf(d.x, v.x - mean, s2); s2 = fmaf(d.y, v.y - mean, s2);
+    s2 = fmaf(d.z, v.z - mean, s2); s2 = fmaf(d.w, v.w - mean, s2);
   }
-  const float v = block_sum_slots<2 * kCH>(acc, red);
-  if (threadIdx.x < 2 * kCH)
-    part[(size_t)(2 * s + (threadIdx.x & 1)) * g.C + c0 + (threadIdx.x >> 1)] = v;
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    part[(size_t)(2 * blockIdx.y) * r.C + c] = s1;
+    part[(size_t)(2 * blockIdx.y + 1) * r.C + c] = s2;
+  }
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(kBT) void ball_bwd_apply_ch_kernel(
+__global__ __launch_bounds__(kBT) void ball_bwd_apply_row_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
     const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ gamma,
-    const float* __restrict__ stats, const float* __restrict__ part, Geo g, BallGeo bg, float* __restrict__ gstats,
+    const float* __restrict__ stats, const float* __restrict__ part, RowGeo r, float* __restrict__ gstats,
     float* __restrict__ dz, float* __restrict__ wpart) {
-  __shared__ float4 wk[kCH];                     // (w0, w1, w2, mean)
-  __shared__ float4 ab[kCH];                     // (a, b, q, -)
-  __shared__ float red[3 * kCH][kBT / 64];
-  const int c0 = blockIdx.x * kCH, s = blockIdx.y;
-  const float invM = 1.f / (float)g.M;
-  for (int cl = threadIdx.x >> 6; cl < kCH; cl += kBT / 64) {
-    const int c = c0 + cl;
-    float p1, p2;
-    merge_partials(part, g, c, p1, p2);
-    if ((threadIdx.x & 63) == 0) {
-      const float mean = stats[c], invstd = stats[g.C + c];
-      wk[cl] = make_float4(Wxyz[3 * c], Wxyz[3 * c + 1], Wxyz[3 * c + 2], mean);
-      ab[cl] = make_float4(gamma[c] * invstd, p1 * invM, p2 * invstd * invstd * invM, 0.f);
-      if (s == 0) {
-        gstats[c] = p2 * invstd;     // d gamma
-        gstats[g.C + c] = p1;        // d beta
-      }
-    }
+  extern __shared__ float row[];
+  __shared__ float sh3[3][kBT / 64];
+  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
+  float p1, p2;
+  merge_slots(part, r.B * r.sub, r.C, c, p1, p2);
+  const float mean = stats[c], invstd = stats[r.C + c];
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    gstats[c] = p2 * invstd;     // d gamma
+    gstats[r.C + c] = p1;        // d beta
   }
+  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  const float invM = 1.f / (float)r.M;
+  const float a = gamma[c] * invstd, b = p1 * invM, q = p2 * invstd * invstd * invM;
   __syncthreads();
-  float t[3 * kCH];
-#pragma unroll
-  for (int k = 0; k < 3 * kCH; ++k) t[k] = 0.f;
-  const int beg = s * g.per, end = min(g.M, beg + g.per);
-  for (int f = beg + threadIdx.x * 4; f < end; f += kVec) {
-    const int n = g.shift >= 0 ? (f >> g.shift) : (f / g.HW);
-    const int w = f - n * g.HW;
-    const int4 id = *reinterpret_cast<const int4*>(idx + (size_t)n * g.HW + w);
-    const float* Dn = D + (size_t)n * 3 * g.HW + w;
-    const float4 d0 = *reinterpret_cast<const float4*>(Dn);
-    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)g.HW);
-    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)g.HW);
-    const float* Pn = P + ((size_t)n * g.C + c0) * bg.N;
-    const size_t o = ((size_t)n * g.C + c0) * (size_t)g.HW + w;
+  const int beg = j * r.per, end = min(r.HW, beg + r.per);
+  const int* idn = idx + (size_t)n * r.HW;
+  const float* Dn = D + (size_t)n * 3 * r.HW;
+  const size_t o0 = ((size_t)n * r.C + c) * (size_t)r.HW;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll 2
-    for (int c = 0; c < kCH; ++c) {
-      const float4 q = wk[c], e = ab[c];
-      float4 d = *reinterpret_cast<const float4*>(dy + o + (size_t)c * g.HW);
-      if (RELU) {
-        const float4 out = *reinterpret_cast<const float4*>(y + o + (size_t)c * g.HW);
-        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
-      }
-      const float4 z = ball_z_ch(Pn + (size_t)c * bg.N, id, d0, d1, d2, q);
-      float4 r;
-      r.x = e.x * (d.x - e.y - (z.x - q.w) * e.z);
-      r.y = e.x * (d.y - e.y - (z.y - q.w) * e.z);
-      r.z = e.x * (d.z - e.y - (z.z - q.w) * e.z);
-      r.w = e.x * (d.w - e.y - (z.w - q.w) * e.z);
-      *reinterpret_cast<float4*>(dz + o + (size_t)c * g.HW) = r;
-      t[3 * c] = fmaf(r.x, d0.x, t[3 * c]); t[3 * c] = fmaf(r.y, d0.y, t[3 * c]);
-      t[3 * c] = fmaf(r.z, d0.z, t[3 * c]); t[3 * c] = fmaf(r.w, d0.w, t[3 * c]);
-      t[3 * c + 1] = fmaf(r.x, d1.x, t[3 * c + 1]); t[3 * c + 1] = fmaf(r.y, d1.y, t[3 * c + 1]);
-      t[3 * c + 1] = fmaf(r.z, d1.z, t[3 * c + 1]); t[3 * c + 1] = fmaf(r.w, d1.w, t[3 * c + 1]);
-      t[3 * c + 2] = fmaf(r.x, d2.x, t[3 * c + 2]); t[3 * c + 2] = fmaf(r.y, d2.y, t[3 * c + 2]);
-      t[3 * c + 2] = fmaf(r.z, d2.z, t[3 * c + 2]); t[3 * c + 2] = fmaf(r.w, d2.w, t[3 * c + 2]);
+  for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
+    float4 d = *reinterpret_cast<const float4*>(dy + o0 + w);
+    if (RELU) {
+      const float4 out = *reinterpret_cast<const float4*>(y + o0 + w);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
     }
+    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
+    float4 g4;
+    g4.x = a * (d.x - b - (v.x - mean) * q);
+    g4.y = a * (d.y - b - (v.y - mean) * q);
+    g4.z = a * (d.z - b - (v.z - mean) * q);
+    g4.w = a * (d.w - b - (v.w - mean) * q);
+    *reinterpret_cast<float4*>(dz + o0 + w) = g4;
+    const float4 d0 = *reinterpret_cast<const float4*>(Dn + w);
+    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)r.HW + w);
+    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)r.HW + w);
+    t0 = fmaf(g4.x, d0.x, t0); t0 = fmaf(g4.y, d0.y, t0); t0 = fmaf(g4.z, d0.z, t0); t0 = fmaf(g4.w, d0.w, t0);
+    t1 = fmaf(g4.x, d1.x, t1); t1 = fmaf(g4.y, d1.y, t1); t1 = fmaf(g4.z, d1.z, t1); t1 = fmaf(g4.w, d1.w, t1);
+    t2 = fmaf(g4.x, d2.x, t2); t2 = fmaf(g4.y, d2.y, t2); t2 = fmaf(g4.z, d2.z, t2); t2 = fmaf(g4.w, d2.w, t2);
   }
-  const float v = block_sum_slots<3 * kCH>(t, red);
-  if (threadIdx.x < 3 * kCH)                      // wpart[s][c][k], c0 + slot / 3, k = slot % 3
-    wpart[((size_t)s * g.C + c0) * 3 + threadIdx.x] = v;
+  t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+  if ((threadIdx.x & 63) == 0) { sh3[0][threadIdx.x >> 6] = t0; sh3[1][threadIdx.x >> 6] = t1; sh3[2][threadIdx.x >> 6] = t2; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    wpart[((size_t)blockIdx.y * r.C + c) * 3 + threadIdx.x] =
+        (sh3[threadIdx.x][0] + sh3[threadIdx.x][1]) + (sh3[threadIdx.x][2] + sh3[threadIdx.x][3]);
 }
+
+constexpr int kRowMaxN = 32768;      // 128 KB of LDS for the row
+inline bool row_ok(const RowGeo& r) { return r.N <= kRowMaxN && (r.HW & 3) == 0 && r.B * r.sub <= 65535; }
 
 bool bad_ball(int N, int C, int np, int ns) {
   if (!(ns == 4 || ns == 8 || ns == 16 || ns == 32 || ns == 64) || np <= 0 || (np & 3) != 0) return true;
@@ -1372,10 +1336,15 @@ int hcm_bn_relu_ballmax_backward(const float* dout, const float* out, const int3
 size_t hcm_ball_project_stats_floats(int B, int C, int np, int ns) {
   if (bad_ball(B, C, np, ns)) return 0;
   const Geo g = make_geo(B, C, np * ns);
-  // [2C results][scratch]: with point features 2 split C partial sums + 3 split C dW_xyz partials (split <= kMaxSplit: the
-  // sixteen-channel kernels slice finer than make_geo); without (the all-channel forward / one-pass backward) kAllBlocks * 2C
+  // [2C results][scratch]: with point features 2 S C partial sums + 3 S C dW_xyz partials (S = the slice count of the
+  // per-channel kernels or the (image, sub-slice) slots of the row kernels, whichever is larger); without (the all-channel forward / one-pass backward) kAllBlocks * 2C
   // forward partials or split * (8C + 3) backward partials
-  size_t scratch = (size_t)5 * kMaxSplit * C;
+  size_t scratch = (size_t)5 * g.split * C;
+  {
+    const RowGeo r = make_row_geo(B, C, 1, np, ns);          // (the slot count does not depend on N)
+    const size_t rows = (size_t)5 * r.B * r.sub * C;
+    if (rows > scratch) scratch = rows;
+  }
   const size_t fwd_all = (size_t)kAllBlocks * 2 * C, bwd_nop = (size_t)g.split * (8 * (size_t)C + 3);
   if (fwd_all > scratch) scratch = fwd_all;
   if (bwd_nop > scratch) scratch = bwd_nop;
@@ -1418,17 +1387,26 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
     HCM_CHECK_LAUNCH();
     return 0;
   }
-  if (P != nullptr && C % kCH == 0) {            // sixteen channels per workgroup: idx and D once per sixteen channels
-    const Geo g = make_geo_grouped(B, C, np * ns, kCH);
-    const dim3 gch(C / kCH, g.split);
-    ball_stats_ch_kernel<<<gch, kBT, 0, st>>>(P, D, Wxyz, idx, g, bg, part);
-    HCM_CHECK_LAUNCH();
-    if (relu) ball_apply_ch_kernel<true><<<gch, kBT, 0, st>>>(P, D, Wxyz, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
-                                                               running_var, stats, y);
-    else ball_apply_ch_kernel<false><<<gch, kBT, 0, st>>>(P, D, Wxyz, idx, gamma, beta, part, g, bg, eps, momentum, running_mean,
+  if (P != nullptr) {
+    const RowGeo r = make_row_geo(B, C, N, np, ns);
+    if (row_ok(r) && hcm_ball_project_stats_floats(B, C, np, ns) >= (size_t)(2 + 5 * (size_t)r.B * r.sub) * C) {
+      const dim3 gr(C, r.B * r.sub);
+      const size_t lds = (size_t)r.N * sizeof(float);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(ball_stats_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      ball_stats_row_kernel<<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, r, part);
+      HCM_CHECK_LAUNCH();
+      if (relu) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ball_apply_row_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ball_apply_row_kernel<true><<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, gamma, beta, part, r, eps, momentum, running_mean,
+                                                          running_var, stats, y);
+      } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ball_apply_row_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ball_apply_row_kernel<false><<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, gamma, beta, part, r, eps, momentum, running_mean,
                                                            running_var, stats, y);
-    HCM_CHECK_LAUNCH();
-    return 0;
+      }
+      HCM_CHECK_LAUNCH();
+      return 0;
+    }
   }
 #define HCM_BALL_FWD(R, HP)                                                                                          \
   do {                                                                                                               \
@@ -1470,19 +1448,29 @@ int hcm_ball_project_backward(const float* dy, const float* y, const float* P, c
     return 0;
   }
   hcm::ProfSpan span(HCM_PROF_BALL_BWD, st, 4.0 * (5.0 * (double)B * C * np * ns + 2.0 * uniq));   // dy, y twice; dz written
-  if (P != nullptr && C % kCH == 0) {
-    const Geo g = make_geo_grouped(B, C, np * ns, kCH);
-    float* wpart = part + 2 * (size_t)g.split * C;
-    const dim3 gch(C / kCH, g.split);
-    if (relu) ball_bwd_reduce_ch_kernel<true><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);
-    else ball_bwd_reduce_ch_kernel<false><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, stats, g, bg, part);
-    HCM_CHECK_LAUNCH();
-    if (relu) ball_bwd_apply_ch_kernel<true><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, g, bg, gstats, dz, wpart);
-    else ball_bwd_apply_ch_kernel<false><<<gch, kBT, 0, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, g, bg, gstats, dz, wpart);
-    HCM_CHECK_LAUNCH();
-    ball_wxyz_merge_kernel<<<(3 * C + 255) / 256, 256, 0, st>>>(wpart, C, g.split, dWxyz);
-    HCM_CHECK_LAUNCH();
-    return 0;
+  if (P != nullptr) {
+    const RowGeo r = make_row_geo(B, C, N, np, ns);
+    if (row_ok(r) && hcm_ball_project_stats_floats(B, C, np, ns) >= (size_t)(2 + 5 * (size_t)r.B * r.sub) * C) {
+      const dim3 gr(C, r.B * r.sub);
+      const size_t lds = (size_t)r.N * sizeof(float);
+      float* wp = part + 2 * (size_t)r.B * r.sub * C;
+#define HCM_BALL_BWD_ROW(R)                                                                                                        \
+  do {                                                                                                                             \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_bwd_reduce_row_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                        (int)lds);                                                                                                 \
+    ball_bwd_reduce_row_kernel<R><<<gr, kBT, lds, st>>>(dy, y, P, D, Wxyz, idx, stats, r, part);                                  \
+    HCM_CHECK_LAUNCH();                                                                                                            \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_bwd_apply_row_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                        (int)lds);                                                                                                 \
+    ball_bwd_apply_row_kernel<R><<<gr, kBT, lds, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, r, gstats, dz, wp);            \
+  } while (0)
+      if (relu) HCM_BALL_BWD_ROW(true); else HCM_BALL_BWD_ROW(false);
+#undef HCM_BALL_BWD_ROW
+      HCM_CHECK_LAUNCH();
+      ball_wxyz_merge_kernel<<<(3 * C + 255) / 256, 256, 0, st>>>(wp, C, r.B * r.sub, dWxyz);
+      HCM_CHECK_LAUNCH();
+      return 0;
+    }
   }
 #define HCM_BALL_BWD(R, HP)                                                                                          \
   do {                                                                                                               \
