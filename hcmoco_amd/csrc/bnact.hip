@@ -958,7 +958,7 @@ RowGeo make_row_geo(int B, int C, int N, int np, int ns) {
   r.C = C; r.HW = np * ns; r.N = N; r.np = np; r.ns = ns; r.B = B; r.M = B * r.HW;
   // enough workgroups for the chip, at least 4 float4 per thread where the image allows it
   int sub = 1;
-  while ((long long)C * B * sub < 2048 && r.HW / (sub * 2) >= kVec * 4) sub *= 2;
+  while ((long long)(C / 4 + 1) * B * sub < 2048 && r.HW / (sub * 2) >= kVec * 2) sub *= 2;
   int per = (r.HW + sub - 1) / sub;
   per = (per + 3) & ~3;
   r.sub = (r.HW + per - 1) / per;
@@ -980,183 +980,247 @@ __device__ __forceinline__ void merge_slots(const float* part, int nslots, int C
   p1 = wave_sum(p1);
   p2 = wave_sum(p2);
 }
-__device__ __forceinline__ float4 ball_z_row(const float* __restrict__ row, const int* __restrict__ idx, const float* __restrict__ Dn,
-                                              int HW, int w, float w0, float w1, float w2) {
-  const int4 id = *reinterpret_cast<const int4*>(idx + w);
-  const float4 d0 = *reinterpret_cast<const float4*>(Dn + w);
-  const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)HW + w);
-  const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)HW + w);
-  return make_float4(row[id.x] + fmaf(w2, d2.x, fmaf(w1, d1.x, w0 * d0.x)), row[id.y] + fmaf(w2, d2.y, fmaf(w1, d1.y, w0 * d0.y)),
-                     row[id.z] + fmaf(w2, d2.z, fmaf(w1, d1.z, w0 * d0.z)), row[id.w] + fmaf(w2, d2.w, fmaf(w1, d1.w, w0 * d0.w)));
-}
 // shift of the one-pass variance: z of the channel's first member (image 0)
 __device__ __forceinline__ float ball_k_row(const float* P, const int* idx, const float* D, int c, int N, int HW, float w0, float w1,
                                             float w2) {
   return P[(size_t)c * N + idx[0]] + fmaf(w2, D[2 * (size_t)HW], fmaf(w1, D[(size_t)HW], w0 * D[0]));
 }
 
+// CG channels per workgroup (their CG rows of P in LDS): idx and D are read once per CG channels (with one channel per workgroup
+// the row kernels ran at ~17 TB/s of L2 reads for 2.2 TB/s of output, r06)
+template <int CG>
+struct RowCtx {
+  float w0[CG], w1[CG], w2[CG];
+};
+template <int CG>
+__device__ __forceinline__ void row_setup(float* __restrict__ rows, const float* __restrict__ P, const float* __restrict__ Wxyz,
+                                          const RowGeo& r, int c0, int n, RowCtx<CG>& x) {
+#pragma unroll
+  for (int u = 0; u < CG; ++u) {
+    stage_row(rows + (size_t)u * r.N, P + ((size_t)n * r.C + c0 + u) * r.N, r.N);
+    x.w0[u] = Wxyz[3 * (c0 + u)]; x.w1[u] = Wxyz[3 * (c0 + u) + 1]; x.w2[u] = Wxyz[3 * (c0 + u) + 2];
+  }
+}
+struct Member4 {
+  int4 id;
+  float4 d0, d1, d2;
+};
+__device__ __forceinline__ Member4 load_members(const int* __restrict__ idn, const float* __restrict__ Dn, int HW, int w) {
+  Member4 m;
+  m.id = *reinterpret_cast<const int4*>(idn + w);
+  m.d0 = *reinterpret_cast<const float4*>(Dn + w);
+  m.d1 = *reinterpret_cast<const float4*>(Dn + (size_t)HW + w);
+  m.d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)HW + w);
+  return m;
+}
+__device__ __forceinline__ float4 z_of(const float* __restrict__ row, const Member4& m, float w0, float w1, float w2) {
+  return make_float4(row[m.id.x] + fmaf(w2, m.d2.x, fmaf(w1, m.d1.x, w0 * m.d0.x)), row[m.id.y] + fmaf(w2, m.d2.y, fmaf(w1, m.d1.y, w0 * m.d0.y)),
+                     row[m.id.z] + fmaf(w2, m.d2.z, fmaf(w1, m.d1.z, w0 * m.d0.z)), row[m.id.w] + fmaf(w2, m.d2.w, fmaf(w1, m.d1.w, w0 * m.d0.w)));
+}
+// workgroup sums of 2 CG values; slot k's total lands in thread k
+template <int NV>
+__device__ __forceinline__ float block_sum_nv(float (&v)[NV]) {
+  __shared__ float red[NV][kBT / 64];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float xx = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = xx;
+  }
+  __syncthreads();
+  const int t = threadIdx.x < NV ? threadIdx.x : 0;
+  return (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+}
+
+template <int CG>
 __global__ __launch_bounds__(kBT) void ball_stats_row_kernel(const float* __restrict__ P, const float* __restrict__ D,
                                                              const float* __restrict__ Wxyz, const int* __restrict__ idx, RowGeo r,
                                                              float* __restrict__ part) {
-  extern __shared__ float row[];
-  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
-  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
-  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
-  const float k = ball_k_row(P, idx, D, c, r.N, r.HW, w0, w1, w2);
+  extern __shared__ float rows[];
+  const int c0 = blockIdx.x * CG, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  RowCtx<CG> x;
+  row_setup<CG>(rows, P, Wxyz, r, c0, n, x);
+  float k[CG], acc[2 * CG];
+#pragma unroll
+  for (int u = 0; u < CG; ++u) {
+    k[u] = ball_k_row(P, idx, D, c0 + u, r.N, r.HW, x.w0[u], x.w1[u], x.w2[u]);
+    acc[2 * u] = 0.f; acc[2 * u + 1] = 0.f;
+  }
   __syncthreads();
   const int beg = j * r.per, end = min(r.HW, beg + r.per);
   const int* idn = idx + (size_t)n * r.HW;
   const float* Dn = D + (size_t)n * 3 * r.HW;
-  float s1 = 0.f, s2 = 0.f;
 #pragma unroll 2
   for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
-    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
-    const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
-    s1 += (a + b) + (cc + d);
-    s2 = fmaf(a, a, s2); s2 = fmaf(b, b, s2); s2 = fmaf(cc, cc, s2); s2 = fmaf(d, d, s2);
+    const Member4 m = load_members(idn, Dn, r.HW, w);
+#pragma unroll
+    for (int u = 0; u < CG; ++u) {
+      const float4 v = z_of(rows + (size_t)u * r.N, m, x.w0[u], x.w1[u], x.w2[u]);
+      const float a = v.x - k[u], b = v.y - k[u], cc = v.z - k[u], d = v.w - k[u];
+      acc[2 * u] += (a + b) + (cc + d);
+      acc[2 * u + 1] = fmaf(a, a, acc[2 * u + 1]); acc[2 * u + 1] = fmaf(b, b, acc[2 * u + 1]);
+      acc[2 * u + 1] = fmaf(cc, cc, acc[2 * u + 1]); acc[2 * u + 1] = fmaf(d, d, acc[2 * u + 1]);
+    }
   }
-  block_sum2(s1, s2);
-  if (threadIdx.x == 0) {
-    part[(size_t)(2 * blockIdx.y) * r.C + c] = s1;
-    part[(size_t)(2 * blockIdx.y + 1) * r.C + c] = s2;
-  }
+  const float v = block_sum_nv<2 * CG>(acc);
+  if (threadIdx.x < 2 * CG) part[(size_t)(2 * blockIdx.y + (threadIdx.x & 1)) * r.C + c0 + (threadIdx.x >> 1)] = v;
 }
 
-template <bool RELU>
+template <int CG, bool RELU>
 __global__ __launch_bounds__(kBT) void ball_apply_row_kernel(
     const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ Wxyz, const int* __restrict__ idx,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part, RowGeo r, float eps,
     float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stats, float* __restrict__ y) {
-  extern __shared__ float row[];
-  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
-  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
-  float p1, p2;
-  merge_slots(part, r.B * r.sub, r.C, c, p1, p2);
-  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
-  const float k = ball_k_row(P, idx, D, c, r.N, r.HW, w0, w1, w2);
+  extern __shared__ float rows[];
+  const int c0 = blockIdx.x * CG, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  RowCtx<CG> x;
+  row_setup<CG>(rows, P, Wxyz, r, c0, n, x);
+  float mean[CG], sc[CG], bt[CG];
   const float invM = 1.f / (float)r.M;
-  const float m1 = p1 * invM;
-  const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
-  const float mean = k + m1;
-  const float invstd = 1.f / sqrtf(var + eps);
-  if (blockIdx.y == 0 && threadIdx.x == 0) {
-    stats[c] = mean;
-    stats[r.C + c] = invstd;
-    if (rmean != nullptr) {
-      const float unbiased = r.M > 1 ? var * ((float)r.M / (float)(r.M - 1)) : var;
-      rmean[c] = fmaf(momentum, mean - rmean[c], rmean[c]);
-      rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+#pragma unroll
+  for (int u = 0; u < CG; ++u) {
+    const int c = c0 + u;
+    float p1, p2;
+    merge_slots(part, r.B * r.sub, r.C, c, p1, p2);
+    const float k = ball_k_row(P, idx, D, c, r.N, r.HW, x.w0[u], x.w1[u], x.w2[u]);
+    const float m1 = p1 * invM;
+    const float var = fmaxf(fmaf(-m1, m1, p2 * invM), 0.f);
+    mean[u] = k + m1;
+    const float invstd = 1.f / sqrtf(var + eps);
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+      stats[c] = mean[u];
+      stats[r.C + c] = invstd;
+      if (rmean != nullptr) {
+        const float unbiased = r.M > 1 ? var * ((float)r.M / (float)(r.M - 1)) : var;
+        rmean[c] = fmaf(momentum, mean[u] - rmean[c], rmean[c]);
+        rvar[c] = fmaf(momentum, unbiased - rvar[c], rvar[c]);
+      }
     }
+    sc[u] = gamma[c] * invstd;
+    bt[u] = beta[c];
   }
-  const float sc = gamma[c] * invstd, bt = beta[c];
   __syncthreads();
   const int beg = j * r.per, end = min(r.HW, beg + r.per);
   const int* idn = idx + (size_t)n * r.HW;
   const float* Dn = D + (size_t)n * 3 * r.HW;
-  float* yn = y + ((size_t)n * r.C + c) * (size_t)r.HW;
+  float* yn = y + ((size_t)n * r.C + c0) * (size_t)r.HW;
 #pragma unroll 2
   for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
-    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
-    float4 o = make_float4(fmaf(v.x - mean, sc, bt), fmaf(v.y - mean, sc, bt), fmaf(v.z - mean, sc, bt), fmaf(v.w - mean, sc, bt));
-    if (RELU) { o.x = relu_nan(o.x); o.y = relu_nan(o.y); o.z = relu_nan(o.z); o.w = relu_nan(o.w); }
-    *reinterpret_cast<float4*>(yn + w) = o;
+    const Member4 m = load_members(idn, Dn, r.HW, w);
+#pragma unroll
+    for (int u = 0; u < CG; ++u) {
+      const float4 v = z_of(rows + (size_t)u * r.N, m, x.w0[u], x.w1[u], x.w2[u]);
+      float4 o = make_float4(fmaf(v.x - mean[u], sc[u], bt[u]), fmaf(v.y - mean[u], sc[u], bt[u]), fmaf(v.z - mean[u], sc[u], bt[u]),
+                             fmaf(v.w - mean[u], sc[u], bt[u]));
+      if (RELU) { o.x = relu_nan(o.x); o.y = relu_nan(o.y); o.z = relu_nan(o.z); o.w = relu_nan(o.w); }
+      *reinterpret_cast<float4*>(yn + (size_t)u * r.HW + w) = o;
+    }
   }
 }
 
-template <bool RELU>
+template <int CG, bool RELU>
 __global__ __launch_bounds__(kBT) void ball_bwd_reduce_row_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
     const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ stats, RowGeo r,
     float* __restrict__ part) {
-  extern __shared__ float row[];
-  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
-  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
-  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
-  const float mean = stats[c];
+  extern __shared__ float rows[];
+  const int c0 = blockIdx.x * CG, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  RowCtx<CG> x;
+  row_setup<CG>(rows, P, Wxyz, r, c0, n, x);
+  float mean[CG], acc[2 * CG];
+#pragma unroll
+  for (int u = 0; u < CG; ++u) { mean[u] = stats[c0 + u]; acc[2 * u] = 0.f; acc[2 * u + 1] = 0.f; }
   __syncthreads();
   const int beg = j * r.per, end = min(r.HW, beg + r.per);
   const int* idn = idx + (size_t)n * r.HW;
   const float* Dn = D + (size_t)n * 3 * r.HW;
-  const size_t o0 = ((size_t)n * r.C + c) * (size_t)r.HW;
-  float s1 = 0.f, s2 = 0.f;
+  const size_t o0 = ((size_t)n * r.C + c0) * (size_t)r.HW;
 #pragma unroll 2
   for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
-    float4 d = *reinterpret_cast<const float4*>(dy + o0 + w);
-    if (RELU) {
-      const float4 out = *reinterpret_cast<const float4*>(y + o0 + w);
-      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+    const Member4 m = load_members(idn, Dn, r.HW, w);
+#pragma unroll
+    for (int u = 0; u < CG; ++u) {
+      float4 d = *reinterpret_cast<const float4*>(dy + o0 + (size_t)u * r.HW + w);
+      if (RELU) {
+        const float4 out = *reinterpret_cast<const float4*>(y + o0 + (size_t)u * r.HW + w);
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      const float4 v = z_of(rows + (size_t)u * r.N, m, x.w0[u], x.w1[u], x.w2[u]);
+      acc[2 * u] += (d.x + d.y) + (d.z + d.w);
+      acc[2 * u + 1] = fmaf(d.x, v.x - mean[u], acc[2 * u + 1]); acc[2 * u + 1] = fmaf(d.y, v.y - mean[u], acc[2 * u + 1]);
+      acc[2 * u + 1] = fmaf(d.z, v.z - mean[u], acc[2 * u + 1]); acc[2 * u + 1] = fmaf(d.w, v.w - mean[u], acc[2 * u + 1]);
     }
-    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
-    s1 += (d.x + d.y) + (d.z + d.w);
-    s2 = fmaf(d.x, v.x - mean, s2); s2 = fmaf(d.y, v.y - mean, s2);
-    s2 = fmaf(d.z, v.z - mean, s2); s2 = fmaf(d.w, v.w - mean, s2);
   }
-  block_sum2(s1, s2);
-  if (threadIdx.x == 0) {
-    part[(size_t)(2 * blockIdx.y) * r.C + c] = s1;
-    part[(size_t)(2 * blockIdx.y + 1) * r.C + c] = s2;
-  }
+  const float v = block_sum_nv<2 * CG>(acc);
+  if (threadIdx.x < 2 * CG) part[(size_t)(2 * blockIdx.y + (threadIdx.x & 1)) * r.C + c0 + (threadIdx.x >> 1)] = v;
 }
 
-template <bool RELU>
+template <int CG, bool RELU>
 __global__ __launch_bounds__(kBT) void ball_bwd_apply_row_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ P, const float* __restrict__ D,
     const float* __restrict__ Wxyz, const int* __restrict__ idx, const float* __restrict__ gamma,
     const float* __restrict__ stats, const float* __restrict__ part, RowGeo r, float* __restrict__ gstats,
     float* __restrict__ dz, float* __restrict__ wpart) {
-  extern __shared__ float row[];
-  __shared__ float sh3[3][kBT / 64];
-  const int c = blockIdx.x, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
-  stage_row(row, P + ((size_t)n * r.C + c) * r.N, r.N);
-  float p1, p2;
-  merge_slots(part, r.B * r.sub, r.C, c, p1, p2);
-  const float mean = stats[c], invstd = stats[r.C + c];
-  if (blockIdx.y == 0 && threadIdx.x == 0) {
-    gstats[c] = p2 * invstd;     // d gamma
-    gstats[r.C + c] = p1;        // d beta
-  }
-  const float w0 = Wxyz[3 * c], w1 = Wxyz[3 * c + 1], w2 = Wxyz[3 * c + 2];
+  extern __shared__ float rows[];
+  const int c0 = blockIdx.x * CG, n = blockIdx.y / r.sub, j = blockIdx.y - n * r.sub;
+  RowCtx<CG> x;
+  row_setup<CG>(rows, P, Wxyz, r, c0, n, x);
+  float mean[CG], a[CG], b[CG], q[CG], t[3 * CG];
   const float invM = 1.f / (float)r.M;
-  const float a = gamma[c] * invstd, b = p1 * invM, q = p2 * invstd * invstd * invM;
+#pragma unroll
+  for (int u = 0; u < CG; ++u) {
+    const int c = c0 + u;
+    float p1, p2;
+    merge_slots(part, r.B * r.sub, r.C, c, p1, p2);
+    mean[u] = stats[c];
+    const float invstd = stats[r.C + c];
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+      gstats[c] = p2 * invstd;     // d gamma
+      gstats[r.C + c] = p1;        // d beta
+    }
+    a[u] = gamma[c] * invstd; b[u] = p1 * invM; q[u] = p2 * invstd * invstd * invM;
+    t[3 * u] = 0.f; t[3 * u + 1] = 0.f; t[3 * u + 2] = 0.f;
+  }
   __syncthreads();
   const int beg = j * r.per, end = min(r.HW, beg + r.per);
   const int* idn = idx + (size_t)n * r.HW;
   const float* Dn = D + (size_t)n * 3 * r.HW;
-  const size_t o0 = ((size_t)n * r.C + c) * (size_t)r.HW;
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  const size_t o0 = ((size_t)n * r.C + c0) * (size_t)r.HW;
 #pragma unroll 2
   for (int w = beg + threadIdx.x * 4; w < end; w += kVec) {
-    float4 d = *reinterpret_cast<const float4*>(dy + o0 + w);
-    if (RELU) {
-      const float4 out = *reinterpret_cast<const float4*>(y + o0 + w);
-      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+    const Member4 m = load_members(idn, Dn, r.HW, w);
+#pragma unroll
+    for (int u = 0; u < CG; ++u) {
+      float4 d = *reinterpret_cast<const float4*>(dy + o0 + (size_t)u * r.HW + w);
+      if (RELU) {
+        const float4 out = *reinterpret_cast<const float4*>(y + o0 + (size_t)u * r.HW + w);
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      const float4 v = z_of(rows + (size_t)u * r.N, m, x.w0[u], x.w1[u], x.w2[u]);
+      float4 g4;
+      g4.x = a[u] * (d.x - b[u] - (v.x - mean[u]) * q[u]);
+      g4.y = a[u] * (d.y - b[u] - (v.y - mean[u]) * q[u]);
+      g4.z = a[u] * (d.z - b[u] - (v.z - mean[u]) * q[u]);
+      g4.w = a[u] * (d.w - b[u] - (v.w - mean[u]) * q[u]);
+      *reinterpret_cast<float4*>(dz + o0 + (size_t)u * r.HW + w) = g4;
+      t[3 * u] = fmaf(g4.x, m.d0.x, t[3 * u]); t[3 * u] = fmaf(g4.y, m.d0.y, t[3 * u]);
+      t[3 * u] = fmaf(g4.z, m.d0.z, t[3 * u]); t[3 * u] = fmaf(g4.w, m.d0.w, t[3 * u]);
+      t[3 * u + 1] = fmaf(g4.x, m.d1.x, t[3 * u + 1]); t[3 * u + 1] = fmaf(g4.y, m.d1.y, t[3 * u + 1]);
+      t[3 * u + 1] = fmaf(g4.z, m.d1.z, t[3 * u + 1]); t[3 * u + 1] = fmaf(g4.w, m.d1.w, t[3 * u + 1]);
+      t[3 * u + 2] = fmaf(g4.x, m.d2.x, t[3 * u + 2]); t[3 * u + 2] = fmaf(g4.y, m.d2.y, t[3 * u + 2]);
+      t[3 * u + 2] = fmaf(g4.z, m.d2.z, t[3 * u + 2]); t[3 * u + 2] = fmaf(g4.w, m.d2.w, t[3 * u + 2]);
     }
-    const float4 v = ball_z_row(row, idn, Dn, r.HW, w, w0, w1, w2);
-    float4 g4;
-    g4.x = a * (d.x - b - (v.x - mean) * q);
-    g4.y = a * (d.y - b - (v.y - mean) * q);
-    g4.z = a * (d.z - b - (v.z - mean) * q);
-    g4.w = a * (d.w - b - (v.w - mean) * q);
-    *reinterpret_cast<float4*>(dz + o0 + w) = g4;
-    const float4 d0 = *reinterpret_cast<const float4*>(Dn + w);
-    const float4 d1 = *reinterpret_cast<const float4*>(Dn + (size_t)r.HW + w);
-    const float4 d2 = *reinterpret_cast<const float4*>(Dn + 2 * (size_t)r.HW + w);
-    t0 = fmaf(g4.x, d0.x, t0); t0 = fmaf(g4.y, d0.y, t0); t0 = fmaf(g4.z, d0.z, t0); t0 = fmaf(g4.w, d0.w, t0);
-    t1 = fmaf(g4.x, d1.x, t1); t1 = fmaf(g4.y, d1.y, t1); t1 = fmaf(g4.z, d1.z, t1); t1 = fmaf(g4.w, d1.w, t1);
-    t2 = fmaf(g4.x, d2.x, t2); t2 = fmaf(g4.y, d2.y, t2); t2 = fmaf(g4.z, d2.z, t2); t2 = fmaf(g4.w, d2.w, t2);
   }
-  t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
-  if ((threadIdx.x & 63) == 0) { sh3[0][threadIdx.x >> 6] = t0; sh3[1][threadIdx.x >> 6] = t1; sh3[2][threadIdx.x >> 6] = t2; }
-  __syncthreads();
-  if (threadIdx.x < 3)
-    wpart[((size_t)blockIdx.y * r.C + c) * 3 + threadIdx.x] =
-        (sh3[threadIdx.x][0] + sh3[threadIdx.x][1]) + (sh3[threadIdx.x][2] + sh3[threadIdx.x][3]);
+  const float v = block_sum_nv<3 * CG>(t);
+  if (threadIdx.x < 3 * CG) wpart[((size_t)blockIdx.y * r.C + c0) * 3 + threadIdx.x] = v;      // [slot][c][k]
 }
 
 constexpr int kRowMaxN = 32768;      // 128 KB of LDS for the row
-inline bool row_ok(const RowGeo& r) { return r.N <= kRowMaxN && (r.HW & 3) == 0 && r.B * r.sub <= 65535; }
+// the row kernels pay where an image holds many members per channel (levels 2 / 3 of Pointnet2MSG: 4096-32768); the coarsest
+// level (1024 / 2048 members per image and channel: thousands of two-iteration workgroups) stays on the per-channel kernels
+inline bool row_ok(const RowGeo& r) { return r.N <= kRowMaxN && (r.HW & 3) == 0 && r.B * r.sub <= 65535 && r.HW >= 8192; }
+inline int row_group(const RowGeo& r) { return (r.C % 4 == 0 && (size_t)4 * r.N * sizeof(float) <= 64 * 1024) ? 4 : 1; }
 
 bool bad_ball(int N, int C, int np, int ns) {
   if (!(ns == 4 || ns == 8 || ns == 16 || ns == 32 || ns == 64) || np <= 0 || (np & 3) != 0) return true;
@@ -1390,20 +1454,23 @@ int hcm_ball_project_forward(const float* P, const float* D, const float* Wxyz, 
   if (P != nullptr) {
     const RowGeo r = make_row_geo(B, C, N, np, ns);
     if (row_ok(r) && hcm_ball_project_stats_floats(B, C, np, ns) >= (size_t)(2 + 5 * (size_t)r.B * r.sub) * C) {
-      const dim3 gr(C, r.B * r.sub);
-      const size_t lds = (size_t)r.N * sizeof(float);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(ball_stats_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      ball_stats_row_kernel<<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, r, part);
-      HCM_CHECK_LAUNCH();
-      if (relu) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(ball_apply_row_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ball_apply_row_kernel<true><<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, gamma, beta, part, r, eps, momentum, running_mean,
-                                                          running_var, stats, y);
-      } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(ball_apply_row_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ball_apply_row_kernel<false><<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, gamma, beta, part, r, eps, momentum, running_mean,
-                                                           running_var, stats, y);
-      }
+      const int cg = row_group(r);
+      const dim3 gr(C / cg, r.B * r.sub);
+      const size_t lds = (size_t)cg * r.N * sizeof(float);
+#define HCM_BALL_FWD_ROW(CG, R)                                                                                                    \
+  do {                                                                                                                             \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_stats_row_kernel<CG>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                        (int)lds);                                                                                                 \
+    ball_stats_row_kernel<CG><<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, r, part);                                                    \
+    HCM_CHECK_LAUNCH();                                                                                                            \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_apply_row_kernel<CG, R>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                        (int)lds);                                                                                                 \
+    ball_apply_row_kernel<CG, R><<<gr, kBT, lds, st>>>(P, D, Wxyz, idx, gamma, beta, part, r, eps, momentum, running_mean,         \
+                                                       running_var, stats, y);                                                    \
+  } while (0)
+      if (cg == 4) { if (relu) HCM_BALL_FWD_ROW(4, true); else HCM_BALL_FWD_ROW(4, false); }
+      else         { if (relu) HCM_BALL_FWD_ROW(1, true); else HCM_BALL_FWD_ROW(1, false); }
+#undef HCM_BALL_FWD_ROW
       HCM_CHECK_LAUNCH();
       return 0;
     }
@@ -1451,20 +1518,22 @@ int hcm_ball_project_backward(const float* dy, const float* y, const float* P, c
   if (P != nullptr) {
     const RowGeo r = make_row_geo(B, C, N, np, ns);
     if (row_ok(r) && hcm_ball_project_stats_floats(B, C, np, ns) >= (size_t)(2 + 5 * (size_t)r.B * r.sub) * C) {
-      const dim3 gr(C, r.B * r.sub);
-      const size_t lds = (size_t)r.N * sizeof(float);
+      const int cg = row_group(r);
+      const dim3 gr(C / cg, r.B * r.sub);
+      const size_t lds = (size_t)cg * r.N * sizeof(float);
       float* wp = part + 2 * (size_t)r.B * r.sub * C;
-#define HCM_BALL_BWD_ROW(R)                                                                                                        \
-  do {                                                                                                                             \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_bwd_reduce_row_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                        (int)lds);                                                                                                 \
-    ball_bwd_reduce_row_kernel<R><<<gr, kBT, lds, st>>>(dy, y, P, D, Wxyz, idx, stats, r, part);                                  \
-    HCM_CHECK_LAUNCH();                                                                                                            \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_bwd_apply_row_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                        (int)lds);                                                                                                 \
-    ball_bwd_apply_row_kernel<R><<<gr, kBT, lds, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, r, gstats, dz, wp);            \
+#define HCM_BALL_BWD_ROW(CG, R)                                                                                                        \
+  do {                                                                                                                                 \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_bwd_reduce_row_kernel<CG, R>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                        (int)lds);                                                                                                     \
+    ball_bwd_reduce_row_kernel<CG, R><<<gr, kBT, lds, st>>>(dy, y, P, D, Wxyz, idx, stats, r, part);                                  \
+    HCM_CHECK_LAUNCH();                                                                                                                \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ball_bwd_apply_row_kernel<CG, R>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                        (int)lds);                                                                                                     \
+    ball_bwd_apply_row_kernel<CG, R><<<gr, kBT, lds, st>>>(dy, y, P, D, Wxyz, idx, gamma, stats, part, r, gstats, dz, wp);            \
   } while (0)
-      if (relu) HCM_BALL_BWD_ROW(true); else HCM_BALL_BWD_ROW(false);
+      if (cg == 4) { if (relu) HCM_BALL_BWD_ROW(4, true); else HCM_BALL_BWD_ROW(4, false); }
+      else         { if (relu) HCM_BALL_BWD_ROW(1, true); else HCM_BALL_BWD_ROW(1, false); }
 #undef HCM_BALL_BWD_ROW
       HCM_CHECK_LAUNCH();
       ball_wxyz_merge_kernel<<<(3 * C + 255) / 256, 256, 0, st>>>(wp, C, r.B * r.sub, dWxyz);
