@@ -816,9 +816,14 @@ def run(a, rank, world, local, fs):
                                   'timed': 'idle GPU after the timed region (kernel time; agrees with rocprofv3)',
                                   'span_ms_inside_the_step_incl_queueing': in_step})
         # config 4: sum(work) / sum(time) per PointNet++ kernel over every shape it was launched at (3 passes of the encoder)
-        PN_SPEC = [('conv1x1_fwd', 'conv1x1_kernel forward (SharedMLP 1x1 convolutions + the source-point projection, fp32 MFMA)', 'mfma'),
-                   ('conv1x1_dx', 'conv1x1_kernel data gradient', 'mfma'),
-                   ('conv1x1_dw', 'wgrad1x1_ball_kernel + wgrad1x1_reduce_kernel (weight gradient)', 'mfma'),
+        # r06: the 1x1 layers run split-bf16 from 64 channels up (3 bf16 MFMA terms, fp32 accumulate) and exact fp32 below: with
+        # the matrix time a fifth of the fp32 form every layer is bound by moving its operands once -- priced against HBM
+        c1_arith = ('exact fp32 MFMA (--fmap_dtype fp32_exact)' if a.fmap_dtype == 'fp32_exact' else
+                    'split-bf16 from 64 channels up (3 bf16 MFMA terms per product, fp32 accumulate, 4.4e-6 of float64), exact fp32 below')
+        PN_SPEC = [('conv1x1_fwd', 'conv1x1_split_kernel / conv1x1_rows_kernel forward (SharedMLP 1x1 convolutions + the source-point '
+                                   'projection); arith: ' + c1_arith, 'hbm'),
+                   ('conv1x1_dx', 'conv1x1_split_kernel / conv1x1_rows_kernel data gradient', 'hbm'),
+                   ('conv1x1_dw', 'wgrad1x1_ball_kernel + wgrad1x1_reduce_kernel (weight gradient)', 'hbm'),
                    ('ball_fwd', 'ball_stats_kernel + ball_apply_kernel (first SharedMLP layer on the implicit grouped tensor)', 'hbm'),
                    ('ball_bwd', 'ball_bwd_reduce_kernel + ball_bwd_apply_kernel (+ dW_xyz merge)', 'hbm'),
                    ('ballmax_fwd', 'bn_stats_kernel + bn_relu_ballmax_kernel (last layer: BatchNorm + ReLU + max over the ball)', 'hbm'),

@@ -105,11 +105,15 @@ SIGNATURES = {
     'hcm_bn_relu_ballmax_stats_floats': (_sz, [_i] * 4),
     'hcm_bn_relu_ballmax_forward': (_i, [_p] * 5 + [_f, _f] + [_i] * 4 + [_p] * 5),
     'hcm_bn_relu_ballmax_backward': (_i, [_p] * 7 + [_i] * 4 + [_p] * 3),
+    'hcm_conv1x1_set_arith': (_i, [_i]),
     'hcm_conv1x1_supported': (_i, [_i] * 3),
     'hcm_conv1x1_forward': (_i, [_p] * 3 + [_i] * 4 + [_p]),
     'hcm_conv1x1_backward_data': (_i, [_p] * 3 + [_i] * 4 + [_p]),
     'hcm_conv1x1_ball_wgrad_workspace_bytes': (C.c_size_t, [_i] * 5),
     'hcm_conv1x1_ball_wgrad': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
+    'hcm_conv1x1_forward_exact': (_i, [_p] * 3 + [_i] * 4 + [_p]),
+    'hcm_conv1x1_backward_data_exact': (_i, [_p] * 3 + [_i] * 4 + [_p]),
+    'hcm_conv1x1_ball_wgrad_exact': (_i, [_p, _p] + [_i] * 5 + [_p, _p, _sz, _p]),
     'hcm_ball_project_stats_floats': (_sz, [_i] * 4),
     'hcm_ball_project_forward': (_i, [_p] * 8 + [_f, _f] + [_i] * 6 + [_p] * 3),
     'hcm_ball_project_backward': (_i, [_p] * 8 + [_i] * 6 + [_p] * 4),
@@ -147,7 +151,7 @@ for _name in ('hcm_bank_nce_fused', 'hcm_bank_nce_fused_timed', 'hcm_bank_logits
     SIGNATURES[_name + '_bf16'] = SIGNATURES[_name]
 
 _lib = None
-ABI_VERSION = 5       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
+ABI_VERSION = 6       # HCM_ABI_VERSION of include/hcmoco_hip.h this binding was written against
 
 
 def build(verbose=False):

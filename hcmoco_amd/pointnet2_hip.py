@@ -260,8 +260,8 @@ class _PointProject(torch.autograd.Function):
         B, Cs, N = src.shape
         K = W.shape[0]
         out = torch.empty(B, K, N, dtype=torch.float32, device=src.device)
-        check(_lib.lib().hcm_conv1x1_forward(_f(src, 'point_project'), _f(W, 'point_project'), _f(out, 'point_project'), B, Cs, K,
-                                             N, _stream()), 'hcm_conv1x1_forward')
+        check(_lib.lib().hcm_conv1x1_forward_exact(_f(src, 'point_project'), _f(W, 'point_project'), _f(out, 'point_project'), B, Cs, K,
+                                             N, _stream()), 'hcm_conv1x1_forward_exact')
         ctx.save_for_backward(W, src)
         return out
 
@@ -275,15 +275,25 @@ class _PointProject(torch.autograd.Function):
         dW = dsrc = None
         if ctx.needs_input_grad[1]:
             dsrc = torch.empty_like(src)
-            check(L.hcm_conv1x1_backward_data(_f(dP, 'point_project'), _f(W, 'point_project'), _f(dsrc, 'point_project'), B, Cs, K,
-                                              N, _stream()), 'hcm_conv1x1_backward_data')
+            check(L.hcm_conv1x1_backward_data_exact(_f(dP, 'point_project'), _f(W, 'point_project'), _f(dsrc, 'point_project'), B, Cs, K,
+                                              N, _stream()), 'hcm_conv1x1_backward_data_exact')
         if ctx.needs_input_grad[0]:
             need = int(L.hcm_conv1x1_ball_wgrad_workspace_bytes(B, Cs, K, N, 1))
             ws = torch.empty(need // 4, dtype=torch.float32, device=src.device)
             dW = torch.empty_like(W)
-            check(L.hcm_conv1x1_ball_wgrad(_f(src, 'point_project'), _f(dP, 'point_project'), B, Cs, K, N, 1, _f(dW, 'point_project'),
-                                           _f(ws, 'point_project'), need, _stream()), 'hcm_conv1x1_ball_wgrad')
+            check(L.hcm_conv1x1_ball_wgrad_exact(_f(src, 'point_project'), _f(dP, 'point_project'), B, Cs, K, N, 1, _f(dW, 'point_project'),
+                                           _f(ws, 'point_project'), need, _stream()), 'hcm_conv1x1_ball_wgrad_exact')
         return dW, dsrc
+
+
+def set_conv1x1_arith(exact):
+    """Arithmetic of hcm_conv1x1_forward / _backward_data / _ball_wgrad (csrc/conv1x1.hip), process-wide: ``exact=False`` (default)
+    = layers of 64+ channels on the bf16 matrix cores with split operands (three terms, fp32 accumulate, 4.4e-6 of float64),
+    ``exact=True`` = exact fp32 MFMA everywhere.  Returns the previous setting."""
+    prev = _lib.lib().hcm_conv1x1_set_arith(1 if exact else 0)
+    if prev < 0:
+        raise RuntimeError('hcm_conv1x1_set_arith failed')
+    return bool(prev)
 
 
 def point_project_supported(K, Cs, N):

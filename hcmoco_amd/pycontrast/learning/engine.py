@@ -20,6 +20,10 @@ class HipLossEngine(object):
         if fmap_dtype not in ('fp32', 'bf16', 'fp32_exact'):
             raise ValueError('fmap_dtype must be fp32, bf16 or fp32_exact')
         self.fmap_dtype = fmap_dtype
+        # fp32_exact means exact fp32 contractions wherever the default is split-bf16: the SharedMLP 1x1 convolutions of the
+        # PointNet++ branch too (hcm_conv1x1_set_arith, process-wide)
+        from ... import pointnet2_hip
+        pointnet2_hip.set_conv1x1_arith(exact=(fmap_dtype == 'fp32_exact'))
 
     # ---- SURVEY 8a rows 1-4 -------------------------------------------------------------
     def bank(self, contrast, f1, f2, f3, index, all_f1, all_f2, all_f3, all_index,

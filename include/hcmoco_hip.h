@@ -31,7 +31,7 @@ typedef void* hcm_stream_t; /* hipStream_t */
  * grouped tensors); nothing removed.  5 (round 6): hcm_ball_project_* take the relative offsets D and W_xyz instead of Q = W_xyz
  * centre (signature change: the coordinate half is no longer a difference of two projections).  A library and a caller must
  * agree on this number. */
-#define HCM_ABI_VERSION 5
+#define HCM_ABI_VERSION 6
 int hcm_abi_version(void);
 /* hipGetErrorString() for a value returned by any entry point. */
 const char* hcm_error_string(int err);
@@ -440,18 +440,32 @@ int hcm_bn_act_forward_pre(const float* x, const float* residual, const float* g
 /* 1x1 convolutions of the PointNet++ shared MLPs on ball tensors (r05; reference: networks/pointnet2/pytorch_utils.py:5-33,
  * nn.Conv2d(kernel_size=1, bias=False)).  x [N, C, P], w [K, C] (nn.Conv2d.weight viewed as a matrix), z [N, K, P], P = the
  * positions of one image (npoint * nsample), fp32, contiguous.  forward: z = w x per image; backward_data: dx = w^T dz.
- * Exact fp32 MFMA on the tensors as they lie (no LDS, no layout change).  hcm_conv1x1_supported: C % 4 == 0, K % 4 == 0,
- * P % 64 == 0; anything else returns hipErrorInvalidValue and the caller keeps its library path.
+ * Matrix-core products on the tensors as they lie (LDS only for the weights, no layout change).  Arithmetic (r06, ABI 6):
+ * layers whose fp32 MFMA floor reaches their HBM floor (reduction length R % 32 == 0 and R * output channels >= 4096: 64 -> 128
+ * channels and up) run on the bf16 matrix cores with split operands -- x = hi + mid, three terms, fp32 accumulation, 4.4e-6 of
+ * float64 as a vector (max 7e-6 of the largest element), the scheme of hcm_dense_soft_nce -- the narrower ones as exact fp32 MFMA
+ * (an fmaf chain per output element).  hcm_conv1x1_set_arith(1) makes every layer exact fp32, (0) restores the default; it
+ * returns the previous mode (-1: bad argument); process-wide, what `--fmap_dtype fp32_exact` sets.  The *_exact entry points
+ * are exact fp32 whatever the mode: the source-point projection of the implicit first layer (hcm_ball_project_* below) uses
+ * them -- its output is gathered and normalised over a ball, and the first-layer accuracy contract of
+ * tests/test_pointnet2_gpu.py::test_first_layer_on_the_implicit_grouped_tensor is an fp32 one.
+ * hcm_conv1x1_supported: C % 4 == 0, K % 4 == 0, P % 64 == 0; anything else returns hipErrorInvalidValue and the caller keeps
+ * its library path.
  * hcm_conv1x1_ball_wgrad: dw [K, C] = sum over n, p of dy[n][k][p] x[n][c][p] (same argument order as hcm_conv1x1_wgrad below:
  * H * W = P); fp32 MFMA over the positions as they lie, per-workgroup partials in the workspace, summed in fixed order
  * (deterministic).  Needs K % 16 == 0, C % 16 == 0, P % 256 == 0: _workspace_bytes returns 0 for anything else and the
  * caller keeps hcm_conv1x1_wgrad / its library path. */
+int hcm_conv1x1_set_arith(int mode);
 int hcm_conv1x1_supported(int C, int K, int P);
 int hcm_conv1x1_forward(const float* x, const float* w, float* z, int N, int C, int K, int P, hcm_stream_t stream);
 int hcm_conv1x1_backward_data(const float* dz, const float* w, float* dx, int N, int C, int K, int P, hcm_stream_t stream);
 size_t hcm_conv1x1_ball_wgrad_workspace_bytes(int N, int C, int K, int H, int W);
 int hcm_conv1x1_ball_wgrad(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
                            void* workspace, size_t workspace_bytes, hcm_stream_t stream);
+int hcm_conv1x1_forward_exact(const float* x, const float* w, float* z, int N, int C, int K, int P, hcm_stream_t stream);
+int hcm_conv1x1_backward_data_exact(const float* dz, const float* w, float* dx, int N, int C, int K, int P, hcm_stream_t stream);
+int hcm_conv1x1_ball_wgrad_exact(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
+                                 void* workspace, size_t workspace_bytes, hcm_stream_t stream);
 
 /* BatchNorm2d (training mode) + ReLU + max over the ball in one piece (r05): the last layer of a PointNet++ SharedMLP
  * followed by F.max_pool2d(y, [1, nsample]) (networks/pointnet2/pointnet2_modules.py:44-55, pytorch_utils.py:5-33 of the
@@ -663,9 +677,9 @@ int hcm_bank_nce_fused_timed_bf16(const uint16_t* bank1, const uint16_t* bank2, 
 #define HCM_PROF_JOINT 10       /* the kernels of hcm_joint_nce                                */
 /* BASELINE config 4 (HRNetPN): the PointNet++ kernels, launched at many shapes per step -- each launch adds its own
  * algorithmic work to the tag (hcm_prof_read_work), so sum(work) / sum(time) is ONE achieved rate per kernel (r06). */
-#define HCM_PROF_CONV1X1_FWD 11   /* conv1x1_kernel of hcm_conv1x1_forward: flops 2 N C K P                          */
-#define HCM_PROF_CONV1X1_DX 12    /* conv1x1_kernel of hcm_conv1x1_backward_data: flops 2 N C K P                    */
-#define HCM_PROF_CONV1X1_DW 13    /* wgrad1x1_ball_kernel + reduce of hcm_conv1x1_ball_wgrad: flops 2 N C K P        */
+#define HCM_PROF_CONV1X1_FWD 11   /* conv1x1_{split,rows}_kernel of hcm_conv1x1_forward: bytes 4 N (C + K) P (r06; r05: flops) */
+#define HCM_PROF_CONV1X1_DX 12    /* the same kernels of hcm_conv1x1_backward_data: bytes 4 N (C + K) P              */
+#define HCM_PROF_CONV1X1_DW 13    /* wgrad1x1_ball_kernel + reduce of hcm_conv1x1_ball_wgrad: bytes 4 N (C + K) P    */
 #define HCM_PROF_BALL_FWD 14      /* ball_stats + ball_apply of hcm_ball_project_forward: bytes                      */
 #define HCM_PROF_BALL_BWD 15      /* ball_bwd_reduce + ball_bwd_apply (+ merge) of hcm_ball_project_backward: bytes  */
 #define HCM_PROF_BALLMAX_FWD 16   /* bn_stats + bn_relu_ballmax of hcm_bn_relu_ballmax_forward: bytes                */

@@ -38,7 +38,7 @@ def test_every_entry_point_cites_the_reference_interface_it_replaces():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.hcm_abi_version() == _lib.ABI_VERSION == 5
+    assert L.hcm_abi_version() == _lib.ABI_VERSION == 6
     assert re.search(r'#define HCM_ABI_VERSION %d\b' % _lib.ABI_VERSION, open(_lib.HEADER).read())
     assert b'invalid' in L.hcm_error_string(1).lower()
 

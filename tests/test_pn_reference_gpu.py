@@ -68,7 +68,8 @@ def test_the_fused_kernels_are_the_path_under_test(golden):
     names = [e.key for e in prof.key_averages()]
     # first SharedMLP layer: level 1 (no point features) on the all-channel / one-pass kernels, levels 2-4 on the LDS-row kernels
     for want in ('ball_all_stats_kernel', 'ball_all_apply_kernel', 'ball_bwd_nop_kernel', 'ball_stats_row_kernel',
-                 'ball_apply_row_kernel', 'ball_bwd_reduce_row_kernel', 'ball_bwd_apply_row_kernel', 'conv1x1_kernel',
+                 'ball_apply_row_kernel', 'ball_bwd_reduce_row_kernel', 'ball_bwd_apply_row_kernel', 'conv1x1_rows_kernel',
+                 'conv1x1_split_kernel',
                  'bn_relu_ballmax_kernel', 'wgrad1x1_ball_kernel', 'ballmax_bwd', 'fps', 'ball_query', 'three_nn'):
         assert any(want in k for k in names), (want, names)
     assert not any('group_points' in k for k in names), names          # the grouped tensor is never built

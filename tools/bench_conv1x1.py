@@ -7,6 +7,8 @@ import ctypes as CT
 import torch
 from hcmoco_amd import _lib
 L = _lib.lib()
+if 'ARITH' in os.environ:                     # 0 = default (split-bf16 from 64 channels up), 1 = exact fp32 everywhere
+    L.hcm_conv1x1_set_arith(int(os.environ['ARITH']))
 dev = 'cuda'
 
 
@@ -22,6 +24,8 @@ def timeit(fn, n=20):
 p = lambda t: CT.c_void_p(t.data_ptr())
 B = int(os.environ.get('B', 32))
 SHAPES = [(16, 32, 4096, 16), (32, 64, 4096, 32), (64, 128, 1024, 16), (64, 128, 1024, 32), (128, 256, 256, 32)]
+if 'SHAPES' in os.environ:                    # e.g. SHAPES=32,64,4104,32;64,128,1032,32 (camping probe: row strides off the powers of two)
+    SHAPES = [tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPES'].split(';')]
 if 'ONLY' in os.environ:                      # tools/probes/pmc_conv1x1.sh: one layer under the counters
     SHAPES = [SHAPES[int(os.environ['ONLY'])]]
 for C, K, npnt, ns in SHAPES:

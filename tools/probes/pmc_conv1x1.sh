@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pc1; mkdir -p /tmp/pc1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  ONLY=3 timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pc1/$ctr -o p -- python $R/tools/bench_conv1x1.py > /tmp/pc1/log_$ctr 2>&1 < /dev/null || tail -3 /tmp/pc1/log_$ctr
+  ONLY=${ONLY:-3} timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pc1/$ctr -o p -- python $R/tools/bench_conv1x1.py > /tmp/pc1/log_$ctr 2>&1 < /dev/null || tail -3 /tmp/pc1/log_$ctr
 done
 python - $R/gpurun_out/${TAG}_conv1x1_pmc.json $(find /tmp/pc1 -name '*counter_collection.csv') <<'PY'
 import csv, json, sys
@@ -16,11 +16,13 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in sys.argv[2:]:
     for r in csv.DictReader(open(f)):
         n = r.get('Kernel_Name', '')
-        key = ('forward' if 'conv1x1_kernel' in n and 'false' in n else 'data_gradient' if 'conv1x1_kernel' in n
+        fd = 'conv1x1_kernel' in n or 'conv1x1_rows_kernel' in n or 'conv1x1_split_kernel' in n
+        key = ('forward' if fd and ', false' in n else 'data_gradient' if fd
                else 'weight_gradient' if 'wgrad1x1_ball_kernel' in n else None)
         if key:
             acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
-B, C, K, P = 32, 64, 128, 32768
+import os
+B, C, K, P = {'1': (32, 32, 64, 131072), '3': (32, 64, 128, 32768), '4': (32, 128, 256, 8192)}[os.environ.get('ONLY', '3')]
 x, z = 4 * B * C * P, 4 * B * K * P
 alg = {'forward': (x, z), 'data_gradient': (z, x), 'weight_gradient': (x + z, 0)}
 out = {}

@@ -15,7 +15,8 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
         n = r.get('Kernel_Name', '')
-        key = ('forward' if 'conv1x1_kernel' in n and 'false' in n else 'data_gradient' if 'conv1x1_kernel' in n
+        fd = 'conv1x1_kernel' in n or 'conv1x1_rows_kernel' in n or 'conv1x1_split_kernel' in n
+        key = ('forward' if fd and ', false' in n else 'data_gradient' if fd
                else 'weight_gradient' if 'wgrad1x1_ball_kernel' in n else None)
         if key:
             acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
