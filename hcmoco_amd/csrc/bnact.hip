@@ -416,36 +416,49 @@ __global__ __launch_bounds__(kBT) void bn_relu_ballmax_kernel(
   const float bt = beta[c];
   constexpr int ns = 4 * L;
   const int beg = s * g.per, end = min(g.M, beg + g.per);
-  for (int f0 = beg; f0 < end; f0 += kVec) {
-    const int f = f0 + threadIdx.x * 4;
-    const bool ok = f < end;                       // a ball row never straddles `end` (per, M are multiples of ns)
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int n = ok ? (g.shift >= 0 ? (f >> g.shift) : (f / g.HW)) : 0;
-    const int w = f - n * g.HW;                    // offset inside the (n, c) plane
-    if (ok) v = *reinterpret_cast<const float4*>(x + ((size_t)n * g.C + c) * (size_t)g.HW + w);
-    const float y0 = relu_nan(fmaf(v.x - mean, sc, bt)), y1 = relu_nan(fmaf(v.y - mean, sc, bt));
-    const float y2 = relu_nan(fmaf(v.z - mean, sc, bt)), y3 = relu_nan(fmaf(v.w - mean, sc, bt));
-    const int j0 = w & (ns - 1);
-    float bv = y0, bz = v.x;
-    int bj = j0;
-    // ATen's max_pool2d: a later value wins if it is larger OR NaN while the running maximum is not (a NaN sticks)
-    if (y1 > bv || (y1 != y1 && bv == bv)) { bv = y1; bz = v.y; bj = j0 + 1; }
-    if (y2 > bv || (y2 != y2 && bv == bv)) { bv = y2; bz = v.z; bj = j0 + 2; }
-    if (y3 > bv || (y3 != y3 && bv == bv)) { bv = y3; bz = v.w; bj = j0 + 3; }
+  // Four float4 per thread and trip, requested together and UNCONDITIONALLY (r06): a guarded load is a branch and a full
+  // s_waitcnt, and one 16-byte load per wave and trip left the latency cover to occupancy alone (0.49 of the HBM rate in the
+  // r06 bench line).  A quad past the slice is clamped to the slice's last one; it is computed and never stored.
+  constexpr int U = 4;
+  for (int f0 = beg; f0 < end; f0 += U * kVec) {
+    float4 v[U];
+    int nn[U], ww[U];
+    bool ok[U];
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) {        // the L lanes of a row are adjacent and aligned
-      const float ov = __shfl_xor(bv, off);
-      const float oz = __shfl_xor(bz, off);
-      const int oj = __shfl_xor(bj, off);
-      const bool onan = ov != ov, bnan = bv != bv;
-      const bool take = (onan && !bnan) || (onan == bnan && (ov > bv || ((ov == bv || onan) && oj < bj)));
-      bv = take ? ov : bv; bz = take ? oz : bz; bj = take ? oj : bj;
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u * kVec + threadIdx.x * 4;
+      ok[u] = f < end;                             // a ball row never straddles `end` (per, M are multiples of ns)
+      const int fc = ok[u] ? f : end - 4;
+      nn[u] = g.shift >= 0 ? (fc >> g.shift) : (fc / g.HW);
+      ww[u] = fc - nn[u] * g.HW;                   // offset inside the (n, c) plane
+      v[u] = *reinterpret_cast<const float4*>(x + ((size_t)nn[u] * g.C + c) * (size_t)g.HW + ww[u]);
     }
-    if (ok && (threadIdx.x & (L - 1)) == 0) {
-      const size_t r = ((size_t)n * g.C + c) * (size_t)np + (size_t)(w / ns);
-      out[r] = bv;
-      arg[r] = bj;
-      zsel[r] = bz;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float y0 = relu_nan(fmaf(v[u].x - mean, sc, bt)), y1 = relu_nan(fmaf(v[u].y - mean, sc, bt));
+      const float y2 = relu_nan(fmaf(v[u].z - mean, sc, bt)), y3 = relu_nan(fmaf(v[u].w - mean, sc, bt));
+      const int j0 = ww[u] & (ns - 1);
+      float bv = y0, bz = v[u].x;
+      int bj = j0;
+      // ATen's max_pool2d: a later value wins if it is larger OR NaN while the running maximum is not (a NaN sticks)
+      if (y1 > bv || (y1 != y1 && bv == bv)) { bv = y1; bz = v[u].y; bj = j0 + 1; }
+      if (y2 > bv || (y2 != y2 && bv == bv)) { bv = y2; bz = v[u].z; bj = j0 + 2; }
+      if (y3 > bv || (y3 != y3 && bv == bv)) { bv = y3; bz = v[u].w; bj = j0 + 3; }
+#pragma unroll
+      for (int off = 1; off < L; off <<= 1) {      // the L lanes of a row are adjacent and aligned
+        const float ov = __shfl_xor(bv, off);
+        const float oz = __shfl_xor(bz, off);
+        const int oj = __shfl_xor(bj, off);
+        const bool onan = ov != ov, bnan = bv != bv;
+        const bool take = (onan && !bnan) || (onan == bnan && (ov > bv || ((ov == bv || onan) && oj < bj)));
+        bv = take ? ov : bv; bz = take ? oz : bz; bj = take ? oj : bj;
+      }
+      if (ok[u] && (threadIdx.x & (L - 1)) == 0) {
+        const size_t r = ((size_t)nn[u] * g.C + c) * (size_t)np + (size_t)(ww[u] / ns);
+        out[r] = bv;
+        arg[r] = bj;
+        zsel[r] = bz;
+      }
     }
   }
 }
