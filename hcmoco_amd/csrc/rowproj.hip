@@ -97,6 +97,13 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
   __shared__ __attribute__((aligned(16))) int s_to[kSR][4][4];      // the tile's stencils: tap offsets ...
   __shared__ __attribute__((aligned(16))) float s_tw[kSR][4][4];    // ... and (hy, ly, hx, lx); the finest branch is the
                                                                     // stencil (p, p, p, p) / (1, 0, 1, 0): hy (hx a + 0 a) + 0 = a
+  // the branches gathered from GLOBAL memory (not staged in LDS), one entry per group k < ng: where its map starts for this
+  // (modality, image), the strides of a pixel and of a channel in floats, its first column in the gathered run and in the tile,
+  // its branch index.  Read per element by a lane-varying k: LDS reads, no control flow (r06: the ternary chains over the
+  // kernel-argument arrays they replace compiled to branch trees, and every element's four tap loads were closed by
+  // s_waitcnt vmcnt(0) -- 4 loads in flight per thread where the loop asks for 16)
+  __shared__ const float* s_gptr[4];
+  __shared__ int s_gmeta[4][6];                                      // pixel stride, channel stride, first cg, tile column, branch, -
   float* lx = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.z, b = blockIdx.y;
@@ -150,8 +157,35 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     }
   }
   const int64_t row0 = ((int64_t)m * B + b) * R;
+  int g_ng = 0, g_ctot = 0, g_end0 = 0, g_end1 = 0, g_end2 = 0;
+  {
+    int col = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool staged = (i == 2 && off2 >= 0) || (i == 3 && off3 >= 0);
+      const int C = e.C[i], hw = e.H[i] * e.W[i];
+      if (!staged) {
+        if (tid == 0) {
+          const float* xt = m ? et.t[4 + i] : et.t[i];
+          const float* xp = m ? e.p[4 + i] : e.p[i];
+          s_gptr[g_ng] = xt != nullptr ? xt + (int64_t)b * hw * C : xp + (int64_t)b * C * hw;
+          s_gmeta[g_ng][0] = xt != nullptr ? C : 1;
+          s_gmeta[g_ng][1] = xt != nullptr ? 1 : hw;
+          s_gmeta[g_ng][2] = g_ctot;
+          s_gmeta[g_ng][3] = col;
+          s_gmeta[g_ng][4] = i;
+        }
+        g_ctot += C;
+        if (g_ng == 0) g_end0 = g_ctot;
+        if (g_ng <= 1) g_end1 = g_ctot;
+        if (g_ng <= 2) g_end2 = g_ctot;
+        ++g_ng;
+      }
+      col += C;
+    }
+  }
   for (int r0 = r_begin; r0 < r_end; r0 += kSR) {
-    __syncthreads();        // the staged maps are in place / the previous tile has been multiplied
+    __syncthreads();        // the staged maps (and the group table) are in place / the previous tile has been multiplied
     if (r0 == r_begin) HCM_STAMP(1);
     // ---- the tile's stencils: one thread per (row, branch)
     if (tid < kSR * 4) {
@@ -178,15 +212,7 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     // second load's wait include the store's round trip (r04 stamps: 23 k cycles per tile with an xs store after every
     // element).  xs is written once per tile from LDS, after the barrier, and retires under the MFMA phase.
     {
-      int gid[4], gend[4], gcol[4], ng = 0, ctot = 0, col = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool staged = (i == 2 && off2 >= 0) || (i == 3 && off3 >= 0);
-        if (!staged) { gid[ng] = i; ctot += e.C[i]; gend[ng] = ctot; gcol[ng] = col; ++ng; }
-        col += e.C[i];
-      }
-      for (int k = ng; k < 4; ++k) { gid[k] = gid[ng - 1]; gend[k] = ctot; gcol[k] = gcol[ng - 1]; }
-      const int total = kSR * ctot;
+      const int ctot = g_ctot, total = kSR * ctot;
       for (int base = tid; base < total; base += 4 * kPW) {
         float rv[4][4];
         int dst[4];
@@ -195,20 +221,22 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
         for (int u = 0; u < 4; ++u) {
           const int ge = min(base + u * kPW, total - 1);
           const int lr = ge / ctot, cg = ge - lr * ctot;
-          const int k = (cg >= gend[0]) + (cg >= gend[1]) + (cg >= gend[2]);
-          const int i = sel4(gid, k), c = cg - (k == 0 ? 0 : sel4(gend, k - 1));
-          const int C = sel4(e.C, i), hw = sel4(e.H, i) * sel4(e.W, i);
+          const int k = (cg >= g_end0) + (cg >= g_end1) + (cg >= g_end2);       // < ng: the ends past the last group equal ctot
+          const int st = s_gmeta[k][0], cs = s_gmeta[k][1], c = cg - s_gmeta[k][2], i = s_gmeta[k][4];
           const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i][0]);
           wv[u] = *reinterpret_cast<const float4*>(&s_tw[lr][i][0]);
           // channels-last copy present (r06): consecutive threads = consecutive channels = consecutive addresses, one
-          // contiguous run of C floats per tap; otherwise the NCHW plane walk (one word per line)
-          const float* xt = sel8(et.t, m * 4 + i);
-          const float* x = xt != nullptr ? xt + (int64_t)b * hw * C + c : sel8(e.p, m * 4 + i) + ((int64_t)b * C + c) * hw;
-          const int st = xt != nullptr ? C : 1;
+          // contiguous run of C floats per tap; otherwise the NCHW plane walk (one word per line).
+          // All four taps UNCONDITIONALLY: the finest branch's stencil is (p, p, p, p) / (1, 0, 1, 0), its three extra loads are
+          // cache hits on the word just requested.
+          // (a pointer that comes out of LDS has no address space for the compiler: say it is global, or the taps are flat loads)
+          typedef const float __attribute__((address_space(1))) gfloat;
+          const gfloat* x = (const gfloat*)(s_gptr[k] + (int64_t)c * cs);
           rv[u][0] = x[o.x * st];
-          rv[u][1] = rv[u][2] = rv[u][3] = 0.f;
-          if (i != 0) { rv[u][1] = x[o.y * st]; rv[u][2] = x[o.z * st]; rv[u][3] = x[o.w * st]; }     // the finest branch is one word
-          dst[u] = lr * XS + sel4(gcol, k) + c;
+          rv[u][1] = x[o.y * st];
+          rv[u][2] = x[o.z * st];
+          rv[u][3] = x[o.w * st];
+          dst[u] = lr * XS + s_gmeta[k][3] + c;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
