@@ -521,7 +521,8 @@ __global__ __launch_bounds__(kPT) void stencil_plan_kernel(const int64_t* __rest
 constexpr int kTP = 64;       // pixels per sub-tile (a workgroup walks `span` of them)
 constexpr int kTS = 130;      // LDS row stride of T: the B-fragment read (lane (g, n) -> T[n][4 s + g]) is conflict-free
 struct TilePlan {
-  int first[5];               // first workgroup (blockIdx.x) of branch i; first[4] = total
+  int first[5];               // first workgroup (blockIdx.z) of the k-th branch in dispatch order; first[4] = total
+  int ord[4];                 // the branch dispatched k-th: most expensive workgroups first (the kernel's tail is its last workgroups)
   int span[4];                // sub-tiles per workgroup of branch i
   int tpix[4];                // pixels per sub-tile of branch i: 64, or 16 on the small maps, where every row of the image lands in
                               // every tile (a 64-pixel tile of an 8 x 8 map collects all 4 R stencil entries: r04 timing stamps
@@ -529,8 +530,43 @@ struct TilePlan {
 };
 
 constexpr int kSpanMax = 4;   // sub-tiles per workgroup on the large (mostly empty) maps
-constexpr int kEB = 2;        // stencil entries per batch and 16-lane group in the T phase
 constexpr int kGW = 256;      // 4 waves; <= 256 VGPRs -> two workgroups per SIMD set (the row ring of the T phase is the cover)
+constexpr int kSE = 4;        // stencil entries per stage of the T phase (two stages in flight per 16-lane group)
+template <int K>
+__device__ __forceinline__ int row_bcast(int v) {       // lane K of every DPP row (16 lanes) to all lanes of that row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+}
+// the 32 bytes this lane owns of the grows rows of entries K0 .. K0 + 3 of the group's chunk (entry l is held by lane l)
+template <int K0>
+__device__ __forceinline__ void fetch_rows(int ex, const float* __restrict__ gl, float4 (&r)[kSE][2]) {
+  const int rows[kSE] = {row_bcast<K0>(ex), row_bcast<K0 + 1>(ex), row_bcast<K0 + 2>(ex), row_bcast<K0 + 3>(ex)};
+#pragma unroll
+  for (int u = 0; u < kSE; ++u) {
+    const float* rp = gl + (int64_t)(rows[u] & ((1 << kRowBits) - 1)) * kF;
+    r[u][0] = *reinterpret_cast<const float4*>(rp);
+    r[u][1] = *reinterpret_cast<const float4*>(rp + 4);
+  }
+}
+template <int K0>
+__device__ __forceinline__ void add_rows(int2 ech, int j, int jend, int q0, int spare, float* __restrict__ tl,
+                                         const float4 (&r)[kSE][2], float (&acc)[8], int& cur) {
+  const int ex[kSE] = {row_bcast<K0>(ech.x), row_bcast<K0 + 1>(ech.x), row_bcast<K0 + 2>(ech.x), row_bcast<K0 + 3>(ech.x)};
+  const int ew[kSE] = {row_bcast<K0>(ech.y), row_bcast<K0 + 1>(ech.y), row_bcast<K0 + 2>(ech.y), row_bcast<K0 + 3>(ech.y)};
+#pragma unroll
+  for (int u = 0; u < kSE; ++u) {
+    const int px = j + K0 + u < jend ? (ex[u] >> kRowBits) - q0 : spare;
+    const float w = __builtin_bit_cast(float, ew[u]);
+    const bool fresh = px != cur;
+    cur = px;
+    const float v[8] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y, r[u][1].z, r[u][1].w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, v[k], fresh ? 0.f : acc[k]);
+    float* z = tl + px * kTS;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 2 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);
+  }
+}
+
 template <int TPX>
 __device__ __forceinline__ void branch_grad_tiles(
     float* __restrict__ T, int* soff, const float* __restrict__ grows, const float* __restrict__ Wp1,
@@ -538,10 +574,12 @@ __device__ __forceinline__ void branch_grad_tiles(
     const int2* __restrict__ ent, const int* __restrict__ off, int R, int B, int Ctot, const Maps8Out& g,
     const TilePlan& tp, const PlanGeom& gm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, m = blockIdx.z;
-  int i = 0;
-  while (i < 3 && (int)blockIdx.x >= tp.first[i + 1]) ++i;
-  const int wg = blockIdx.x - tp.first[i], span = sel4(tp.span, i);
+  const int b = blockIdx.x, m = blockIdx.y;
+  int k0 = 0;
+  while (k0 < 3 && (int)blockIdx.z >= tp.first[k0 + 1]) ++k0;
+  const int i = sel4(tp.ord, k0);
+  const int wg = blockIdx.z - (k0 == 0 ? tp.first[0] : k0 == 1 ? tp.first[1] : k0 == 2 ? tp.first[2] : tp.first[3]);
+  const int span = sel4(tp.span, i);
   constexpr int tpx = TPX, ppg = TPX >> 4, ntl = TPX >> 4;     // pixels per 16-lane group, 16-pixel MFMA tiles per sub-tile
   const int C = sel4(g.C, i), hw = sel4(g.H, i) * sel4(g.W, i);
   int coff = 0;
@@ -561,6 +599,7 @@ __device__ __forceinline__ void branch_grad_tiles(
   // 5.4 k cycles, most of it this load; the finest maps are mostly empty tiles)
   int* const soff_all = soff;
   for (int e0 = tid; e0 <= span * tpx; e0 += kGW) soff_all[e0] = offb[min(wg * span * tpx + e0, hw)];
+  HCM_STAMP(6);
   __syncthreads();
   bool used_t = false;
   for (int sub = 0; sub < span; ++sub) {
@@ -591,10 +630,17 @@ __device__ __forceinline__ void branch_grad_tiles(
       continue;
     }
     // ---- T[pixel][f] = sum over the pixel's entries of weight * grows[row][f], entries in (row, tap) order.  Sixteen
-    // lanes (one DPP row, 32 bytes of the 512-byte row each) own four consecutive pixels = ONE run of the sorted entry list;
-    // the sixteen groups of the workgroup walk their runs side by side.  Software pipeline per group: the entries of
-    // batch k + 2 and the rows of batch k + 1 are requested before the adds of batch k (four entries per batch); the adds
-    // stay in entry order and a pixel's sum is stored when the next pixel begins.
+    // lanes (one DPP row, 32 bytes of the 512-byte row each) own `ppg` consecutive pixels = ONE run of the sorted entry list;
+    // the sixteen groups of the workgroup walk their runs side by side.  The walk has NO control flow inside a trip (r06;
+    // the ISA of the r04 loop showed a `vmcnt(0)` on its back edge -- register copies of a ring with loads in flight -- and a
+    // scratch reload + `vmcnt(0)` inside the "next pixel begins" branch: every pixel change drained the ring):
+    //   * lane l of a group loads entry j + l of the run -- ONE 8-byte load per sixteen entries, the next sixteen a trip ahead --
+    //     and an entry reaches the group's lanes through a DPP row broadcast (no memory, no LDS);
+    //   * the rows of four entries are requested while the previous four are added (two named buffers, trip unrolled four
+    //     stages deep: no copies);
+    //   * "a new pixel begins" is a select on the accumulator (restart from 0) and the running sum is stored to T after
+    //     EVERY entry -- the last store of a pixel is its sum, in the same (row, tap) order with the same fmaf chain as before:
+    //     bit-identical -- and an entry beyond the run adds into the group's own spare row of T.
     {
       const int grp = tid >> 4, l16 = tid & 15;
 #pragma unroll
@@ -606,62 +652,34 @@ __device__ __forceinline__ void branch_grad_tiles(
       int j = soff[grp * ppg];
       const int jend = soff[grp * ppg + ppg], jlast = soff[tpx] - 1;      // jlast >= 0: the sub-tile has entries
       const float* gl = grows + ((int64_t)m * B + b) * R * kF + 8 * l16;
-      int2 ec[kEB], en[kEB];
-      float4 rc[kEB][2];
-#pragma unroll
-      for (int u = 0; u < kEB; ++u) ec[u] = entb[min(j + u, jlast)];
-#pragma unroll
-      for (int u = 0; u < kEB; ++u) en[u] = entb[min(j + kEB + u, jlast)];
-#pragma unroll
-      for (int u = 0; u < kEB; ++u) {
-        const float* rp = gl + (int64_t)(ec[u].x & ((1 << kRowBits) - 1)) * kF;
-        rc[u][0] = *reinterpret_cast<const float4*>(rp);
-        rc[u][1] = *reinterpret_cast<const float4*>(rp + 4);
-      }
-      int cur = -1;
+      const int spare = kTP + grp;                                        // this group's spare row of T
+      float* const tl = T + 8 * l16;
+      float4 ra[kSE][2], rb[kSE][2];
       float acc[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      int cur = spare;
+      int2 ech = entb[min(j + l16, jlast)];
+      fetch_rows<0>(ech.x, gl, ra);
       while (j < jend) {
-        float4 rn[kEB][2];
-        int2 e2[kEB];
-#pragma unroll
-        for (int u = 0; u < kEB; ++u) {
-          const float* rp = gl + (int64_t)(en[u].x & ((1 << kRowBits) - 1)) * kF;
-          rn[u][0] = *reinterpret_cast<const float4*>(rp);
-          rn[u][1] = *reinterpret_cast<const float4*>(rp + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < kEB; ++u) e2[u] = entb[min(j + 2 * kEB + u, jlast)];
-#pragma unroll
-        for (int u = 0; u < kEB; ++u) {
-          if (j + u < jend) {
-            const int px = (ec[u].x >> kRowBits) - q0;
-            const float w = __builtin_bit_cast(float, ec[u].y);
-            if (px != cur) {
-              if (cur >= 0) {
-                float* z = &T[cur * kTS + 8 * l16];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 2 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);
-              }
-#pragma unroll
-              for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-              cur = px;
-            }
-            acc[0] = fmaf(w, rc[u][0].x, acc[0]); acc[1] = fmaf(w, rc[u][0].y, acc[1]);
-            acc[2] = fmaf(w, rc[u][0].z, acc[2]); acc[3] = fmaf(w, rc[u][0].w, acc[3]);
-            acc[4] = fmaf(w, rc[u][1].x, acc[4]); acc[5] = fmaf(w, rc[u][1].y, acc[5]);
-            acc[6] = fmaf(w, rc[u][1].z, acc[6]); acc[7] = fmaf(w, rc[u][1].w, acc[7]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kEB; ++u) { ec[u] = en[u]; en[u] = e2[u]; rc[u][0] = rn[u][0]; rc[u][1] = rn[u][1]; }
-        j += kEB;
-      }
-      if (cur >= 0) {
-        float* z = &T[cur * kTS + 8 * l16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 2 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);
+        const int2 enx = entb[min(j + 16 + l16, jlast)];
+        fetch_rows<4>(ech.x, gl, rb);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));      // (left alone all sixteen broadcasts are lifted to the top of the trip)
+        add_rows<0>(ech, j, jend, q0, spare, tl, ra, acc, cur);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));
+        fetch_rows<8>(ech.x, gl, ra);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));
+        add_rows<4>(ech, j, jend, q0, spare, tl, rb, acc, cur);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));
+        fetch_rows<12>(ech.x, gl, rb);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));
+        add_rows<8>(ech, j, jend, q0, spare, tl, ra, acc, cur);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));
+        fetch_rows<0>(enx.x, gl, ra);
+        asm volatile("" : "+v"(ech.x), "+v"(ech.y));
+        add_rows<12>(ech, j, jend, q0, spare, tl, rb, acc, cur);
+        ech = enx;
+        j += 16;
       }
     }
     __syncthreads();
@@ -670,22 +688,26 @@ __device__ __forceinline__ void branch_grad_tiles(
     // (four accumulator chains sharing the A fragments).  A = W^T straight from global memory (64-byte runs per lane
     // group); B = T from LDS, four k-steps ahead.
     {
+      // (lane coordinates the optimiser cannot see through: it otherwise lifts the ~40 64-bit addresses of this phase out of
+      // the sub-tile loop and they live, spilled to scratch, across the T phase)
+      int nn = n, gg = gq;
+      asm volatile("" : "+v"(nn), "+v"(gg));
       auto load_a = [&](int mt, float (&a)[32]) {
-        const int cc = min(16 * mt + n, C - 1);
-#pragma unroll
-        for (int s = 0; s < 32; ++s) a[s] = Wp[(int64_t)(4 * s + gq) * Ctot + cc];
+        const unsigned lo = (unsigned)(gg * Ctot + min(16 * mt + nn, C - 1));   // uniform base + 32-bit lane offset: one
+#pragma unroll                                                                  // VGPR of address for all 32 loads
+        for (int s = 0; s < 32; ++s) a[s] = (Wp + (size_t)(4 * s) * Ctot)[lo];
       };
       for (int mt = wave; mt < nmt; mt += kGW / 64) {
         float a[32];
         load_a(mt, a);
-        if (16 * mt + n >= C) {
+        if (16 * mt + nn >= C) {
 #pragma unroll
           for (int s = 0; s < 32; ++s) a[s] = 0.f;
         }
         v4f acc4[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-        const float* tq = T + n * kTS + gq;
+        const float* tq = T + nn * kTS + gg;
         float tb[2][4][4];                               // [buffer][k-step][pixel tile]
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -707,15 +729,15 @@ __device__ __forceinline__ void branch_grad_tiles(
               if (t < ntl) acc4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * c + u], tb[c & 1][u][t], acc4[t], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // D: lane (gq, n) holds channels 16 mt + 4 gq + j, pixel 16 t + n
+        // D: lane (gg, nn) holds channels 16 mt + 4 gg + j, pixel 16 t + nn
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int c = 16 * mt + 4 * gq + j;
+          const int c = 16 * mt + 4 * gg + j;
           if (c >= C) continue;
           const float pool = dp != nullptr ? dp[c] * inv : 0.f;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int q = q0 + 16 * t + n;
+            const int q = q0 + 16 * t + nn;
             if (t < ntl && q < hw) out[(int64_t)c * hw + q] = fmaf(sc, acc4[t][j], pool);
           }
         }
@@ -725,14 +747,137 @@ __device__ __forceinline__ void branch_grad_tiles(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The finest branch in the reference's own order, dX_0 = S_0^T (grows W_0) (r06).  Branch 0 is a gather: one entry of
+// weight 1 per sampled row, R entries on a map of H_0 W_0 >> R pixels.  The transposed order above multiplies 64-pixel
+// tiles of T of which ~8 columns are not zero and pays a T pass + a multiply per 64 pixels (r06 stamps: 58 k cycles per
+// 256-pixel workgroup, HALF of the kernel's wave time for 7 % of its channels).  Instead:
+//   finest_rows_kernel   dxs0[m][b][r][0 .. C_0) = grows[m][b][r][:] W_m[:, 0 .. C_0): [R x 128] x [128 x C_0] per image and
+//                        modality on the matrix cores (64 rows per workgroup, staged in LDS with 16-byte loads), 1.9 MB;
+//   finest_tiles         a workgroup of branch_grad_t_kernel owns 256 pixels: offsets + pooling gradient, the entries of its
+//                        range, their dxs0 rows (three round trips, everything of a trip in flight together), then ONE pass over
+//                        (channel, four pixels): pixel sums in entry order out of LDS, 16-byte stores.  No T, no multiply.
+// More entries in a workgroup's range than its LDS holds (a pixel sampled hundreds of times) -> the generic path, any input.
+// ------------------------------------------------------------------------------------------
+constexpr int kFR = 64;       // rows per workgroup of finest_rows_kernel
+__global__ __launch_bounds__(256) void finest_rows_kernel(const float* __restrict__ grows, const float* __restrict__ Wp1,
+                                                          const float* __restrict__ Wp2, int R, int B, int Ctot, int C0,
+                                                          int C0p, float* __restrict__ dxs0) {
+  __shared__ __attribute__((aligned(16))) float Tl[kFR * kTS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * kFR, b = blockIdx.y, m = blockIdx.z;
+  const float* gsrc = grows + (((int64_t)m * B + b) * R + r0) * kF;
+  const int nr = min(kFR, R - r0);
+#pragma unroll
+  for (int k = 0; k < kFR * (kF / 4) / 256; ++k) {
+    const int e = tid + 256 * k, r = e >> 5, c4 = e & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nr) v = *reinterpret_cast<const float4*>(gsrc + (int64_t)r * kF + 4 * c4);
+    float* z = &Tl[r * kTS + 4 * c4];
+    *reinterpret_cast<float2*>(z) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(z + 2) = make_float2(v.z, v.w);
+  }
+  __syncthreads();
+  const int n = lane & 15, gq = lane >> 4;
+  const float* Wp = m ? Wp2 : Wp1;
+  const float* tq = Tl + (16 * wave + n) * kTS + gq;
+  const int r = r0 + 16 * wave + n;
+  float* drow = dxs0 + (((int64_t)m * B + b) * R + r) * C0p;
+  for (int mt = 0; 16 * mt < C0p; ++mt) {
+    const unsigned lo = (unsigned)(gq * Ctot + min(16 * mt + n, C0 - 1));
+    const bool live = 16 * mt + n < C0;
+    float a[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) a[s] = (Wp + (size_t)(4 * s) * Ctot)[lo];
+    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? a[s] : 0.f, tq[4 * s], acc, 0, 0, 0);
+    // D: lane (gq, n) holds channels 16 mt + 4 gq + j of row 16 wave + n (channels >= C0: A was zero)
+    if (r < R && 16 * mt + 4 * gq < C0p) *reinterpret_cast<float4*>(drow + 16 * mt + 4 * gq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+constexpr int kTFloats = (kTP + 256 / 16) * kTS;       // floats of the tile kernel's T region (64 pixel rows + 16 spare rows)
+// entries a workgroup of the finest path can stage: each costs an int2 + a row of C0p floats of the T region
+__host__ __device__ inline int finest_cap(int C0p) { return (kTFloats - 4) / (C0p + 2); }
+
+// -> true: the workgroup's tiles are written; false: too many entries in its range, the caller runs the generic path
+__device__ __forceinline__ bool finest_tiles(float* __restrict__ T, int* __restrict__ soff, float* __restrict__ pool_l,
+                                             const float* __restrict__ dxs0, int C0p, const float* __restrict__ dpooled,
+                                             const float* __restrict__ scale, const int2* __restrict__ ent,
+                                             const int* __restrict__ off, int R, int B, int Ctot, const Maps8Out& g,
+                                             const PlanGeom& gm, int wg, int wpx) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x, m = blockIdx.y;
+  const int C = g.C[0], hw = g.H[0] * g.W[0];
+  const int P0 = wg * wpx, npx = min(wpx, hw - P0);            // wpx = pixels per workgroup (sub-tiles x pixels of a sub-tile)
+  const int* offb = off + (int64_t)b * gm.off_per_image + gm.off_off[0];
+  const int2* entb = ent + (int64_t)b * gm.ent_per_image + gm.ent_off[0];
+  const float* dp = dpooled != nullptr ? dpooled + ((int64_t)m * B + b) * Ctot : nullptr;
+  const float sc = scale != nullptr ? scale[0] : 1.f;
+  const float inv = 1.f / (float)hw;
+  HCM_STAMP(0);
+  // ---- trip 1: the per-pixel offsets of the range and the pooling gradient of the branch's channels
+  for (int e = tid; e <= npx; e += kGW) soff[e] = offb[P0 + e];
+  for (int c = tid; c < C; c += kGW) pool_l[c] = dp != nullptr ? dp[c] * inv : 0.f;
+  __syncthreads();
+  const int j0 = soff[0], ne = soff[npx] - j0;
+  if (ne > finest_cap(C0p)) return false;                // block-uniform
+  HCM_STAMP(1);
+  // ---- trip 2: the entries; trip 3: their rows of dxs0, 16 bytes per thread and load
+  int2* el = reinterpret_cast<int2*>(T);
+  float* dl = T + ((2 * ne + 3) & ~3);
+  for (int e = tid; e < ne; e += kGW) el[e] = entb[j0 + e];
+  __syncthreads();
+  const int C4 = C0p >> 2;
+  const float* dsrc = dxs0 + ((int64_t)m * B + b) * R * C0p;
+  for (int k = tid; k < ne * C4; k += kGW) {
+    const int e = k / C4, c4 = k - e * C4;
+    const int r = el[e].x & ((1 << kRowBits) - 1);
+    *reinterpret_cast<float4*>(dl + e * C0p + 4 * c4) = *reinterpret_cast<const float4*>(dsrc + (int64_t)r * C0p + 4 * c4);
+  }
+  __syncthreads();
+  HCM_STAMP(2);
+  // ---- one pass over (channel, four pixels): consecutive threads = consecutive quads of one channel's row of the map
+  float* out = sel8(g.p, m * 4) + (int64_t)b * C * hw + P0;
+  const int nq = npx >> 2;                                // hw % 4 == 0 on this path, P0 is a multiple of 16
+  for (int it = tid; it < C * nq; it += kGW) {
+    const int c = it / nq, quad = it - c * nq;
+    const float pool = pool_l[c];
+    int o[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = soff[4 * quad + k] - j0;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float acc = 0.f;
+      for (int e = o[k]; e < o[k + 1]; ++e) acc = fmaf(__builtin_bit_cast(float, el[e].y), dl[e * C0p + c], acc);
+      v[k] = fmaf(sc, acc, pool);
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)c * hw + 4 * quad) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  HCM_STAMP(3);
+  return true;
+}
+
+
 __global__ __launch_bounds__(kGW, 3) void branch_grad_t_kernel(
     const float* __restrict__ grows, const float* __restrict__ Wp1, const float* __restrict__ Wp2,
     const float* __restrict__ dpooled, const float* __restrict__ scale, const int2* __restrict__ ent,
-    const int* __restrict__ off, int R, int B, int Ctot, Maps8Out g, TilePlan tp, PlanGeom gm) {
-  __shared__ __attribute__((aligned(16))) float T[kTP * kTS];
+    const int* __restrict__ off, int R, int B, int Ctot, Maps8Out g, TilePlan tp, PlanGeom gm,
+    const float* __restrict__ dxs0, int C0p) {
+  __shared__ __attribute__((aligned(16))) float T[kTFloats];                   // 64 pixel rows + one spare row per 16-lane group
   __shared__ int soff[kSpanMax * kTP + 1];
-  int i = 0;
-  while (i < 3 && (int)blockIdx.x >= tp.first[i + 1]) ++i;
+  __shared__ float pool_l[64];
+  HCM_STAMP(5);
+  int k0 = 0;
+  while (k0 < 3 && (int)blockIdx.z >= tp.first[k0 + 1]) ++k0;
+  const int i = sel4(tp.ord, k0);
+  if (i == 0 && dxs0 != nullptr) {
+    const int wg = blockIdx.z - (k0 == 0 ? tp.first[0] : k0 == 1 ? tp.first[1] : k0 == 2 ? tp.first[2] : tp.first[3]);
+    if (finest_tiles(T, soff, pool_l, dxs0, C0p, dpooled, scale, ent, off, R, B, Ctot, g, gm, wg, tp.span[0] * tp.tpix[0])) return;
+    __syncthreads();                                     // (soff is loaded again below)
+  }
   if (sel4(tp.tpix, i) == 16)
     branch_grad_tiles<16>(T, soff, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
   else
@@ -905,6 +1050,14 @@ int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale,
 }
 
 
+// the finest branch takes the rows-first path (finest_rows_kernel + finest_tiles) when its map rows split into 16-byte quads
+// and a row of its channels fits the tile kernel's LDS: floats of dxs0 per modality, 0 = generic path
+static size_t finest_rows_floats(int B, int R, const hcm_branches_out& g1) {
+  const int C0p = (g1.C[0] + 3) & ~3;
+  if (((g1.H[0] * g1.W[0]) & 3) != 0 || C0p > 64 || finest_cap(C0p) < 64) return 0;
+  return (size_t)B * R * C0p;
+}
+
 static int plan_geom(const hcm_branches_out& g1, int R, PlanGeom* gm) {
   int eo = 0, oo = 0;
   for (int i = 0; i < 4; ++i) {
@@ -922,7 +1075,8 @@ size_t hcm_project_rows_backward_workspace_bytes(int B, int R, int Ctot, hcm_bra
   PlanGeom gm;
   plan_geom(g1, R, &gm);
   const size_t dw = hcm_project_rows_dw_workspace_bytes(B, Ctot);
-  return dw + (size_t)B * gm.ent_per_image * sizeof(int2) + (size_t)B * gm.off_per_image * sizeof(int) + 256;
+  return dw + (size_t)B * gm.ent_per_image * sizeof(int2) + (size_t)B * gm.off_per_image * sizeof(int) + 256 +
+         finest_rows_floats(B, R, g1) * 2 * sizeof(float);
 }
 
 int hcm_project_rows_backward(const float* grows, const float* xs, const float* Wp1, const float* Wp2,
@@ -940,6 +1094,8 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
   plan_geom(g1, R, &gm);
   TilePlan tp;
   int v = 0, n2 = 2;
+  int nwg[4];
+  double cost[4];
   for (int i = 0; i < 4; ++i) {
     if (nmod == 2 && (g1.C[i] != g2.C[i] || g1.H[i] != g2.H[i] || g1.W[i] != g2.W[i])) return (int)hipErrorInvalidValue;
     // keys are pixel * E + entry in 32 bits
@@ -947,10 +1103,21 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
     if (g1.H[i] * g1.W[i] >= (1 << 17) || R >= (1 << kRowBits)) return (int)hipErrorInvalidValue;
     tp.tpix[i] = g1.H[i] * g1.W[i] <= 256 ? 16 : kTP;
     const int nt = (g1.H[i] * g1.W[i] + tp.tpix[i] - 1) / tp.tpix[i];
-    tp.span[i] = nt >= 32 ? kSpanMax : 1;            // maps of >= 2048 pixels: four 64-pixel sub-tiles per workgroup
-    tp.first[i] = v;
-    v += (nt + tp.span[i] - 1) / tp.span[i];
+    tp.span[i] = nt >= 32 ? kSpanMax : 1;            // maps of >= 2048 pixels: kSpanMax 64-pixel sub-tiles per workgroup
+    nwg[i] = (nt + tp.span[i] - 1) / tp.span[i];
+    // a workgroup's expected life, in "sub-tile passes": its sub-tiles x (walk of its share of the entries + multiply rounds)
+    const double ent_per_wg = (double)(i == 0 ? 1 : 4) * R / nwg[i];
+    cost[i] = tp.span[i] * (1.0 + ((g1.C[i] + 15) / 16 + 3) / 4) + ent_per_wg / (16.0 * tp.tpix[i] / 4);
+    if (i == 0 && finest_rows_floats(B, R, g1) != 0) cost[i] = 1.0;          // rows-first path: three round trips and stores
   }
+  // dispatch order: expensive workgroups first.  grid (B, nmod, tiles): x runs fastest, so ALL images' workgroups of the most
+  // expensive kind start before the first cheap one (r06 stamps: with the tiles in x every image's heaviest workgroups started
+  // behind its light ones, the last image's at the very end of the kernel)
+  for (int k = 0; k < 4; ++k) tp.ord[k] = k;
+  for (int a = 0; a < 4; ++a)
+    for (int c = a + 1; c < 4; ++c)
+      if (cost[tp.ord[c]] > cost[tp.ord[a]]) { const int t = tp.ord[a]; tp.ord[a] = tp.ord[c]; tp.ord[c] = t; }
+  for (int k = 0; k < 4; ++k) { tp.first[k] = v; v += nwg[tp.ord[k]]; }
   tp.first[4] = v;
   n2 = 128;
   while (n2 < 4 * R) n2 <<= 1;
@@ -969,8 +1136,18 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
     if (rc != 0) return rc;
   }
   hcm::ProfSpan span(HCM_PROF_ROW8_BWD, s);
-  branch_grad_t_kernel<<<dim3(v, B, nmod), kGW, 0, s>>>(grows, Wp1, nmod == 2 ? Wp2 : Wp1, dpooled, scale, ent, off, R, B, Ctot,
-                                                        pack8(g1, nmod == 2 ? g2 : g1), tp, gm);
+  const size_t fr = finest_rows_floats(B, R, g1);
+  const int C0p = (g1.C[0] + 3) & ~3;
+  float* dxs0 = nullptr;
+  if (fr != 0) {
+    dxs0 = reinterpret_cast<float*>(base + ((dwb + 15) & ~(size_t)15) + (((size_t)B * gm.ent_per_image * sizeof(int2) +
+                                    (size_t)B * gm.off_per_image * sizeof(int) + 15) & ~(size_t)15));
+    finest_rows_kernel<<<dim3((R + kFR - 1) / kFR, B, nmod), 256, 0, s>>>(grows, Wp1, nmod == 2 ? Wp2 : Wp1, R, B, Ctot, g1.C[0],
+                                                                         C0p, dxs0);
+    HCM_CHECK_LAUNCH();
+  }
+  branch_grad_t_kernel<<<dim3(B, nmod, v), kGW, 0, s>>>(grows, Wp1, nmod == 2 ? Wp2 : Wp1, dpooled, scale, ent, off, R, B, Ctot,
+                                                        pack8(g1, nmod == 2 ? g2 : g1), tp, gm, dxs0, C0p);
   span.stop();
   HCM_CHECK_LAUNCH();
   return 0;

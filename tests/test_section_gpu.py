@@ -277,19 +277,21 @@ def test_row8_on_the_matrix_cores_against_torch(B, width, size, R):
         assert rel_l2(a, b_) < 1e-5, rel_l2(a, b_)
 
 
-def test_row8_backward_with_a_pixel_sampled_hundreds_of_times():
+@pytest.mark.parametrize('R,hub', [(417, 400), (700, 660)])
+def test_row8_backward_with_a_pixel_sampled_hundreds_of_times(R, hub):
     """A mask with a single valid pixel puts all S samples of every image on it (contrast_trainer.py:685 draws with
     replacement): the per-pixel entry lists are then 400 long.  r03's list construction was quadratic there (736 us at
-    the bench size); the sorted plan is linear -- and still exact."""
+    the bench size); the sorted plan is linear -- and still exact.  660 entries on one pixel are more than a workgroup of
+    the finest branch's rows-first path (r06: finest_tiles) stages in LDS: that workgroup takes the generic tile path."""
     torch.manual_seed(5)
     d = dev()
-    B, width, size, R = 4, 18, 64, 417
+    B, width, size = 4, 18, 64
     m1, m2 = make_maps(B, width, size, 3), make_maps(B, width, size, 4)
     Ctot, Fd = 15 * width, 128
     Wp = [torch.randn(Fd, Ctot, 1, 1) * 0.05 for _ in range(2)]
     bp = [torch.randn(Fd) * 0.1 for _ in range(2)]
     pix = torch.full((B, R), 1234)
-    pix[:, 400:] = torch.randint(0, size * size, (B, 17))
+    pix[:, hub:] = torch.randint(0, size * size, (B, R - hub))
     g = lambda t: t.to(d)
     rows, xs, grows = ops().project_rows([g(t) for t in m1], [g(t) for t in m2], g(pix), g(Wp[0]), g(bp[0]), g(Wp[1]), g(bp[1]))
     gr = torch.randn(2, B * R, Fd)

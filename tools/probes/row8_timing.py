@@ -46,6 +46,8 @@ def run(fn, name, nslots):
     setbuf(None)
     t = buf.cpu()
     used = t[:, 0] != 0
+    global wg_index
+    wg_index = used.nonzero().view(-1)
     t = t[used]
     print('%s: %d workgroups stamped' % (name, t.shape[0]))
     t0 = t[:, 0].min()
@@ -78,7 +80,7 @@ print('  workgroups: %d with entries, %d empty' % (int(full.sum()), int(empty.su
 e = t[empty]
 print('  empty: start -> offsets %.0f, -> stored %.0f (mean)' % ((e[:, 1] - e[:, 0]).float().mean(), (e[:, 4] - e[:, 1]).float().mean()))
 f = t[full]
-for name, a, b in (('offsets', 0, 1), ('T accumulate', 1, 2), ('multiply + store', 2, 3)):
+for name, a, b in (('entry -> tiles()', 5, 0), ('offsets issued', 0, 6), ('offsets landed', 6, 1), ('offsets', 0, 1), ('T accumulate', 1, 2), ('multiply + store', 2, 3)):
     v = (f[:, b] - f[:, a]).float()
     print('  with entries: %-18s mean %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f' % (name, v.mean(), v.median(), v.quantile(0.9), v.max()))
 life = (t.max(dim=1).values - t[:, 0]).float()
@@ -87,3 +89,21 @@ print('  lifetime mean %.0f max %.0f; start offsets mean %.0f max %.0f (span %.0
 span = float(t.max() - t0)
 starts, ends = (t[:, 0] - t0).float(), (t.max(dim=1).values - t0).float()
 print('  alive workgroups at 10 %% steps:', [int(((starts <= x * span / 10) & (ends > x * span / 10)).sum()) for x in range(10)])
+
+# per branch: grid (B, 2, tiles), tiles in dispatch order (hcm_project_rows_backward: most expensive kind first; at 256 x 256
+# with HRNet-w18 that is branch 3, 2, 1, 0 (rows-first path: cheapest) with 4 / 16 / 16 / 16 workgroups per image and modality)
+if crop == 256:
+    order, cnt = [3, 2, 1, 0], [4, 16, 16, 16]
+    z = wg_index // (2 * B)
+    lo = 0
+    for i, c in zip(order, cnt):
+        sel = (z >= lo) & (z < lo + c)
+        lo += c
+        tt = t[sel]
+        fl = tt[:, 3] != 0
+        lf = (tt.max(dim=1).values - tt[:, 0]).float()
+        msg = '  branch %d: %4d workgroups (%4d with entries) lifetime mean %6.0f max %6.0f' % (i, int(sel.sum()), int(fl.sum()), lf.mean(), lf.max())
+        if bool(fl.any()):
+            ff = tt[fl]
+            msg += '   offsets %6.0f  T %6.0f  multiply %6.0f (means, with entries)' % ((ff[:, 1] - ff[:, 0]).float().mean(), (ff[:, 2] - ff[:, 1]).float().mean(), (ff[:, 3] - ff[:, 2]).float().mean())
+        print(msg)
