@@ -569,7 +569,7 @@ __device__ __forceinline__ void add_rows(int2 ech, int j, int jend, int q0, int 
 
 template <int TPX>
 __device__ __forceinline__ void branch_grad_tiles(
-    float* __restrict__ T, int* soff, const float* __restrict__ grows, const float* __restrict__ Wp1,
+    float* __restrict__ T, int* soff, float* __restrict__ pool_l, const float* __restrict__ grows, const float* __restrict__ Wp1,
     const float* __restrict__ Wp2, const float* __restrict__ dpooled, const float* __restrict__ scale,
     const int2* __restrict__ ent, const int* __restrict__ off, int R, int B, int Ctot, const Maps8Out& g,
     const TilePlan& tp, const PlanGeom& gm) {
@@ -599,6 +599,8 @@ __device__ __forceinline__ void branch_grad_tiles(
   // 5.4 k cycles, most of it this load; the finest maps are mostly empty tiles)
   int* const soff_all = soff;
   for (int e0 = tid; e0 <= span * tpx; e0 += kGW) soff_all[e0] = offb[min(wg * span * tpx + e0, hw)];
+  // (and the pooling gradient of the branch's channels: read after the multiply it was a dependent global load per round)
+  for (int c = tid; c < C; c += kGW) pool_l[c] = dp != nullptr ? dp[c] * inv : 0.f;
   HCM_STAMP(6);
   __syncthreads();
   bool used_t = false;
@@ -616,19 +618,32 @@ __device__ __forceinline__ void branch_grad_tiles(
         for (int e0 = tid; e0 < C * (tpx >> 2); e0 += kGW) {
           const int c = e0 / (tpx >> 2), q = q0 + 4 * (e0 - c * (tpx >> 2));
           if (q < hw) {
-            const float pool = dp != nullptr ? dp[c] * inv : 0.f;
+            const float pool = pool_l[c];
             *reinterpret_cast<float4*>(out + (int64_t)c * hw + q) = make_float4(pool, pool, pool, pool);
           }
         }
       } else {
         for (int e0 = tid; e0 < C * tpx; e0 += kGW) {
           const int c = e0 / tpx, q = q0 + e0 - c * tpx;
-          if (q < hw) out[(int64_t)c * hw + q] = dp != nullptr ? dp[c] * inv : 0.f;
+          if (q < hw) out[(int64_t)c * hw + q] = pool_l[c];
         }
       }
       HCM_STAMP(4);
       continue;
     }
+    // (lane coordinates the optimiser cannot see through: it otherwise lifts the ~40 64-bit addresses of the multiply out of
+    // the sub-tile loop and they live, spilled to scratch, across the T phase)
+    int nn = n, gg = gq;
+    asm volatile("" : "+v"(nn), "+v"(gg));
+    auto load_a = [&](int mt, float (&a)[32]) {
+      const unsigned lo = (unsigned)(gg * Ctot + min(16 * mt + nn, C - 1));   // uniform base + 32-bit lane offset: one
+#pragma unroll                                                                  // VGPR of address for all 32 loads
+      for (int s = 0; s < 32; ++s) a[s] = (Wp + (size_t)(4 * s) * Ctot)[lo];
+    };
+    // the A fragments of the wave's first channel tile are requested HERE: their round trip runs under the T walk (r06
+    // stamps: ~2 k cycles of every multiply round were this latency)
+    float a0[32];
+    load_a(min(wave, nmt - 1), a0);
     // ---- T[pixel][f] = sum over the pixel's entries of weight * grows[row][f], entries in (row, tap) order.  Sixteen
     // lanes (one DPP row, 32 bytes of the 512-byte row each) own `ppg` consecutive pixels = ONE run of the sorted entry list;
     // the sixteen groups of the workgroup walk their runs side by side.  The walk has NO control flow inside a trip (r06;
@@ -688,18 +703,14 @@ __device__ __forceinline__ void branch_grad_tiles(
     // (four accumulator chains sharing the A fragments).  A = W^T straight from global memory (64-byte runs per lane
     // group); B = T from LDS, four k-steps ahead.
     {
-      // (lane coordinates the optimiser cannot see through: it otherwise lifts the ~40 64-bit addresses of this phase out of
-      // the sub-tile loop and they live, spilled to scratch, across the T phase)
-      int nn = n, gg = gq;
-      asm volatile("" : "+v"(nn), "+v"(gg));
-      auto load_a = [&](int mt, float (&a)[32]) {
-        const unsigned lo = (unsigned)(gg * Ctot + min(16 * mt + nn, C - 1));   // uniform base + 32-bit lane offset: one
-#pragma unroll                                                                  // VGPR of address for all 32 loads
-        for (int s = 0; s < 32; ++s) a[s] = (Wp + (size_t)(4 * s) * Ctot)[lo];
-      };
       for (int mt = wave; mt < nmt; mt += kGW / 64) {
         float a[32];
-        load_a(mt, a);
+        if (mt == wave) {
+#pragma unroll
+          for (int s = 0; s < 32; ++s) a[s] = a0[s];
+        } else {
+          load_a(mt, a);
+        }
         if (16 * mt + nn >= C) {
 #pragma unroll
           for (int s = 0; s < 32; ++s) a[s] = 0.f;
@@ -734,7 +745,7 @@ __device__ __forceinline__ void branch_grad_tiles(
         for (int j = 0; j < 4; ++j) {
           const int c = 16 * mt + 4 * gg + j;
           if (c >= C) continue;
-          const float pool = dp != nullptr ? dp[c] * inv : 0.f;
+          const float pool = pool_l[c];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int q = q0 + 16 * t + nn;
@@ -759,6 +770,7 @@ __device__ __forceinline__ void branch_grad_tiles(
 //                        (channel, four pixels): pixel sums in entry order out of LDS, 16-byte stores.  No T, no multiply.
 // More entries in a workgroup's range than its LDS holds (a pixel sampled hundreds of times) -> the generic path, any input.
 // ------------------------------------------------------------------------------------------
+constexpr int kPoolMax = 8 * 48;   // channels of the widest branch (HRNet-w48)
 constexpr int kFR = 64;       // rows per workgroup of finest_rows_kernel
 __global__ __launch_bounds__(256) void finest_rows_kernel(const float* __restrict__ grows, const float* __restrict__ Wp1,
                                                           const float* __restrict__ Wp2, int R, int B, int Ctot, int C0,
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(kGW, 3) void branch_grad_t_kernel(
     const float* __restrict__ dxs0, int C0p) {
   __shared__ __attribute__((aligned(16))) float T[kTFloats];                   // 64 pixel rows + one spare row per 16-lane group
   __shared__ int soff[kSpanMax * kTP + 1];
-  __shared__ float pool_l[64];
+  __shared__ float pool_l[kPoolMax];            // the pooling gradient of the workgroup's branch, / (H W)
   HCM_STAMP(5);
   int k0 = 0;
   while (k0 < 3 && (int)blockIdx.z >= tp.first[k0 + 1]) ++k0;
@@ -879,9 +891,9 @@ __global__ __launch_bounds__(kGW, 3) void branch_grad_t_kernel(
     __syncthreads();                                     // (soff is loaded again below)
   }
   if (sel4(tp.tpix, i) == 16)
-    branch_grad_tiles<16>(T, soff, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
+    branch_grad_tiles<16>(T, soff, pool_l, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
   else
-    branch_grad_tiles<kTP>(T, soff, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
+    branch_grad_tiles<kTP>(T, soff, pool_l, grows, Wp1, Wp2, dpooled, scale, ent, off, R, B, Ctot, g, tp, gm);
 }
 
 int num_cus() {
@@ -1098,6 +1110,7 @@ int hcm_project_rows_backward(const float* grows, const float* xs, const float* 
   double cost[4];
   for (int i = 0; i < 4; ++i) {
     if (nmod == 2 && (g1.C[i] != g2.C[i] || g1.H[i] != g2.H[i] || g1.W[i] != g2.W[i])) return (int)hipErrorInvalidValue;
+    if (g1.C[i] > kPoolMax) return (int)hipErrorInvalidValue;      // the tile kernel keeps a branch's pooling gradient in LDS
     // keys are pixel * E + entry in 32 bits
     if ((uint64_t)g1.H[i] * g1.W[i] * 4ull * (uint64_t)R >= 0xffffffffull) return (int)hipErrorInvalidValue;
     if (g1.H[i] * g1.W[i] >= (1 << 17) || R >= (1 << kRowBits)) return (int)hipErrorInvalidValue;
