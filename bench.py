@@ -746,8 +746,12 @@ def run(a, rank, world, local, fs):
         row8_dw_flops = nmod * 2.0 * (B * R) * D * ld
         row8_dw_bytes = nmod * B * R * (D + ld) * 4
         pix_c = sum(widths[i] * (hw0 >> (2 * i)) for i in range(4))            # sum_i C_i H_i W_i
-        row8_bwd_flops = nmod * B * 2.0 * pix_c * D
-        row8_bwd_bytes = nmod * B * (pix_c * 4 + R * D * 4)
+        # (r06: the finest branch runs rows-first, S_0^T (grows W_0): R x C_0 x 128 per image instead of H_0 W_0 x C_0 x 128, and
+        # its projected rows dxs0 [R, C_0 padded to 4] are written once and gathered once)
+        c0p = (widths[0] + 3) // 4 * 4
+        rows_first = (hw0 % 4 == 0) and c0p <= 64
+        row8_bwd_flops = nmod * B * 2.0 * D * ((R * widths[0] + pix_c - widths[0] * hw0) if rows_first else pix_c)
+        row8_bwd_bytes = nmod * B * (pix_c * 4 + R * D * 4 + (2 * R * c0p * 4 if rows_first else 0))
         joint_bytes = 3 * B * J * D * 4 * 2                                    # rows in, row gradients out
         spec = [('dense_stats', 'strip_kernel<Dense, stats> (S x S similarity + online softmax / soft targets)', 'mfma', dense_gemm),
                 ('dense_grad', 'strip_kernel<Dense, grad> (similarity re-formed + G K contraction)', 'mfma', 2 * dense_gemm),
@@ -759,7 +763,8 @@ def run(a, rank, world, local, fs):
                  'hbm', row8_nhwc_bytes),
                 ('row8_dw', 'proj_dw_partial + proj_dw_reduce (d[W | b] = grows^T xs, fp32 MFMA)', 'mfma+bytes',
                  (row8_dw_flops, row8_dw_bytes)),
-                ('row8_bwd', 'branch_grad_t_kernel (branch-map gradients W_i^T (S_i^T grows) + pooling gradient, fp32 MFMA)',
+                ('row8_bwd', 'finest_rows_kernel + branch_grad_t_kernel (branch-map gradients: finest branch S_0^T (grows W_0), the others '
+                             'W_i^T (S_i^T grows), + pooling gradient, fp32 MFMA)',
                  'mfma+bytes', (row8_bwd_flops, row8_bwd_bytes)),
                 ('joint', 'joint_nce_kernel + joint_finish_kernel (joint <-> graph-node InfoNCE)', 'latency', joint_bytes),
                 ('sgc_fwd', 'SemGCN layer forward (sgc_mix + sgc_norm), per layer', 'latency', sgc_fwd_bytes),

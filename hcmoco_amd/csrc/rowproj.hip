@@ -23,6 +23,11 @@
 //                         gradient included.  No dxs matrix, no per-workgroup list building (r03: 70 % of the wave
 //                         cycles of branch_grad_kernel were barrier / LDS waits of its list construction), linear in the
 //                         length of a pixel's list (r03 was quadratic for a pixel sampled hundreds of times).
+//                         r06: workgroups dispatched most expensive kind first; the walk of the entry lists without control
+//                         flow (DPP row broadcasts of a 16-entry chunk, two named row buffers: 8-16 row loads in flight);
+//                         the pooling gradient and the first A fragments requested with the offsets.
+//   finest_rows_kernel, finest_tiles (inside branch_grad_t_kernel)
+//                         r06: the finest branch in the reference's order, S_0^T (grows W_0) -- see the comment above them.
 // Everything is fp32; an fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md), sums run in a fixed order.
 #include "hcm_common.h"
 #include "../../include/hcmoco_hip.h"
@@ -33,6 +38,12 @@ namespace {
 using namespace hcm;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+// n / d by one multiply: magic(d) = floor((2^32 - 1) / d) + 1 once (block-uniform), then the high word of n * magic.  Exact
+// while n d < 2^32: n (magic d - 2^32) <= n d.  d = 1 has no 32-bit magic (0 stands for it).  (A run-time unsigned division is
+// ~30 VALU instructions; the gather loops of the forward kernel did one per element.)
+__device__ __forceinline__ unsigned div_magic(int d) { return (unsigned)(0xffffffffu / (unsigned)d) + 1u; }
+__device__ __forceinline__ int fast_div(int n, unsigned magic) { return magic != 0u ? (int)__umulhi((unsigned)n, magic) : n; }
 
 // Diagnostic build only (-DHCM_ROW8_TIMING, tools/probes/row8_timing.sh): s_memtime stamps of the phases of a workgroup,
 // 16 slots per workgroup in a buffer the probe hands over.  Compiled out of the product library.
@@ -122,14 +133,17 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     float* dst = lds + off;
     if ((hw & 3) == 0) {
       const int n4 = (C * hw) >> 2;
+      const unsigned mw = div_magic(hw);
       for (int base = tid; base < n4; base += 16 * kPW) {         // sixteen 16-byte loads in flight per thread
         float4 v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) v[u] = reinterpret_cast<const float4*>(src)[min(base + u * kPW, n4 - 1)];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {                   // (a clamped index rewrites the last quad with itself)
-          {
-            const int e0 = min(base + u * kPW, n4 - 1) << 2, c = e0 / hw, q = e0 - c * hw;
+        for (int u = 0; u < 16; ++u) {
+          // (only the loads are clamped: a clamped WRITE is the whole workgroup storing to one LDS address, a 64-way bank
+          // conflict per instruction -- r06 stamps: 40 k cycles of staging, 38 k of them the 18 clamped slots x 4 words x 8 waves)
+          if (base + u * kPW < n4) {
+            const int e0 = (base + u * kPW) << 2, c = fast_div(e0, mw), q = e0 - c * hw;
             float* d = dst + c * P + q;
             d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
           }
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
       }
     }
   }
+  HCM_STAMP(12);
   // ---- the wave's B fragments: [W | b | 0]^T, column 16 wave + n, rows 4 s + g
   float breg[KS];
   {
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
       breg[s] = k < Ctot ? breg[s] : (k == Ctot ? bias : 0.f);
     }
   }
+  HCM_STAMP(13);
   const int64_t row0 = ((int64_t)m * B + b) * R;
   int g_ng = 0, g_ctot = 0, g_end0 = 0, g_end1 = 0, g_end2 = 0;
   {
@@ -213,6 +229,7 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     // element).  xs is written once per tile from LDS, after the barrier, and retires under the MFMA phase.
     {
       const int ctot = g_ctot, total = kSR * ctot;
+      const unsigned mg = div_magic(max(ctot, 1));
       for (int base = tid; base < total; base += 4 * kPW) {
         float rv[4][4];
         int dst[4];
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int ge = min(base + u * kPW, total - 1);
-          const int lr = ge / ctot, cg = ge - lr * ctot;
+          const int lr = fast_div(ge, mg), cg = ge - lr * ctot;
           const int k = (cg >= g_end0) + (cg >= g_end1) + (cg >= g_end2);       // < ng: the ends past the last group equal ctot
           const int st = s_gmeta[k][0], cs = s_gmeta[k][1], c = cg - s_gmeta[k][2], i = s_gmeta[k][4];
           const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i][0]);
@@ -250,10 +267,11 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
         if (off >= 0) {                                     // block-uniform
           const float* xl = lds + off;
           const int P = hw | 1, tot = kSR * C;
+          const unsigned mc = div_magic(C);
 #pragma unroll 4
           for (int e0 = tid; e0 < tot + kPW - 1 - (tot + kPW - 1) % kPW; e0 += kPW) {
             const int ec = min(e0, tot - 1);
-            const int lr = ec / C, c = ec - lr * C;
+            const int lr = fast_div(ec, mc), c = ec - lr * C;
             const int4 o = *reinterpret_cast<const int4*>(&s_to[lr][i][0]);
             const float4 w = *reinterpret_cast<const float4*>(&s_tw[lr][i][0]);
             RowTaps q;
@@ -265,8 +283,9 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
         coff += C;
       }
       const int npad = 4 * KS - Ctot;                          // the bias column, then padding
+      const unsigned mp = div_magic(npad);
       for (int e0 = tid; e0 < kSR * npad; e0 += kPW) {
-        const int lr = e0 / npad, k = Ctot + e0 - lr * npad;
+        const int lr = fast_div(e0, mp), k = Ctot + e0 - lr * npad;
         lx[lr * XS + k] = k == Ctot ? 1.f : 0.f;
       }
     }
@@ -274,8 +293,9 @@ __global__ __launch_bounds__(kPW) void project_rows_kernel(
     HCM_STAMP(2 + 2 * ((r0 - r_begin) / kSR));
     if (xs != nullptr) {                                       // the sampled rows, coalesced 8-byte stores out of the tile
       const int h2 = ld >> 1, nrow = min(kSR, r_end - r0);
+      const unsigned mh = div_magic(h2);
       for (int e0 = tid; e0 < nrow * h2; e0 += kPW) {
-        const int lr = e0 / h2, k2 = e0 - lr * h2;
+        const int lr = fast_div(e0, mh), k2 = e0 - lr * h2;
         *reinterpret_cast<float2*>(xs + (row0 + r0 + lr) * ld + 2 * k2) = *reinterpret_cast<const float2*>(lx + lr * XS + 2 * k2);
       }
     }

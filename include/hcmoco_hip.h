@@ -365,9 +365,13 @@ int hcm_project_rows_dw(const float* grows, const float* xs, const float* scale,
  *                         + (*scale) * sum_f W_m[f, coff_i + c] * ( sum over the stencil entries (r, tap) of image b that
  *                           land on pixel q of weight(r, tap) * grows[m, b*R + r, f] ),
  * entries in ascending (row, tap) order, f ascending: owner computes, no atomics, every element written exactly once.
- * keep / S as in hcm_branch_grad.  Three launches: the stencil plan (entries sorted by pixel, shared by both modalities),
- * the weight-gradient partials + reduction, the branch tiles.  workspace:
- * hcm_project_rows_backward_workspace_bytes(B, R, Ctot, g1).  H_i W_i * 4R < 2^32, R <= 9600. */
+ * The finest branch (a gather: one entry of weight 1 per row) is evaluated in the reference's own order since r06,
+ *   sum over the entries of pixel q of weight * ( sum_f W_m[f, c] * grows[m, b*R + r, f] )
+ * (the projected rows first, on the matrix cores; then offsets / entries / rows / one store pass per 256 pixels), whenever
+ * H_0 W_0 is a multiple of 4; a workgroup whose pixel range holds more entries than its LDS stages takes the order above.
+ * keep / S as in hcm_branch_grad.  Launches: the stencil plan (entries sorted by pixel, shared by both modalities), the
+ * weight-gradient partials + reduction, the finest branch's projected rows, the branch tiles.  workspace:
+ * hcm_project_rows_backward_workspace_bytes(B, R, Ctot, g1).  H_i W_i * 4R < 2^32, R <= 9600, C_i <= 384. */
 size_t hcm_project_rows_backward_workspace_bytes(int B, int R, int Ctot, hcm_branches_out g1);
 int hcm_project_rows_backward(const float* grows, const float* xs, const float* Wp1, const float* Wp2,
                               const float* dpooled, const float* scale, const int64_t* pix, int R, int B, int Ctot,

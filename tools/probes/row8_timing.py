@@ -59,6 +59,7 @@ rows_, xs_, _ = hip_ops.project_rows(maps1, maps2, pix, Wp[0], bp[0], Wp[1], bp[
 t, t0 = run(lambda: hip_ops.project_rows(maps1, maps2, pix, Wp[0], bp[0], Wp[1], bp[1]), 'project_rows_kernel', 12)
 st = (t[:, 1] - t[:, 0]).float()
 print('  start -> maps staged + B fragments: mean %.0f max %.0f' % (st.mean(), st.max()))
+print('    of which: staging loops issued %.0f, B fragment loads issued %.0f, to the first barrier passed %.0f (means, wave 0)' % ((t[:, 12] - t[:, 0]).float().mean(), (t[:, 13] - t[:, 12]).float().mean(), (t[:, 1] - t[:, 13]).float().mean()))
 for k in range(5):
     ok = t[:, 3 + 2 * k] != 0
     if not bool(ok.any()):
