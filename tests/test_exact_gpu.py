@@ -105,18 +105,26 @@ def test_plain_autograd_is_reproducible_and_its_first_update_matches_per_paramet
     _assert_identical(a, _run('plain'))
     assert abs(a[0][0] - default_run[0][0]) <= 1e-5 * abs(a[0][0])              # same forward
     # first SGD update (lr * gradient): per parameter, relative L2
-    worst, worst_name, big = 0.0, None, 0
+    worst, worst_name, big, num, den2, big_mass = 0.0, None, 0, 0.0, 0.0, 0.0
     for n, ua in a[3].items():
         ub = default_run[3][n]
         den = float(ua.norm())
         if den == 0:
             assert float(ub.norm()) == 0, n
             continue
-        e = float((ua - ub).norm()) / den
+        d2 = float((ua - ub).norm()) ** 2
+        e = d2 ** 0.5 / den
+        num, den2 = num + d2, den2 + den * den
         big += e > 1e-2
+        big_mass += den * den if e > 1e-2 else 0.0
         if e > worst:
             worst, worst_name = e, n
-    print('worst per-parameter relative L2 of the first update: %.3e (%s); %d of %d above 1e-2' % (worst, worst_name, big, len(a[3])))
-    # all within 5e-2; at most 2 % of the ~1900 tensors above 1e-2 (seen on different boxes of the pool: 12-20 of them,
-    # all small bias vectors behind many batch norms)
-    assert worst < 5e-2 and big <= len(a[3]) // 50, (worst, worst_name, big)
+    whole = (num / den2) ** 0.5
+    print('worst per-parameter relative L2 of the first update: %.3e (%s); %d of %d above 1e-2 (%.2e of the update\'s squared '
+          'norm); whole update, relative L2: %.3e' % (worst, worst_name, big, len(a[3]), big_mass / den2, whole))
+    # Every tensor within 5e-2.  How many sit above 1e-2 depends on the BOX (which solvers MIOpen's Find picks for the encoders'
+    # convolutions): 12-20, 28 and -- r06, the round's last full-suite run -- 103 of 1888 were seen with the same library, and an
+    # A/B of two libraries on one box gave the same 28 tensors to the last digit; they are small bias vectors in front of batch
+    # norms (true gradient zero: what is compared is amplified rounding).  So the count is bounded loosely (10 % of the tensors) and
+    # what is bounded tightly is where the update's norm is: the tensors above 1e-2 carry < 1e-4 of its squared norm (measured: 7e-10).
+    assert worst < 5e-2 and big <= len(a[3]) // 10 and big_mass / den2 < 1e-4, (worst, worst_name, big, big_mass / den2, whole)
