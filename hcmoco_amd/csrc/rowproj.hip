@@ -560,6 +560,12 @@ struct TilePlan {
 
 constexpr int kSpanMax = 4;   // sub-tiles per workgroup on the large (mostly empty) maps
 constexpr int kGW = 256;      // 4 waves; <= 256 VGPRs -> two workgroups per SIMD set (the row ring of the T phase is the cover)
+// Where feature f of a pixel sits inside its row of T (r06 counters: SQ_LDS_BANK_CONFLICT 5.0 M quad-cycles against 2.5 M of LDS
+// activity).  A lane of the walk owns features 8 l .. 8 l + 7 (its 32 bytes of a grows row) and stores them as four 8-byte pairs;
+// in feature order lanes l and l + 8 of a 16-lane store hit the same banks (8 l mod 64).  Pair k of lane l goes to words
+// 2 l + 32 k (+ 0 / 1): sixteen lanes = 32 consecutive words.  The multiply's B-fragment read (lane (g, n): feature 4 s + g of pixel
+// n) then sees banks 2 n + {0, 1 | 32, 33}: conflict-free in each half wave like the plain order was.
+__host__ __device__ constexpr int t_col(int f) { return 2 * (f >> 3) + 32 * ((f & 7) >> 1) + (f & 1); }
 constexpr int kSE = 4;        // stencil entries per stage of the T phase (two stages in flight per 16-lane group)
 template <int K>
 __device__ __forceinline__ int row_bcast(int v) {       // lane K of every DPP row (16 lanes) to all lanes of that row
@@ -592,7 +598,7 @@ __device__ __forceinline__ void add_rows(int2 ech, int j, int jend, int q0, int 
     for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, v[k], fresh ? 0.f : acc[k]);
     float* z = tl + px * kTS;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 2 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(z + 32 * k) = make_float2(acc[2 * k], acc[2 * k + 1]);    // t_col(8 l + 2 k)
   }
 }
 
@@ -689,15 +695,15 @@ __device__ __forceinline__ void branch_grad_tiles(
       const int grp = tid >> 4, l16 = tid & 15;
 #pragma unroll
       for (int k = 0; k < ppg; ++k) {
-        float* z = &T[(grp * ppg + k) * kTS + 8 * l16];
+        float* z = &T[(grp * ppg + k) * kTS + 2 * l16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float2*>(z + 2 * u) = make_float2(0.f, 0.f);
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float2*>(z + 32 * u) = make_float2(0.f, 0.f);
       }
       int j = soff[grp * ppg];
       const int jend = soff[grp * ppg + ppg], jlast = soff[tpx] - 1;      // jlast >= 0: the sub-tile has entries
       const float* gl = grows + ((int64_t)m * B + b) * R * kF + 8 * l16;
       const int spare = kTP + grp;                                        // this group's spare row of T
-      float* const tl = T + 8 * l16;
+      float* const tl = T + 2 * l16;                                      // t_col(8 l16)
       float4 ra[kSE][2], rb[kSE][2];
       float acc[8];
 #pragma unroll
@@ -747,19 +753,19 @@ __device__ __forceinline__ void branch_grad_tiles(
         v4f acc4[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-        const float* tq = T + nn * kTS + gg;
+        const float* tq = T + nn * kTS + t_col(gg);                     // feature 4 s + gg: t_col(4 s) + t_col(gg)
         float tb[2][4][4];                               // [buffer][k-step][pixel tile]
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) tb[0][u][t] = tq[(t < ntl ? 16 * t : 0) * kTS + 4 * u];
+          for (int t = 0; t < 4; ++t) tb[0][u][t] = tq[(t < ntl ? 16 * t : 0) * kTS + t_col(4 * u)];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           if (c < 7) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-              for (int t = 0; t < 4; ++t) tb[(c + 1) & 1][u][t] = tq[(t < ntl ? 16 * t : 0) * kTS + 4 * (4 * c + 4 + u)];
+              for (int t = 0; t < 4; ++t) tb[(c + 1) & 1][u][t] = tq[(t < ntl ? 16 * t : 0) * kTS + t_col(4 * (4 * c + 4 + u))];
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
