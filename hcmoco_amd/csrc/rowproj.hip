@@ -813,34 +813,57 @@ __global__ __launch_bounds__(256) void finest_rows_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float Tl[kFR * kTS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * kFR, b = blockIdx.y, m = blockIdx.z;
-  const float* gsrc = grows + (((int64_t)m * B + b) * R + r0) * kF;
-  const int nr = min(kFR, R - r0);
-#pragma unroll
-  for (int k = 0; k < kFR * (kF / 4) / 256; ++k) {
-    const int e = tid + 256 * k, r = e >> 5, c4 = e & 31;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nr) v = *reinterpret_cast<const float4*>(gsrc + (int64_t)r * kF + 4 * c4);
-    float* z = &Tl[r * kTS + 4 * c4];
-    *reinterpret_cast<float2*>(z) = make_float2(v.x, v.y);
-    *reinterpret_cast<float2*>(z + 2) = make_float2(v.z, v.w);
-  }
-  __syncthreads();
   const int n = lane & 15, gq = lane >> 4;
   const float* Wp = m ? Wp2 : Wp1;
+  // A fragments of TWO channel tiles (W^T, columns 16 mt + n; uniform base + 32-bit lane offset), requested before the rows are
+  // staged: their round trip runs under the staging, and the two tiles are two independent accumulator chains (the first form --
+  // A after the barrier, one chain -- took 15 us for 0.12 GFLOP)
+  float a[2][32];
+  auto load_a = [&](int mt) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned lo = (unsigned)(gq * Ctot + min(16 * (mt + h) + n, C0 - 1));
+#pragma unroll
+      for (int s = 0; s < 32; ++s) a[h][s] = (Wp + (size_t)(4 * s) * Ctot)[lo];
+    }
+  };
+  load_a(0);
+  const float* gsrc = grows + (((int64_t)m * B + b) * R + r0) * kF;
+  const int nr = min(kFR, R - r0);
+  {
+    float4 v[kFR * (kF / 4) / 256];
+#pragma unroll
+    for (int k = 0; k < kFR * (kF / 4) / 256; ++k) {                 // eight 16-byte loads in flight (clamped row, zeroed below)
+      const int e = tid + 256 * k, r = e >> 5, c4 = e & 31;
+      v[k] = *reinterpret_cast<const float4*>(gsrc + (int64_t)min(r, nr - 1) * kF + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < kFR * (kF / 4) / 256; ++k) {
+      const int e = tid + 256 * k, r = e >> 5, c4 = e & 31;
+      const float4 w = r < nr ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float* z = &Tl[r * kTS + 4 * c4];
+      *reinterpret_cast<float2*>(z) = make_float2(w.x, w.y);
+      *reinterpret_cast<float2*>(z + 2) = make_float2(w.z, w.w);
+    }
+  }
+  __syncthreads();
   const float* tq = Tl + (16 * wave + n) * kTS + gq;
   const int r = r0 + 16 * wave + n;
   float* drow = dxs0 + (((int64_t)m * B + b) * R + r) * C0p;
-  for (int mt = 0; 16 * mt < C0p; ++mt) {
-    const unsigned lo = (unsigned)(gq * Ctot + min(16 * mt + n, C0 - 1));
-    const bool live = 16 * mt + n < C0;
-    float a[32];
+  for (int mt = 0; 16 * mt < C0p; mt += 2) {
+    if (mt != 0) load_a(mt);
+    const bool live0 = 16 * mt + n < C0, live1 = 16 * (mt + 1) + n < C0;
+    v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 32; ++s) a[s] = (Wp + (size_t)(4 * s) * Ctot)[lo];
-    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? a[s] : 0.f, tq[4 * s], acc, 0, 0, 0);
+    for (int s = 0; s < 32; ++s) {
+      const float bv = tq[4 * s];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(live0 ? a[0][s] : 0.f, bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(live1 ? a[1][s] : 0.f, bv, acc1, 0, 0, 0);
+    }
     // D: lane (gq, n) holds channels 16 mt + 4 gq + j of row 16 wave + n (channels >= C0: A was zero)
-    if (r < R && 16 * mt + 4 * gq < C0p) *reinterpret_cast<float4*>(drow + 16 * mt + 4 * gq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (r < R && 16 * mt + 4 * gq < C0p) *reinterpret_cast<float4*>(drow + 16 * mt + 4 * gq) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+    if (r < R && 16 * (mt + 1) + 4 * gq < C0p)
+      *reinterpret_cast<float4*>(drow + 16 * (mt + 1) + 4 * gq) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
   }
 }
 
@@ -1035,6 +1058,12 @@ extern "C" {
 #ifdef HCM_ROW8_TIMING
 int hcm_debug_row8_timing(unsigned long long* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_row8_dbg), &buf, sizeof(buf));
+}
+// resident workgroups per CU the runtime computes for the backward tile kernel (registers, LDS, wave slots)
+int hcm_debug_row8_occupancy() {
+  int nb = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(branch_grad_t_kernel), kGW, 0) != hipSuccess) return -1;
+  return nb;
 }
 #endif
 

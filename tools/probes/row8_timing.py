@@ -32,6 +32,10 @@ scale = torch.tensor(1.0, device=d)
 shapes = [tuple(m.shape) for m in maps1]
 setbuf = C.CDLL(os.environ['HCM_LIB']).hcm_debug_row8_timing
 setbuf.argtypes = [C.c_void_p]
+try:
+    print('hipOccupancyMaxActiveBlocksPerMultiprocessor(branch_grad_t_kernel, 256 threads) =', C.CDLL(os.environ['HCM_LIB']).hcm_debug_row8_occupancy())
+except AttributeError:
+    pass
 buf = torch.zeros(1 << 20, 16, dtype=torch.int64, device=d)
 
 
