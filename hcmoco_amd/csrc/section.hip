@@ -99,21 +99,34 @@ __global__ __launch_bounds__(kWG) void heads_fwd_kernel(
     }
   }
   __syncthreads();
-  // a wave owns outputs wave, wave + 4, ...; eight of them per trip, so that eight weight rows are in flight
-  for (int o0 = wave; o0 < F; o0 += 32) {
-    float acc[8];
+  // a wave owns outputs wave, wave + 4, ...: 32 of them per trip (all of them at F = 128) x two 64-wide steps of the input = 64
+  // weight loads in flight (r06; one step of eight outputs per trip was 20 dependent round trips per workgroup: 19 us for a
+  // 128 x 270 matrix-vector product; now 3).  Unconditional clamped loads; the same fmaf chain per lane and output as before.
+  for (int o0 = wave; o0 < F; o0 += 128) {
+    float acc[32];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int i = lane; i < Cin; i += 64) {
-      const float xv = x[i];
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int i0 = lane; i0 < Cin; i0 += 128) {
+      float wv[2][32], xv[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int o = o0 + 4 * j;
-        acc[j] = fmaf(o < F ? W[(int64_t)o * Cin + i] : 0.f, xv, acc[j]);
+      for (int it = 0; it < 2; ++it) {
+        const int ic = min(i0 + 64 * it, Cin - 1);
+        xv[it] = x[ic];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wv[it][j] = W[(int64_t)min(o0 + 4 * j, F - 1) * Cin + ic];
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const bool in = i0 + 64 * it < Cin;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const float t = fmaf(o0 + 4 * j < F ? wv[it][j] : 0.f, xv[it], acc[j]);
+          acc[j] = in ? t : acc[j];
+        }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 32; ++j) {
       const int o = o0 + 4 * j;
       const float a = wave_sum(acc[j]);
       if (lane == 0 && o < F) y[o] = a + bias[o];
@@ -167,16 +180,40 @@ __global__ __launch_bounds__(kWG) void heads_bwd_kernel(
     dyws[((int64_t)h * B + b) * F + tid] = d;
   }
   __syncthreads();
-  for (int i = tid; i < Cin; i += kWG) {
-    float acc = 0.f;
-    for (int o = 0; o < F; ++o) acc = fmaf(W[(int64_t)o * Cin + i], dy[o], acc);
-    if (h < 2) {
-      dpooled[((int64_t)h * B + b) * Ctot + i] = acc;
-    } else {
-      const float share = acc / (float)J;
-      for (int j = 0; j < J; ++j) {
-        const int64_t o = ((int64_t)b * J + j) * D3 + i;
-        gfeat3[o] = (gjoint != nullptr ? sc * gjoint[o] : 0.f) + share;
+  // two inputs per thread and pass (i, i + 256: at 270 inputs the second pass of a one-input loop was 14 threads paying the
+  // whole chain again), 32 weight rows each in flight; o ascending in every sum as before
+  for (int i0 = tid; i0 < Cin; i0 += 2 * kWG) {
+    const int i1 = i0 + kWG, ic1 = min(i1, Cin - 1);
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int o = 0; o < F; o += 32) {
+      float w0[32], w1[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int64_t ro = (int64_t)min(o + u, F - 1) * Cin;
+        w0[u] = W[ro + i0];
+        w1[u] = W[ro + ic1];
+      }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const float dv = dy[min(o + u, F - 1)];
+        const float t0 = fmaf(w0[u], dv, acc0), t1 = fmaf(w1[u], dv, acc1);
+        acc0 = o + u < F ? t0 : acc0;
+        acc1 = o + u < F ? t1 : acc1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = k == 0 ? i0 : i1;
+      const float acc = k == 0 ? acc0 : acc1;
+      if (i >= Cin) continue;
+      if (h < 2) {
+        dpooled[((int64_t)h * B + b) * Ctot + i] = acc;
+      } else {
+        const float share = acc / (float)J;
+        for (int j = 0; j < J; ++j) {
+          const int64_t o = ((int64_t)b * J + j) * D3 + i;
+          gfeat3[o] = (gjoint != nullptr ? sc * gjoint[o] : 0.f) + share;
+        }
       }
     }
   }
@@ -197,10 +234,20 @@ __global__ __launch_bounds__(kWG) void heads_dw_kernel(const float* __restrict__
   const float* x = h < 2 ? pooled + (int64_t)h * B * Ctot : mean3;
   const float* dy = dyws + (int64_t)h * B * F;
   float acc = 0.f, accb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float d = dy[(int64_t)b * F + o];
-    acc = fmaf(d, x[(int64_t)b * Cin + i], acc);
-    accb += d;
+  for (int b0 = 0; b0 < B; b0 += 16) {            // sixteen images in flight; b ascending in the sums as before
+    float dv[16], xv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int b = min(b0 + u, B - 1);
+      dv[u] = dy[(int64_t)b * F + o];
+      xv[u] = x[(int64_t)b * Cin + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float t = fmaf(dv[u], xv[u], acc), tb = accb + dv[u];
+      acc = b0 + u < B ? t : acc;
+      accb = b0 + u < B ? tb : accb;
+    }
   }
   float* dW = h == 0 ? dW1 : (h == 1 ? dW2 : dW3);
   float* db = h == 0 ? db1 : (h == 1 ? db2 : db3);
