@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kPT) void stencil_plan_kernel(const int64_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Branch gradients, transposed order.  grid (tiles of all four branches, B, 2), 512 threads.
+// Branch gradients, transposed order.  grid (B, modalities, tiles of all four branches: the most expensive kind first), 256 threads.
 // ------------------------------------------------------------------------------------------
 constexpr int kTP = 64;       // pixels per sub-tile (a workgroup walks `span` of them)
 constexpr int kTS = 130;      // LDS row stride of T: the B-fragment read (lane (g, n) -> T[n][4 s + g]) is conflict-free
