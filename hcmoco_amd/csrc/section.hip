@@ -210,9 +210,16 @@ __global__ __launch_bounds__(kWG) void heads_bwd_kernel(
         dpooled[((int64_t)h * B + b) * Ctot + i] = acc;
       } else {
         const float share = acc / (float)J;
-        for (int j = 0; j < J; ++j) {
-          const int64_t o = ((int64_t)b * J + j) * D3 + i;
-          gfeat3[o] = (gjoint != nullptr ? sc * gjoint[o] : 0.f) + share;
+        // sixteen joints' gradients in flight, then their stores (one load, one store per trip was J dependent round trips: loads
+        // and stores retire through one in-order counter)
+        for (int j0 = 0; j0 < J; j0 += 16) {
+          float gj[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            gj[u] = gjoint != nullptr ? gjoint[((int64_t)b * J + min(j0 + u, J - 1)) * D3 + i] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (j0 + u < J) gfeat3[((int64_t)b * J + j0 + u) * D3 + i] = (gjoint != nullptr ? sc * gj[u] : 0.f) + share;
         }
       }
     }
