@@ -687,12 +687,26 @@ __global__ __launch_bounds__(1024) void dense_finish_kernel(const float* __restr
   __shared__ float sh[4][16];
   const int n = B * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < n; i += 1024) {
-    if (keep[i / S] != 0) {
-      v[0] += rowloss[n + i];      // loss_r2d: orientation 1
-      v[1] += rowloss[i];          // loss_d2r: orientation 0
-      v[2] += rowcorrect[n + i];
-      v[3] += rowcorrect[i];
+  // ONE workgroup walks B S rows: four strides of it in flight per trip, unconditional (clamped) loads and a select -- the guarded
+  // form (keep, then the four values inside the branch) was two dependent round trips per stride, 10 us for 12800 rows (r06).  The
+  // rows of a dropped image hold whatever the workspace held: they are loaded and never added.  Same adds in the same order.
+  for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+    float x[4][4];
+    int kp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + 1024 * u, n - 1);
+      kp[u] = keep[i / S];
+      x[u][0] = rowloss[n + i];      // loss_r2d: orientation 1
+      x[u][1] = rowloss[i];          // loss_d2r: orientation 0
+      x[u][2] = rowcorrect[n + i];
+      x[u][3] = rowcorrect[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = i0 + 1024 * u < n && kp[u] != 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = ok ? v[k] + x[u][k] : v[k];
     }
   }
 #pragma unroll
@@ -914,11 +928,25 @@ __global__ __launch_bounds__(kWG) void joint_finish_kernel(const float* __restri
   if (blockIdx.x == 0 && threadIdx.x < 2) {
     const int mm = threadIdx.x;
     float lsum = 0.f, cnt = 0.f, accsum = 0.f, nimg = 0.f;
-    for (int b = 0; b < B; ++b) {
-      lsum += part[b * 6 + 0 + mm];
-      const float nv = part[b * 6 + 4 + mm];
-      cnt += nv;
-      if (nv > 0.f) { accsum += part[b * 6 + 2 + mm] / nv; nimg += 1.f; }
+    // sixteen images' partials in flight (the third value sat behind a branch on the second: two dependent round trips per image
+    // on two lanes, 9 us for B = 32 -- the whole kernel's duration, r06); b ascending in every sum as before
+    for (int b0 = 0; b0 < B; b0 += 16) {
+      float pl[16], pn[16], pa[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = min(b0 + u, B - 1);
+        pl[u] = part[b * 6 + 0 + mm];
+        pn[u] = part[b * 6 + 4 + mm];
+        pa[u] = part[b * 6 + 2 + mm];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (b0 + u < B) {
+          lsum += pl[u];
+          cnt += pn[u];
+          if (pn[u] > 0.f) { accsum += pa[u] / pn[u]; nimg += 1.f; }
+        }
+      }
     }
     out4[mm] = lsum / cnt;
     out4[2 + mm] = accsum / nimg;
